@@ -1,0 +1,195 @@
+/* lightkrylov_hip.h -- C ABI of the MI355X-native Krylov inner-loop engine.
+ *
+ * This is the drop-in boundary for LightKrylov's hot path: everything the reference's
+ * Krylov layer (src/Krylov, src/IterativeSolvers) asks of a vector type goes through the
+ * six deferred type-bound procedures of `abstract_vector_{rdp,cdp}` and the helpers built
+ * on them.  Each entry point below names the reference interface it replaces
+ * (file:line under the LightKrylov source tree).  Plain pointers and sizes only: a
+ * Fortran `bind(C)` interface block (fortran/lk_hip_iso_c.f90), a ctypes stub
+ * (lightkrylov_amd/_capi.py) or C code can bind it as is.
+ *
+ * Model
+ *   - one context per process = one GPU (HIP device + stream).  Multi-GPU = one process
+ *     per GPU, each holding a contiguous ROW BLOCK of every vector; the only coupling is
+ *     the sum-reduction of dot/norm/projection coefficients, delivered through a
+ *     user-installed all-reduce callback (RCCL in production).
+ *   - a Krylov basis is ONE column-contiguous panel in HBM: element (i, j) lives at
+ *     data[j * ld + i]; ld is padded so every column starts 256-byte aligned.
+ *     A single vector is a 1-column basis; every vector argument is a (basis, column) pair
+ *     with 0-based column indices.
+ *   - dtype LK_F64  = real(dp)     (reference kind "rdp")
+ *           LK_C128 = complex(dp)  (reference kind "cdp"), interleaved (re, im).
+ *     Scalars cross the ABI as `const double*` to 1 (F64) or 2 (C128) doubles.
+ *   - every call returns LK_OK (0) or a negative error code; lk_last_error() gives the text
+ *     (the Fortran shim maps non-zero to LightKrylov's stop_error,
+ *     src/Utilities/Logger.f90:290-298).  `info` out-arguments follow the reference
+ *     convention (src/Krylov/BaseKrylov.fypp:106-109): 0 ok, >0 informational, <0 failure.
+ *   - calls are asynchronous on the context's stream except those that return host
+ *     scalars, which synchronise that stream once.
+ *   There is NO CPU fallback: without a HIP device lk_init fails.
+ */
+#ifndef LIGHTKRYLOV_HIP_H
+#define LIGHTKRYLOV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lk_context_s *lk_context_t;
+typedef struct lk_basis_s *lk_basis_t;
+typedef struct lk_linop_s *lk_linop_t;
+
+enum { LK_F64 = 0, LK_C128 = 1 };
+
+enum {
+    LK_OK = 0,
+    LK_ERR_INVALID = -1, /* bad argument / shape / dtype mismatch (reference: stop_error) */
+    LK_ERR_HIP = -2,     /* HIP runtime error */
+    LK_ERR_NOMEM = -3,
+    LK_ERR_COMM = -4,    /* all-reduce callback failed */
+    LK_ERR_NAN = -5      /* |beta| = NaN detected (src/Krylov/qr.fypp:137-143) */
+};
+
+/* lk_dgs flags */
+enum {
+    LK_DGS_NORMALIZE = 1 /* fold qr_no_pivoting's 1-column normalise (qr.fypp:134,164) into the call:
+                            y <- y / ||y|| on the device when ||y|| >= atol_dp */
+};
+
+/* matvec transposition selector for lk_linop_apply (AbstractLinops.fypp:391-424) */
+enum { LK_OP_N = 0, LK_OP_H = 1 };
+
+/* ---- context ------------------------------------------------------------------------- */
+
+/* Sum all-reduce over the ranks that share a row-sharded vector: `count` doubles at device
+ * address `dev_buf`, in place, ordered on `stream` (a hipStream_t).  Return 0 on success.
+ * The reference has no collective at all (reductions are "the user's job inside dot",
+ * paper/paper.md:35,97,101); this hook is where that job is done once per sweep. */
+typedef int (*lk_allreduce_fn)(void *user, void *dev_buf, int64_t count, void *stream);
+
+int lk_version(void);
+const char *lk_last_error(void);
+
+/* device: HIP device ordinal.  stream: a hipStream_t to run on, or NULL for a stream owned
+ * by the context. */
+int lk_init(int device, void *stream, lk_context_t *ctx);
+int lk_finalize(lk_context_t ctx);
+int lk_sync(lk_context_t ctx);
+int lk_set_allreduce(lk_context_t ctx, lk_allreduce_fn fn, void *user, int nranks, int rank);
+/* row block owned by this rank: global rows [row0, row0 + n_local) of n_global; only used
+ * so that counter-based rand fills are identical for every partition. */
+int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
+/* tuning knobs (integers): "grid_mult" blocks per CU for the panel sweeps. */
+int lk_set_tuning(lk_context_t ctx, const char *key, int value);
+
+/* per-kernel HIP-event timing on the context's stream (bench.py roofline leg).
+ * tags: "dgs_sweep" (the panel sweep kernel), "dgs" (whole lk_dgs call), "matvec", "blas1". */
+int lk_profile_enable(lk_context_t ctx, int on);
+int lk_profile_get(lk_context_t ctx, const char *tag, int64_t *count, double *total_ms,
+                   double *total_bytes);
+int lk_profile_reset(lk_context_t ctx);
+
+/* ---- basis = array of vectors, X(:) in the reference --------------------------------- */
+
+/* replaces `allocate(X(ncols), source=...)` + `zero_basis(X)` (AbstractVectors.fypp:711-715,
+ * IterativeSolvers.fypp:1032-1034): n_local rows on this rank, columns zero-filled. */
+int lk_basis_create(lk_context_t ctx, int dtype, int64_t n_local, int ncols, lk_basis_t *B);
+/* wrap caller-owned device memory (e.g. a torch tensor).  ld in elements; dev_ptr 16-byte
+ * aligned; ld even for LK_F64.  Rows [n_local, ld) are never read or written. */
+int lk_basis_wrap(lk_context_t ctx, int dtype, int64_t n_local, int ncols, int64_t ld,
+                  void *dev_ptr, lk_basis_t *B);
+int lk_basis_destroy(lk_basis_t B);
+int lk_basis_info(lk_basis_t B, int *dtype, int64_t *n_local, int *ncols, int64_t *ld,
+                  void **dev_ptr);
+/* host <-> device, `ncols` columns starting at col0; host is column-major with leading
+ * dimension ldh (elements).  Synchronous. */
+int lk_basis_upload(lk_basis_t B, int col0, int ncols, const void *host, int64_t ldh);
+int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh);
+
+/* ---- abstract_vector type-bound procedures (AbstractVectors.fypp:295-381) ------------ */
+
+/* zero(self)                         AbstractVectors.fypp:322-326, dense: 476-486 */
+int lk_vec_zero(lk_basis_t B, int j);
+/* rand(self, ifnorm)                 :328-336, dense: 488-503.  Counter-based generator:
+ * entry i (global row row0+i) = 2u-1, u = (splitmix64(seed*2^32 + ctr) >> 11) * 2^-53;
+ * ctr = row for F64, 2*row / 2*row+1 for re / im.  ifnorm != 0 normalises (what eigs expects
+ * of rand(.true.), IterativeSolvers.fypp:1040). */
+int lk_vec_rand(lk_basis_t B, int j, uint64_t seed, int64_t row0, int ifnorm);
+/* scal(self, alpha)                  :338-344, dense: 505-512 */
+int lk_vec_scal(lk_basis_t B, int j, const double *alpha);
+/* axpby(alpha, vec, beta, self): self <- alpha*vec + beta*self   :346-356, dense: 514-536.
+ * True axpby in ONE pass (the reference's dense version does scal-then-axpy). */
+int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta, lk_basis_t By,
+                 int jy);
+/* dot(self, vec) = sum conj(self) * vec, all-reduced over ranks   :358-365, dense: 538-555.
+ * out: 1 or 2 doubles. */
+int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out);
+/* norm(self) = sqrt(abs(dot(self,self)))   :424-432 */
+int lk_vec_norm(lk_basis_t B, int j, double *out);
+/* get_size(self): GLOBAL size is the caller's business; this returns the local row count.  :367-372 */
+int lk_vec_size(lk_basis_t B, int64_t *n_local);
+/* copy(out, from)                    :717-723 */
+int lk_vec_copy(lk_basis_t Bdst, int jd, lk_basis_t Bsrc, int js);
+
+/* ---- basis helpers built on the TBPs (cannot be specialised by a Fortran plugin; here
+ *      they are fused panel kernels) ---------------------------------------------------- */
+
+/* innerprod(X(:k), Y(jy0:jy0+p)) -> M = X^H Y, k x p column-major on the host.
+ * AbstractVectors.fypp:659-695 */
+int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M);
+/* linear_combination(Y, X(:k), B): Y(:, jy0+j) = X(:, :k) * C(:, j), C is k x q column-major
+ * on the host.  AbstractVectors.fypp:571-643 */
+int lk_lincomb(lk_basis_t Bx, int k, const double *C, int q, lk_basis_t By, int jy0);
+/* Gram(X(:k)) -> G k x k (upper computed, mirrored without conjugation like the reference).
+ * AbstractVectors.fypp:645-657 */
+int lk_gram(lk_basis_t Bx, int k, double *G);
+/* orthogonalize_against_basis(y, X(:k), info, beta=h): ONE classical Gram-Schmidt pass.
+ * src/Krylov/gram_schmidt.fypp:113-154.  h: k scalars on the host (may be NULL). */
+int lk_orthogonalize(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, int *info);
+/* double_gram_schmidt_step(y, X(:k), info, if_chk_orthonormal=.false., beta=h)
+ * src/Krylov/gram_schmidt.fypp:12-57; interface src/Krylov/BaseKrylov.fypp:634-712.
+ * Three fused panel sweeps (h1 = X^H y | y' = y - X h1, h2 = X^H y' | y'' = y' - X h2);
+ * h = h1 + h2 on the host (k scalars, may be NULL).
+ * norms[0..2] = ||y||, ||y'||, ||y''|| (may be NULL).  info = 1 when ||y'|| < atol_dp (the
+ * reference's pass-2 zero-vector flag, gram_schmidt.fypp:126-127), else 0. */
+int lk_dgs(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, double *norms, int flags,
+           int *info);
+/* basis-against-basis variant (gram_schmidt.fypp:59-105): Y(jy0:jy0+p) against X(:k),
+ * h is k x p column-major. */
+int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h, int *info);
+
+/* ---- operators (stand where a user's abstract_linop matvec/rmatvec stands,
+ *      AbstractLinops.fypp:58-87); synthetic drivers of the path ------------------------ */
+
+/* y = d .* x; d: n_local host values of the basis dtype. */
+int lk_linop_diag_create(lk_context_t ctx, int dtype, int64_t n_local, const void *d_host,
+                         lk_linop_t *op);
+/* d_i = d0 + dstep * (row0 + i), generated on the device (F64 only). */
+int lk_linop_diag_linspace_create(lk_context_t ctx, int64_t n_local, int64_t row0, double d0,
+                                  double dstep, lk_linop_t *op);
+/* dense_linop: y = A x ('N') or A^H x ('H'); A is n x n column-major on the host.
+ * AbstractLinops.fypp:265-271, 608-660.  Single-rank only. */
+int lk_linop_dense_create(lk_context_t ctx, int dtype, int64_t n, const void *A_host, int64_t lda,
+                          lk_linop_t *op);
+/* 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (BASELINE config 3).
+ * F64, single-rank only. */
+int lk_linop_lap5_create(lk_context_t ctx, int64_t N, lk_linop_t *op);
+int lk_linop_destroy(lk_linop_t op);
+/* apply_matvec / apply_rmatvec: y(:, jy) = op(A) x(:, jx).  AbstractLinops.fypp:391-424 */
+int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t By, int jy);
+
+/* ---- the caller of the path: Arnoldi --------------------------------------------------
+ * arnoldi(A, X, H, info, kstart, kend, tol, transpose) with blksize = 1.
+ * src/Krylov/arnoldi.fypp:8-76 (+ the 1-column qr_no_pivoting, src/Krylov/qr.fypp:116-167).
+ * X: basis with m+1 columns; H: host (ldh x m) column-major array of the basis dtype;
+ * kstart/kend 1-based inclusive; tol: breakdown tolerance (reference default atol_dp).
+ * info = 0, or k when |H(k+1,k)| < tol (invariant subspace, loop exits). */
+int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend,
+               double tol, int trans, int *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIGHTKRYLOV_HIP_H */

@@ -1,0 +1,132 @@
+"""Engine context: one per process = one GPU (+ optional torch.distributed process group).
+
+PyTorch is plumbing here: it provides the current HIP stream and the RCCL communicator
+(`torch.distributed` backend "nccl" is RCCL on ROCm).  All arithmetic happens in the HIP
+library behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _capi
+
+
+class _DevMem:
+    """Zero-copy view of device memory for torch (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {
+            "shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def row_partition(n_global: int, nranks: int, rank: int):
+    """Contiguous row block of `rank`: (row0, n_local).  Every block but the last has an even
+    number of rows (n_global // nranks rounded down to even); the last takes the remainder."""
+    if nranks < 1 or not (0 <= rank < nranks):
+        raise ValueError(f"bad rank {rank}/{nranks}")
+    base = (n_global // nranks) & ~1
+    row0 = base * rank
+    n_local = base if rank < nranks - 1 else n_global - base * (nranks - 1)
+    return row0, n_local
+
+
+class Context:
+    def __init__(self, device: int | None = None, stream: int | None = None, process_group=None,
+                 use_torch_stream: bool = True):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        self._torch = None
+        self._pg = None
+        self.nranks, self.rank = 1, 0
+        self.row0, self.n_global = 0, None
+        self._cb = None
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        if stream is None and use_torch_stream:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    torch.cuda.set_device(device)
+                    stream = torch.cuda.current_stream(device).cuda_stream
+                    self._torch = torch
+            except ImportError:
+                pass
+        _capi.check(self._lib.lk_init(int(device), C.c_void_p(stream or 0), C.byref(self._h)))
+        self.device = int(device)
+        self.stream = stream
+        if process_group is not None:
+            self.set_process_group(process_group)
+
+    # -- multi-GPU: sum all-reduce of the (<= 258) reduction scalars over RCCL ------------
+    def set_process_group(self, pg) -> None:
+        import torch
+        import torch.distributed as dist
+        self._torch = torch
+        self._pg = pg
+        self.nranks = dist.get_world_size(pg)
+        self.rank = dist.get_rank(pg)
+        ext_stream_cache = {}
+
+        def _allreduce(_user, dev_ptr, count, stream_ptr):
+            try:
+                t = torch.as_tensor(_DevMem(int(dev_ptr), int(count)), device=f"cuda:{self.device}")
+                sp = int(stream_ptr or 0)
+                if sp not in ext_stream_cache:
+                    ext_stream_cache[sp] = torch.cuda.ExternalStream(sp, device=self.device) if sp else None
+                st = ext_stream_cache[sp]
+                if st is not None:
+                    with torch.cuda.stream(st):
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
+                return 0
+            except Exception as exc:  # noqa: BLE001 - must not propagate through C
+                import sys
+                print(f"[lightkrylov_amd] all-reduce callback failed: {exc!r}", file=sys.stderr)
+                return 1
+
+        self._cb = _capi.ALLREDUCE_FN(_allreduce)
+        _capi.check(self._lib.lk_set_allreduce(self._h, self._cb, None, self.nranks, self.rank))
+
+    def set_partition(self, row0: int, n_global: int) -> None:
+        _capi.check(self._lib.lk_set_partition(self._h, int(row0), int(n_global)))
+        self.row0, self.n_global = int(row0), int(n_global)
+
+    def set_tuning(self, key: str, value: int) -> None:
+        _capi.check(self._lib.lk_set_tuning(self._h, key.encode(), int(value)))
+
+    def sync(self) -> None:
+        _capi.check(self._lib.lk_sync(self._h))
+
+    def profile_enable(self, on: bool = True) -> None:
+        _capi.check(self._lib.lk_profile_enable(self._h, 1 if on else 0))
+
+    def profile_reset(self) -> None:
+        _capi.check(self._lib.lk_profile_reset(self._h))
+
+    def profile_get(self, tag: str):
+        cnt, ms, by = C.c_int64(), C.c_double(), C.c_double()
+        _capi.check(self._lib.lk_profile_get(self._h, tag.encode(), C.byref(cnt), C.byref(ms), C.byref(by)))
+        return cnt.value, ms.value, by.value
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.lk_finalize(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+_default: Context | None = None
+
+
+def default_context() -> Context:
+    global _default
+    if _default is None:
+        _default = Context()
+    return _default

@@ -1,0 +1,871 @@
+// lk_engine.hip -- host side of the C ABI declared in include/lightkrylov_hip.h.
+// HIP only: there is no CPU code path in this library.
+#include "../../include/lightkrylov_hip.h"
+#include "lk_kernels.hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace lk;
+
+namespace {
+
+constexpr double ATOL_DP = 1.0e-15;  // src/Constants.f90:35  atol_dp = 10**(-precision(1.0_dp))
+constexpr int KMAX_FUSED = 128;      // columns one fused sweep can hold (KC * NW)
+constexpr int MAX_GRID = 4096;       // upper bound on sweep blocks (partial buffer stride)
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(LK_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
+                                          hipGetErrorString(e_), __FILE__, __LINE__);        \
+    } while (0)
+
+#define LKCHK(expr)            \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != LK_OK) return rc_; \
+    } while (0)
+
+struct ProfRec {
+    hipEvent_t e0, e1;
+    std::string tag;
+    double bytes;
+};
+struct ProfAcc {
+    int64_t count = 0;
+    double ms = 0.0, bytes = 0.0;
+};
+
+}  // namespace
+
+struct lk_context_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    int grid_mult = 2;  // sweep blocks per CU
+    // reduction workspace
+    double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
+    double *red = nullptr;      // device results: 3 sections of (KMAX_FUSED+1)*2 doubles
+    double *red_host = nullptr; // pinned mirror
+    double *coef = nullptr;     // device coefficients for lincomb (KMAX_FUSED*2 doubles)
+    double *scratch = nullptr;  // scratch vector (grown on demand), scratch_n doubles
+    int64_t scratch_n = 0;
+    // communication
+    lk_allreduce_fn allreduce = nullptr;
+    void *allreduce_user = nullptr;
+    int nranks = 1, rank = 0;
+    int64_t row0 = 0, n_global = -1;  // this rank's row block [row0, row0 + n_local) of n_global rows
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> prof_pending;
+    std::vector<hipEvent_t> ev_pool;
+    std::map<std::string, ProfAcc> prof_acc;
+};
+
+struct lk_basis_s {
+    lk_context_t ctx;
+    int dtype;
+    int64_t n, ld;
+    int ncols;
+    double *data;
+    bool own;
+    int ed() const { return dtype == LK_C128 ? 2 : 1; }
+    double *col(int j) const { return data + (int64_t)j * ld * ed(); }
+};
+
+enum OpKind { OP_DIAG, OP_DIAG_LIN, OP_DENSE, OP_LAP5 };
+struct lk_linop_s {
+    lk_context_t ctx;
+    OpKind kind;
+    int dtype;
+    int64_t n;
+    double *dev = nullptr;  // diag values / dense matrix
+    int64_t lda = 0;
+    int64_t row0 = 0;
+    double d0 = 0, dstep = 0;
+    int64_t N = 0;
+};
+
+namespace {
+
+constexpr int RED_SECTION = (KMAX_FUSED + 1) * 2;  // doubles per result section
+
+// ---- profiling helpers ----------------------------------------------------------------
+struct ProfScope {
+    lk_context_t c;
+    bool on;
+    ProfRec rec;
+    ProfScope(lk_context_t ctx, const char *tag, double bytes) : c(ctx), on(ctx->prof) {
+        if (!on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        rec.e0 = get();
+        rec.e1 = get();
+        rec.tag = tag;
+        rec.bytes = bytes;
+        (void)hipEventRecord(rec.e0, c->stream);
+    }
+    void end() {
+        if (!on) return;
+        on = false;
+        (void)hipEventRecord(rec.e1, c->stream);
+        c->prof_pending.push_back(rec);
+    }
+    ~ProfScope() { end(); }
+};
+
+void prof_collect(lk_context_t c) {
+    for (auto &r : c->prof_pending) {
+        (void)hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        auto &a = c->prof_acc[r.tag];
+        a.count += 1;
+        a.ms += ms;
+        a.bytes += r.bytes;
+        c->ev_pool.push_back(r.e0);
+        c->ev_pool.push_back(r.e1);
+    }
+    c->prof_pending.clear();
+}
+
+inline int blas1_grid(lk_context_t c, int64_t nvec) {
+    int64_t g = (nvec + 255) / 256;
+    int64_t cap = (int64_t)c->num_cu * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int check_vec(lk_basis_t B, int j, const char *what) {
+    if (!B) return fail(LK_ERR_INVALID, "%s: null basis", what);
+    if (j < 0 || j >= B->ncols) return fail(LK_ERR_INVALID, "%s: column %d out of range [0,%d)", what, j, B->ncols);
+    return LK_OK;
+}
+int check_pair(lk_basis_t A, lk_basis_t B, const char *what) {
+    if (A->ctx != B->ctx) return fail(LK_ERR_INVALID, "%s: bases belong to different contexts", what);
+    if (A->dtype != B->dtype) return fail(LK_ERR_INVALID, "%s: dtype mismatch", what);
+    if (A->n != B->n) return fail(LK_ERR_INVALID, "%s: Inconsistent size between the two vectors (%lld vs %lld)", what,
+                                  (long long)A->n, (long long)B->n);
+    return LK_OK;
+}
+
+int allreduce(lk_context_t c, double *dev, int64_t count) {
+    if (c->nranks > 1) {
+        if (!c->allreduce) return fail(LK_ERR_COMM, "nranks=%d but no all-reduce installed", c->nranks);
+        int rc = c->allreduce(c->allreduce_user, dev, count, (void *)c->stream);
+        if (rc != 0) return fail(LK_ERR_COMM, "all-reduce callback returned %d", rc);
+    }
+    return LK_OK;
+}
+
+// ---- sweep launcher ---------------------------------------------------------------------
+struct SweepCfg { int WC, kcw, grid; };
+
+template <bool CPLX, int KC, int NW>
+SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n) {
+    SweepCfg s;
+    int wc = (k + KC - 1) / KC;  // waves needed across columns
+    if (wc < 1) wc = 1;
+    int WC = 1;
+    while (WC < wc) WC <<= 1;    // power of two so it divides NW
+    if (WC > NW) WC = NW;
+    s.WC = WC;
+    s.kcw = (k + WC - 1) / WC;
+    if (s.kcw < 1) s.kcw = 1;
+    const int64_t tile_rows = (int64_t)(NW / WC) * 64 * K<CPLX>::ROWS;
+    int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    int64_t g = (int64_t)c->num_cu * c->grid_mult;
+    if (g > ntiles) g = ntiles;
+    if (g > MAX_GRID) g = MAX_GRID;
+    if (g < 1) g = 1;
+    s.grid = (int)g;
+    return s;
+}
+
+// One sweep over columns [0,k) of X (k <= KMAX_FUSED) + finish into `out` (k+1 slots of ED doubles).
+template <bool CPLX, bool UPDATE, bool DOT>
+int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y, int64_t n, const double *hin,
+                 double *out) {
+    constexpr int KC = CPLX ? 8 : 16;
+    constexpr int NW = CPLX ? 16 : 8;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    static_assert(KC * NW == KMAX_FUSED, "fused capacity");
+    SweepCfg s = sweep_cfg<CPLX, KC, NW>(c, k, n);
+    const double bytes = (double)n * ED * 8.0 * (k + 1 + (UPDATE ? 1 : 0));
+    {
+        ProfScope ps(c, "dgs_sweep", bytes);
+        hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X, ldx, k,
+                           y, n, hin, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw);
+    }
+    HIPCHK(hipGetLastError());
+    // slots: DOT -> 0..k*ED-1 valid; norm at slot k*ED.  Without DOT only the norm slot is defined.
+    const int first = DOT ? 0 : k * ED;
+    const int nslots = (k + 1) * ED - first;
+    hipLaunchKernelGGL(finish_partials, dim3((nslots + 3) / 4), dim3(256), 0, c->stream,
+                       c->partial + (int64_t)first * MAX_GRID, (int64_t)MAX_GRID, s.grid, nslots, out + first);
+    HIPCHK(hipGetLastError());
+    return allreduce(c, out + first, nslots);
+}
+
+template <bool UPDATE, bool DOT>
+int sweep(lk_basis_t Bx, int c0, int k, double *y, const double *hin, double *out) {
+    lk_context_t c = Bx->ctx;
+    const double *X = Bx->col(c0);
+    if (Bx->dtype == LK_C128) return launch_sweep<true, UPDATE, DOT>(c, X, Bx->ld, k, y, Bx->n, hin, out);
+    return launch_sweep<false, UPDATE, DOT>(c, X, Bx->ld, k, y, Bx->n, hin, out);
+}
+
+int ensure_scratch(lk_context_t c, int64_t doubles) {
+    if (c->scratch_n >= doubles) return LK_OK;
+    if (c->scratch) HIPCHK(hipFree(c->scratch));
+    c->scratch = nullptr;
+    c->scratch_n = 0;
+    HIPCHK(hipMalloc((void **)&c->scratch, (size_t)doubles * sizeof(double)));
+    c->scratch_n = doubles;
+    return LK_OK;
+}
+
+int dot_device(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out_dev) {
+    lk_context_t c = Bx->ctx;
+    const int64_t nv = Bx->n * Bx->ed() / 2 + 1;
+    int g = blas1_grid(c, nv);
+    if (g > MAX_GRID) g = MAX_GRID;
+    {
+        ProfScope ps(c, "blas1", (double)Bx->n * Bx->ed() * 16.0);
+        if (Bx->dtype == LK_C128)
+            hipLaunchKernelGGL(k_dot<true>, dim3(g), dim3(256), 0, c->stream, Bx->col(jx), By->col(jy), Bx->n, c->partial,
+                               (int64_t)MAX_GRID);
+        else
+            hipLaunchKernelGGL(k_dot<false>, dim3(g), dim3(256), 0, c->stream, Bx->col(jx), By->col(jy), Bx->n, c->partial,
+                               (int64_t)MAX_GRID);
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(finish_partials, dim3(1), dim3(256), 0, c->stream, c->partial, (int64_t)MAX_GRID, g, 2, out_dev);
+    HIPCHK(hipGetLastError());
+    return allreduce(c, out_dev, 2);
+}
+
+int fetch(lk_context_t c, int section0, int nsections) {
+    // copy result sections to the pinned mirror and wait
+    HIPCHK(hipMemcpyAsync(c->red_host + (size_t)section0 * RED_SECTION, c->red + (size_t)section0 * RED_SECTION,
+                          (size_t)nsections * RED_SECTION * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    return LK_OK;
+}
+
+int scal_launch(lk_basis_t B, int j, double ar, double ai, const double *inv_sqrt_of, double tol) {
+    lk_context_t c = B->ctx;
+    const int64_t nv = B->n * B->ed() / 2 + 1;
+    ProfScope ps(c, "blas1", (double)B->n * B->ed() * 16.0);
+    if (B->dtype == LK_C128)
+        hipLaunchKernelGGL(k_scal<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, B->col(j), B->n, ar, ai,
+                           inv_sqrt_of, tol);
+    else
+        hipLaunchKernelGGL(k_scal<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, B->col(j), B->n, ar, ai,
+                           inv_sqrt_of, tol);
+    HIPCHK(hipGetLastError());
+    return LK_OK;
+}
+
+// Core of double_gram_schmidt_step for one vector; results stay in c->red (device):
+//   section 0: h1[0..k), nrm2(y)    section 1: h2[0..k), nrm2(y')   section 2 (slot k): nrm2(y'')
+int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass) {
+    lk_context_t c = Bx->ctx;
+    const int ED = Bx->ed();
+    double *r0 = c->red, *r1 = c->red + RED_SECTION, *r2 = c->red + 2 * RED_SECTION;
+    if (k <= KMAX_FUSED) {
+        LKCHK((sweep<false, true>(Bx, 0, k, y, nullptr, r0)));       // h1 = X^H y ; ||y||^2
+        if (two_pass) {
+            LKCHK((sweep<true, true>(Bx, 0, k, y, r0, r1)));         // y' = y - X h1 ; h2 = X^H y' ; ||y'||^2
+            LKCHK((sweep<true, false>(Bx, 0, k, y, r1, r2)));        // y'' = y' - X h2 ; ||y''||^2
+        } else {
+            LKCHK((sweep<true, false>(Bx, 0, k, y, r0, r1)));        // y' = y - X h1 ; ||y'||^2
+        }
+        return LK_OK;
+    }
+    (void)ED;
+    return fail(LK_ERR_INVALID, "internal: dgs_device called with k=%d > %d", k, KMAX_FUSED);
+}
+
+}  // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+int lk_version(void) { return 100; }
+const char *lk_last_error(void) { return g_err; }
+
+int lk_init(int device, void *stream, lk_context_t *ctx) {
+    if (!ctx) return fail(LK_ERR_INVALID, "lk_init: null ctx pointer");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(LK_ERR_HIP, "lk_init: no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(LK_ERR_INVALID, "lk_init: device %d out of range [0,%d)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    lk_context_t c = new lk_context_s();
+    c->device = device;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    HIPCHK(hipMalloc((void **)&c->partial, (size_t)RED_SECTION * MAX_GRID * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&c->red, (size_t)3 * RED_SECTION * sizeof(double)));
+    HIPCHK(hipMemsetAsync(c->red, 0, (size_t)3 * RED_SECTION * sizeof(double), c->stream));
+    HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)3 * RED_SECTION * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&c->coef, (size_t)KMAX_FUSED * 2 * sizeof(double)));
+    *ctx = c;
+    return LK_OK;
+}
+
+int lk_finalize(lk_context_t c) {
+    if (!c) return LK_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    prof_collect(c);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->partial) (void)hipFree(c->partial);
+    if (c->red) (void)hipFree(c->red);
+    if (c->coef) (void)hipFree(c->coef);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->red_host) (void)hipHostFree(c->red_host);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return LK_OK;
+}
+
+int lk_sync(lk_context_t c) {
+    if (!c) return fail(LK_ERR_INVALID, "lk_sync: null context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    return LK_OK;
+}
+
+int lk_set_allreduce(lk_context_t c, lk_allreduce_fn fn, void *user, int nranks, int rank) {
+    if (!c) return fail(LK_ERR_INVALID, "lk_set_allreduce: null context");
+    if (nranks < 1 || rank < 0 || rank >= nranks) return fail(LK_ERR_INVALID, "lk_set_allreduce: bad rank %d/%d", rank, nranks);
+    if (nranks > 1 && !fn) return fail(LK_ERR_INVALID, "lk_set_allreduce: nranks>1 needs a callback");
+    c->allreduce = fn;
+    c->allreduce_user = user;
+    c->nranks = nranks;
+    c->rank = rank;
+    return LK_OK;
+}
+
+int lk_set_partition(lk_context_t c, int64_t row0, int64_t n_global) {
+    if (!c) return fail(LK_ERR_INVALID, "lk_set_partition: null context");
+    if (row0 < 0 || (n_global >= 0 && row0 > n_global)) return fail(LK_ERR_INVALID, "lk_set_partition: bad row0");
+    c->row0 = row0;
+    c->n_global = n_global;
+    return LK_OK;
+}
+
+int lk_set_tuning(lk_context_t c, const char *key, int value) {
+    if (!c || !key) return fail(LK_ERR_INVALID, "lk_set_tuning: null argument");
+    if (!strcmp(key, "grid_mult")) {
+        if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "grid_mult must be in [1,16]");
+        c->grid_mult = value;
+        return LK_OK;
+    }
+    return fail(LK_ERR_INVALID, "lk_set_tuning: unknown key '%s'", key);
+}
+
+int lk_profile_enable(lk_context_t c, int on) {
+    if (!c) return fail(LK_ERR_INVALID, "null context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    c->prof = on != 0;
+    return LK_OK;
+}
+int lk_profile_reset(lk_context_t c) {
+    if (!c) return fail(LK_ERR_INVALID, "null context");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    c->prof_acc.clear();
+    return LK_OK;
+}
+int lk_profile_get(lk_context_t c, const char *tag, int64_t *count, double *total_ms, double *total_bytes) {
+    if (!c || !tag) return fail(LK_ERR_INVALID, "null argument");
+    HIPCHK(hipStreamSynchronize(c->stream));
+    prof_collect(c);
+    auto it = c->prof_acc.find(tag);
+    ProfAcc a = it == c->prof_acc.end() ? ProfAcc() : it->second;
+    if (count) *count = a.count;
+    if (total_ms) *total_ms = a.ms;
+    if (total_bytes) *total_bytes = a.bytes;
+    return LK_OK;
+}
+
+// ---- basis --------------------------------------------------------------------------------
+int lk_basis_create(lk_context_t c, int dtype, int64_t n_local, int ncols, lk_basis_t *B) {
+    if (!c || !B) return fail(LK_ERR_INVALID, "lk_basis_create: null argument");
+    if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "lk_basis_create: bad dtype %d", dtype);
+    if (n_local < 0 || ncols < 1) return fail(LK_ERR_INVALID, "lk_basis_create: bad shape %lld x %d", (long long)n_local, ncols);
+    if (n_local > 2147483647LL) return fail(LK_ERR_INVALID, "lk_basis_create: n_local exceeds get_size's default integer");
+    const int ed = dtype == LK_C128 ? 2 : 1;
+    const int64_t align_elems = 256 / (8 * ed);  // 256-byte column alignment
+    int64_t ld = ((n_local + align_elems - 1) / align_elems) * align_elems;
+    if (ld == 0) ld = align_elems;
+    lk_basis_t b = new lk_basis_s();
+    b->ctx = c; b->dtype = dtype; b->n = n_local; b->ld = ld; b->ncols = ncols; b->own = true; b->data = nullptr;
+    const size_t bytes = (size_t)ld * ncols * ed * sizeof(double);
+    hipError_t e = hipMalloc((void **)&b->data, bytes);
+    if (e != hipSuccess) { delete b; return fail(LK_ERR_NOMEM, "lk_basis_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    e = hipMemsetAsync(b->data, 0, bytes, c->stream);
+    if (e != hipSuccess) { (void)hipFree(b->data); delete b; return fail(LK_ERR_HIP, "memset failed: %s", hipGetErrorString(e)); }
+    *B = b;
+    return LK_OK;
+}
+
+int lk_basis_wrap(lk_context_t c, int dtype, int64_t n_local, int ncols, int64_t ld, void *dev_ptr, lk_basis_t *B) {
+    if (!c || !B || !dev_ptr) return fail(LK_ERR_INVALID, "lk_basis_wrap: null argument");
+    if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "lk_basis_wrap: bad dtype %d", dtype);
+    if (n_local < 0 || ncols < 1 || ld < n_local) return fail(LK_ERR_INVALID, "lk_basis_wrap: bad shape");
+    if (((uintptr_t)dev_ptr & 15) != 0) return fail(LK_ERR_INVALID, "lk_basis_wrap: pointer must be 16-byte aligned");
+    if (dtype == LK_F64 && (ld & 1) && ncols > 1) return fail(LK_ERR_INVALID, "lk_basis_wrap: ld must be even for LK_F64");
+    lk_basis_t b = new lk_basis_s();
+    b->ctx = c; b->dtype = dtype; b->n = n_local; b->ld = ld; b->ncols = ncols; b->own = false; b->data = (double *)dev_ptr;
+    *B = b;
+    return LK_OK;
+}
+
+int lk_basis_destroy(lk_basis_t B) {
+    if (!B) return LK_OK;
+    if (B->own && B->data) {
+        (void)hipStreamSynchronize(B->ctx->stream);
+        (void)hipFree(B->data);
+    }
+    delete B;
+    return LK_OK;
+}
+
+int lk_basis_info(lk_basis_t B, int *dtype, int64_t *n_local, int *ncols, int64_t *ld, void **dev_ptr) {
+    if (!B) return fail(LK_ERR_INVALID, "lk_basis_info: null basis");
+    if (dtype) *dtype = B->dtype;
+    if (n_local) *n_local = B->n;
+    if (ncols) *ncols = B->ncols;
+    if (ld) *ld = B->ld;
+    if (dev_ptr) *dev_ptr = B->data;
+    return LK_OK;
+}
+
+int lk_basis_upload(lk_basis_t B, int col0, int ncols, const void *host, int64_t ldh) {
+    if (!B || !host) return fail(LK_ERR_INVALID, "lk_basis_upload: null argument");
+    if (col0 < 0 || ncols < 0 || col0 + ncols > B->ncols || ldh < B->n) return fail(LK_ERR_INVALID, "lk_basis_upload: bad range");
+    if (ncols == 0 || B->n == 0) return LK_OK;
+    const size_t es = (size_t)B->ed() * sizeof(double);
+    HIPCHK(hipMemcpy2DAsync(B->col(col0), (size_t)B->ld * es, host, (size_t)ldh * es, (size_t)B->n * es, ncols,
+                            hipMemcpyHostToDevice, B->ctx->stream));
+    HIPCHK(hipStreamSynchronize(B->ctx->stream));
+    return LK_OK;
+}
+
+int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh) {
+    if (!B || !host) return fail(LK_ERR_INVALID, "lk_basis_download: null argument");
+    if (col0 < 0 || ncols < 0 || col0 + ncols > B->ncols || ldh < B->n) return fail(LK_ERR_INVALID, "lk_basis_download: bad range");
+    if (ncols == 0 || B->n == 0) return LK_OK;
+    const size_t es = (size_t)B->ed() * sizeof(double);
+    HIPCHK(hipMemcpy2DAsync(host, (size_t)ldh * es, B->col(col0), (size_t)B->ld * es, (size_t)B->n * es, ncols,
+                            hipMemcpyDeviceToHost, B->ctx->stream));
+    HIPCHK(hipStreamSynchronize(B->ctx->stream));
+    return LK_OK;
+}
+
+// ---- vector TBPs ----------------------------------------------------------------------------
+int lk_vec_zero(lk_basis_t B, int j) {
+    LKCHK(check_vec(B, j, "lk_vec_zero"));
+    HIPCHK(hipMemsetAsync(B->col(j), 0, (size_t)B->n * B->ed() * sizeof(double), B->ctx->stream));
+    return LK_OK;
+}
+
+int lk_vec_scal(lk_basis_t B, int j, const double *alpha) {
+    LKCHK(check_vec(B, j, "lk_vec_scal"));
+    if (!alpha) return fail(LK_ERR_INVALID, "lk_vec_scal: null alpha");
+    return scal_launch(B, j, alpha[0], B->dtype == LK_C128 ? alpha[1] : 0.0, nullptr, 0.0);
+}
+
+int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta, lk_basis_t By, int jy) {
+    LKCHK(check_vec(Bx, jx, "lk_vec_axpby(vec)"));
+    LKCHK(check_vec(By, jy, "lk_vec_axpby(self)"));
+    LKCHK(check_pair(Bx, By, "lk_vec_axpby"));
+    if (!alpha || !beta) return fail(LK_ERR_INVALID, "lk_vec_axpby: null scalar");
+    lk_context_t c = Bx->ctx;
+    const bool cp = Bx->dtype == LK_C128;
+    const int64_t nv = Bx->n * Bx->ed() / 2 + 1;
+    ProfScope ps(c, "blas1", (double)Bx->n * Bx->ed() * 24.0);
+    if (cp)
+        hipLaunchKernelGGL(k_axpby<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, alpha[0], alpha[1], Bx->col(jx),
+                           beta[0], beta[1], By->col(jy), Bx->n);
+    else
+        hipLaunchKernelGGL(k_axpby<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, alpha[0], 0.0, Bx->col(jx),
+                           beta[0], 0.0, By->col(jy), Bx->n);
+    HIPCHK(hipGetLastError());
+    return LK_OK;
+}
+
+int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
+    LKCHK(check_vec(Bx, jx, "lk_vec_dot(self)"));
+    LKCHK(check_vec(By, jy, "lk_vec_dot(vec)"));
+    LKCHK(check_pair(Bx, By, "lk_vec_dot"));
+    if (!out) return fail(LK_ERR_INVALID, "lk_vec_dot: null out");
+    lk_context_t c = Bx->ctx;
+    LKCHK(dot_device(Bx, jx, By, jy, c->red));
+    LKCHK(fetch(c, 0, 1));
+    out[0] = c->red_host[0];
+    if (Bx->dtype == LK_C128) out[1] = c->red_host[1];
+    return LK_OK;
+}
+
+int lk_vec_norm(lk_basis_t B, int j, double *out) {
+    LKCHK(check_vec(B, j, "lk_vec_norm"));
+    if (!out) return fail(LK_ERR_INVALID, "lk_vec_norm: null out");
+    lk_context_t c = B->ctx;
+    LKCHK(dot_device(B, j, B, j, c->red));
+    LKCHK(fetch(c, 0, 1));
+    // alpha = abs(self%dot(self)); alpha = sqrt(alpha)   AbstractVectors.fypp:431
+    *out = std::sqrt(std::hypot(c->red_host[0], B->dtype == LK_C128 ? c->red_host[1] : 0.0));
+    return LK_OK;
+}
+
+int lk_vec_size(lk_basis_t B, int64_t *n_local) {
+    if (!B || !n_local) return fail(LK_ERR_INVALID, "lk_vec_size: null argument");
+    *n_local = B->n;
+    return LK_OK;
+}
+
+int lk_vec_copy(lk_basis_t Bd, int jd, lk_basis_t Bs, int js) {
+    LKCHK(check_vec(Bd, jd, "lk_vec_copy(out)"));
+    LKCHK(check_vec(Bs, js, "lk_vec_copy(from)"));
+    LKCHK(check_pair(Bd, Bs, "lk_vec_copy"));
+    if (Bd->col(jd) == Bs->col(js)) return LK_OK;
+    ProfScope ps(Bd->ctx, "blas1", (double)Bd->n * Bd->ed() * 16.0);
+    HIPCHK(hipMemcpyAsync(Bd->col(jd), Bs->col(js), (size_t)Bd->n * Bd->ed() * sizeof(double), hipMemcpyDeviceToDevice,
+                          Bd->ctx->stream));
+    return LK_OK;
+}
+
+int lk_vec_rand(lk_basis_t B, int j, uint64_t seed, int64_t row0, int ifnorm) {
+    LKCHK(check_vec(B, j, "lk_vec_rand"));
+    lk_context_t c = B->ctx;
+    if (B->dtype == LK_C128)
+        hipLaunchKernelGGL(k_rand<true>, dim3(blas1_grid(c, B->n)), dim3(256), 0, c->stream, B->col(j), B->n, seed, row0);
+    else
+        hipLaunchKernelGGL(k_rand<false>, dim3(blas1_grid(c, B->n)), dim3(256), 0, c->stream, B->col(j), B->n, seed, row0);
+    HIPCHK(hipGetLastError());
+    if (ifnorm) {
+        LKCHK(dot_device(B, j, B, j, c->red));
+        LKCHK(scal_launch(B, j, 1.0, 0.0, c->red, 0.0));
+    }
+    return LK_OK;
+}
+
+// ---- basis helpers ---------------------------------------------------------------------------
+int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M) {
+    if (!Bx || !By || !M) return fail(LK_ERR_INVALID, "lk_innerprod: null argument");
+    LKCHK(check_pair(Bx, By, "lk_innerprod"));
+    if (k < 1 || k > Bx->ncols || p < 1 || jy0 < 0 || jy0 + p > By->ncols) return fail(LK_ERR_INVALID, "lk_innerprod: bad range");
+    lk_context_t c = Bx->ctx;
+    const int ED = Bx->ed();
+    for (int j = 0; j < p; ++j) {
+        for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
+            const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
+            LKCHK((sweep<false, true>(Bx, c0, kk, By->col(jy0 + j), nullptr, c->red)));
+            LKCHK(fetch(c, 0, 1));
+            memcpy(M + ((size_t)j * k + c0) * ED, c->red_host, (size_t)kk * ED * sizeof(double));
+        }
+    }
+    return LK_OK;
+}
+
+int lk_gram(lk_basis_t Bx, int k, double *G) {
+    if (!Bx || !G) return fail(LK_ERR_INVALID, "lk_gram: null argument");
+    if (k < 1 || k > Bx->ncols) return fail(LK_ERR_INVALID, "lk_gram: bad k");
+    const int ED = Bx->ed();
+    std::vector<double> M((size_t)k * k * ED);
+    LKCHK(lk_innerprod(Bx, k, Bx, 0, k, M.data()));
+    // G(i,j) = X(i)%dot(X(j)) for j >= i; G(j,i) = G(i,j) (no conjugation)   AbstractVectors.fypp:650-655
+    for (int i = 0; i < k; ++i)
+        for (int j = i; j < k; ++j)
+            for (int e = 0; e < ED; ++e) {
+                const double v = M[((size_t)j * k + i) * ED + e];
+                G[((size_t)j * k + i) * ED + e] = v;
+                G[((size_t)i * k + j) * ED + e] = v;
+            }
+    return LK_OK;
+}
+
+int lk_lincomb(lk_basis_t Bx, int k, const double *C, int q, lk_basis_t By, int jy0) {
+    if (!Bx || !By || !C) return fail(LK_ERR_INVALID, "lk_lincomb: null argument");
+    LKCHK(check_pair(Bx, By, "lk_lincomb"));
+    if (k < 1 || k > Bx->ncols || q < 1 || jy0 < 0 || jy0 + q > By->ncols)
+        return fail(LK_ERR_INVALID, "Krylov basis X and combination matrix B have incompatible sizes.");
+    lk_context_t c = Bx->ctx;
+    const int ED = Bx->ed();
+    std::vector<double> neg((size_t)KMAX_FUSED * ED);
+    for (int j = 0; j < q; ++j) {
+        double *y = By->col(jy0 + j);
+        // Y(j)%zero(); then y <- y - X*(-C(:,j)) panel by panel
+        HIPCHK(hipMemsetAsync(y, 0, (size_t)By->n * ED * sizeof(double), c->stream));
+        for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
+            const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
+            for (int i = 0; i < kk * ED; ++i) neg[i] = -C[((size_t)j * k + c0) * ED + i];
+            HIPCHK(hipStreamSynchronize(c->stream));  // coef buffer reuse
+            HIPCHK(hipMemcpyAsync(c->coef, neg.data(), (size_t)kk * ED * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            LKCHK((sweep<true, false>(Bx, c0, kk, y, c->coef, c->red + 2 * RED_SECTION)));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return LK_OK;
+}
+
+static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, double *norms, int flags, int *info,
+                       bool two_pass) {
+    if (!Bx || !By) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: null basis");
+    LKCHK(check_vec(By, jy, "double_gram_schmidt_step(y)"));
+    LKCHK(check_pair(Bx, By, "double_gram_schmidt_step"));
+    if (k < 1 || k > Bx->ncols) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: k=%d out of range [1,%d]", k, Bx->ncols);
+    lk_context_t c = Bx->ctx;
+    const int ED = Bx->ed();
+    double *y = By->col(jy);
+    if (Bx == By && jy < k) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: y is one of the basis columns");
+    double n0 = 0, n1 = 0, n2 = 0;
+    ProfScope ps(c, "dgs", (double)Bx->n * ED * 8.0 * (two_pass ? (3.0 * k + 5.0) : (2.0 * k + 3.0)));
+    if (k <= KMAX_FUSED) {
+        LKCHK(dgs_device(Bx, k, y, two_pass));
+        const int last = two_pass ? 2 : 1;
+        if (flags & LK_DGS_NORMALIZE)
+            LKCHK(scal_launch(By, jy, 1.0, 0.0, c->red + last * RED_SECTION + (size_t)k * ED, ATOL_DP));
+        ps.end();
+        LKCHK(fetch(c, 0, 3));
+        const double *r0 = c->red_host, *r1 = c->red_host + RED_SECTION, *r2 = c->red_host + 2 * RED_SECTION;
+        if (h)
+            for (int i = 0; i < k * ED; ++i) h[i] = two_pass ? (r0[i] + r1[i]) : r0[i];   // gram_schmidt.fypp:49
+        n0 = r0[k * ED];
+        n1 = r1[k * ED];
+        n2 = two_pass ? r2[k * ED] : n1;
+    } else {
+        // wide basis: column panels of KMAX_FUSED, unfused schedule (dots of all panels, then updates)
+        std::vector<double> hacc((size_t)k * ED, 0.0), hp((size_t)k * ED);
+        const int npass = two_pass ? 2 : 1;
+        for (int pass = 0; pass < npass; ++pass) {
+            for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
+                const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
+                LKCHK((sweep<false, true>(Bx, c0, kk, y, nullptr, c->red)));
+                LKCHK(fetch(c, 0, 1));
+                memcpy(hp.data() + (size_t)c0 * ED, c->red_host, (size_t)kk * ED * sizeof(double));
+                if (c0 == 0) (pass == 0 ? n0 : n1) = c->red_host[kk * ED];
+            }
+            for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
+                const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
+                HIPCHK(hipMemcpyAsync(c->coef, hp.data() + (size_t)c0 * ED, (size_t)kk * ED * sizeof(double),
+                                      hipMemcpyHostToDevice, c->stream));
+                LKCHK((sweep<true, false>(Bx, c0, kk, y, c->coef, c->red + 2 * RED_SECTION)));
+                LKCHK(fetch(c, 2, 1));
+                (pass == 0 && two_pass ? n1 : n2) = c->red_host[2 * RED_SECTION + kk * ED];
+            }
+            for (size_t i = 0; i < hacc.size(); ++i) hacc[i] += hp[i];
+        }
+        if (!two_pass) n1 = n2;
+        if (flags & LK_DGS_NORMALIZE) {
+            const double nr = std::sqrt(std::fabs(n2));
+            if (nr >= ATOL_DP) LKCHK(scal_launch(By, jy, 1.0 / nr, 0.0, nullptr, 0.0));
+        }
+        if (h) memcpy(h, hacc.data(), hacc.size() * sizeof(double));
+    }
+    const double s0 = std::sqrt(std::fabs(n0)), s1 = std::sqrt(std::fabs(n1)), s2 = std::sqrt(std::fabs(n2));
+    if (norms) { norms[0] = s0; norms[1] = s1; norms[2] = s2; }
+    // zero-vector flag of the LAST pass executed (gram_schmidt.fypp:126-127; pass 2 overwrites pass 1)
+    if (info) *info = ((two_pass ? s1 : s0) < ATOL_DP) ? 1 : 0;
+    if (s2 != s2) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+    return LK_OK;
+}
+
+int lk_orthogonalize(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, int *info) {
+    return dgs_generic(Bx, k, By, jy, h, nullptr, 0, info, false);
+}
+
+int lk_dgs(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, double *norms, int flags, int *info) {
+    return dgs_generic(Bx, k, By, jy, h, norms, flags, info, true);
+}
+
+int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h, int *info) {
+    if (!Bx || !By) return fail(LK_ERR_INVALID, "lk_dgs_block: null basis");
+    if (p < 1 || jy0 < 0 || jy0 + p > By->ncols) return fail(LK_ERR_INVALID, "lk_dgs_block: bad column range");
+    const int ED = Bx->ed();
+    int inf = 0;
+    for (int j = 0; j < p; ++j) {
+        int ij = 0;
+        LKCHK(dgs_generic(Bx, k, By, jy0 + j, h ? h + (size_t)j * k * ED : nullptr, nullptr, 0, &ij, true));
+        if (ij) inf = j + 1;  // `info = i` for the last zero column   gram_schmidt.fypp:171-173
+    }
+    if (info) *info = inf;
+    return LK_OK;
+}
+
+// ---- operators ------------------------------------------------------------------------------------
+int lk_linop_diag_create(lk_context_t c, int dtype, int64_t n_local, const void *d_host, lk_linop_t *op) {
+    if (!c || !d_host || !op) return fail(LK_ERR_INVALID, "lk_linop_diag_create: null argument");
+    if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "bad dtype");
+    lk_linop_t o = new lk_linop_s();
+    o->ctx = c; o->kind = OP_DIAG; o->dtype = dtype; o->n = n_local;
+    const size_t bytes = (size_t)(n_local + 2) * (dtype == LK_C128 ? 2 : 1) * sizeof(double);
+    hipError_t e = hipMalloc((void **)&o->dev, bytes);
+    if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    HIPCHK(hipMemcpy(o->dev, d_host, (size_t)n_local * (dtype == LK_C128 ? 2 : 1) * sizeof(double), hipMemcpyHostToDevice));
+    *op = o;
+    return LK_OK;
+}
+
+int lk_linop_diag_linspace_create(lk_context_t c, int64_t n_local, int64_t row0, double d0, double dstep, lk_linop_t *op) {
+    if (!c || !op) return fail(LK_ERR_INVALID, "null argument");
+    lk_linop_t o = new lk_linop_s();
+    o->ctx = c; o->kind = OP_DIAG_LIN; o->dtype = LK_F64; o->n = n_local; o->row0 = row0; o->d0 = d0; o->dstep = dstep;
+    *op = o;
+    return LK_OK;
+}
+
+int lk_linop_dense_create(lk_context_t c, int dtype, int64_t n, const void *A_host, int64_t lda, lk_linop_t *op) {
+    if (!c || !A_host || !op) return fail(LK_ERR_INVALID, "lk_linop_dense_create: null argument");
+    if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "bad dtype");
+    if (lda < n) return fail(LK_ERR_INVALID, "lda < n");
+    if (c->nranks > 1) return fail(LK_ERR_INVALID, "dense_linop is single-rank only");
+    lk_linop_t o = new lk_linop_s();
+    o->ctx = c; o->kind = OP_DENSE; o->dtype = dtype; o->n = n; o->lda = n;
+    const size_t es = (dtype == LK_C128 ? 2 : 1) * sizeof(double);
+    hipError_t e = hipMalloc((void **)&o->dev, (size_t)n * n * es + 16);
+    if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    HIPCHK(hipMemcpy2D(o->dev, (size_t)n * es, A_host, (size_t)lda * es, (size_t)n * es, n, hipMemcpyHostToDevice));
+    *op = o;
+    return LK_OK;
+}
+
+int lk_linop_lap5_create(lk_context_t c, int64_t N, lk_linop_t *op) {
+    if (!c || !op || N < 1) return fail(LK_ERR_INVALID, "lk_linop_lap5_create: bad argument");
+    if (c->nranks > 1) return fail(LK_ERR_INVALID, "lap5 operator is single-rank only");
+    lk_linop_t o = new lk_linop_s();
+    o->ctx = c; o->kind = OP_LAP5; o->dtype = LK_F64; o->n = N * N; o->N = N;
+    *op = o;
+    return LK_OK;
+}
+
+int lk_linop_destroy(lk_linop_t op) {
+    if (!op) return LK_OK;
+    if (op->dev) { (void)hipStreamSynchronize(op->ctx->stream); (void)hipFree(op->dev); }
+    delete op;
+    return LK_OK;
+}
+
+int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t By, int jy) {
+    if (!op) return fail(LK_ERR_INVALID, "lk_linop_apply: null operator");
+    LKCHK(check_vec(Bx, jx, "lk_linop_apply(vec_in)"));
+    LKCHK(check_vec(By, jy, "lk_linop_apply(vec_out)"));
+    LKCHK(check_pair(Bx, By, "lk_linop_apply"));
+    if (Bx->dtype != op->dtype || Bx->n != op->n) return fail(LK_ERR_INVALID, "lk_linop_apply: operator/vector mismatch");
+    lk_context_t c = op->ctx;
+    const double *x = Bx->col(jx);
+    double *y = By->col(jy);
+    if (x == y) return fail(LK_ERR_INVALID, "lk_linop_apply: vec_in and vec_out alias");
+    const bool cp = op->dtype == LK_C128;
+    const int64_t n = op->n;
+    const int64_t nv = n * Bx->ed() / 2 + 1;
+    ProfScope ps(c, "matvec", 0.0);
+    switch (op->kind) {
+    case OP_DIAG:
+        if (cp) hipLaunchKernelGGL(k_diag<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->dev, x, y, n, trans == LK_OP_H);
+        else hipLaunchKernelGGL(k_diag<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->dev, x, y, n, 0);
+        break;
+    case OP_DIAG_LIN:
+        hipLaunchKernelGGL(k_diag_linspace, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->d0, op->dstep, op->row0, x, y, n);
+        break;
+    case OP_DENSE:
+        if (trans == LK_OP_N) {
+            if (cp) hipLaunchKernelGGL(k_gemv_n<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y);
+            else hipLaunchKernelGGL(k_gemv_n<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y);
+        } else {
+            if (cp) hipLaunchKernelGGL(k_gemv_h<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y);
+            else hipLaunchKernelGGL(k_gemv_h<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y);
+        }
+        break;
+    case OP_LAP5: {
+        const int64_t N = op->N;
+        const double s = (double)(N + 1) * (double)(N + 1);
+        dim3 grid((unsigned)((N / 2 + 1 + 255) / 256), (unsigned)N);
+        hipLaunchKernelGGL(k_lap5, grid, dim3(256), 0, c->stream, x, y, N, s);
+        break;
+    }
+    }
+    HIPCHK(hipGetLastError());
+    return LK_OK;
+}
+
+// ---- Arnoldi -----------------------------------------------------------------------------------------
+int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend, double tol, int trans, int *info) {
+    if (!A || !X || !H || !info) return fail(LK_ERR_INVALID, "lk_arnoldi: null argument");
+    const int kdim = X->ncols - 1;                               // arnoldi.fypp:26 (p = 1)
+    if (kdim < 1) return fail(LK_ERR_INVALID, "lk_arnoldi: basis needs at least 2 columns");
+    if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_arnoldi: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
+    if (ldh < kdim + 1) return fail(LK_ERR_INVALID, "lk_arnoldi: ldh too small");
+    const int ED = X->ed();
+    *info = 0;
+    std::vector<double> h((size_t)kdim * ED);
+    for (int k = kstart; k <= kend; ++k) {
+        // matvec X(k) -> X(k+1)                                   arnoldi.fypp:39-47
+        LKCHK(lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, k - 1, X, k));
+        // DGS with beta = H(:k, k), normalise folded in            arnoldi.fypp:50-55
+        double norms[3];
+        int dinfo = 0;
+        LKCHK(lk_dgs(X, k, X, k, h.data(), norms, LK_DGS_NORMALIZE, &dinfo));
+        double *Hk = H + (size_t)(k - 1) * ldh * ED;
+        memcpy(Hk, h.data(), (size_t)k * ED * sizeof(double));
+        double beta = norms[2];
+        if (beta < ATOL_DP) {
+            // qr_no_pivoting, colinear column: R(1,1) = 0, rand, re-normalise   qr.fypp:146-162
+            Hk[(size_t)k * ED] = 0.0;
+            if (ED == 2) Hk[(size_t)k * ED + 1] = 0.0;
+            LKCHK(lk_vec_rand(X, k, 0x5EEDull + (uint64_t)k, X->ctx->row0, 1));
+            beta = 0.0;
+        } else {
+            Hk[(size_t)k * ED] = beta;
+            if (ED == 2) Hk[(size_t)k * ED + 1] = 0.0;
+        }
+        // breakdown test   arnoldi.fypp:58-71
+        if (std::fabs(Hk[(size_t)k * ED]) < tol) {
+            *info = k;
+            break;
+        }
+    }
+    return LK_OK;
+}
+
+}  // extern "C"

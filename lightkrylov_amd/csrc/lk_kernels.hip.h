@@ -1,0 +1,452 @@
+// lk_kernels.hip.h -- gfx950 device kernels of the Krylov inner-loop engine.
+//
+// Everything here is HBM-bandwidth bound BLAS-1/2 work on a column-contiguous panel
+// (element (i, j) at X[j*ld + i]).  No MFMA: arithmetic intensity is ~1/6 flop/byte.
+// Wavefront = 64 lanes; every global access is 16 bytes per lane (1 KiB per wave
+// instruction); reductions are register -> wave shuffle -> LDS -> per-block partial ->
+// fixed-order finish kernel (deterministic, no float atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lk {
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// ---- scalar traits -----------------------------------------------------------------
+// Real kind: one v2d = two consecutive rows.  Complex kind: one v2d = (re, im) of one row.
+template <bool CPLX> struct K;
+template <> struct K<false> {
+    static constexpr int ROWS = 2;  // rows per 16-byte lane access
+    static constexpr int ELEM_DOUBLES = 1;
+};
+template <> struct K<true> {
+    static constexpr int ROWS = 1;
+    static constexpr int ELEM_DOUBLES = 2;
+};
+
+__device__ __forceinline__ v2d cmul(v2d a, v2d b) { return v2d{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ v2d cmulconj(v2d a, v2d b) {  // conj(a) * b
+    return v2d{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x};
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double u01(uint64_t seed, uint64_t ctr) {
+    return (double)(splitmix64((seed << 32) + ctr) >> 11) * 0x1.0p-53;
+}
+
+// =====================================================================================
+// Panel sweep: the kernel behind innerprod / linear_combination / orthogonalize / DGS.
+//
+//   UPDATE: y <- y - X(:, :k) * hin          (linear_combination + sub, gram_schmidt.fypp:144-145)
+//   DOT   : partial h[j] += conj(X(:, j)) . y_out   (innerprod, gram_schmidt.fypp:141)
+//   always: partial nrm2 += |y_out|^2        (the next pass's zero-vector check / qr's norm)
+//
+// A block of NW waves owns a tile of WR*64*ROWS rows x all k columns per iteration:
+// lanes run along rows (coalesced 16 B/lane), the NW waves are split WC ways across the
+// columns (each wave keeps <= KC columns of the tile in registers) and WR = NW/WC ways along
+// rows.  With UPDATE the per-wave partial products meet in LDS (one barrier per tile, double
+// buffered), and the SAME registers then feed the dot phase, so X is read from HBM exactly
+// once per sweep.  Accumulators persist over the grid-stride tile loop; one shuffle+LDS
+// reduction per block at the end.
+//
+// partial layout: partial[slot * pstride + blockIdx.x], slots 0..k-1 = h, slot k = nrm2.
+// =====================================================================================
+template <bool CPLX, int KC, int NW, bool UPDATE, bool DOT>
+__global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict__ X, int64_t ldx, int k,
+                                                        double *__restrict__ y, int64_t n,
+                                                        const double *__restrict__ hin,
+                                                        double *__restrict__ partial, int64_t pstride,
+                                                        int WC, int kcw) {
+    constexpr int ROWS = K<CPLX>::ROWS;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int WROWS = 64 * ROWS;  // rows one wave covers per tile
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wc = wave % WC;
+    const int wr = wave / WC;
+    const int WR = NW / WC;
+    const int c0 = wc * kcw;
+    int nc = k - c0;
+    nc = nc > kcw ? kcw : nc;
+    nc = nc < 0 ? 0 : nc;
+
+    __shared__ v2d u_lds[UPDATE ? 2 * NW * 64 : 1];
+    __shared__ double red_lds[NW * (KC * ED + 1)];
+
+    // projection coefficients of this wave's columns (wave-uniform)
+    v2d hc[KC];
+    if constexpr (UPDATE) {
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) {
+            if (jj < nc) {
+                if constexpr (CPLX) hc[jj] = v2d{hin[2 * (c0 + jj)], hin[2 * (c0 + jj) + 1]};
+                else hc[jj] = v2d{hin[c0 + jj], 0.0};
+            } else hc[jj] = v2d{0.0, 0.0};
+        }
+    }
+
+    v2d acc[KC];  // real: (sum over even rows, sum over odd rows) ; complex: (re, im)
+#pragma unroll
+    for (int jj = 0; jj < KC; ++jj) acc[jj] = v2d{0.0, 0.0};
+    double nrm = 0.0;
+
+    const int64_t tile_rows = (int64_t)WR * WROWS;
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const double *Xw = X + (int64_t)c0 * ldx * ED;
+    const int64_t colstride = ldx * ED;  // doubles between consecutive columns
+    int buf = 0;
+
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t r = t * tile_rows + (int64_t)wr * WROWS + (int64_t)lane * ROWS;  // first row of this lane
+        const bool full = (t + 1) * tile_rows <= n;  // block-uniform
+        v2d xv[KC];
+        v2d yv;
+        if (full) {
+            yv = *reinterpret_cast<const v2d *>(y + r * ED);
+            if (nc == KC) {
+#pragma unroll
+                for (int jj = 0; jj < KC; ++jj)
+                    xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Xw + jj * colstride + r * ED));
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < KC; ++jj) {
+                    if (jj < nc)
+                        xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Xw + jj * colstride + r * ED));
+                    else xv[jj] = v2d{0.0, 0.0};
+                }
+            }
+        } else {
+            // ragged last tile: element-wise guards, zero fill
+            if constexpr (CPLX) {
+                yv = (r < n) ? *reinterpret_cast<const v2d *>(y + r * 2) : v2d{0.0, 0.0};
+            } else {
+                yv.x = (r < n) ? y[r] : 0.0;
+                yv.y = (r + 1 < n) ? y[r + 1] : 0.0;
+            }
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) {
+                xv[jj] = v2d{0.0, 0.0};
+                if (jj < nc) {
+                    const double *p = Xw + jj * colstride;
+                    if constexpr (CPLX) {
+                        if (r < n) xv[jj] = *reinterpret_cast<const v2d *>(p + r * 2);
+                    } else {
+                        if (r < n) xv[jj].x = p[r];
+                        if (r + 1 < n) xv[jj].y = p[r + 1];
+                    }
+                }
+            }
+        }
+
+        if constexpr (UPDATE) {
+            v2d u = v2d{0.0, 0.0};
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) {
+                if constexpr (CPLX) u += cmul(xv[jj], hc[jj]);
+                else u += xv[jj] * hc[jj].x;
+            }
+            if (WC > 1) {
+                v2d *ub = u_lds + buf * (NW * 64);
+                ub[wave * 64 + lane] = u;
+                __syncthreads();
+                v2d s = v2d{0.0, 0.0};
+                for (int w = 0; w < WC; ++w) s += ub[(wr * WC + w) * 64 + lane];
+                u = s;
+                buf ^= 1;
+            }
+            yv -= u;
+            if (wc == 0) {
+                if (full) {
+                    *reinterpret_cast<v2d *>(y + r * ED) = yv;
+                } else {
+                    if constexpr (CPLX) {
+                        if (r < n) *reinterpret_cast<v2d *>(y + r * 2) = yv;
+                    } else {
+                        if (r < n) y[r] = yv.x;
+                        if (r + 1 < n) y[r + 1] = yv.y;
+                    }
+                }
+            }
+        }
+        if constexpr (DOT) {
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) {
+                if constexpr (CPLX) acc[jj] += cmulconj(xv[jj], yv);
+                else acc[jj] += xv[jj] * yv;
+            }
+        }
+        if (wc == 0) nrm += yv.x * yv.x + yv.y * yv.y;
+    }
+
+    // ---- block reduction: lanes (shuffle) -> waves sharing a column set (LDS) -> partial
+    constexpr int SLOTS = KC * ED + 1;
+    if constexpr (DOT) {
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) {
+            if constexpr (CPLX) {
+                double re = wave_sum(acc[jj].x), im = wave_sum(acc[jj].y);
+                if (lane == 0) { red_lds[wave * SLOTS + 2 * jj] = re; red_lds[wave * SLOTS + 2 * jj + 1] = im; }
+            } else {
+                double s = wave_sum(acc[jj].x + acc[jj].y);
+                if (lane == 0) red_lds[wave * SLOTS + jj] = s;
+            }
+        }
+    }
+    {
+        double s = wave_sum(nrm);
+        if (lane == 0) red_lds[wave * SLOTS + KC * ED] = s;
+    }
+    __syncthreads();
+    // thread tid < k*ED handles one output double: column j = tid/ED lives in wave column wc_j
+    const int tid = threadIdx.x;
+    if constexpr (DOT) {
+        if (tid < k * ED) {
+            const int j = tid / ED, part = tid % ED;
+            const int wcj = j / kcw, jj = j - wcj * kcw;
+            double s = 0.0;
+            for (int w = 0; w < WR; ++w) s += red_lds[(w * WC + wcj) * SLOTS + jj * ED + part];
+            partial[((int64_t)j * ED + part) * pstride + blockIdx.x] = s;
+        }
+    }
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < WR; ++w) s += red_lds[(w * WC) * SLOTS + KC * ED];
+        partial[((int64_t)k * ED) * pstride + blockIdx.x] = s;
+        if constexpr (CPLX) partial[((int64_t)k * ED + 1) * pstride + blockIdx.x] = 0.0;
+    }
+}
+
+// out[s] = sum_b partial[s*pstride + b], b < nblocks, fixed order: one wave per slot.
+__global__ __launch_bounds__(256) void finish_partials(const double *__restrict__ partial, int64_t pstride,
+                                                       int nblocks, int nslots, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= nslots) return;
+    const double *p = partial + (int64_t)slot * pstride;
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += p[b];
+    s = wave_sum(s);
+    if (lane == 0) out[slot] = s;
+}
+
+// =====================================================================================
+// BLAS-1 (abstract_vector TBPs).  Grid-stride, 16 B per lane.
+// =====================================================================================
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_scal(double *__restrict__ x, int64_t n, double ar, double ai,
+                                              const double *__restrict__ inv_sqrt_of, double tol) {
+    // inv_sqrt_of != NULL: alpha = 1/sqrt(|*inv_sqrt_of|) read on the device (fused normalise);
+    // skipped (alpha = 1) when the norm is below tol so the host can take the breakdown path.
+    if (inv_sqrt_of) {
+        const double nr = sqrt(fabs(*inv_sqrt_of));
+        if (!(nr >= tol)) return;
+        ar = 1.0 / nr;
+        ai = 0.0;
+    }
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    const int64_t nd = n * ED, nv = nd / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    v2d *xv = reinterpret_cast<v2d *>(x);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        v2d v = xv[i];
+        if constexpr (CPLX) v = cmul(v2d{ar, ai}, v);
+        else v = v * ar;
+        xv[i] = v;
+    }
+    if (!CPLX && (nd & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[nd - 1] *= ar;
+}
+
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_axpby(double ar, double ai, const double *__restrict__ x, double br,
+                                               double bi, double *__restrict__ y, int64_t n) {
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    const int64_t nd = n * ED, nv = nd / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const v2d *xv = reinterpret_cast<const v2d *>(x);
+    v2d *yv = reinterpret_cast<v2d *>(y);
+    const bool bzero = (br == 0.0 && bi == 0.0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        v2d a = xv[i];
+        v2d r;
+        if constexpr (CPLX) {
+            r = cmul(v2d{ar, ai}, a);
+            if (!bzero) r += cmul(v2d{br, bi}, yv[i]);
+        } else {
+            r = a * ar;
+            if (!bzero) r += yv[i] * br;
+        }
+        yv[i] = r;
+    }
+    if (!CPLX && (nd & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double r = ar * x[nd - 1];
+        if (!bzero) r += br * y[nd - 1];
+        y[nd - 1] = r;
+    }
+}
+
+// partial[0*pstride + b] (+ [1*pstride + b] imag) = sum conj(x) y over this block's rows
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_dot(const double *__restrict__ x, const double *__restrict__ y, int64_t n,
+                                             double *__restrict__ partial, int64_t pstride) {
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    const int64_t nd = n * ED, nv = nd / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const v2d *xv = reinterpret_cast<const v2d *>(x);
+    const v2d *yv = reinterpret_cast<const v2d *>(y);
+    v2d acc = v2d{0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        v2d a = xv[i], b = yv[i];
+        if constexpr (CPLX) acc += cmulconj(a, b);
+        else acc += a * b;
+    }
+    if (!CPLX && (nd & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc.x += x[nd - 1] * y[nd - 1];
+    __shared__ double red[2 * 4];
+    double re, im = 0.0;
+    if constexpr (CPLX) { re = wave_sum(acc.x); im = wave_sum(acc.y); }
+    else re = wave_sum(acc.x + acc.y);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { red[wave] = re; red[4 + wave] = im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        partial[pstride + blockIdx.x] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_rand(double *__restrict__ x, int64_t n, uint64_t seed, int64_t row0) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t g = (uint64_t)(row0 + i);
+        if constexpr (CPLX) {
+            x[2 * i] = 2.0 * u01(seed, 2 * g) - 1.0;
+            x[2 * i + 1] = 2.0 * u01(seed, 2 * g + 1) - 1.0;
+        } else {
+            x[i] = 2.0 * u01(seed, g) - 1.0;
+        }
+    }
+}
+
+// =====================================================================================
+// Operators
+// =====================================================================================
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_diag(const double *__restrict__ d, const double *__restrict__ x,
+                                              double *__restrict__ y, int64_t n, int conj_d) {
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    const int64_t nd = n * ED, nv = nd / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const v2d *dv = reinterpret_cast<const v2d *>(d);
+    const v2d *xv = reinterpret_cast<const v2d *>(x);
+    v2d *yv = reinterpret_cast<v2d *>(y);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        v2d a = dv[i], b = xv[i];
+        if constexpr (CPLX) yv[i] = conj_d ? cmulconj(a, b) : cmul(a, b);
+        else yv[i] = a * b;
+    }
+    if (!CPLX && (nd & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[nd - 1] = d[nd - 1] * x[nd - 1];
+}
+
+__global__ __launch_bounds__(256) void k_diag_linspace(double d0, double dstep, int64_t row0,
+                                                       const double *__restrict__ x, double *__restrict__ y,
+                                                       int64_t n) {
+    const int64_t nv = n / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const v2d *xv = reinterpret_cast<const v2d *>(x);
+    v2d *yv = reinterpret_cast<v2d *>(y);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const double g = (double)(row0 + 2 * i);
+        v2d dd = v2d{d0 + dstep * g, d0 + dstep * (g + 1.0)};
+        yv[i] = dd * xv[i];
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = (d0 + dstep * (double)(row0 + n - 1)) * x[n - 1];
+}
+
+// y = A x, A n x n column-major.  Block = 4 waves x 64 rows; wave w sums columns j == w (mod 4).
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_gemv_n(const double *__restrict__ A, int64_t lda, int64_t n,
+                                                const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    v2d acc = v2d{0.0, 0.0};
+    if (i < n) {
+        for (int64_t j = wave; j < n; j += 4) {
+            if constexpr (CPLX) {
+                v2d a = *reinterpret_cast<const v2d *>(A + (j * lda + i) * 2);
+                v2d b = *reinterpret_cast<const v2d *>(x + j * 2);
+                acc += cmul(a, b);
+            } else {
+                acc.x += A[j * lda + i] * x[j];
+            }
+        }
+    }
+    __shared__ v2d red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (wave == 0 && i < n) {
+        v2d s = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+        if constexpr (CPLX) *reinterpret_cast<v2d *>(y + i * ED) = s;
+        else y[i] = s.x;
+    }
+}
+
+// y = A^H x: one wave per column j, lanes over rows.
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_gemv_h(const double *__restrict__ A, int64_t lda, int64_t n,
+                                                const double *__restrict__ x, double *__restrict__ y) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+    if (j >= n) return;
+    v2d acc = v2d{0.0, 0.0};
+    for (int64_t i = lane; i < n; i += 64) {
+        if constexpr (CPLX) {
+            v2d a = *reinterpret_cast<const v2d *>(A + (j * lda + i) * 2);
+            v2d b = *reinterpret_cast<const v2d *>(x + i * 2);
+            acc += cmulconj(a, b);
+        } else {
+            acc.x += A[j * lda + i] * x[i];
+        }
+    }
+    double re = wave_sum(acc.x), im = wave_sum(acc.y);
+    if (lane == 0) {
+        if constexpr (CPLX) { y[2 * j] = re; y[2 * j + 1] = im; }
+        else y[j] = re;
+    }
+}
+
+// 5-point Laplacian, N x N grid, Dirichlet, scale s = (N+1)^2.  One thread per 2 grid points
+// along the fast index; neighbours come from L1/L2 (each row is re-used by 3 stencil rows).
+__global__ __launch_bounds__(256) void k_lap5(const double *__restrict__ u, double *__restrict__ v, int64_t N,
+                                              double s) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int64_t j = blockIdx.y;
+    if (i >= N) return;
+    const int64_t c = i + j * N;
+    const bool two = (i + 1 < N);
+    double c0 = u[c], c1 = two ? u[c + 1] : 0.0;
+    double a0 = 4.0 * c0, a1 = 4.0 * c1;
+    if (i > 0) a0 -= u[c - 1];
+    a0 -= two ? c1 : 0.0;
+    a1 -= c0;
+    if (i + 2 < N) a1 -= u[c + 2];
+    if (j > 0) { a0 -= u[c - N]; if (two) a1 -= u[c + 1 - N]; }
+    if (j < N - 1) { a0 -= u[c + N]; if (two) a1 -= u[c + 1 + N]; }
+    v[c] = s * a0;
+    if (two) v[c + 1] = s * a1;
+}
+
+}  // namespace lk

@@ -1,0 +1,126 @@
+"""abstract_linop and GPU operators -- mirror of src/AbstractTypes/AbstractLinops.fypp.
+
+`abstract_linop` keeps the reference contract: deferred `matvec(vec_in, vec_out)` /
+`rmatvec`, and the counting wrappers `apply_matvec` / `apply_rmatvec` every Krylov routine
+calls (AbstractLinops.fypp:58-87, 391-424).  Operators whose matvec is a kernel of the HIP
+engine carry an engine handle (`_h`), which lets `arnoldi` run its whole step loop inside
+the library (lk_arnoldi) with no Python between the matvec and the DGS sweeps.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from .context import Context, default_context
+from .vectors import _DT, abstract_vector, dense_vector_gpu
+
+
+class abstract_linop:
+    """AbstractLinops.fypp:30-87"""
+
+    def __init__(self):
+        self.matvec_counter = 0
+        self.rmatvec_counter = 0
+
+    def matvec(self, vec_in: abstract_vector, vec_out: abstract_vector) -> None:
+        raise NotImplementedError
+
+    def rmatvec(self, vec_in: abstract_vector, vec_out: abstract_vector) -> None:
+        raise NotImplementedError
+
+    def apply_matvec(self, vec_in, vec_out) -> None:
+        """AbstractLinops.fypp:391-407"""
+        self.matvec_counter += 1
+        self.matvec(vec_in, vec_out)
+
+    def apply_rmatvec(self, vec_in, vec_out) -> None:
+        """AbstractLinops.fypp:409-424"""
+        self.rmatvec_counter += 1
+        self.rmatvec(vec_in, vec_out)
+
+    def get_counter(self, trans: bool = False) -> int:
+        return self.rmatvec_counter if trans else self.matvec_counter
+
+    def reset_counter(self, trans: bool = False, _procedure: str = "") -> None:
+        if trans:
+            self.rmatvec_counter = 0
+        else:
+            self.matvec_counter = 0
+
+
+class _engine_linop(abstract_linop):
+    """An operator implemented by a kernel of the HIP engine."""
+
+    def __init__(self, ctx: Context | None):
+        super().__init__()
+        self.ctx = ctx or default_context()
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+
+    def _apply(self, trans: int, vec_in, vec_out) -> None:
+        if not (isinstance(vec_in, dense_vector_gpu) and isinstance(vec_out, dense_vector_gpu)):
+            raise TypeError("engine operators act on dense_vector_gpu")  # type_error(...)
+        _capi.check(self._lib.lk_linop_apply(self._h, trans, vec_in.basis._h, vec_in.col,
+                                             vec_out.basis._h, vec_out.col))
+
+    def matvec(self, vec_in, vec_out) -> None:
+        self._apply(_capi.LK_OP_N, vec_in, vec_out)
+
+    def rmatvec(self, vec_in, vec_out) -> None:
+        self._apply(_capi.LK_OP_H, vec_in, vec_out)
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.lk_linop_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class dense_linop_gpu(_engine_linop):
+    """dense_linop_{rdp,cdp}: y = A x via gemv('N') / ('T'|'C').  AbstractLinops.fypp:265-271, 608-660"""
+
+    def __init__(self, A: np.ndarray, ctx: Context | None = None):
+        super().__init__(ctx)
+        A = np.asfortranarray(A)
+        if A.dtype not in _DT or A.ndim != 2 or A.shape[0] != A.shape[1]:
+            raise TypeError("dense_linop_gpu needs a square float64/complex128 matrix")
+        self.dtype, self.n = A.dtype, A.shape[0]
+        _capi.check(self._lib.lk_linop_dense_create(self.ctx._h, _DT[A.dtype], self.n,
+                                                    A.ctypes.data_as(C.c_void_p), A.shape[0], C.byref(self._h)))
+
+
+class diag_linop_gpu(_engine_linop):
+    """y = d .* x (config "arnoldi with synthetic diagonal linop")."""
+
+    def __init__(self, d: np.ndarray | None = None, ctx: Context | None = None, *, n_local: int | None = None,
+                 row0: int = 0, d0: float = 1.0, dstep: float = 0.0):
+        super().__init__(ctx)
+        if d is not None:
+            d = np.ascontiguousarray(d)
+            self.dtype, self.n = d.dtype, d.shape[0]
+            _capi.check(self._lib.lk_linop_diag_create(self.ctx._h, _DT[d.dtype], self.n,
+                                                       d.ctypes.data_as(C.c_void_p), C.byref(self._h)))
+        else:
+            # d_i = d0 + dstep * (row0 + i), never materialised in HBM
+            self.dtype, self.n = np.dtype(np.float64), int(n_local)
+            _capi.check(self._lib.lk_linop_diag_linspace_create(self.ctx._h, self.n, int(row0), float(d0),
+                                                                float(dstep), C.byref(self._h)))
+
+
+class laplacian2d_linop_gpu(_engine_linop):
+    """5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (config 3, Poisson)."""
+
+    def __init__(self, N: int, ctx: Context | None = None):
+        super().__init__(ctx)
+        self.dtype, self.n, self.N = np.dtype(np.float64), N * N, N
+        _capi.check(self._lib.lk_linop_lap5_create(self.ctx._h, int(N), C.byref(self._h)))
+
+    def rmatvec(self, vec_in, vec_out) -> None:  # symmetric
+        self._apply(_capi.LK_OP_N, vec_in, vec_out)

@@ -1,0 +1,239 @@
+"""Iterative solvers that call the hot path -- mirror of src/IterativeSolvers (gmres, eigs).
+
+Control flow, defaults, `info` and metadata follow the reference line by line; the small
+host problems (Givens / trtrs / geev / gees / trsen on <= 129 x 128 matrices) are LAPACK
+calls on the host exactly where the reference makes them (scipy's LAPACK here).  All O(n)
+work goes through the vector type, i.e. the HIP engine for `dense_vector_gpu`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+from scipy.linalg import lapack as _lapack
+
+from .constants import atol_dp, rtol_dp
+from .krylov import arnoldi, double_gram_schmidt_step, krylov_schur
+from .linops import abstract_linop
+from .vectors import abstract_vector, copy, dense_vector_gpu, krylov_basis_gpu, linear_combination, zero_basis
+
+
+# ------------------------------------------------------------------------------------------
+@dataclass
+class gmres_dp_opts:
+    """IterativeSolvers.fypp:141-151"""
+    kdim: int = 30
+    maxiter: int = 10
+    if_print_metadata: bool = False
+    sanity_check: bool = True
+
+
+@dataclass
+class gmres_dp_metadata:
+    """IterativeSolvers.fypp:153-170"""
+    n_iter: int = 0
+    n_inner: int = 0
+    n_outer: int = 0
+    res: list = field(default_factory=list)
+    converged: bool = False
+    info: int = 0
+
+
+def eig(Hk: np.ndarray):
+    """eig(A, vecs, vals): LAPACK geev, right eigenvectors in LAPACK layout (real pairs are NOT
+    combined).  src/Utilities/submodule_utility_functions.fypp:55-85"""
+    if Hk.dtype == np.float64:
+        wr, wi, _vl, vr, info = _lapack.dgeev(np.asfortranarray(Hk), compute_vl=0, compute_vr=1)
+        vals = wr + 1j * wi
+    else:
+        vals, _vl, vr, info = _lapack.zgeev(np.asfortranarray(Hk), compute_vl=0, compute_vr=1)
+    if info != 0:
+        raise RuntimeError(f"GEEV failed, info={info}")
+    return vr, vals
+
+
+def apply_givens_rotation(h: np.ndarray, c: np.ndarray, s: np.ndarray) -> None:
+    """submodule_utility_functions.fypp:173-204.  h has k+1 entries; c, s have k."""
+    k = h.size - 1
+    if h.dtype == np.float64:
+        for j in range(k - 1):                    # lasr("L","V","F"): apply the previous rotations
+            t = h[j + 1]
+            h[j + 1] = c[j] * t - s[j] * h[j]
+            h[j] = s[j] * t + c[j] * h[j]
+        cc, ss, r = _lapack.dlartg(h[k - 1], h[k])
+        c[k - 1], s[k - 1] = cc, ss
+        h[k - 1], h[k] = r, 0.0
+    else:
+        for i in range(k - 1):
+            t = c[i] * h[i] + s[i] * h[i + 1]
+            h[i + 1] = -s[i] * h[i] + c[i] * h[i + 1]
+            h[i] = t
+        g = np.array([h[k - 1], h[k]])
+        g = g / np.sqrt(np.sum(np.abs(g) ** 2))   # givens_rotation: x / norm(x, 2)
+        c[k - 1], s[k - 1] = g[0], g[1]
+        h[k - 1] = c[k - 1] * h[k - 1] + s[k - 1] * h[k]
+        h[k] = 0.0
+
+
+def _new_basis(proto: abstract_vector, ncols: int):
+    """allocate(V(ncols), source=proto); zero_basis(V)"""
+    if isinstance(proto, dense_vector_gpu):
+        return krylov_basis_gpu(proto.basis.n_local, ncols, proto.dtype, proto.basis.ctx)
+    V = [proto.zeros_like() for _ in range(ncols)]
+    zero_basis(V)
+    return V
+
+
+def _dtype_of(v: abstract_vector):
+    return getattr(v, "dtype", np.dtype(np.float64))
+
+
+# ------------------------------------------------------------------------------------------
+def gmres(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float = rtol_dp,
+          atol: float = atol_dp, preconditioner=None, options: gmres_dp_opts | None = None,
+          transpose: bool = False, meta: gmres_dp_metadata | None = None) -> int:
+    """Restarted GMRES(kdim).  src/IterativeSolvers/GMRES/gmres.fypp:65-255.
+    x is the initial guess and is overwritten by the solution.  Returns info = +n_iter if
+    converged, -n_iter otherwise (:234-238); `meta` (if given) receives the residual history."""
+    opts = options or gmres_dp_opts()
+    kdim, maxiter = opts.kdim, opts.maxiter
+    dt = _dtype_of(b)
+    tol = atol + rtol * b.norm()                                                   # :106
+    wrk = b.zeros_like()
+    V = _new_basis(b, kdim + 1)
+    H = np.zeros((kdim + 1, kdim), dtype=dt, order="F")
+    m = gmres_dp_metadata()
+    A.reset_counter(transpose, "gmres%init")
+    mv = A.apply_rmatvec if transpose else A.apply_matvec
+
+    while (not m.converged) and m.n_outer <= maxiter:                              # :131
+        H[...] = 0
+        zero_basis(V)
+        if x.norm() != 0.0:
+            mv(x, V[0])                                                            # :134-140
+        V[0].sub(b)
+        V[0].chsgn()                                                               # :141
+        e = np.zeros(kdim + 1, dtype=dt)
+        beta = V[0].norm()
+        e[0] = beta
+        V[0].scal(1.0 / beta)
+        c = np.zeros(kdim, dtype=dt)
+        s = np.zeros(kdim, dtype=dt)
+        if m.n_outer == 0:
+            m.res = [abs(beta)]
+        k = 0
+        for k in range(1, kdim + 1):
+            copy(wrk, V[k - 1])                                                    # :155  wrk = V(k)
+            if preconditioner is not None:
+                preconditioner.apply(wrk, k, beta, tol)
+            mv(wrk, V[k])                                                          # :161-165
+            hcol = np.zeros(k, dtype=dt)
+            norms: list = []
+            if isinstance(V, krylov_basis_gpu):
+                double_gram_schmidt_step(V[k], V[:k], False, hcol, _norms=norms)   # :167-168
+                hk1 = norms[2]                                                     # :171 (norm comes out of sweep 3)
+            else:
+                double_gram_schmidt_step(V[k], V[:k], False, hcol)
+                hk1 = V[k].norm()
+            H[:k, k - 1] = hcol
+            H[k, k - 1] = hk1
+            if abs(H[k, k - 1]) > tol:
+                V[k].scal(1.0 / hk1)                                               # :172
+            apply_givens_rotation(H[:k + 1, k - 1], c[:k], s[:k])                  # :178
+            e[k] = -s[k - 1] * e[k - 1]
+            e[k - 1] = c[k - 1] * e[k - 1]                                         # :180
+            beta = abs(e[k])
+            m.n_iter += 1
+            m.n_inner += 1
+            m.res.append(abs(beta))
+            if abs(beta) < tol:
+                m.converged = True
+                break
+        k = min(k, kdim)
+        trtrs = _lapack.dtrtrs if dt == np.float64 else _lapack.ztrtrs
+        yk, tinfo = trtrs(np.asfortranarray(H[:k, :k]), e[:k].copy(), lower=0, trans=0, unitdiag=0)  # :199-200
+        if tinfo != 0:
+            raise RuntimeError(f"TRTRS failed, info={tinfo}")
+        dx = linear_combination(V[:k], yk)                                         # :201
+        if preconditioner is not None:
+            preconditioner.apply(dx)
+        x.add(dx)
+        mv(x, V[0])                                                                # :205-210
+        V[0].sub(b)
+        V[0].chsgn()
+        beta = V[0].norm()
+        if abs(beta) > 0.0:
+            V[0].scal(1.0 / beta)
+        m.n_iter += 1
+        m.n_outer += 1
+        m.res.append(abs(beta))
+        if abs(beta) < tol:
+            m.converged = True
+            break
+    info = m.n_iter if m.converged else -m.n_iter                                  # :234-238
+    m.info = info
+    if meta is not None:
+        meta.__dict__.update(m.__dict__)
+    A.reset_counter(transpose, "gmres%post")
+    return info
+
+
+# ------------------------------------------------------------------------------------------
+def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | None = None,
+         tolerance: float = rtol_dp, transpose: bool = False, write_intermediate: bool = False):
+    """Krylov-Schur eigensolver for the leading len(X) eigenpairs.
+    src/IterativeSolvers/IterativeSolvers.fypp:972-1143.
+    X (sequence / basis of nev vectors) receives the eigenvectors.
+    Returns (eigvals[nev] complex, residuals[nev], info = number of Arnoldi steps).
+    (`write_intermediate` defaults to False here: the per-step text dump is file I/O outside the path.)"""
+    nev = len(X)
+    kdim_ = 4 * nev if kdim is None else kdim                                      # :1023
+    proto = X[0]
+    dt = _dtype_of(proto)
+    Xwrk = _new_basis(proto, kdim_ + 1)                                            # :1032-1034
+    if x0 is not None:
+        copy(Xwrk[0], x0)
+        Xwrk[0].scal(1.0 / x0.norm())                                              # :1036-1038
+    else:
+        Xwrk[0].rand(True)                                                         # :1040
+    H = np.zeros((kdim_ + 1, kdim_), dtype=dt, order="F")
+    res = np.zeros(kdim_)
+    kstart, conv, niter, k = 1, 0, 0, 0
+
+    def median_selector(lam):                                                      # :1137-1142
+        return np.abs(lam) > np.median(np.abs(lam))
+
+    while conv < nev:
+        for k in range(kstart, kdim_ + 1):
+            arnoldi(A, Xwrk, H, kstart=k, kend=k, transpose=transpose)            # :1059
+            vecs, vals = eig(H[:k, :k])                                           # :1065
+            beta = H[k, k - 1]
+            if dt == np.complex128:
+                res[:k] = np.abs(beta * vecs[k - 1, :k])                           # :1071
+            else:
+                for i in range(k):                                                 # :1073-1082
+                    if vals[i].imag > 0:
+                        alpha = abs(complex(vecs[k - 1, i], vecs[k - 1, i + 1]))
+                    elif vals[i].imag < 0:
+                        alpha = abs(complex(vecs[k - 1, i - 1], vecs[k - 1, i]))
+                    else:
+                        alpha = abs(vecs[k - 1, i])
+                    res[i] = abs(beta * alpha)
+            niter += 1
+            conv = int(np.count_nonzero(res[:k] < tolerance))                      # :1087
+            if conv >= nev:
+                break
+        kstart = krylov_schur(Xwrk, H, median_selector) + 1                        # :1100
+    k = min(k, kdim_)
+    vecs, vals = eig(H[:k, :k])                                                    # :1115
+    vals_f = np.zeros(kdim_, dtype=np.complex128)
+    vals_f[:k] = vals
+    vecs_f = np.zeros((kdim_, kdim_), dtype=vecs.dtype)
+    vecs_f[:k, :k] = vecs
+    idx = np.argsort(-np.abs(vals_f), kind="stable")                               # :1118-1120
+    vals_f, vecs_f, res_f = vals_f[idx], vecs_f[:, idx], res[idx]
+    # eigenvectors X(i) = sum_j eigvecs(j, i) Xwrk(j)                                :1127-1132
+    coef = np.asfortranarray(vecs_f[:k, :nev].astype(dt))
+    Y = linear_combination(Xwrk[:k], coef)
+    copy(X, Y)
+    return vals_f[:nev].copy(), res_f[:nev].copy(), niter

@@ -1,0 +1,149 @@
+/* lk_oracle.c -- CPU ORACLE for the LightKrylov hot path.  TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * This file is a plain-C restatement of the reference's algorithm for the path
+ * abstract_vector primitives -> innerprod / linear_combination -> double_gram_schmidt_step
+ * -> arnoldi, in the reference's own per-primitive schedule (one BLAS-1 call per dot/axpby,
+ * sequential accumulation, single thread: the reference has no threading).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ * The product path (lightkrylov_amd) never imports, links or calls anything from here.
+ *
+ * Parity pinning: the reference's tests hold no golden H/Ritz vectors for this path
+ * (inputs are unseeded random_number); what they hold are known-answer tests (analytic
+ * spectra, test/TestIterativeSolvers.fypp:164-209, 254-280) and invariants
+ * (test/TestKrylov.fypp:194-242, test/TestVectors.fypp:50-179).  tests/test_oracle_kat.py
+ * checks this oracle against every one of those.  The Fortran reference itself is
+ * unbuildable in this image without writing stand-ins for fortran-lang/stdlib (absent),
+ * so no oracle/_ref build exists.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction, so the
+ * accumulation order and rounding are exactly the loops written here).
+ */
+#include <complex.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* atol_dp = 10**(-precision(1.0_dp)) = 1e-15.   src/Constants.f90:33-37 */
+#define ORA_ATOL_DP 1.0e-15
+
+typedef void (*ora_matvec_fn)(void *op, int64_t n, const void *x, void *y);
+
+static inline uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline double u01(uint64_t seed, uint64_t ctr)
+{
+    return (double)(splitmix64((seed << 32) + ctr) >> 11) * 0x1.0p-53;
+}
+static inline double fill_d(uint64_t seed, uint64_t i) { return 2.0 * u01(seed, i) - 1.0; }
+static inline double _Complex fill_z(uint64_t seed, uint64_t i)
+{
+    return (2.0 * u01(seed, 2 * i) - 1.0) + (2.0 * u01(seed, 2 * i + 1) - 1.0) * I;
+}
+
+/* ---- real(dp) instance ---- */
+#define T double
+#define FN(name) name##_d
+#define CONJ(x) (x)
+#define ABS(x) fabs(x)
+#define ISZERO(x) ((x) == 0.0)
+#define REALPART(x) (x)
+#define FILLVAL(seed, i) fill_d(seed, i)
+#include "lk_oracle_body.inc"
+#undef T
+#undef FN
+#undef CONJ
+#undef ABS
+#undef ISZERO
+#undef REALPART
+#undef FILLVAL
+
+/* ---- complex(dp) instance ---- */
+#define T double _Complex
+#define FN(name) name##_z
+#define CONJ(x) conj(x)
+#define ABS(x) cabs(x)
+#define ISZERO(x) (creal(x) == 0.0 && cimag(x) == 0.0)
+#define REALPART(x) creal(x)
+#define FILLVAL(seed, i) fill_z(seed, i)
+#include "lk_oracle_body.inc"
+#undef T
+#undef FN
+#undef CONJ
+#undef ABS
+#undef ISZERO
+#undef REALPART
+#undef FILLVAL
+
+/* ------------------------------------------------------------------------------------
+ * Synthetic operators used to drive the path (SURVEY 8d "concrete synthetic inputs").
+ * They stand where a user's `matvec` TBP stands (src/AbstractTypes/AbstractLinops.fypp:74-87).
+ * ---------------------------------------------------------------------------------- */
+
+/* diagonal operator: y_i = d_i x_i */
+typedef struct { const void *d; } ora_diag_op;
+void ora_matvec_diag_d(void *op, int64_t n, const void *x, void *y)
+{
+    const double *d = (const double *)((ora_diag_op *)op)->d;
+    const double *xx = (const double *)x; double *yy = (double *)y;
+    for (int64_t i = 0; i < n; ++i) yy[i] = d[i] * xx[i];
+}
+void ora_matvec_diag_z(void *op, int64_t n, const void *x, void *y)
+{
+    const double _Complex *d = (const double _Complex *)((ora_diag_op *)op)->d;
+    const double _Complex *xx = (const double _Complex *)x; double _Complex *yy = (double _Complex *)y;
+    for (int64_t i = 0; i < n; ++i) yy[i] = d[i] * xx[i];
+}
+
+/* dense operator y = A x: `vec_out = vec_in` then gemv('N').  AbstractLinops.fypp:608-631.
+ * Reference-BLAS DGEMV 'N' (column sweep: y += x_j * A(:,j)), alpha=1, beta=0. */
+typedef struct { const void *a; int64_t lda; } ora_dense_op;
+void ora_matvec_dense_d(void *op, int64_t n, const void *x, void *y)
+{
+    const ora_dense_op *o = (const ora_dense_op *)op;
+    const double *A = (const double *)o->a; const double *xx = (const double *)x; double *yy = (double *)y;
+    for (int64_t i = 0; i < n; ++i) yy[i] = 0.0;
+    for (int64_t j = 0; j < n; ++j) {
+        const double t = xx[j];
+        const double *col = A + j * o->lda;
+        for (int64_t i = 0; i < n; ++i) yy[i] = yy[i] + t * col[i];
+    }
+}
+void ora_matvec_dense_z(void *op, int64_t n, const void *x, void *y)
+{
+    const ora_dense_op *o = (const ora_dense_op *)op;
+    const double _Complex *A = (const double _Complex *)o->a;
+    const double _Complex *xx = (const double _Complex *)x; double _Complex *yy = (double _Complex *)y;
+    for (int64_t i = 0; i < n; ++i) yy[i] = 0.0;
+    for (int64_t j = 0; j < n; ++j) {
+        const double _Complex t = xx[j];
+        const double _Complex *col = A + j * o->lda;
+        for (int64_t i = 0; i < n; ++i) yy[i] = yy[i] + t * col[i];
+    }
+}
+
+/* 5-point Laplacian on an N x N grid, Dirichlet, scaled by 1/h^2, h = 1/(N+1)
+ * (BASELINE.json config 3; the reference's Poisson example lives outside the tree). */
+typedef struct { int64_t N; } ora_lap5_op;
+void ora_matvec_lap5_d(void *op, int64_t n, const void *x, void *y)
+{
+    const int64_t N = ((ora_lap5_op *)op)->N;
+    const double *u = (const double *)x; double *v = (double *)y;
+    const double s = (double)(N + 1) * (double)(N + 1);
+    (void)n;
+    for (int64_t j = 0; j < N; ++j)
+        for (int64_t i = 0; i < N; ++i) {
+            const int64_t c = i + j * N;
+            double acc = 4.0 * u[c];
+            if (i > 0) acc -= u[c - 1];
+            if (i < N - 1) acc -= u[c + 1];
+            if (j > 0) acc -= u[c - N];
+            if (j < N - 1) acc -= u[c + N];
+            v[c] = s * acc;
+        }
+}

@@ -1,0 +1,454 @@
+"""CPU ORACLE for the LightKrylov hot path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Python face of ``oracle/lk_oracle.c`` (plain C, reference schedule, one thread) plus a
+restatement of the reference's *callers* of that path (arnoldi / lanczos / gmres / eigs /
+krylov_schur) with the small host LAPACK work done by scipy, exactly where the reference
+calls stdlib's LAPACK.  Every function cites the reference file:line it follows (paths are
+relative to /root/reference; nothing is read from there at run time).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  ``lightkrylov_amd`` never does.
+
+Parity pinning: see the header of lk_oracle.c -- pinned by the reference's known-answer
+tests (tests/test_oracle_kat.py); no oracle/_ref build exists because the Fortran
+reference needs fortran-lang/stdlib, which this image lacks.
+
+Bases are numpy arrays of shape (n, ncols), Fortran order, dtype float64 / complex128
+(column j == reference ``X(j+1)``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+from scipy.linalg import lapack as _lp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ATOL_DP = 1.0e-15                     # src/Constants.f90:35
+RTOL_DP = float(np.sqrt(ATOL_DP))     # src/Constants.f90:37
+
+MATVEC_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liblk_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("lk_oracle.c", "lk_oracle_body.inc")]
+    if force or not os.path.exists(so) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in src
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liblk_oracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        for sfx in ("_d", "_z"):
+            getattr(_LIB, "ora_norm" + sfx).restype = C.c_double
+            getattr(_LIB, "ora_orthogonalize" + sfx).restype = C.c_int
+            getattr(_LIB, "ora_dgs" + sfx).restype = C.c_int
+            getattr(_LIB, "ora_arnoldi" + sfx).restype = C.c_int
+    return _LIB
+
+
+def _sfx(a: np.ndarray) -> str:
+    if a.dtype == np.float64:
+        return "_d"
+    if a.dtype == np.complex128:
+        return "_z"
+    raise TypeError(f"oracle supports float64/complex128 only, got {a.dtype}")
+
+
+def _p(a: np.ndarray):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _scalar(val, dtype) -> np.ndarray:
+    return np.array([val], dtype=dtype)
+
+
+def _ld(X: np.ndarray) -> int:
+    assert X.flags.f_contiguous or X.ndim == 1
+    return X.strides[1] // X.itemsize if X.ndim == 2 and X.shape[1] > 1 else X.shape[0]
+
+
+# ----------------------------------------------------------------------------------------
+# abstract_vector primitives as dense_vector implements them
+# ----------------------------------------------------------------------------------------
+def scal(x: np.ndarray, alpha) -> None:
+    """AbstractVectors.fypp:505-512"""
+    a = _scalar(alpha, x.dtype)
+    getattr(lib(), "ora_scal" + _sfx(x))(C.c_int64(x.size), _p(a), _p(x))
+
+
+def axpby(alpha, x: np.ndarray, beta, y: np.ndarray) -> None:
+    """y <- alpha*x + beta*y the way dense_axpby does it.  AbstractVectors.fypp:514-536"""
+    a, b = _scalar(alpha, y.dtype), _scalar(beta, y.dtype)
+    getattr(lib(), "ora_dense_axpby" + _sfx(y))(C.c_int64(y.size), _p(a), _p(x), _p(b), _p(y))
+
+
+def dot(x: np.ndarray, y: np.ndarray):
+    """x%dot(y) = sum conj(x) y.  AbstractVectors.fypp:538-555"""
+    out = np.zeros(1, dtype=x.dtype)
+    getattr(lib(), "ora_dot" + _sfx(x))(C.c_int64(x.size), _p(x), _p(y), _p(out))
+    return out[0]
+
+
+def norm(x: np.ndarray) -> float:
+    """AbstractVectors.fypp:424-432"""
+    return float(getattr(lib(), "ora_norm" + _sfx(x))(C.c_int64(x.size), _p(x)))
+
+
+def innerprod(X: np.ndarray, Y: np.ndarray) -> np.ndarray:
+    """M = X^H Y, one dot per entry.  AbstractVectors.fypp:659-695"""
+    Y2 = Y.reshape(Y.shape[0], -1, order="F")
+    k, p = X.shape[1], Y2.shape[1]
+    M = np.zeros((k, p), dtype=X.dtype, order="F")
+    getattr(lib(), "ora_innerprod" + _sfx(X))(
+        C.c_int64(X.shape[0]), C.c_int(k), _p(X), C.c_int64(_ld(X)), C.c_int(p), _p(Y2),
+        C.c_int64(_ld(Y2)), _p(M))
+    return M[:, 0] if Y.ndim == 1 else M
+
+
+def linear_combination(X: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """y = X v by k axpby calls.  AbstractVectors.fypp:571-603"""
+    v = np.ascontiguousarray(v, dtype=X.dtype)
+    out = np.empty(X.shape[0], dtype=X.dtype)
+    getattr(lib(), "ora_lincomb" + _sfx(X))(
+        C.c_int64(X.shape[0]), C.c_int(X.shape[1]), _p(X), C.c_int64(_ld(X)), _p(v), _p(out))
+    return out
+
+
+def gram(X: np.ndarray) -> np.ndarray:
+    """AbstractVectors.fypp:645-657 (mirrors without conjugation)."""
+    k = X.shape[1]
+    G = np.zeros((k, k), dtype=X.dtype, order="F")
+    getattr(lib(), "ora_gram" + _sfx(X))(C.c_int64(X.shape[0]), C.c_int(k), _p(X),
+                                        C.c_int64(_ld(X)), _p(G))
+    return G
+
+
+def orthogonalize_against_basis(y: np.ndarray, X: np.ndarray):
+    """One CGS pass; returns (h, info).  gram_schmidt.fypp:113-154"""
+    h = np.zeros(X.shape[1], dtype=X.dtype)
+    info = getattr(lib(), "ora_orthogonalize" + _sfx(X))(
+        C.c_int64(X.shape[0]), C.c_int(X.shape[1]), _p(X), C.c_int64(_ld(X)), _p(y), _p(h))
+    return h, int(info)
+
+
+def double_gram_schmidt_step(y: np.ndarray, X: np.ndarray):
+    """Returns (beta = h1 + h2, info).  y is updated in place.  gram_schmidt.fypp:12-57"""
+    k = X.shape[1]
+    h = np.zeros(max(k, 1), dtype=X.dtype)
+    wrk = np.zeros(max(k, 1), dtype=X.dtype)
+    info = getattr(lib(), "ora_dgs" + _sfx(X))(
+        C.c_int64(X.shape[0]), C.c_int(k), _p(X), C.c_int64(_ld(X)), _p(y), _p(h), _p(wrk))
+    return h[:k], int(info)
+
+
+def fill_counter(x: np.ndarray, seed: int, i0: int = 0) -> None:
+    """x_i = 2u-1 with u = (splitmix64(seed*2^32 + i0+i) >> 11) 2^-53."""
+    getattr(lib(), "ora_fill_counter" + _sfx(x))(C.c_int64(x.size), C.c_int64(i0),
+                                                C.c_uint64(seed), _p(x))
+
+
+# ----------------------------------------------------------------------------------------
+# operators standing in for a user's abstract_linop (AbstractLinops.fypp:58-87)
+# ----------------------------------------------------------------------------------------
+class _OpBase:
+    def c_matvec(self):          # -> (function pointer as c_void_p-castable, op struct pointer)
+        raise NotImplementedError
+
+    def matvec(self, x: np.ndarray, y: np.ndarray) -> None:
+        fn, op = self.c_matvec()
+        fn(op, C.c_int64(x.size), _p(x), _p(y))
+
+
+class _DiagStruct(C.Structure):
+    _fields_ = [("d", C.c_void_p)]
+
+
+class _DenseStruct(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("lda", C.c_int64)]
+
+
+class _Lap5Struct(C.Structure):
+    _fields_ = [("N", C.c_int64)]
+
+
+class DiagOp(_OpBase):
+    def __init__(self, d: np.ndarray):
+        self.d = np.ascontiguousarray(d)
+        self._s = _DiagStruct(self.d.ctypes.data)
+
+    def c_matvec(self):
+        return getattr(lib(), "ora_matvec_diag" + _sfx(self.d)), C.byref(self._s)
+
+
+class DenseOp(_OpBase):
+    """dense_linop: gemv('N').  AbstractLinops.fypp:608-631"""
+
+    def __init__(self, A: np.ndarray):
+        self.A = np.asfortranarray(A)
+        self._s = _DenseStruct(self.A.ctypes.data, self.A.shape[0])
+
+    def c_matvec(self):
+        return getattr(lib(), "ora_matvec_dense" + _sfx(self.A)), C.byref(self._s)
+
+
+class Lap5Op(_OpBase):
+    def __init__(self, N: int):
+        self.N = N
+        self._s = _Lap5Struct(N)
+
+    def c_matvec(self):
+        return lib().ora_matvec_lap5_d, C.byref(self._s)
+
+
+class PyOp(_OpBase):
+    """Any python callable f(x)->y as an operator (small cases only)."""
+
+    def __init__(self, f, dtype):
+        self.f, self.dtype = f, np.dtype(dtype)
+
+        def _cb(_op, n, xp, yp):
+            x = np.ctypeslib.as_array(C.cast(xp, C.POINTER(C.c_double)),
+                                      shape=(n * (2 if self.dtype.kind == "c" else 1),)).view(self.dtype)
+            y = np.ctypeslib.as_array(C.cast(yp, C.POINTER(C.c_double)),
+                                      shape=(n * (2 if self.dtype.kind == "c" else 1),)).view(self.dtype)
+            y[:] = self.f(x)
+        self._cb = MATVEC_FN(_cb)
+
+    def c_matvec(self):
+        return self._cb, None
+
+
+# ----------------------------------------------------------------------------------------
+# Krylov factorisations
+# ----------------------------------------------------------------------------------------
+def arnoldi(A: _OpBase, X: np.ndarray, H: np.ndarray, kstart: int = 1, kend: int | None = None,
+            tol: float = ATOL_DP, rand_seed: int = 12345) -> int:
+    """arnoldi (blksize 1).  src/Krylov/arnoldi.fypp:8-76.  X: (n, m+1) F-order, H: (m+1, m) F-order."""
+    m = X.shape[1] - 1
+    kend = m if kend is None else kend
+    fn, op = A.c_matvec()
+    fnp = C.cast(fn, C.c_void_p)
+    info = getattr(lib(), "ora_arnoldi" + _sfx(X))(
+        C.c_int64(X.shape[0]), C.c_int(m), _p(X), C.c_int64(_ld(X)), _p(H), C.c_int64(H.shape[0]),
+        C.c_int(kstart), C.c_int(kend), C.c_double(tol), fnp, op, C.c_uint64(rand_seed))
+    return int(info)
+
+
+def lanczos(A: _OpBase, X: np.ndarray, T: np.ndarray, kstart: int = 1, kend: int | None = None,
+            tol: float = ATOL_DP) -> int:
+    """lanczos_tridiagonalization.  src/Krylov/lanczos.fypp:7-64"""
+    kdim = X.shape[1] - 1
+    kend = kdim if kend is None else kend
+    info = 0
+    for k in range(kstart, kend + 1):
+        A.matvec(X[:, k - 1], X[:, k])                                   # :26
+        for i in range(max(1, k - 1), k + 1):                            # :57-60
+            T[i - 1, k - 1] = dot(X[:, i - 1], X[:, k])
+            axpby(-T[i - 1, k - 1], X[:, i - 1], 1.0, X[:, k])
+        double_gram_schmidt_step(X[:, k], X[:, :k])                      # :62
+        beta = norm(X[:, k])
+        T[k, k - 1] = beta                                               # :29
+        if beta < tol:
+            info = k
+            break
+        scal(X[:, k], 1.0 / beta)                                        # :39
+    return info
+
+
+# ----------------------------------------------------------------------------------------
+# small host LAPACK pieces (src/Utilities/submodule_utility_functions.fypp)
+# ----------------------------------------------------------------------------------------
+def eig(Hk: np.ndarray):
+    """geev, right vectors in LAPACK layout (real pairs NOT combined).  :55-85"""
+    if Hk.dtype == np.float64:
+        wr, wi, _vl, vr, info = _lp.dgeev(Hk, compute_vl=0, compute_vr=1)
+        assert info == 0
+        return wr + 1j * wi, vr
+    w, _vl, vr, info = _lp.zgeev(Hk, compute_vl=0, compute_vr=1)
+    assert info == 0
+    return w, vr
+
+
+def apply_givens_rotation(h: np.ndarray, c: np.ndarray, s: np.ndarray) -> None:
+    """:173-204.  Real: lasr('L','V','F') + lartg; complex: the in-house unconjugated rotation."""
+    k = h.size - 1
+    if h.dtype == np.float64:
+        for j in range(k - 1):                    # dlasr, SIDE=L, PIVOT=V, DIRECT=F
+            t = h[j + 1]
+            h[j + 1] = c[j] * t - s[j] * h[j]
+            h[j] = s[j] * t + c[j] * h[j]
+        cc, ss, r = _lp.dlartg(h[k - 1], h[k])
+        c[k - 1], s[k - 1] = cc, ss
+        h[k - 1], h[k] = r, 0.0
+    else:
+        for i in range(k - 1):
+            t = c[i] * h[i] + s[i] * h[i + 1]
+            h[i + 1] = -s[i] * h[i] + c[i] * h[i + 1]
+            h[i] = t
+        g = np.array([h[k - 1], h[k]])
+        g = g / np.sqrt(np.sum(np.abs(g) ** 2))   # givens_rotation: x / norm(x,2)
+        c[k - 1], s[k - 1] = g[0], g[1]
+        h[k - 1] = c[k - 1] * h[k - 1] + s[k - 1] * h[k]
+        h[k] = 0.0
+
+
+def gmres(A: _OpBase, b: np.ndarray, x: np.ndarray, rtol: float = RTOL_DP, atol: float = ATOL_DP,
+          kdim: int = 30, maxiter: int = 10):
+    """Restarted GMRES, no preconditioner.  src/IterativeSolvers/GMRES/gmres.fypp:105-239.
+    Returns (info, residual history); x updated in place."""
+    n, dt = b.size, b.dtype
+    tol = atol + rtol * norm(b)                                          # :106
+    V = np.zeros((n, kdim + 1), dtype=dt, order="F")
+    H = np.zeros((kdim + 1, kdim), dtype=dt, order="F")
+    res, n_iter, n_outer, converged = [], 0, 0, False
+    while (not converged) and n_outer <= maxiter:                        # :131
+        H[:] = 0
+        V[:] = 0
+        if norm(x) != 0.0:
+            A.matvec(x, V[:, 0])                                         # :134-140
+        axpby(-1.0, b, 1.0, V[:, 0])
+        scal(V[:, 0], -1.0)                                              # :141
+        e = np.zeros(kdim + 1, dtype=dt)
+        beta = norm(V[:, 0])
+        e[0] = beta
+        scal(V[:, 0], 1.0 / beta)
+        c = np.zeros(kdim, dtype=dt)
+        s = np.zeros(kdim, dtype=dt)
+        if n_outer == 0:
+            res.append(abs(beta))
+        k = 0
+        for k in range(1, kdim + 1):
+            wrk = V[:, k - 1].copy()                                     # :155
+            A.matvec(wrk, V[:, k])
+            h, _ = double_gram_schmidt_step(V[:, k], V[:, :k])           # :167-168
+            H[:k, k - 1] = h
+            H[k, k - 1] = norm(V[:, k])                                  # :171
+            if abs(H[k, k - 1]) > tol:
+                scal(V[:, k], 1.0 / H[k, k - 1])                         # :172
+            apply_givens_rotation(H[:k + 1, k - 1], c[:k], s[:k])        # :178
+            e[k] = -s[k - 1] * e[k - 1]
+            e[k - 1] = c[k - 1] * e[k - 1]                               # :180
+            beta = abs(e[k])
+            n_iter += 1
+            res.append(abs(beta))
+            if abs(beta) < tol:
+                converged = True
+                break
+        k = min(k, kdim)
+        trtrs = _lp.dtrtrs if dt == np.float64 else _lp.ztrtrs
+        yk, info = trtrs(H[:k, :k], e[:k], lower=0, trans=0, unitdiag=0)  # :199-200
+        assert info == 0
+        dx = linear_combination(V[:, :k], yk)                            # :201
+        axpby(1.0, dx, 1.0, x)
+        A.matvec(x, V[:, 0])                                             # :205-210
+        axpby(-1.0, b, 1.0, V[:, 0])
+        scal(V[:, 0], -1.0)
+        beta = norm(V[:, 0])
+        if abs(beta) > 0.0:
+            scal(V[:, 0], 1.0 / beta)
+        n_iter += 1
+        n_outer += 1
+        res.append(abs(beta))
+        if abs(beta) < tol:
+            converged = True
+            break
+    info = n_iter if converged else -n_iter                              # :234-238
+    return info, np.array(res)
+
+
+def krylov_schur(X: np.ndarray, H: np.ndarray, select):
+    """src/Krylov/BaseKrylov.fypp:782-834.  Returns n (number of selected eigenvalues)."""
+    kdim = X.shape[1] - 1
+    m = H.shape[1]
+    if H.dtype == np.float64:
+        T, sdim, wr, wi, Z, work, info = _lp.dgees(lambda *a: False, H[:m, :].copy(order="F"), sort_t=0)
+        eigvals = wr + 1j * wi
+    else:
+        T, sdim, eigvals, Z, work, info = _lp.zgees(lambda *a: False, H[:m, :].copy(order="F"), sort_t=0)
+    assert info == 0
+    H[:m, :] = T
+    selected = np.asarray(select(eigvals), dtype=bool)
+    n = int(np.count_nonzero(selected))
+    Hk = np.asfortranarray(H[:kdim, :])
+    if H.dtype == np.float64:
+        out = _lp.dtrsen(selected.astype(np.int32), Hk, np.asfortranarray(Z), job="N", wantq=1)
+    else:
+        out = _lp.ztrsen(selected.astype(np.int32), Hk, np.asfortranarray(Z), job="N", wantq=1)
+    assert out[-1] == 0
+    H[:kdim, :] = out[0]
+    Z = out[1]
+    # basis update: Xwrk = X(:m) Z(:, :n) by n*m axpby;  X(:n) = Xwrk ; X(n+1) = X(kdim+1) ; rest zero
+    Xw = np.zeros((X.shape[0], n), dtype=X.dtype, order="F")
+    for j in range(n):
+        Xw[:, j] = linear_combination(X[:, :m], np.ascontiguousarray(Z[:, j]))
+    X[:, :n] = Xw
+    X[:, n] = X[:, kdim]
+    X[:, n + 1:] = 0
+    b = H[kdim, :] @ Z
+    H[n, :] = b
+    H[n + 1:, :] = 0
+    H[:, n:] = 0
+    return n
+
+
+def eigs(A: _OpBase, x0: np.ndarray, nev: int, kdim: int | None = None, tolerance: float = RTOL_DP,
+         max_restarts: int = 1000):
+    """Krylov-Schur eigensolver.  src/IterativeSolvers/IterativeSolvers.fypp:972-1143.
+    Returns (eigvals[nev], residuals[nev], eigvecs (n, nev), info=niter)."""
+    n, dt = x0.size, x0.dtype
+    kdim = 4 * nev if kdim is None else kdim
+    X = np.zeros((n, kdim + 1), dtype=dt, order="F")
+    X[:, 0] = x0
+    scal(X[:, 0], 1.0 / norm(x0))                                        # :1036-1038
+    H = np.zeros((kdim + 1, kdim), dtype=dt, order="F")
+    res = np.zeros(kdim)
+    kstart, conv, niter, k = 1, 0, 0, 0
+    restarts = 0
+    while conv < nev:
+        for k in range(kstart, kdim + 1):
+            info = arnoldi(A, X, H, kstart=k, kend=k)                    # :1059
+            w, vr = eig(np.asfortranarray(H[:k, :k]))                    # :1065
+            beta = H[k, k - 1]
+            if dt == np.complex128:
+                res[:k] = np.abs(beta * vr[k - 1, :k])                   # :1071
+            else:
+                for i in range(k):                                       # :1073-1082
+                    if w[i].imag > 0:
+                        alpha = abs(complex(vr[k - 1, i], vr[k - 1, i + 1]))
+                    elif w[i].imag < 0:
+                        alpha = abs(complex(vr[k - 1, i - 1], vr[k - 1, i]))
+                    else:
+                        alpha = abs(vr[k - 1, i])
+                    res[i] = abs(beta * alpha)
+            niter += 1
+            conv = int(np.count_nonzero(res[:k] < tolerance))
+            if conv >= nev:
+                break
+        restarts += 1
+        if restarts > max_restarts:
+            raise RuntimeError("oracle eigs: too many restarts")
+        # NB the reference restarts unconditionally, also after convergence (:1100)
+        nsel = krylov_schur(X, H, lambda lam: np.abs(lam) > np.median(np.abs(lam)))
+        kstart = nsel + 1
+    k = min(k, kdim)
+    w, vr = eig(np.asfortranarray(H[:k, :k]))                            # :1115
+    wfull = np.zeros(kdim, dtype=np.complex128)
+    wfull[:k] = w
+    idx = np.argsort(-np.abs(wfull), kind="stable")                      # :1118-1120
+    vfull = np.zeros((kdim, kdim), dtype=vr.dtype)
+    vfull[:k, :k] = vr
+    wsorted, vsorted, rsorted = wfull[idx], vfull[:, idx], res[idx]
+    vecs = np.zeros((n, nev), dtype=dt, order="F")
+    for i in range(nev):                                                 # :1127-1132
+        vecs[:, i] = linear_combination(X[:, :k], np.ascontiguousarray(vsorted[:k, i].astype(dt)))
+    return wsorted[:nev], rsorted[:nev], vecs, niter

@@ -1,0 +1,410 @@
+"""GPU parity tests: the HIP engine (through the C ABI / its host mirror) against the CPU oracle
+on the same seeded inputs.  Floating-point path => tolerances, stated per test:
+
+  * primitives that are one rounding per element (scal, axpby, copy, zero, rand, diag matvec):
+    element-wise <= 4 ulp-ish (1e-15 relative) -- FMA contraction on the GPU is the only difference;
+  * reductions (dot, norm, innerprod, DGS coefficients, H): NORMWISE 1e-12 -- the GPU sums in a
+    tree, the reference sequentially; north_star's tolerance is 1e-12 rtol.
+"""
+import numpy as np
+import pytest
+
+import lightkrylov_amd as lk
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+
+KINDS = [np.float64, np.complex128]
+SIZES = [1, 2, 3, 63, 64, 65, 127, 128, 129, 1000, 4099, 100_003]
+RTOL_RED = 1e-12
+
+
+def seeded(n, dtype, seed):
+    x = np.empty(n, dtype=dtype)
+    ora.fill_counter(x, seed)
+    return x
+
+
+def basis(n, k, dtype, seed):
+    X = np.empty((n, k), dtype=dtype, order="F")
+    for j in range(k):
+        ora.fill_counter(X[:, j], seed + j)
+    return X
+
+
+def orthonormal_basis(n, k, dtype, seed):
+    Q, _ = np.linalg.qr(basis(n, k, dtype, seed))
+    return np.asfortranarray(Q)
+
+
+def scalars(dtype):
+    return (0.37 - 1.2j, -1.5 + 0.25j) if np.dtype(dtype).kind == "c" else (0.37, -1.5)
+
+
+# ----------------------------------------------------------------------------- primitives
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("n", SIZES)
+def test_blas1_against_oracle(ctx, dtype, n):
+    a, b = scalars(dtype)
+    x, y = seeded(n, dtype, 1), seeded(n, dtype, 2)
+    vx, vy = lk.dense_vector_gpu.from_array(x, ctx), lk.dense_vector_gpu.from_array(y, ctx)
+    assert vx.get_size() == n
+
+    # dot / norm (conjugation on self)
+    ref = ora.dot(x, y)
+    got = vx.dot(vy)
+    scale = np.linalg.norm(x) * np.linalg.norm(y)
+    assert abs(got - ref) <= RTOL_RED * scale
+    assert abs(vx.norm() - ora.norm(x)) <= RTOL_RED * ora.norm(x)
+
+    # scal
+    xs = x.copy()
+    ora.scal(xs, a)
+    vx.scal(a)
+    np.testing.assert_allclose(vx.to_array(), xs, rtol=1e-15, atol=1e-15)
+
+    # axpby (true y = a x + b y)
+    ys = y.copy()
+    ora.axpby(a, xs, b, ys)
+    vy.axpby(a, vx, b)
+    np.testing.assert_allclose(vy.to_array(), ys, rtol=4e-15, atol=4e-15)
+
+    # add / sub / chsgn
+    vy.add(vx); ora.axpby(1.0, xs, 1.0, ys)
+    vy.sub(vx); vy.sub(vx); ora.axpby(-1.0, xs, 1.0, ys); ora.axpby(-1.0, xs, 1.0, ys)
+    vy.chsgn(); ora.scal(ys, -1.0)
+    np.testing.assert_allclose(vy.to_array(), ys, rtol=1e-14, atol=1e-14)
+
+    # copy / zero
+    vz = vx.zeros_like()
+    lk.copy(vz, vx)
+    assert np.array_equal(vz.to_array(), vx.to_array())
+    vz.zero()
+    assert not vz.to_array().any()
+    # axpby with beta = 0 overwrites (true axpby)
+    vz.axpby(a, vx, 0.0)
+    np.testing.assert_allclose(vz.to_array(), a * vx.to_array(), rtol=4e-15, atol=1e-300)
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_rand_is_the_shared_counter_generator(ctx, dtype):
+    n = 10_007
+    v = lk.dense_vector_gpu(n, dtype, ctx)
+    v.rand(False, seed=42)
+    assert np.array_equal(v.to_array(), seeded(n, dtype, 42))      # bit-exact: integer hash + exact scaling
+    v.rand(True, seed=43)
+    assert abs(v.norm() - 1.0) < 1e-14
+
+
+def test_empty_vector(ctx):
+    v = lk.dense_vector_gpu(0, np.float64, ctx)
+    w = lk.dense_vector_gpu(0, np.float64, ctx)
+    v.zero(); v.scal(2.0); v.axpby(1.0, w, 1.0)
+    assert v.dot(w) == 0.0 and v.norm() == 0.0 and v.get_size() == 0
+
+
+def test_size_mismatch_is_an_error(ctx):
+    v = lk.dense_vector_gpu(10, np.float64, ctx)
+    w = lk.dense_vector_gpu(11, np.float64, ctx)
+    with pytest.raises(lk._capi.LightKrylovHipError, match="Inconsistent size"):
+        v.axpby(1.0, w, 1.0)                       # reference: stop_error("Inconsistent size between the two vectors.")
+    c = lk.dense_vector_gpu(10, np.complex128, ctx)
+    with pytest.raises(lk._capi.LightKrylovHipError):
+        v.dot(c)
+
+
+# ----------------------------------------------------------------------------- basis helpers
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("n,k,p", [(1000, 1, 1), (1003, 7, 1), (4099, 16, 2), (4099, 17, 1), (20_001, 64, 1),
+                                   (20_001, 128, 1), (777, 130, 1), (5000, 200, 2)])
+def test_innerprod_lincomb_gram(ctx, dtype, n, k, p):
+    X, Y = basis(n, k, dtype, 10), basis(n, p, dtype, 500)
+    Bx = lk.krylov_basis_gpu(n, k, dtype, ctx); Bx.upload(X)
+    By = lk.krylov_basis_gpu(n, p, dtype, ctx); By.upload(Y)
+    M = lk.innerprod(Bx, By)
+    Mo = ora.innerprod(X, Y)
+    scale = np.linalg.norm(X, axis=0).max() * np.linalg.norm(Y, axis=0).max()
+    assert np.abs(M - Mo).max() <= RTOL_RED * scale
+    m1 = lk.innerprod(Bx, By[0])
+    assert np.abs(m1 - Mo[:, 0]).max() <= RTOL_RED * scale
+
+    # linear_combination: Y = X C
+    Cm = basis(k, p, dtype, 900)
+    Yg = lk.linear_combination(Bx, Cm).download()
+    for j in range(p):
+        ref = ora.linear_combination(X, np.ascontiguousarray(Cm[:, j]))
+        assert np.abs(Yg[:, j] - ref).max() <= 1e-13 * np.abs(ref).max() * max(1, k) ** 0.5
+
+    if k <= 17:
+        G = lk.Gram(Bx)
+        Go = ora.gram(X)
+        assert np.abs(G - Go).max() <= RTOL_RED * scale * (n / 1000)
+
+
+# ----------------------------------------------------------------------------- the sweep
+DGS_CASES = [(1000, 1), (1001, 2), (999, 3), (4096, 15), (4097, 16), (4099, 17), (10_000, 31), (10_001, 33),
+             (30_000, 64), (30_011, 100), (30_011, 127), (30_011, 128), (5003, 129), (5003, 200), (129, 64), (65, 8),
+             (1, 1), (300_007, 32)]
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("n,k", DGS_CASES)
+def test_double_gram_schmidt_step_against_oracle(ctx, dtype, n, k):
+    k = min(k, n)
+    Q = orthonormal_basis(n, k, dtype, 3)
+    y = seeded(n, dtype, 77)
+    B = lk.krylov_basis_gpu(n, k + 1, dtype, ctx)
+    B.upload(Q, 0)
+    B.upload(y.reshape(-1, 1), k)
+    beta = np.zeros(k, dtype=dtype)
+    info = lk.double_gram_schmidt_step(B[k], B[:k], if_chk_orthonormal=False, beta=beta)
+
+    yo = y.copy()
+    ho, info_o = ora.double_gram_schmidt_step(yo, Q)
+    assert info == info_o
+    ynorm = np.linalg.norm(y)
+    assert np.abs(beta - ho).max() <= RTOL_RED * ynorm                    # coefficients, normwise
+    yg = B.download(k, 1)[:, 0]
+    assert np.abs(yg - yo).max() <= RTOL_RED * ynorm                      # the orthogonalised vector
+    if k < n:
+        assert np.abs(Q.conj().T @ yg).max() <= 1e-13 * ynorm             # orthogonality after two passes
+
+    # single pass + shape assertion on beta
+    B.upload(y.reshape(-1, 1), k)
+    b1 = np.zeros(k, dtype=dtype)
+    lk.orthogonalize_against_basis(B[k], B[:k], if_chk_orthonormal=False, beta=b1)
+    y1 = y.copy()
+    h1, _ = ora.orthogonalize_against_basis(y1, Q)
+    assert np.abs(b1 - h1).max() <= RTOL_RED * ynorm
+    assert np.abs(B.download(k, 1)[:, 0] - y1).max() <= RTOL_RED * ynorm
+    with pytest.raises(ValueError):
+        lk.double_gram_schmidt_step(B[k], B[:k], False, beta=np.zeros(k + 1, dtype=dtype))
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_dgs_zero_vector_flag_and_orthonormality_check(ctx, dtype):
+    n, k = 2000, 5
+    Q = orthonormal_basis(n, k, dtype, 5)
+    B = lk.krylov_basis_gpu(n, k + 1, dtype, ctx)
+    B.upload(Q, 0)                                                      # y = 0
+    assert lk.double_gram_schmidt_step(B[k], B[:k], if_chk_orthonormal=False) == 1   # gram_schmidt.fypp:126-127
+    B.upload(seeded(n, dtype, 9).reshape(-1, 1), k)
+    assert lk.double_gram_schmidt_step(B[k], B[:k]) == 0                # default if_chk_orthonormal=True passes
+    B.upload((2.0 * Q[:, 0]).reshape(-1, 1), 0)
+    with pytest.raises(RuntimeError, match="not orthonormal"):
+        lk.double_gram_schmidt_step(B[k], B[:k])
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_block_dgs_and_qr(ctx, dtype):
+    n, k, p = 6001, 12, 3
+    Q = orthonormal_basis(n, k, dtype, 21)
+    Y = basis(n, p, dtype, 99)
+    B = lk.krylov_basis_gpu(n, k + p, dtype, ctx)
+    B.upload(Q, 0); B.upload(Y, k)
+    beta = np.zeros((k, p), dtype=dtype, order="F")
+    info = lk.double_gram_schmidt_step(B[k:k + p], B[:k], False, beta)
+    assert info == 0
+    for j in range(p):
+        yo = Y[:, j].copy()
+        ho, _ = ora.double_gram_schmidt_step(yo, Q)
+        assert np.abs(beta[:, j] - ho).max() <= RTOL_RED * np.linalg.norm(Y[:, j])
+    # qr_no_pivoting on the block: A = Q R, Q^H Q = I   (test/TestKrylov.fypp:52-99)
+    A = B.download(k, p)
+    R = np.zeros((p, p), dtype=dtype, order="F")
+    assert lk.qr(B[k:k + p], R) == 0
+    Qg = B.download(k, p)
+    assert np.abs(Qg @ R - A).max() <= 1e-13 * np.abs(A).max() * 10
+    assert np.abs(Qg.conj().T @ Qg - np.eye(p)).max() <= 1e-13
+
+
+# ----------------------------------------------------------------------------- Arnoldi
+def _arnoldi_pair(ctx, dtype, n, m, d, x0, fused=True):
+    X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+    X.upload(x0.reshape(-1, 1), 0)
+    H = np.zeros((m + 1, m), dtype=dtype, order="F")
+    A = lk.diag_linop_gpu(d, ctx)
+    if not fused:
+        class wrapped(lk.abstract_linop):                      # python operator => python step loop
+            def matvec(self, vi, vo): A.matvec(vi, vo)
+        info = lk.arnoldi(wrapped(), X, H)
+    else:
+        info = lk.arnoldi(A, X, H)
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F")
+    Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), dtype=dtype, order="F")
+    info_o = ora.arnoldi(ora.DiagOp(d), Xo, Ho)
+    return X, H, info, Xo, Ho, info_o
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("n,m,fused", [(1000, 8, True), (1000, 8, False), (100_000, 64, True), (1_000_000, 32, True),
+                                       (50_001, 128, True), (20_000, 140, False)])
+def test_arnoldi_diag_against_oracle(ctx, dtype, n, m, fused):
+    d = (1.0 + np.arange(n) / n).astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        d = d * np.exp(1j * 0.3 * np.arange(n) / n)
+    x0 = seeded(n, dtype, 7)
+    x0 /= np.linalg.norm(x0)
+    X, H, info, Xo, Ho, info_o = _arnoldi_pair(ctx, dtype, n, m, d, x0, fused)
+    assert info == info_o == 0
+    # Hessenberg entries: normwise per column, 1e-12 (north_star)
+    for j in range(m):
+        assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL_RED * np.abs(Ho[:, j]).max(), f"column {j}"
+    # Ritz values within 1e-12 (relative to the spectral radius: the operator is normal)
+    rg = np.sort_complex(np.linalg.eigvals(H[:m, :m]))
+    ro = np.sort_complex(np.linalg.eigvals(Ho[:m, :m]))
+    assert np.abs(rg - ro).max() <= 1e-12 * np.abs(ro).max() * (10 if m > 100 else 1)
+    # invariants of test/TestKrylov.fypp:194-242 at machine precision instead of rtol_dp
+    Xg = X.download()
+    assert np.abs(Xg.conj().T @ Xg - np.eye(m + 1)).max() <= 1e-12
+    assert np.abs(d[:, None] * Xg[:, :m] - Xg @ H).max() <= 1e-12
+
+
+def test_arnoldi_kstart_kend_and_breakdown(ctx):
+    n, m = 5000, 12
+    d = 1.0 + np.arange(n) / n
+    x0 = seeded(n, np.float64, 7); x0 /= np.linalg.norm(x0)
+    X, H, *_ = _arnoldi_pair(ctx, np.float64, n, m, d, x0)
+    X2 = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx); X2.upload(x0.reshape(-1, 1), 0)
+    H2 = np.zeros((m + 1, m), order="F")
+    A = lk.diag_linop_gpu(d, ctx)
+    for k in range(1, m + 1):                                   # one step at a time, as eigs drives it
+        assert lk.arnoldi(A, X2, H2, kstart=k, kend=k) == 0
+    assert np.array_equal(H, H2)
+    assert A.matvec_counter == m
+    # invariant subspace: x0 supported on 3 distinct eigenvalues => breakdown at k = 3 (arnoldi.fypp:65-71)
+    d3 = np.where(np.arange(n) % 3 == 0, 1.0, np.where(np.arange(n) % 3 == 1, 2.0, 3.0))
+    Xb = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx); Xb.upload(x0.reshape(-1, 1), 0)
+    Hb = np.zeros((m + 1, m), order="F")
+    info = lk.arnoldi(lk.diag_linop_gpu(d3, ctx), Xb, Hb, tol=1e-10)
+    Xo = np.zeros((n, m + 1), order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), order="F")
+    assert info == ora.arnoldi(ora.DiagOp(d3), Xo, Ho, tol=1e-10) == 3
+    assert np.allclose(np.sort(np.linalg.eigvals(Hb[:3, :3]).real), [1, 2, 3], rtol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_arnoldi_dense_linop_cfg1_shape(ctx, dtype):
+    """configs[0]: 1000 x 1000 random dense linop, m = 30 (the reference's CPU-runnable case)."""
+    n, m = 1000, 30
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    if np.dtype(dtype).kind == "c":
+        A = A + 1j * rng.standard_normal((n, n)) / np.sqrt(n)
+    A = np.asfortranarray(A.astype(dtype))
+    x0 = seeded(n, dtype, 2); x0 /= np.linalg.norm(x0)
+    X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X.upload(x0.reshape(-1, 1), 0)
+    H = np.zeros((m + 1, m), dtype=dtype, order="F")
+    op = lk.dense_linop_gpu(A, ctx)
+    assert lk.arnoldi(op, X, H) == 0
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.arnoldi(ora.DenseOp(A), Xo, Ho) == 0
+    for j in range(m):
+        assert np.abs(H[:, j] - Ho[:, j]).max() <= 1e-11 * np.abs(Ho[:, j]).max()   # gemv order differs too
+    # rmatvec: A^H x   (test/TestLinops.fypp:48-184)
+    v, w = lk.dense_vector_gpu.from_array(x0, ctx), lk.dense_vector_gpu(n, dtype, ctx)
+    op.apply_rmatvec(v, w)
+    assert np.abs(w.to_array() - A.conj().T @ x0).max() <= 1e-13
+    op.apply_matvec(v, w)
+    assert np.abs(w.to_array() - A @ x0).max() <= 1e-13
+
+
+def test_lanczos_spd_toeplitz_known_answer(ctx):
+    """SPD tridiagonal Toeplitz => eigenvalues a + 2|b| cos(i pi/(n+1))  (test/TestIterativeSolvers.fypp:254-280)."""
+    n = 128
+    a, b = 2.5, 0.8
+    A = a * np.eye(n) + b * (np.eye(n, k=1) + np.eye(n, k=-1))
+    X = lk.krylov_basis_gpu(n, n + 1, np.float64, ctx)
+    x0 = seeded(n, np.float64, 5); X.upload((x0 / np.linalg.norm(x0)).reshape(-1, 1), 0)
+    T = np.zeros((n + 1, n), order="F")
+    info = lk.lanczos(lk.dense_linop_gpu(A, ctx), X, T)
+    k = info if info > 0 else n
+    lam = np.sort(np.linalg.eigvalsh((T[:k, :k] + T[:k, :k].T) / 2))[::-1]
+    true = np.array([a + 2 * abs(b) * np.cos(i * np.pi / (n + 1)) for i in range(1, n + 1)])
+    assert np.abs(lam - true[:k]).max() / np.abs(true).max() < lk.rtol_dp
+
+
+# ----------------------------------------------------------------------------- solvers on the path
+def test_eigs_complex_known_answer(ctx):
+    """The reference's deterministic complex KAT: eigenvalues 2(n-i+1)-1 (TestIterativeSolvers.fypp:176-203)."""
+    n = 128
+    A = np.zeros((n, n), dtype=np.complex128)
+    for i in range(1, n + 1):
+        A[i - 1, i - 1] = n
+        if i < n:
+            A[i - 1, i] = 1j * np.sqrt(1.0 * i * (n - i))
+            A[i, i - 1] = -A[i - 1, i]
+    X = lk.krylov_basis_gpu(n, n, np.complex128, ctx)
+    x0 = lk.dense_vector_gpu.from_array(seeded(n, np.complex128, 3), ctx)
+    vals, res, info = lk.eigs(lk.dense_linop_gpu(A, ctx), X, x0=x0, tolerance=lk.atol_dp)
+    true = np.array([2 * (n - i + 1) - 1 for i in range(1, n + 1)], dtype=float)
+    assert np.abs(vals - true).max() / np.abs(true).max() < lk.rtol_dp
+    V = X.download()
+    assert np.abs(A @ V - V * vals[None, :]).max() < 1e-8 * np.abs(true).max()
+
+
+def test_eigs_leading_pairs_against_oracle(ctx):
+    """configs[0] as an eigenproblem: nev = 4 outliers planted on a 1000 x 1000 random matrix, kdim = 30."""
+    n, nev, kdim = 1000, 4, 30
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    A[np.arange(4), np.arange(4)] += np.array([2.0, 1.8, 1.6, 1.4])
+    A = np.asfortranarray(A)
+    x0 = rng.standard_normal(n)
+    X = lk.krylov_basis_gpu(n, nev, np.float64, ctx)
+    vals, res, info = lk.eigs(lk.dense_linop_gpu(A, ctx), X, x0=lk.dense_vector_gpu.from_array(x0, ctx), kdim=kdim,
+                              tolerance=1e-10)
+    vo, ro, Vo, info_o = ora.eigs(ora.DenseOp(A), x0, nev, kdim, 1e-10)
+    assert info == info_o
+    assert np.abs(vals - vo).max() <= 1e-10 * np.abs(vo).max()
+    V = X.download()
+    for i in range(nev):
+        r = A @ V[:, i] - vals[i].real * V[:, i] if abs(vals[i].imag) < 1e-14 else None
+        if r is not None:
+            assert np.linalg.norm(r) <= 1e-8
+
+
+def test_gmres_poisson_against_oracle(ctx):
+    """configs[2] at a size the oracle finishes in seconds: 5-point Laplacian, N = 96, GMRES(30), 3 cycles."""
+    N = 96
+    n = N * N
+    b = seeded(n, np.float64, 11)
+    opts = lk.gmres_dp_opts(kdim=30, maxiter=2)
+    x = lk.dense_vector_gpu(n, np.float64, ctx)
+    meta = lk.gmres_dp_metadata()
+    info = lk.gmres(lk.laplacian2d_linop_gpu(N, ctx), lk.dense_vector_gpu.from_array(b, ctx), x, rtol=1e-8,
+                    options=opts, meta=meta)
+    xo = np.zeros(n)
+    info_o, res_o = ora.gmres(ora.Lap5Op(N), b, xo, rtol=1e-8, kdim=30, maxiter=2)
+    assert info == info_o
+    assert len(meta.res) == len(res_o)
+    assert np.abs(np.array(meta.res) - res_o).max() <= 1e-10 * res_o[0]
+    assert np.abs(x.to_array() - xo).max() <= 1e-10 * np.abs(xo).max()
+
+
+# ----------------------------------------------------------------------------- size-independent properties
+@pytest.mark.parametrize("dtype,n,m", [(np.float64, 10_000_000, 64), (np.complex128, 1_000_000, 128)])
+def test_arnoldi_full_size_properties(ctx, dtype, n, m):
+    """BASELINE configs 2 and 4 sizes: no oracle run (too slow); factorisation + orthonormality invariants,
+    and linearity of the sweep (DGS of a y + b z equals a DGS(y) + b DGS(z) up to rounding)."""
+    if np.dtype(dtype).kind == "c":
+        dvals = (1.0 + np.arange(n) / n) * np.exp(1j * np.arange(n) / n)
+        op = lk.diag_linop_gpu(dvals.astype(dtype), ctx)
+    else:
+        dvals = 1.0 + np.arange(n) / n
+        op = lk.diag_linop_gpu(n_local=n, d0=1.0, dstep=1.0 / n, ctx=ctx)
+    X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+    X[0].rand(True, seed=7)
+    H = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.arnoldi(op, X, H) == 0
+    G = lk.Gram(X[:m + 1]) if m <= 64 else None
+    if G is not None:
+        assert np.abs(G - np.eye(m + 1)).max() <= 1e-12
+    # A X_m - X_{m+1} H = 0 checked through random probes:  w^H (A X - X H) for a few rows blocks
+    Xh = X.download(0, m + 1)[:200_000]
+    assert np.abs(dvals[:200_000, None] * Xh[:, :m] - Xh @ H).max() <= 1e-12
+    # Ritz values are those of a normal operator with spectrum on a known curve
+    ritz = np.linalg.eigvals(H[:m, :m])
+    assert (np.abs(ritz) >= 1.0 - 1e-9).all() and (np.abs(ritz) <= 2.0 + 1e-9).all()
