@@ -112,25 +112,28 @@ int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh
 
 /* zero(self)                         AbstractVectors.fypp:322-326, dense: 476-486 */
 int lk_vec_zero(lk_basis_t B, int j);
-/* rand(self, ifnorm)                 :328-336, dense: 488-503.  Counter-based generator:
+/* rand(self, ifnorm)                 AbstractVectors.fypp:328-336, dense: 488-503.  Counter-based generator:
  * entry i (global row row0+i) = 2u-1, u = (splitmix64(seed*2^32 + ctr) >> 11) * 2^-53;
  * ctr = row for F64, 2*row / 2*row+1 for re / im.  ifnorm != 0 normalises (what eigs expects
  * of rand(.true.), IterativeSolvers.fypp:1040). */
 int lk_vec_rand(lk_basis_t B, int j, uint64_t seed, int64_t row0, int ifnorm);
-/* scal(self, alpha)                  :338-344, dense: 505-512 */
+/* scal(self, alpha)                  AbstractVectors.fypp:338-344, dense: 505-512 */
 int lk_vec_scal(lk_basis_t B, int j, const double *alpha);
-/* axpby(alpha, vec, beta, self): self <- alpha*vec + beta*self   :346-356, dense: 514-536.
+/* axpby(alpha, vec, beta, self): self <- alpha*vec + beta*self   AbstractVectors.fypp:346-356,
+ * dense: 514-536.
  * True axpby in ONE pass (the reference's dense version does scal-then-axpy). */
 int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta, lk_basis_t By,
                  int jy);
-/* dot(self, vec) = sum conj(self) * vec, all-reduced over ranks   :358-365, dense: 538-555.
+/* dot(self, vec) = sum conj(self) * vec, all-reduced over ranks.
+ * AbstractVectors.fypp:358-365, dense: 538-555.
  * out: 1 or 2 doubles. */
 int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out);
-/* norm(self) = sqrt(abs(dot(self,self)))   :424-432 */
+/* norm(self) = sqrt(abs(dot(self,self)))   AbstractVectors.fypp:424-432 */
 int lk_vec_norm(lk_basis_t B, int j, double *out);
-/* get_size(self): GLOBAL size is the caller's business; this returns the local row count.  :367-372 */
+/* get_size(self): GLOBAL size is the caller's business; this returns the local row count.
+ * AbstractVectors.fypp:367-372 */
 int lk_vec_size(lk_basis_t B, int64_t *n_local);
-/* copy(out, from)                    :717-723 */
+/* copy(out, from)                    AbstractVectors.fypp:717-723 */
 int lk_vec_copy(lk_basis_t Bdst, int jd, lk_basis_t Bsrc, int js);
 
 /* ---- basis helpers built on the TBPs (cannot be specialised by a Fortran plugin; here

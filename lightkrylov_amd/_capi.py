@@ -84,6 +84,14 @@ def load():
         raise LightKrylovHipError(
             f"HIP engine not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C lightkrylov_amd/csrc`. There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64.  Import
+    # torch FIRST so this library's DT_NEEDED libamdhip64.so resolves to the copy torch already
+    # loaded (same SONAME); loading ours first puts two HSA runtimes in the process and the second
+    # one finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

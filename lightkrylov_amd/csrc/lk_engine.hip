@@ -462,10 +462,8 @@ int lk_basis_wrap(lk_context_t c, int dtype, int64_t n_local, int ncols, int64_t
 
 int lk_basis_destroy(lk_basis_t B) {
     if (!B) return LK_OK;
-    if (B->own && B->data) {
-        (void)hipStreamSynchronize(B->ctx->stream);
-        (void)hipFree(B->data);
-    }
+    // hipFree waits for outstanding device work itself; the context may already be finalized.
+    if (B->own && B->data) (void)hipFree(B->data);
     delete B;
     return LK_OK;
 }
@@ -781,7 +779,7 @@ int lk_linop_lap5_create(lk_context_t c, int64_t N, lk_linop_t *op) {
 
 int lk_linop_destroy(lk_linop_t op) {
     if (!op) return LK_OK;
-    if (op->dev) { (void)hipStreamSynchronize(op->ctx->stream); (void)hipFree(op->dev); }
+    if (op->dev) (void)hipFree(op->dev);  // synchronises; the context may already be finalized
     delete op;
     return LK_OK;
 }

@@ -1,0 +1,169 @@
+"""Host logic of lightkrylov_amd without a GPU: the generic abstract_vector path of
+double_gram_schmidt_step / qr / arnoldi / lanczos / gmres / eigs / krylov_schur, driven with the
+test-only oracle-backed vector type, must reproduce the oracle's own restatement of the reference
+drivers (same arithmetic underneath, so agreement is to rounding of the host LAPACK calls)."""
+import numpy as np
+import pytest
+
+import lightkrylov_amd as lk
+from oracle import oracle as ora
+from tests._oracle_vector import oracle_dense_linop, oracle_diag_linop, oracle_lap5_linop, oracle_vector
+
+
+def seeded(n, dtype, seed):
+    x = np.empty(n, dtype=dtype)
+    ora.fill_counter(x, seed)
+    return x
+
+
+def list_basis(n, ncols, dtype):
+    return [oracle_vector(np.zeros(n, dtype=dtype)) for _ in range(ncols)]
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_generic_arnoldi_equals_oracle(dtype):
+    n, m = 500, 20
+    d = (1.0 + np.arange(n) / n).astype(dtype)
+    x0 = seeded(n, dtype, 7); x0 /= np.linalg.norm(x0)
+    X = list_basis(n, m + 1, dtype); X[0].data[:] = x0
+    H = np.zeros((m + 1, m), dtype=dtype, order="F")
+    A = oracle_diag_linop(d)
+    assert lk.arnoldi(A, X, H) == 0 and A.matvec_counter == m
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.arnoldi(ora.DiagOp(d), Xo, Ho) == 0
+    assert np.array_equal(H, Ho)                               # same arithmetic, same order => bit-exact
+    assert all(np.array_equal(X[j].data, Xo[:, j]) for j in range(m + 1))
+
+
+def test_generic_block_arnoldi_invariants():
+    """test/TestKrylov.fypp:244-296 (blksize = 2)."""
+    n, kdim, p = 128, 10, 2
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((n, n))
+    X = list_basis(n, (kdim + 1) * p, np.float64)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, p)))
+    for i in range(p):
+        X[i].data[:] = Q[:, i]
+    H = np.zeros(((kdim + 1) * p, kdim * p), order="F")
+    assert lk.arnoldi(oracle_dense_linop(A), X, H, blksize=p) == 0
+    Xm = np.stack([x.data for x in X], axis=1)
+    assert np.abs(A @ Xm[:, :kdim * p] - Xm @ H).max() < 1e-12
+    assert np.abs(Xm.T @ Xm - np.eye((kdim + 1) * p)).max() < 1e-13
+
+
+def test_dgs_checks_and_beta_shape():
+    n, k = 200, 6
+    Q, _ = np.linalg.qr(np.random.default_rng(1).standard_normal((n, k)))
+    X = [oracle_vector(Q[:, j].copy()) for j in range(k)]
+    y = oracle_vector(seeded(n, np.float64, 3))
+    yo = y.data.copy()
+    beta = np.zeros(k)
+    assert lk.double_gram_schmidt_step(y, X, beta=beta) == 0           # default orthonormality check passes
+    ho, _ = ora.double_gram_schmidt_step(yo, np.asfortranarray(Q))
+    assert np.array_equal(beta, ho) and np.array_equal(y.data, yo)
+    with pytest.raises(ValueError):
+        lk.double_gram_schmidt_step(y, X, False, beta=np.zeros(k + 1))
+    X[0].scal(3.0)
+    with pytest.raises(RuntimeError, match="not orthonormal"):
+        lk.double_gram_schmidt_step(y, X)
+    z = oracle_vector(np.zeros(n))
+    X[0].scal(1.0 / 3.0)
+    assert lk.double_gram_schmidt_step(z, X, False) == 1
+
+
+def test_qr_rank_deficient_column_is_flagged():
+    """qr.fypp:146-162: a colinear column sets info = j, R(j,j) = 0 and is replaced by a random direction."""
+    n = 100
+    a = seeded(n, np.float64, 1)
+    Q = [oracle_vector(a.copy()), oracle_vector(2.0 * a), oracle_vector(seeded(n, np.float64, 2))]
+    R = np.zeros((3, 3), order="F")
+    assert lk.qr(Q, R) == 2 and R[1, 1] == 0.0
+    Qm = np.stack([q.data for q in Q], axis=1)
+    assert np.abs(Qm.T @ Qm - np.eye(3)).max() < 1e-13
+
+
+def test_generic_lanczos_equals_oracle():
+    n = 64
+    A = 2.5 * np.eye(n) + 0.8 * (np.eye(n, k=1) + np.eye(n, k=-1))
+    x0 = seeded(n, np.float64, 5); x0 /= np.linalg.norm(x0)
+    X = list_basis(n, n + 1, np.float64); X[0].data[:] = x0
+    T = np.zeros((n + 1, n), order="F")
+    info = lk.lanczos(oracle_dense_linop(A), X, T)
+    Xo = np.zeros((n, n + 1), order="F"); Xo[:, 0] = x0
+    To = np.zeros((n + 1, n), order="F")
+    assert info == ora.lanczos(ora.DenseOp(A), Xo, To)
+    assert np.array_equal(T, To)
+
+
+def test_generic_gmres_equals_oracle():
+    N = 24
+    n = N * N
+    b = seeded(n, np.float64, 11)
+    x = oracle_vector(np.zeros(n))
+    meta = lk.gmres_dp_metadata()
+    A = oracle_lap5_linop(N)
+    info = lk.gmres(A, oracle_vector(b.copy()), x, rtol=1e-8, options=lk.gmres_dp_opts(kdim=30, maxiter=2), meta=meta)
+    xo = np.zeros(n)
+    info_o, res_o = ora.gmres(ora.Lap5Op(N), b, xo, rtol=1e-8, kdim=30, maxiter=2)
+    assert info == info_o and meta.n_iter == abs(info)
+    np.testing.assert_allclose(meta.res, res_o, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(x.data, xo, rtol=1e-12, atol=1e-300)
+    # info sign convention (gmres.fypp:234-238): converged => +n_iter
+    x2 = oracle_vector(np.zeros(n))
+    assert lk.gmres(A, oracle_vector(b.copy()), x2, rtol=1e-6, options=lk.gmres_dp_opts(kdim=60, maxiter=20)) > 0
+    r = np.empty(n); ora.Lap5Op(N).matvec(x2.data, r)
+    assert np.linalg.norm(r - b) < 1e-6 * np.linalg.norm(b) * 1.01
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_generic_eigs_equals_oracle_and_known_answer(dtype):
+    n = 128
+    if np.dtype(dtype).kind == "c":
+        A = np.zeros((n, n), dtype=dtype)
+        for i in range(1, n + 1):
+            A[i - 1, i - 1] = n
+            if i < n:
+                A[i - 1, i] = 1j * np.sqrt(1.0 * i * (n - i)); A[i, i - 1] = -A[i - 1, i]
+    else:
+        A = 0.37 * np.eye(n) + 0.61 * np.eye(n, k=1) - 0.61 * np.eye(n, k=-1)
+    nev, kdim = 6, 40
+    x0 = seeded(n, dtype, 3)
+    X = list_basis(n, nev, dtype)
+    vals, res, info = lk.eigs(oracle_dense_linop(A), X, x0=oracle_vector(x0.copy()), kdim=kdim, tolerance=1e-10)
+    vo, ro, Vo, info_o = ora.eigs(ora.DenseOp(A), x0, nev, kdim, 1e-10)
+    assert info == info_o
+    np.testing.assert_allclose(vals, vo, rtol=1e-12)
+    np.testing.assert_allclose(res, ro, rtol=1e-6, atol=1e-14)
+    V = np.stack([x.data for x in X], axis=1)
+    np.testing.assert_allclose(V, Vo, rtol=1e-9, atol=1e-12)
+    exact = np.linalg.eigvals(A)
+    for lam in vals:
+        assert np.abs(exact - lam).min() < 1e-9 * np.abs(exact).max()
+
+
+def test_krylov_schur_residual():
+    """test/TestKrylov.fypp:298-347: after the restart A X(:n) = X(:n+1) H(:n+1, :n) still holds."""
+    n, kdim = 128, 32
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    X = list_basis(n, kdim + 1, np.float64)
+    x0 = seeded(n, np.float64, 8); X[0].data[:] = x0 / np.linalg.norm(x0)
+    H = np.zeros((kdim + 1, kdim), order="F")
+    op = oracle_dense_linop(A)
+    assert lk.arnoldi(op, X, H) == 0
+    nsel = lk.krylov_schur(X, H, lambda lam: np.abs(lam) > np.median(np.abs(lam)))
+    assert 0 < nsel < kdim
+    Xm = np.stack([x.data for x in X], axis=1)
+    assert np.abs(A @ Xm[:, :nsel] - Xm[:, :nsel + 1] @ H[:nsel + 1, :nsel]).max() < 1e-12
+    assert np.abs(Xm[:, :nsel + 1].T @ Xm[:, :nsel + 1] - np.eye(nsel + 1)).max() < 1e-12
+    assert not Xm[:, nsel + 1:].any()
+
+
+def test_row_partition_covers_every_row_once():
+    for n in (0, 1, 7, 10, 10**8, 10**8 + 3):
+        for P in (1, 2, 3, 4, 8):
+            blocks = [lk.row_partition(n, P, r) for r in range(P)]
+            assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == n
+            for (r0, nl), (r1, _) in zip(blocks, blocks[1:]):
+                assert r0 + nl == r1 and nl % 2 == 0
