@@ -144,7 +144,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    n_sweeps, sweep_ms, sweep_bytes = ctx.profile_get("dgs_sweep")
+    n_sweeps, sweep_ms, sweep_bytes = ctx.profile_get("dgs_sweep*")
     n_dgs, dgs_ms, dgs_bytes = ctx.profile_get("dgs")
     n_mv, mv_ms, _ = ctx.profile_get("matvec")
 

@@ -81,11 +81,14 @@ int lk_set_allreduce(lk_context_t ctx, lk_allreduce_fn fn, void *user, int nrank
 /* row block owned by this rank: global rows [row0, row0 + n_local) of n_global; only used
  * so that counter-based rand fills are identical for every partition. */
 int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
-/* tuning knobs (integers): "grid_mult" blocks per CU for the panel sweeps. */
+/* tuning knobs (integers): "grid_mult" / "update_grid_mult" blocks per CU for the panel sweeps,
+ * "prefetch" (sweep 2 register double-buffering), "stream_update" (barrier-free sweep 3),
+ * "defer_store" (write y one tile late). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
 
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg).
- * tags: "dgs_sweep" (the panel sweep kernel), "dgs" (whole lk_dgs call), "matvec", "blas1". */
+ * tags: "dgs_sweep1|2|3" (the three panel sweeps; "dgs_sweep*" sums them -- a trailing '*' is a
+ * prefix match), "dgs" (whole lk_dgs call), "matvec", "blas1". */
 int lk_profile_enable(lk_context_t ctx, int on);
 int lk_profile_get(lk_context_t ctx, const char *tag, int64_t *count, double *total_ms,
                    double *total_bytes);

@@ -60,6 +60,10 @@ struct lk_context_s {
     bool own_stream = false;
     int num_cu = 256;
     int grid_mult = 2;  // sweep blocks per CU
+    int prefetch = 0;   // sweep 2: issue the next tile's loads before the barrier (A/B: no gain)
+    int stream_update = 1;  // sweep 3 / lincomb: barrier-free streaming kernel
+    int update_grid_mult = 4;
+    int defer_store = 0; // sweeps 2/3: write y' one tile late, after the next tile's loads are issued (A/B: no gain)
     // reduction workspace
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
     double *red = nullptr;      // device results: 3 sections of (KMAX_FUSED+1)*2 doubles
@@ -172,8 +176,8 @@ int check_pair(lk_basis_t A, lk_basis_t B, const char *what) {
 }
 
 int allreduce(lk_context_t c, double *dev, int64_t count) {
-    if (c->nranks > 1) {
-        if (!c->allreduce) return fail(LK_ERR_COMM, "nranks=%d but no all-reduce installed", c->nranks);
+    if (c->nranks > 1 && !c->allreduce) return fail(LK_ERR_COMM, "nranks=%d but no all-reduce installed", c->nranks);
+    if (c->allreduce) {
         int rc = c->allreduce(c->allreduce_user, dev, count, (void *)c->stream);
         if (rc != 0) return fail(LK_ERR_COMM, "all-reduce callback returned %d", rc);
     }
@@ -214,17 +218,33 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
     static_assert(KC * NW == KMAX_FUSED, "fused capacity");
     SweepCfg s = sweep_cfg<CPLX, KC, NW>(c, k, n);
     const double bytes = (double)n * ED * 8.0 * (k + 1 + (UPDATE ? 1 : 0));
+    int nblocks = s.grid;
     {
-        ProfScope ps(c, "dgs_sweep", bytes);
-        hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X, ldx, k,
-                           y, n, hin, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw);
+        ProfScope ps(c, !UPDATE ? "dgs_sweep1" : (DOT ? "dgs_sweep2" : "dgs_sweep3"), bytes);
+        if (UPDATE && !DOT && c->stream_update) {
+            const int64_t tile_rows = (int64_t)NW * 64 * K<CPLX>::ROWS;
+            int64_t g = (n + tile_rows - 1) / tile_rows;
+            const int64_t cap = (int64_t)c->num_cu * c->update_grid_mult;
+            if (g > cap) g = cap;
+            if (g > MAX_GRID) g = MAX_GRID;
+            if (g < 1) g = 1;
+            nblocks = (int)g;
+            hipLaunchKernelGGL((panel_update<CPLX, KC, NW>), dim3(nblocks), dim3(NW * 64), 0, c->stream, X, ldx, k, y, n, hin,
+                               c->partial, (int64_t)MAX_GRID, c->defer_store);
+        } else if (UPDATE && DOT && c->prefetch) {
+            hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, UPDATE && DOT>), dim3(s.grid), dim3(NW * 64), 0, c->stream,
+                               X, ldx, k, y, n, hin, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, c->defer_store);
+        } else {
+            hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, false>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X, ldx,
+                               k, y, n, hin, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, c->defer_store);
+        }
     }
     HIPCHK(hipGetLastError());
     // slots: DOT -> 0..k*ED-1 valid; norm at slot k*ED.  Without DOT only the norm slot is defined.
     const int first = DOT ? 0 : k * ED;
     const int nslots = (k + 1) * ED - first;
     hipLaunchKernelGGL(finish_partials, dim3((nslots + 3) / 4), dim3(256), 0, c->stream,
-                       c->partial + (int64_t)first * MAX_GRID, (int64_t)MAX_GRID, s.grid, nslots, out + first);
+                       c->partial + (int64_t)first * MAX_GRID, (int64_t)MAX_GRID, nblocks, nslots, out + first);
     HIPCHK(hipGetLastError());
     return allreduce(c, out + first, nslots);
 }
@@ -398,6 +418,14 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         c->grid_mult = value;
         return LK_OK;
     }
+    if (!strcmp(key, "prefetch")) { c->prefetch = value != 0; return LK_OK; }
+    if (!strcmp(key, "stream_update")) { c->stream_update = value != 0; return LK_OK; }
+    if (!strcmp(key, "defer_store")) { c->defer_store = value != 0; return LK_OK; }
+    if (!strcmp(key, "update_grid_mult")) {
+        if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "update_grid_mult must be in [1,16]");
+        c->update_grid_mult = value;
+        return LK_OK;
+    }
     return fail(LK_ERR_INVALID, "lk_set_tuning: unknown key '%s'", key);
 }
 
@@ -419,8 +447,15 @@ int lk_profile_get(lk_context_t c, const char *tag, int64_t *count, double *tota
     if (!c || !tag) return fail(LK_ERR_INVALID, "null argument");
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
-    auto it = c->prof_acc.find(tag);
-    ProfAcc a = it == c->prof_acc.end() ? ProfAcc() : it->second;
+    ProfAcc a;
+    const size_t len = strlen(tag);
+    if (len > 0 && tag[len - 1] == '*') {   // prefix match: "dgs_sweep*" sums the three sweep kinds
+        for (auto &kv : c->prof_acc)
+            if (kv.first.compare(0, len - 1, tag, len - 1) == 0) { a.count += kv.second.count; a.ms += kv.second.ms; a.bytes += kv.second.bytes; }
+    } else {
+        auto it = c->prof_acc.find(tag);
+        if (it != c->prof_acc.end()) a = it->second;
+    }
     if (count) *count = a.count;
     if (total_ms) *total_ms = a.ms;
     if (total_bytes) *total_bytes = a.bytes;

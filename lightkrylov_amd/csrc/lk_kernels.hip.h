@@ -63,12 +63,83 @@ __device__ __forceinline__ double u01(uint64_t seed, uint64_t ctr) {
 //
 // partial layout: partial[slot * pstride + blockIdx.x], slots 0..k-1 = h, slot k = nrm2.
 // =====================================================================================
-template <bool CPLX, int KC, int NW, bool UPDATE, bool DOT>
+// One wave's slice of a tile: y (ROWS rows per lane) and the lane's rows of columns [0, nc) of Xw.
+// `full` (block-uniform) selects the unguarded 16-byte path; the ragged last tile is guarded
+// element-wise and zero filled.
+template <bool CPLX>
+__device__ __forceinline__ v2d load_y(const double *__restrict__ y, int64_t r, int64_t n, bool full) {
+    if (full) return *reinterpret_cast<const v2d *>(y + r * K<CPLX>::ELEM_DOUBLES);
+    if constexpr (CPLX) {
+        return (r < n) ? *reinterpret_cast<const v2d *>(y + r * 2) : v2d{0.0, 0.0};
+    } else {
+        v2d yv;
+        yv.x = (r < n) ? y[r] : 0.0;
+        yv.y = (r + 1 < n) ? y[r + 1] : 0.0;
+        return yv;
+    }
+}
+
+template <bool CPLX, int KC>
+__device__ __forceinline__ void load_cols(const double *__restrict__ Xw, int64_t colstride, int64_t r, int64_t n,
+                                          bool full, int nc, v2d (&xv)[KC]) {
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    if (full) {
+        if (nc == KC) {
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj)
+                xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Xw + jj * colstride + r * ED));
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) {
+                if (jj < nc)
+                    xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Xw + jj * colstride + r * ED));
+                else xv[jj] = v2d{0.0, 0.0};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) {
+            xv[jj] = v2d{0.0, 0.0};
+            if (jj < nc) {
+                const double *p = Xw + jj * colstride;
+                if constexpr (CPLX) {
+                    if (r < n) xv[jj] = *reinterpret_cast<const v2d *>(p + r * 2);
+                } else {
+                    if (r < n) xv[jj].x = p[r];
+                    if (r + 1 < n) xv[jj].y = p[r + 1];
+                }
+            }
+        }
+    }
+}
+
+template <bool CPLX, int KC>
+__device__ __forceinline__ void load_tile(const double *__restrict__ Xw, int64_t colstride, const double *__restrict__ y,
+                                          int64_t r, int64_t n, bool full, int nc, v2d (&xv)[KC], v2d &yv) {
+    yv = load_y<CPLX>(y, r, n, full);
+    load_cols<CPLX, KC>(Xw, colstride, r, n, full, nc, xv);
+}
+
+template <bool CPLX>
+__device__ __forceinline__ void store_rows(double *__restrict__ y, int64_t r, int64_t n, bool full, v2d yv) {
+    if (full) {
+        *reinterpret_cast<v2d *>(y + r * K<CPLX>::ELEM_DOUBLES) = yv;
+    } else if constexpr (CPLX) {
+        if (r < n) *reinterpret_cast<v2d *>(y + r * 2) = yv;
+    } else {
+        if (r < n) y[r] = yv.x;
+        if (r + 1 < n) y[r + 1] = yv.y;
+    }
+}
+
+// PREFETCH: the next tile's loads are issued BEFORE the current tile's LDS exchange + barrier, so
+// HBM requests stay in flight while the block synchronises (costs a second register tile).
+template <bool CPLX, int KC, int NW, bool UPDATE, bool DOT, bool PREFETCH>
 __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict__ X, int64_t ldx, int k,
                                                         double *__restrict__ y, int64_t n,
                                                         const double *__restrict__ hin,
                                                         double *__restrict__ partial, int64_t pstride,
-                                                        int WC, int kcw) {
+                                                        int WC, int kcw, int defer) {
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;  // rows one wave covers per tile
@@ -107,48 +178,34 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
     const double *Xw = X + (int64_t)c0 * ldx * ED;
     const int64_t colstride = ldx * ED;  // doubles between consecutive columns
+    const int64_t roff = (int64_t)wr * WROWS + (int64_t)lane * ROWS;
     int buf = 0;
 
+    v2d xv[KC], xn[KC];
+    v2d yv, yn;
+    // Optional deferred store (`defer`): y'(t) is written one iteration late, right AFTER the next
+    // tile's loads have been issued (vmcnt retires in order, so a store issued before those loads must
+    // be acknowledged before the wave may touch the loaded tile).  Interleaved A/B on MI355X: within
+    // +-1% of the immediate store for every k and kind (tuning log) -- kept as a knob, off.
+    v2d ypend = v2d{0.0, 0.0};
+    int64_t rpend = 0;
+    bool fullpend = false, have_pend = false;
+    if constexpr (PREFETCH) {
+        const int64_t t0 = blockIdx.x;
+        if (t0 < ntiles) load_tile<CPLX, KC>(Xw, colstride, y, t0 * tile_rows + roff, n, (t0 + 1) * tile_rows <= n, nc, xv, yv);
+    }
+
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t r = t * tile_rows + (int64_t)wr * WROWS + (int64_t)lane * ROWS;  // first row of this lane
-        const bool full = (t + 1) * tile_rows <= n;  // block-uniform
-        v2d xv[KC];
-        v2d yv;
-        if (full) {
-            yv = *reinterpret_cast<const v2d *>(y + r * ED);
-            if (nc == KC) {
-#pragma unroll
-                for (int jj = 0; jj < KC; ++jj)
-                    xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Xw + jj * colstride + r * ED));
-            } else {
-#pragma unroll
-                for (int jj = 0; jj < KC; ++jj) {
-                    if (jj < nc)
-                        xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Xw + jj * colstride + r * ED));
-                    else xv[jj] = v2d{0.0, 0.0};
-                }
-            }
+        const int64_t r = t * tile_rows + roff;        // first row of this lane
+        const bool full = (t + 1) * tile_rows <= n;   // block-uniform
+        if constexpr (PREFETCH) {
+            const int64_t tn = t + gridDim.x;
+            if (tn < ntiles) load_tile<CPLX, KC>(Xw, colstride, y, tn * tile_rows + roff, n, (tn + 1) * tile_rows <= n, nc, xn, yn);
         } else {
-            // ragged last tile: element-wise guards, zero fill
-            if constexpr (CPLX) {
-                yv = (r < n) ? *reinterpret_cast<const v2d *>(y + r * 2) : v2d{0.0, 0.0};
-            } else {
-                yv.x = (r < n) ? y[r] : 0.0;
-                yv.y = (r + 1 < n) ? y[r + 1] : 0.0;
-            }
-#pragma unroll
-            for (int jj = 0; jj < KC; ++jj) {
-                xv[jj] = v2d{0.0, 0.0};
-                if (jj < nc) {
-                    const double *p = Xw + jj * colstride;
-                    if constexpr (CPLX) {
-                        if (r < n) xv[jj] = *reinterpret_cast<const v2d *>(p + r * 2);
-                    } else {
-                        if (r < n) xv[jj].x = p[r];
-                        if (r + 1 < n) xv[jj].y = p[r + 1];
-                    }
-                }
-            }
+            load_tile<CPLX, KC>(Xw, colstride, y, r, n, full, nc, xv, yv);
+        }
+        if constexpr (UPDATE) {
+            if (have_pend && wc == 0) store_rows<CPLX>(y, rpend, n, fullpend, ypend);
         }
 
         if constexpr (UPDATE) {
@@ -168,18 +225,8 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
                 buf ^= 1;
             }
             yv -= u;
-            if (wc == 0) {
-                if (full) {
-                    *reinterpret_cast<v2d *>(y + r * ED) = yv;
-                } else {
-                    if constexpr (CPLX) {
-                        if (r < n) *reinterpret_cast<v2d *>(y + r * 2) = yv;
-                    } else {
-                        if (r < n) y[r] = yv.x;
-                        if (r + 1 < n) y[r + 1] = yv.y;
-                    }
-                }
-            }
+            if (defer) { ypend = yv; rpend = r; fullpend = full; have_pend = true; }
+            else if (wc == 0) store_rows<CPLX>(y, r, n, full, yv);
         }
         if constexpr (DOT) {
 #pragma unroll
@@ -189,6 +236,15 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
             }
         }
         if (wc == 0) nrm += yv.x * yv.x + yv.y * yv.y;
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) xv[jj] = xn[jj];
+            yv = yn;
+        }
+    }
+
+    if constexpr (UPDATE) {
+        if (have_pend && wc == 0) store_rows<CPLX>(y, rpend, n, fullpend, ypend);
     }
 
     // ---- block reduction: lanes (shuffle) -> waves sharing a column set (LDS) -> partial
@@ -225,6 +281,67 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
         double s = 0.0;
         for (int w = 0; w < WR; ++w) s += red_lds[(w * WC) * SLOTS + KC * ED];
         partial[((int64_t)k * ED) * pstride + blockIdx.x] = s;
+        if constexpr (CPLX) partial[((int64_t)k * ED + 1) * pstride + blockIdx.x] = 0.0;
+    }
+}
+
+// Streaming update y <- y - X(:, :k) * hin with ||y_out||^2: no dots, so nothing has to stay in
+// registers and every wave can walk ALL k columns of its own rows in chunks of KC -- no LDS
+// exchange, no barrier in the loop.  Used for DGS sweep 3 and for linear_combination.
+template <bool CPLX, int KC, int NW>
+__global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict__ X, int64_t ldx, int k,
+                                                         double *__restrict__ y, int64_t n,
+                                                         const double *__restrict__ hin,
+                                                         double *__restrict__ partial, int64_t pstride, int defer) {
+    constexpr int ROWS = K<CPLX>::ROWS;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int WROWS = 64 * ROWS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile_rows = (int64_t)NW * WROWS;
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const int64_t colstride = ldx * ED;
+    double nrm = 0.0;
+    __shared__ double red_lds[NW];
+    v2d ypend = v2d{0.0, 0.0};   // deferred store, see panel_sweep
+    int64_t rpend = 0;
+    bool fullpend = false, have_pend = false;
+
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t r = t * tile_rows + (int64_t)wave * WROWS + (int64_t)lane * ROWS;
+        const bool full = (t + 1) * tile_rows <= n;
+        v2d u = v2d{0.0, 0.0};
+        v2d yv = load_y<CPLX>(y, r, n, full);
+        for (int c0 = 0; c0 < k; c0 += KC) {
+            int nc = k - c0;
+            nc = nc > KC ? KC : nc;
+            v2d xv[KC];
+            load_cols<CPLX, KC>(X + (int64_t)c0 * colstride, colstride, r, n, full, nc, xv);
+            if (c0 == 0 && have_pend) {
+                store_rows<CPLX>(y, rpend, n, fullpend, ypend);
+                have_pend = false;
+            }
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) {
+                if (jj < nc) {
+                    if constexpr (CPLX) u += cmul(xv[jj], v2d{hin[2 * (c0 + jj)], hin[2 * (c0 + jj) + 1]});
+                    else u += xv[jj] * hin[c0 + jj];
+                }
+            }
+        }
+        yv -= u;
+        if (defer) { ypend = yv; rpend = r; fullpend = full; have_pend = true; }
+        else store_rows<CPLX>(y, r, n, full, yv);
+        nrm += yv.x * yv.x + yv.y * yv.y;
+    }
+    if (have_pend) store_rows<CPLX>(y, rpend, n, fullpend, ypend);
+    const double s = wave_sum(nrm);
+    if (lane == 0) red_lds[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < NW; ++w) tot += red_lds[w];
+        partial[((int64_t)k * ED) * pstride + blockIdx.x] = tot;
         if constexpr (CPLX) partial[((int64_t)k * ED + 1) * pstride + blockIdx.x] = 0.0;
     }
 }
