@@ -1,0 +1,249 @@
+!> LightKrylov plugin: `dense_vector_gpu_rdp` / `dense_linop_gpu_rdp` extend LightKrylov's
+!> `abstract_vector_rdp` / `abstract_linop_rdp` (src/AbstractTypes/AbstractVectors.fypp:295-381,
+!> src/AbstractTypes/AbstractLinops.fypp:58-87) on top of the C ABI in
+!> include/lightkrylov_hip.h, so that `arnoldi`, `gmres`, `eigs`, ... of an UNCHANGED LightKrylov
+!> run their O(n) work on the MI355X.
+!>
+!> Build: compile AFTER LightKrylov's own modules (needs LightKrylov + fortran-lang/stdlib; this
+!> image has neither stdlib nor fpm, so this file is NOT compiled by __graft_entry__.build(); the
+!> ISO_C_BINDING layer it relies on, fortran/lk_hip_iso_c.f90, is compiled and run on the GPU by
+!> tests/test_fortran_binding.py).  See INTEGRATION.md for the fpm stanza.
+!>
+!> Object semantics (probed with flang 22, SURVEY.md Appendix B).  The reference creates vectors by
+!> sourced allocation (`allocate(V(kdim+1), source=b)`, gmres.fypp:110-113; IterativeSolvers.fypp:1032),
+!> which BIT-COPIES components with no hook, by polymorphic assignment (`wrk = V(k)`, gmres.fypp:155)
+!> and by passing to `intent(out)` dummies (`matvec`'s vec_out, `copy`'s out).  Hence:
+!>   * the device handle is a plain `type(c_ptr)` component WITHOUT default initialisation and the
+!>     type has NO `final` procedure (an intent(out) dummy then keeps its buffer; nothing is freed
+!>     behind our back; bit-copies cannot double free);
+!>   * every handle remembers the address of the Fortran object that owns it (`owner`).  A mutating
+!>     call through an object whose address differs from `owner` has found a bit-copy: it takes a
+!>     fresh device vector first (copying the contents only if the operation reads them);
+!>   * device memory is reclaimed explicitly with `lk_gpu_release_all()` after a solver call (the
+!>     reference never frees vectors explicitly either; it relies on automatic deallocation).
+!> This per-object path drives one BLAS-1 kernel per type-bound call, i.e. the reference's own
+!> schedule of k dots + k axpbys per Gram-Schmidt pass.  The fused three-sweep DGS is reached from
+!> Fortran through `lk_dgs` / `lk_arnoldi` on a panel (`gpu_arnoldi_rdp` below).
+module lightkrylov_gpu
+    use, intrinsic :: iso_c_binding
+    use lightkrylov_hip_c
+    use LightKrylov_Constants, only: dp
+    use LightKrylov_Logger, only: stop_error, type_error
+    use LightKrylov_AbstractVectors, only: abstract_vector_rdp
+    use LightKrylov_AbstractLinops, only: abstract_linop_rdp
+    implicit none
+    private
+    character(len=*), parameter :: this_module = 'LK_GPU'
+
+    public :: dense_vector_gpu_rdp, dense_linop_gpu_rdp
+    public :: lk_gpu_init, lk_gpu_finalize, lk_gpu_release_all, gpu_arnoldi_rdp
+
+    type(c_ptr), save :: ctx = c_null_ptr
+    ! every device vector handed out since the last release (1-column bases)
+    type(c_ptr), allocatable, save :: pool(:)
+    integer, save :: npool = 0
+
+    type, extends(abstract_vector_rdp) :: dense_vector_gpu_rdp
+        integer :: n                        !! number of (local) rows; set by the user like dense_vector%n
+        type(c_ptr) :: buf                  !! 1-column basis handle; NO default init, NO final (see above)
+        integer(c_intptr_t) :: owner        !! loc() of the object this handle was bound to
+        integer :: magic                    !! = MAGIC once `buf` is a live handle
+    contains
+        procedure, pass(self) :: zero => gpu_zero
+        procedure, pass(self) :: rand => gpu_rand
+        procedure, pass(self) :: scal => gpu_scal
+        procedure, pass(self) :: axpby => gpu_axpby
+        procedure, pass(self) :: dot => gpu_dot
+        procedure, pass(self) :: get_size => gpu_get_size
+        procedure, pass(self) :: upload => gpu_upload
+        procedure, pass(self) :: download => gpu_download
+    end type
+
+    !> dense_linop on the device (AbstractLinops.fypp:265-271, 608-660)
+    type, extends(abstract_linop_rdp) :: dense_linop_gpu_rdp
+        type(c_ptr) :: op = c_null_ptr
+    contains
+        procedure, pass(self) :: matvec => gpu_dense_matvec
+        procedure, pass(self) :: rmatvec => gpu_dense_rmatvec
+    end type
+
+    integer, parameter :: MAGIC = 1263225675
+
+contains
+
+    subroutine lk_gpu_init(device)
+        integer, intent(in) :: device
+        call chk(lk_init(int(device, c_int), c_null_ptr, ctx), 'lk_gpu_init')
+        allocate (pool(1024)); npool = 0
+    end subroutine
+
+    subroutine lk_gpu_release_all()
+        integer :: i
+        integer(c_int) :: rc
+        do i = 1, npool
+            rc = lk_basis_destroy(pool(i))
+        end do
+        npool = 0
+    end subroutine
+
+    subroutine lk_gpu_finalize()
+        integer(c_int) :: rc
+        call lk_gpu_release_all()
+        rc = lk_finalize(ctx); ctx = c_null_ptr
+    end subroutine
+
+    subroutine chk(rc, procedure)
+        integer(c_int), intent(in) :: rc
+        character(len=*), intent(in) :: procedure
+        ! non-zero status => LightKrylov's fatal path (Logger.f90:290-298): log_error + STOP 1
+        if (rc /= LK_OK) call stop_error(lk_error_message(), this_module, procedure)
+    end subroutine
+
+    !> Make sure `self` owns a private device vector; keep=.true. preserves the current contents.
+    subroutine bind(self, keep)
+        class(dense_vector_gpu_rdp), intent(inout), target :: self
+        logical, intent(in) :: keep
+        type(c_ptr) :: fresh, old
+        type(c_ptr), allocatable :: grown(:)
+        logical :: live
+        live = (self%magic == MAGIC)
+        if (live .and. self%owner == transfer(c_loc(self%n), self%owner)) return
+        call chk(lk_basis_create(ctx, LK_F64, int(self%n, c_int64_t), 1_c_int, fresh), 'bind')
+        if (live .and. keep) then
+            old = self%buf
+            call chk(lk_vec_copy(fresh, 0_c_int, old, 0_c_int), 'bind')
+        end if
+        if (npool == size(pool)) then
+            allocate (grown(2*npool)); grown(:npool) = pool; call move_alloc(grown, pool)
+        end if
+        npool = npool + 1; pool(npool) = fresh
+        self%buf = fresh; self%owner = transfer(c_loc(self%n), self%owner); self%magic = MAGIC
+    end subroutine
+
+    subroutine gpu_zero(self)
+        class(dense_vector_gpu_rdp), intent(inout) :: self
+        call bind(self, .false.)
+        call chk(lk_vec_zero(self%buf, 0_c_int), 'zero')
+    end subroutine
+
+    subroutine gpu_rand(self, ifnorm)
+        class(dense_vector_gpu_rdp), intent(inout) :: self
+        logical, optional, intent(in) :: ifnorm
+        integer(c_int) :: nrm
+        integer(c_int64_t), save :: seed = 1
+        nrm = 0; if (present(ifnorm)) nrm = merge(1_c_int, 0_c_int, ifnorm)
+        call bind(self, .false.)
+        seed = seed + 1
+        call chk(lk_vec_rand(self%buf, 0_c_int, seed, 0_c_int64_t, nrm), 'rand')
+    end subroutine
+
+    subroutine gpu_scal(self, alpha)
+        class(dense_vector_gpu_rdp), intent(inout) :: self
+        real(dp), intent(in) :: alpha
+        call bind(self, .true.)
+        call chk(lk_vec_scal(self%buf, 0_c_int, [alpha]), 'scal')
+    end subroutine
+
+    subroutine gpu_axpby(alpha, vec, beta, self)
+        real(dp), intent(in) :: alpha, beta
+        class(abstract_vector_rdp), intent(in) :: vec
+        class(dense_vector_gpu_rdp), intent(inout) :: self
+        select type (vec)
+        type is (dense_vector_gpu_rdp)
+            if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'axpby')
+            call bind(self, beta /= 0.0_dp)      ! beta == 0: old contents are not read (true axpby)
+            call chk(lk_vec_axpby([alpha], vec%buf, 0_c_int, [beta], self%buf, 0_c_int), 'axpby')
+        class default
+            call type_error('vec', 'dense_vector_gpu_rdp', 'IN', this_module, 'axpby')
+        end select
+    end subroutine
+
+    function gpu_dot(self, vec) result(alpha)
+        class(dense_vector_gpu_rdp), intent(in) :: self
+        class(abstract_vector_rdp), intent(in) :: vec
+        real(dp) :: alpha
+        real(c_double) :: res(2)
+        alpha = 0.0_dp
+        select type (vec)
+        type is (dense_vector_gpu_rdp)
+            call chk(lk_vec_dot(self%buf, 0_c_int, vec%buf, 0_c_int, res), 'dot')
+            alpha = res(1)
+        class default
+            call type_error('vec', 'dense_vector_gpu_rdp', 'IN', this_module, 'dot')
+        end select
+    end function
+
+    function gpu_get_size(self) result(n)
+        class(dense_vector_gpu_rdp), intent(in) :: self
+        integer :: n
+        n = self%n
+    end function
+
+    subroutine gpu_upload(self, x)
+        class(dense_vector_gpu_rdp), intent(inout) :: self
+        real(dp), intent(in), target :: x(:)
+        self%n = size(x)
+        call bind(self, .false.)
+        call chk(lk_basis_upload(self%buf, 0_c_int, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'upload')
+    end subroutine
+
+    subroutine gpu_download(self, x)
+        class(dense_vector_gpu_rdp), intent(in) :: self
+        real(dp), intent(out), target :: x(:)
+        call chk(lk_basis_download(self%buf, 0_c_int, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'download')
+    end subroutine
+
+    ! ---- dense_linop on the device -----------------------------------------------------------
+    subroutine apply_dense(self, trans, vec_in, vec_out, procedure)
+        class(dense_linop_gpu_rdp), intent(inout) :: self
+        integer(c_int), intent(in) :: trans
+        class(abstract_vector_rdp), intent(in) :: vec_in
+        class(abstract_vector_rdp), intent(out) :: vec_out     ! intent(out): components keep their bits (no default init)
+        character(len=*), intent(in) :: procedure
+        select type (vec_in)
+        type is (dense_vector_gpu_rdp)
+            select type (vec_out)
+            type is (dense_vector_gpu_rdp)
+                vec_out%n = vec_in%n
+                call bind(vec_out, .false.)
+                call chk(lk_linop_apply(self%op, trans, vec_in%buf, 0_c_int, vec_out%buf, 0_c_int), procedure)
+            class default
+                call type_error('vec_out', 'dense_vector_gpu_rdp', 'OUT', this_module, procedure)
+            end select
+        class default
+            call type_error('vec_in', 'dense_vector_gpu_rdp', 'IN', this_module, procedure)
+        end select
+    end subroutine
+
+    subroutine gpu_dense_matvec(self, vec_in, vec_out)
+        class(dense_linop_gpu_rdp), intent(inout) :: self
+        class(abstract_vector_rdp), intent(in) :: vec_in
+        class(abstract_vector_rdp), intent(out) :: vec_out
+        call apply_dense(self, LK_OP_N, vec_in, vec_out, 'matvec')
+    end subroutine
+
+    subroutine gpu_dense_rmatvec(self, vec_in, vec_out)
+        class(dense_linop_gpu_rdp), intent(inout) :: self
+        class(abstract_vector_rdp), intent(in) :: vec_in
+        class(abstract_vector_rdp), intent(out) :: vec_out
+        call apply_dense(self, LK_OP_H, vec_in, vec_out, 'rmatvec')
+    end subroutine
+
+    ! ---- fused path from Fortran: the whole Arnoldi step loop inside the engine ----------------
+    !> Same contract as LightKrylov's `arnoldi` (src/Krylov/arnoldi.fypp:8-76) for an engine operator
+    !> and a panel basis: X is an engine basis handle with kdim+1 columns, H the host Hessenberg array.
+    subroutine gpu_arnoldi_rdp(op, X, H, info, kstart, kend, tol)
+        type(c_ptr), intent(in) :: op, X
+        real(dp), intent(inout) :: H(:, :)
+        integer, intent(out) :: info
+        integer, optional, intent(in) :: kstart, kend
+        real(dp), optional, intent(in) :: tol
+        integer(c_int) :: k0, k1, cinfo
+        real(c_double) :: t
+        k0 = 1; if (present(kstart)) k0 = kstart
+        k1 = size(H, 2); if (present(kend)) k1 = kend
+        t = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) t = tol      ! atol_dp, Constants.f90:35
+        call chk(lk_arnoldi(op, X, H, int(size(H, 1), c_int64_t), k0, k1, t, 0_c_int, cinfo), 'gpu_arnoldi_rdp')
+        info = cinfo
+    end subroutine
+end module lightkrylov_gpu

@@ -1,0 +1,211 @@
+!> ISO_C_BINDING interface to the MI355X Krylov engine (include/lightkrylov_hip.h).
+!> One `bind(C)` interface per C entry point, same names, same argument order.
+!> This module has no dependency on LightKrylov: it is the layer a LightKrylov plugin
+!> (fortran/dense_vector_gpu.f90) and any other Fortran host code build on.
+module lightkrylov_hip_c
+    use, intrinsic :: iso_c_binding
+    implicit none
+    public
+
+    integer(c_int), parameter :: LK_F64 = 0, LK_C128 = 1
+    integer(c_int), parameter :: LK_OK = 0
+    integer(c_int), parameter :: LK_DGS_NORMALIZE = 1
+    integer(c_int), parameter :: LK_OP_N = 0, LK_OP_H = 1
+
+    interface
+        function lk_version() bind(C, name="lk_version") result(v)
+            import :: c_int
+            integer(c_int) :: v
+        end function
+        function lk_last_error() bind(C, name="lk_last_error") result(msg)
+            import :: c_ptr
+            type(c_ptr) :: msg
+        end function
+        function lk_init(device, stream, ctx) bind(C, name="lk_init") result(rc)
+            import :: c_int, c_ptr
+            integer(c_int), value :: device
+            type(c_ptr), value :: stream
+            type(c_ptr), intent(out) :: ctx
+            integer(c_int) :: rc
+        end function
+        function lk_finalize(ctx) bind(C, name="lk_finalize") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int) :: rc
+        end function
+        function lk_sync(ctx) bind(C, name="lk_sync") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int) :: rc
+        end function
+        function lk_set_allreduce(ctx, fn, user, nranks, rank) bind(C, name="lk_set_allreduce") result(rc)
+            import :: c_int, c_ptr, c_funptr
+            type(c_ptr), value :: ctx, user
+            type(c_funptr), value :: fn
+            integer(c_int), value :: nranks, rank
+            integer(c_int) :: rc
+        end function
+        function lk_set_partition(ctx, row0, n_global) bind(C, name="lk_set_partition") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), value :: row0, n_global
+            integer(c_int) :: rc
+        end function
+        function lk_basis_create(ctx, dtype, n_local, ncols, B) bind(C, name="lk_basis_create") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: dtype, ncols
+            integer(c_int64_t), value :: n_local
+            type(c_ptr), intent(out) :: B
+            integer(c_int) :: rc
+        end function
+        function lk_basis_destroy(B) bind(C, name="lk_basis_destroy") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: B
+            integer(c_int) :: rc
+        end function
+        function lk_basis_upload(B, col0, ncols, host, ldh) bind(C, name="lk_basis_upload") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: B, host
+            integer(c_int), value :: col0, ncols
+            integer(c_int64_t), value :: ldh
+            integer(c_int) :: rc
+        end function
+        function lk_basis_download(B, col0, ncols, host, ldh) bind(C, name="lk_basis_download") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: B, host
+            integer(c_int), value :: col0, ncols
+            integer(c_int64_t), value :: ldh
+            integer(c_int) :: rc
+        end function
+        function lk_vec_zero(B, j) bind(C, name="lk_vec_zero") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: B
+            integer(c_int), value :: j
+            integer(c_int) :: rc
+        end function
+        function lk_vec_rand(B, j, seed, row0, ifnorm) bind(C, name="lk_vec_rand") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: B
+            integer(c_int), value :: j, ifnorm
+            integer(c_int64_t), value :: seed, row0
+            integer(c_int) :: rc
+        end function
+        function lk_vec_scal(B, j, alpha) bind(C, name="lk_vec_scal") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: B
+            integer(c_int), value :: j
+            real(c_double), intent(in) :: alpha(*)
+            integer(c_int) :: rc
+        end function
+        function lk_vec_axpby(alpha, Bx, jx, beta, By, jy) bind(C, name="lk_vec_axpby") result(rc)
+            import :: c_int, c_ptr, c_double
+            real(c_double), intent(in) :: alpha(*), beta(*)
+            type(c_ptr), value :: Bx, By
+            integer(c_int), value :: jx, jy
+            integer(c_int) :: rc
+        end function
+        function lk_vec_dot(Bx, jx, By, jy, res) bind(C, name="lk_vec_dot") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: Bx, By
+            integer(c_int), value :: jx, jy
+            real(c_double), intent(out) :: res(*)
+            integer(c_int) :: rc
+        end function
+        function lk_vec_norm(B, j, res) bind(C, name="lk_vec_norm") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: B
+            integer(c_int), value :: j
+            real(c_double), intent(out) :: res
+            integer(c_int) :: rc
+        end function
+        function lk_vec_copy(Bd, jd, Bs, js) bind(C, name="lk_vec_copy") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: Bd, Bs
+            integer(c_int), value :: jd, js
+            integer(c_int) :: rc
+        end function
+        function lk_innerprod(Bx, k, By, jy0, p, M) bind(C, name="lk_innerprod") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: Bx, By
+            integer(c_int), value :: k, jy0, p
+            real(c_double), intent(out) :: M(*)
+            integer(c_int) :: rc
+        end function
+        function lk_lincomb(Bx, k, C, q, By, jy0) bind(C, name="lk_lincomb") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: Bx, By
+            integer(c_int), value :: k, q, jy0
+            real(c_double), intent(in) :: C(*)
+            integer(c_int) :: rc
+        end function
+        function lk_dgs(Bx, k, By, jy, h, norms, flags, info) bind(C, name="lk_dgs") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: Bx, By
+            integer(c_int), value :: k, jy, flags
+            real(c_double), intent(out) :: h(*), norms(3)
+            integer(c_int), intent(out) :: info
+            integer(c_int) :: rc
+        end function
+        function lk_linop_diag_create(ctx, dtype, n_local, d_host, op) bind(C, name="lk_linop_diag_create") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx, d_host
+            integer(c_int), value :: dtype
+            integer(c_int64_t), value :: n_local
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
+        function lk_linop_dense_create(ctx, dtype, n, A_host, lda, op) bind(C, name="lk_linop_dense_create") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx, A_host
+            integer(c_int), value :: dtype
+            integer(c_int64_t), value :: n, lda
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
+        function lk_linop_destroy(op) bind(C, name="lk_linop_destroy") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: op
+            integer(c_int) :: rc
+        end function
+        function lk_linop_apply(op, trans, Bx, jx, By, jy) bind(C, name="lk_linop_apply") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: op, Bx, By
+            integer(c_int), value :: trans, jx, jy
+            integer(c_int) :: rc
+        end function
+        function lk_arnoldi(A, X, H, ldh, kstart, kend, tol, trans, info) bind(C, name="lk_arnoldi") result(rc)
+            import :: c_int, c_ptr, c_double, c_int64_t
+            type(c_ptr), value :: A, X
+            real(c_double), intent(inout) :: H(*)
+            integer(c_int64_t), value :: ldh
+            integer(c_int), value :: kstart, kend, trans
+            real(c_double), value :: tol
+            integer(c_int), intent(out) :: info
+            integer(c_int) :: rc
+        end function
+    end interface
+
+contains
+
+    !> lk_last_error() as a Fortran string.
+    function lk_error_message() result(msg)
+        character(len=:), allocatable :: msg
+        character(kind=c_char), pointer :: p(:)
+        type(c_ptr) :: cp
+        integer :: i, n
+        cp = lk_last_error()
+        msg = ''
+        if (.not. c_associated(cp)) return
+        call c_f_pointer(cp, p, [512])
+        n = 0
+        do i = 1, 512
+            if (p(i) == c_null_char) exit
+            n = i
+        end do
+        allocate (character(len=n) :: msg)
+        do i = 1, n
+            msg(i:i) = p(i)
+        end do
+    end function
+end module lightkrylov_hip_c

@@ -1,0 +1,56 @@
+!> Fortran host program driving the engine through ISO_C_BINDING only (no LightKrylov needed):
+!> Arnoldi on the diagonal operator d_i = 1 + (i-1)/n, x0_i = sin(i)/||.||, n = 1000, m = 8 --
+!> the case SURVEY.md Appendix A records for the reference's own arnoldi.  Prints H(1,1), H(2,1),
+!> H(m+1,m) and max |X^T X - I| so tests/test_fortran_binding.py can compare with the oracle.
+program test_iso_c
+    use, intrinsic :: iso_c_binding
+    use lightkrylov_hip_c
+    implicit none
+    integer, parameter :: n = 1000, m = 8
+    type(c_ptr) :: ctx, X, A
+    real(c_double), target :: d(n), x0(n), Xh(n, m + 1)
+    real(c_double) :: H(m + 1, m), G, orth, nrm
+    integer(c_int) :: rc, info
+    integer :: i, j, k
+
+    rc = lk_init(0_c_int, c_null_ptr, ctx); call chk(rc, 'lk_init')
+    do i = 1, n
+        d(i) = 1.0d0 + real(i - 1, c_double)/real(n, c_double)
+        x0(i) = sin(real(i, c_double))
+    end do
+    x0 = x0/sqrt(sum(x0**2))
+    rc = lk_basis_create(ctx, LK_F64, int(n, c_int64_t), int(m + 1, c_int), X); call chk(rc, 'lk_basis_create')
+    rc = lk_basis_upload(X, 0_c_int, 1_c_int, c_loc(x0), int(n, c_int64_t)); call chk(rc, 'lk_basis_upload')
+    rc = lk_linop_diag_create(ctx, LK_F64, int(n, c_int64_t), c_loc(d), A); call chk(rc, 'lk_linop_diag_create')
+    H = 0.0d0
+    rc = lk_arnoldi(A, X, H, int(m + 1, c_int64_t), 1_c_int, int(m, c_int), 1.0d-15, 0_c_int, info)
+    call chk(rc, 'lk_arnoldi')
+    rc = lk_basis_download(X, 0_c_int, int(m + 1, c_int), c_loc(Xh), int(n, c_int64_t)); call chk(rc, 'lk_basis_download')
+    orth = 0.0d0
+    do j = 1, m + 1
+        do k = 1, m + 1
+            G = dot_product(Xh(:, j), Xh(:, k))
+            if (j == k) G = G - 1.0d0
+            orth = max(orth, abs(G))
+        end do
+    end do
+    rc = lk_vec_norm(X, int(m, c_int), nrm); call chk(rc, 'lk_vec_norm')
+    print '(A,I0)', 'info ', info
+    print '(A,ES24.16)', 'H11 ', H(1, 1)
+    print '(A,ES24.16)', 'H21 ', H(2, 1)
+    print '(A,ES24.16)', 'Hlast ', H(m + 1, m)
+    print '(A,ES12.4)', 'orth ', orth
+    print '(A,ES24.16)', 'norm_last ', nrm
+    rc = lk_linop_destroy(A)
+    rc = lk_basis_destroy(X)
+    rc = lk_finalize(ctx)
+contains
+    subroutine chk(rc, what)
+        integer(c_int), intent(in) :: rc
+        character(len=*), intent(in) :: what
+        if (rc /= LK_OK) then
+            print '(A,A,A,I0,A,A)', 'ERROR in ', what, ': rc=', rc, ' ', lk_error_message()
+            stop 1
+        end if
+    end subroutine
+end program test_iso_c

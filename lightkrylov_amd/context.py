@@ -67,10 +67,16 @@ class Context:
         self.nranks = dist.get_world_size(pg)
         self.rank = dist.get_rank(pg)
         ext_stream_cache = {}
+        view_cache = {}
 
         def _allreduce(_user, dev_ptr, count, stream_ptr):
             try:
-                t = torch.as_tensor(_DevMem(int(dev_ptr), int(count)), device=f"cuda:{self.device}")
+                key = (int(dev_ptr), int(count))
+                t = view_cache.get(key)
+                if t is None:
+                    t = torch.as_tensor(_DevMem(*key), device=f"cuda:{self.device}")
+                    if len(view_cache) < 4096:
+                        view_cache[key] = t
                 sp = int(stream_ptr or 0)
                 if sp not in ext_stream_cache:
                     ext_stream_cache[sp] = torch.cuda.ExternalStream(sp, device=self.device) if sp else None

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz: OUTPUTS of the CPU oracle (reference schedule) on seeded inputs that
+every backend regenerates from the shared counter RNG / closed formulas, so only results are stored.
+Provenance: oracle/ (pinned by the reference's KATs and by the reference-run values recorded in
+SURVEY.md Appendix A).  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as ora  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def seeded(n, dtype, seed):
+    x = np.empty(n, dtype=dtype)
+    ora.fill_counter(x, seed)
+    return x
+
+
+def diag_values(n, dtype):
+    d = (1.0 + np.arange(n) / n).astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        d = d * np.exp(1j * 0.3 * np.arange(n) / n)
+    return d
+
+
+def arnoldi_diag(n, m, dtype, seed=7):
+    d = diag_values(n, dtype)
+    X = np.zeros((n, m + 1), dtype=dtype, order="F")
+    x0 = seeded(n, dtype, seed)
+    X[:, 0] = x0 / np.linalg.norm(x0)
+    H = np.zeros((m + 1, m), dtype=dtype, order="F")
+    info = ora.arnoldi(ora.DiagOp(d), X, H)
+    return dict(H=H, info=info, ritz=np.sort_complex(np.linalg.eigvals(H[:m, :m])), n=n, m=m, seed=seed,
+                orth=np.abs(X.conj().T @ X - np.eye(m + 1)).max())
+
+
+def cfg1_matrix():
+    rng = np.random.default_rng(1)                       # numpy PCG64(seed=1), SURVEY 8d cfg1
+    A = rng.standard_normal((1000, 1000)) / np.sqrt(1000)
+    A[np.arange(4), np.arange(4)] += np.array([2.0, 1.8, 1.6, 1.4])
+    x0 = np.random.default_rng(2).standard_normal(1000)
+    return np.asfortranarray(A), x0 / np.linalg.norm(x0)
+
+
+def main():
+    for n, m in ((1000, 8), (100_000, 64), (20_011, 128)):
+        for dtype, tag in ((np.float64, "rdp"), (np.complex128, "cdp")):
+            np.savez(os.path.join(OUT, f"arnoldi_diag_n{n}_m{m}_{tag}.npz"), **arnoldi_diag(n, m, dtype))
+    # cfg1: dense 1000 x 1000, m = 30, then eigs(nev=4, kdim=30, tol=1e-10)
+    A, x0 = cfg1_matrix()
+    X = np.zeros((1000, 31), order="F"); X[:, 0] = x0
+    H = np.zeros((31, 30), order="F")
+    info = ora.arnoldi(ora.DenseOp(A), X, H)
+    vals, res, _V, niter = ora.eigs(ora.DenseOp(A), x0, 4, 30, 1e-10)
+    np.savez(os.path.join(OUT, "cfg1_dense1000_m30_rdp.npz"), H=H, info=info, eig_vals=vals, eig_res=res, eig_niter=niter)
+    # Poisson 64^2, GMRES(30), maxiter=2, rtol=1e-8, b from seed 11
+    N = 64
+    b = seeded(N * N, np.float64, 11)
+    x = np.zeros(N * N)
+    ginfo, hist = ora.gmres(ora.Lap5Op(N), b, x, rtol=1e-8, kdim=30, maxiter=2)
+    np.savez(os.path.join(OUT, "gmres_poisson64_k30.npz"), info=ginfo, res=hist, x_norm=np.linalg.norm(x), x_head=x[:64])
+    # reference-run values recorded by the survey: reference arnoldi,
+    # n=1000, m=8, d_i = 1+(i-1)/n, x0_i = sin(i)/||.||
+    np.savez(os.path.join(OUT, "survey_reference_run_n1000_m8.npz"), H11=1.4991929804973552,
+             H21=0.28878608972273856, Hlast=0.2505741778943683)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+"""The ISO_C_BINDING layer (fortran/lk_hip_iso_c.f90) drives the engine from a Fortran host program
+(fortran/test_iso_c.f90, built by __graft_entry__.build() with amdflang): same case the survey ran
+through the reference's own arnoldi -- compare with those recorded values."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "fortran", "test_iso_c")
+
+
+def test_interface_module_declares_the_c_abi():
+    """Every bind(C) name in the Fortran interface module is a symbol of the C header."""
+    import re
+    f90 = open(os.path.join(ROOT, "fortran", "lk_hip_iso_c.f90")).read()
+    hdr = open(os.path.join(ROOT, "include", "lightkrylov_hip.h")).read()
+    names = set(re.findall(r'bind\(C, name="(lk_[a-z0-9_]+)"\)', f90))
+    assert len(names) >= 25
+    for nme in names:
+        assert re.search(rf"\b{nme}\s*\(", hdr), f"{nme} is not declared in the C header"
+
+
+@pytest.mark.gpu
+def test_fortran_host_program_runs_arnoldi_on_the_gpu():
+    if not os.path.exists(EXE):
+        pytest.fail("fortran/test_iso_c not built: run __graft_entry__.build()")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.pathsep.join([os.path.join(ROOT, "lightkrylov_amd"), "/opt/rocm/lib", "/opt/rocm/lib/llvm/lib",
+                                              env.get("LD_LIBRARY_PATH", "")])
+    out = subprocess.run([EXE], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    vals = {ln.split()[0]: float(ln.split()[1]) for ln in out.stdout.splitlines() if len(ln.split()) == 2}
+    z = np.load(os.path.join(ROOT, "tests", "golden", "survey_reference_run_n1000_m8.npz"))
+    assert vals["info"] == 0
+    for key, ref in (("H11", float(z["H11"])), ("H21", float(z["H21"])), ("Hlast", float(z["Hlast"]))):
+        assert abs(vals[key] - ref) <= 1e-12 * abs(ref), (key, vals[key], ref)
+    assert vals["orth"] < 1e-13
+    assert abs(vals["norm_last"] - 1.0) < 1e-14

@@ -1,0 +1,41 @@
+"""The RCCL all-reduce plumbing on a real GPU: bench.py under torch.distributed.run with ONE rank goes
+through init_process_group("nccl"), the ctypes callback, the zero-copy tensor view of the engine's
+reduction buffer and dist.all_reduce on the engine's stream.  With one rank the sum is the identity, so
+the factorisation must be bit-identical to the run without a process group.  (N > 1 GPUs are the
+driver's to launch; the N > 1 host logic is covered on CPU by tests/test_distributed_gloo.py.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_single_rank_rccl_path_is_bit_identical():
+    args = ["--gpus", "1", "--n", "2000001", "--m", "24", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    plain = _run([sys.executable, "bench.py"] + args)
+    dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                 "127.0.0.1", "--master-port", str(_free_port()), "bench.py"] + args)
+    assert plain["config"]["all_reduce"].startswith("none") and dist["config"]["all_reduce"].startswith("RCCL")
+    assert dist["config"]["H_fro"] == plain["config"]["H_fro"]
+    assert dist["config"]["H_last_subdiag"] == plain["config"]["H_last_subdiag"]
+    assert dist["config"]["info"] == plain["config"]["info"] == 0
+    assert dist["n_gpus"] == 1 and dist["roofline"]["launches"] == plain["roofline"]["launches"]
