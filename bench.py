@@ -68,8 +68,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=100_000_000, help="global rows (metric config: 1e8)")
-    ap.add_argument("--m", type=int, default=128, help="Krylov dimension (metric config: 128)")
+    ap.add_argument("--rows", dest="n", type=int, default=100_000_000, help="global rows (metric config: 1e8)")
+    ap.add_argument("--kdim", dest="m", type=int, default=128, help="Krylov dimension (metric config: 128)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "c128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=8_000_000)

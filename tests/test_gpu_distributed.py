@@ -30,7 +30,7 @@ def _run(cmd):
 
 
 def test_single_rank_rccl_path_is_bit_identical():
-    args = ["--gpus", "1", "--n", "2000001", "--m", "24", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    args = ["--gpus", "1", "--rows", "2000001", "--kdim", "24", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     plain = _run([sys.executable, "bench.py"] + args)
     dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                  "127.0.0.1", "--master-port", str(_free_port()), "bench.py"] + args)
