@@ -182,6 +182,14 @@ int lk_linop_dense_create(lk_context_t ctx, int dtype, int64_t n, const void *A_
 /* 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (BASELINE config 3).
  * F64, single-rank only. */
 int lk_linop_lap5_create(lk_context_t ctx, int64_t N, lk_linop_t *op);
+/* Exponential-propagator stand-in of the Ginzburg-Landau example (BASELINE config 4): y = Phi_tau x,
+ * Phi_tau = `nsub` classical RK4 steps of the linearised complex GL right-hand side with the reference's
+ * stencil and boundary rows (example/ginzburg_landau/Ginzburg_Landau.f90:126-136; LK_OP_H uses the adjoint
+ * right-hand side, :170-179).  x_i = -L/2 + i*dx, L = dx*(n+1); mu_i = mu_c + (mu2/2) x_i^2.
+ * nu, gamma: 2 doubles each.  LK_C128, single-rank only.  (The reference integrates with rklib's adaptive
+ * rks54, an un-vendored dependency; a fixed-step RK4 is used by oracle and engine alike.) */
+int lk_linop_gl_create(lk_context_t ctx, int64_t n, double dx, double tau, int nsub, const double *nu,
+                       const double *gamma, double mu_c, double mu2, lk_linop_t *op);
 int lk_linop_destroy(lk_linop_t op);
 /* apply_matvec / apply_rmatvec: y(:, jy) = op(A) x(:, jx).  AbstractLinops.fypp:391-424 */
 int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t By, int jy);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "lk_linop_diag_linspace_create": (_int, [_p, _i64, _i64, C.c_double, C.c_double, _pp]),
     "lk_linop_dense_create": (_int, [_p, _int, _i64, _p, _i64, _pp]),
     "lk_linop_lap5_create": (_int, [_p, _i64, _pp]),
+    "lk_linop_gl_create": (_int, [_p, _i64, C.c_double, C.c_double, _int, _dp, _dp, C.c_double, C.c_double, _pp]),
     "lk_linop_destroy": (_int, [_p]),
     "lk_linop_apply": (_int, [_p, _int, _p, _int, _p, _int]),
     "lk_arnoldi": (_int, [_p, _p, _dp, _i64, _int, _int, C.c_double, _int, _ip]),

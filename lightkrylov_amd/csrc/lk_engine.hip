@@ -94,7 +94,7 @@ struct lk_basis_s {
     double *col(int j) const { return data + (int64_t)j * ld * ed(); }
 };
 
-enum OpKind { OP_DIAG, OP_DIAG_LIN, OP_DENSE, OP_LAP5 };
+enum OpKind { OP_DIAG, OP_DIAG_LIN, OP_DENSE, OP_LAP5, OP_GL };
 struct lk_linop_s {
     lk_context_t ctx;
     OpKind kind;
@@ -105,6 +105,11 @@ struct lk_linop_s {
     int64_t row0 = 0;
     double d0 = 0, dstep = 0;
     int64_t N = 0;
+    // Ginzburg-Landau stepper
+    double gl[8] = {0};   // dx, halfL, nu_re, nu_im, ga_re, ga_im, mu_c, mu2
+    double tau = 0;
+    int nsub = 1;
+    double *wk = nullptr; // 3 work vectors (k_a, k_b, u_sub)
 };
 
 namespace {
@@ -812,8 +817,23 @@ int lk_linop_lap5_create(lk_context_t c, int64_t N, lk_linop_t *op) {
     return LK_OK;
 }
 
+int lk_linop_gl_create(lk_context_t c, int64_t n, double dx, double tau, int nsub, const double *nu, const double *gamma,
+                       double mu_c, double mu2, lk_linop_t *op) {
+    if (!c || !op || !nu || !gamma || n < 1 || nsub < 1 || !(dx > 0.0)) return fail(LK_ERR_INVALID, "lk_linop_gl_create: bad argument");
+    if (c->nranks > 1) return fail(LK_ERR_INVALID, "Ginzburg-Landau operator is single-rank only");
+    lk_linop_t o = new lk_linop_s();
+    o->ctx = c; o->kind = OP_GL; o->dtype = LK_C128; o->n = n; o->tau = tau; o->nsub = nsub;
+    o->gl[0] = dx; o->gl[1] = 0.5 * dx * (double)(n + 1);   // L = dx (n+1), x = linspace(-L/2, L/2, n+2)
+    o->gl[2] = nu[0]; o->gl[3] = nu[1]; o->gl[4] = gamma[0]; o->gl[5] = gamma[1]; o->gl[6] = mu_c; o->gl[7] = mu2;
+    hipError_t e = hipMalloc((void **)&o->wk, (size_t)3 * n * 2 * sizeof(double));
+    if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    *op = o;
+    return LK_OK;
+}
+
 int lk_linop_destroy(lk_linop_t op) {
     if (!op) return LK_OK;
+    if (op->wk) (void)hipFree(op->wk);
     if (op->dev) (void)hipFree(op->dev);  // synchronises; the context may already be finalized
     delete op;
     return LK_OK;
@@ -850,6 +870,29 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
             else hipLaunchKernelGGL(k_gemv_h<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y);
         }
         break;
+    case OP_GL: {
+        // nsub classical RK4 steps of dt = tau/nsub; 4 stage launches per step.
+        const double dt = op->tau / op->nsub;
+        const double *g = op->gl;
+        double *ka = op->wk, *kb = op->wk + 2 * n, *us = op->wk + 4 * n;
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        const int adj = trans == LK_OP_H;
+        const double *uin = x;
+        for (int sstep = 0; sstep < op->nsub; ++sstep) {
+            double *uout = (sstep == op->nsub - 1) ? y : ((uin == us) ? y : us);
+            if (uout == uin) uout = (uin == y) ? us : y;
+#define GL_STAGE(KPREV, A, KOUT, B, FIRST) \
+            hipLaunchKernelGGL(k_gl_stage, dim3(grid), dim3(256), 0, c->stream, uin, KPREV, A, KOUT, uout, B, FIRST, n, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], adj)
+            GL_STAGE((const double *)nullptr, 0.0, ka, dt / 6.0, 1);
+            GL_STAGE((const double *)ka, 0.5 * dt, kb, dt / 3.0, 0);
+            GL_STAGE((const double *)kb, 0.5 * dt, ka, dt / 3.0, 0);
+            GL_STAGE((const double *)ka, dt, kb, dt / 6.0, 0);
+#undef GL_STAGE
+            uin = uout;
+        }
+        if (uin != y) HIPCHK(hipMemcpyAsync(y, uin, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        break;
+    }
     case OP_LAP5: {
         const int64_t N = op->N;
         const double s = (double)(N + 1) * (double)(N + 1);

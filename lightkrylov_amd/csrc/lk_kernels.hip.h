@@ -566,4 +566,52 @@ __global__ __launch_bounds__(256) void k_lap5(const double *__restrict__ u, doub
     if (two) v[c + 1] = s * a1;
 }
 
+// Linearised complex Ginzburg-Landau right-hand side, the reference example's stencil INCLUDING its
+// boundary rows (example/ginzburg_landau/Ginzburg_Landau.f90:126-136; adjoint :170-179):
+//   f(v)_i = -nu*cu + gamma*d2u + mu_i v_i,   mu_i = mu_c + (mu2/2) x_i^2,  x_i = -L/2 + i*dx (i = 1..n).
+// One classical RK4 stage per launch: v = u + a*kprev (formed on the fly at the 3 stencil points),
+// kout = f(v), acc (+)= b*kout (first stage: acc = u + b*kout).
+__global__ __launch_bounds__(256) void k_gl_stage(const double *__restrict__ u, const double *__restrict__ kprev,
+                                                  double a, double *__restrict__ kout, double *__restrict__ acc,
+                                                  double b, int first, int64_t n, double dx, double halfL,
+                                                  double nu_re, double nu_im, double ga_re, double ga_im,
+                                                  double mu_c, double mu2, int adjoint) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 0-based; reference index i+1
+    if (i >= n) return;
+    const v2d *uv = reinterpret_cast<const v2d *>(u);
+    const v2d *kv = reinterpret_cast<const v2d *>(kprev);
+    auto val = [&](int64_t j) -> v2d {
+        v2d r = uv[j];
+        if (kprev) r += kv[j] * a;
+        return r;
+    };
+    const v2d c = val(i);
+    v2d cu, d2u;
+    const double inv2dx = 1.0 / (2.0 * dx), invdx2 = 1.0 / (dx * dx);
+    if (n == 1) {
+        cu = v2d{0.0, 0.0};
+        d2u = c * (-2.0) * invdx2;
+    } else if (i == 0) {
+        const v2d r = val(1);
+        cu = r * inv2dx;
+        d2u = (r - c * 2.0) * invdx2;
+    } else if (i == n - 1) {
+        const v2d l = val(n - 2);
+        cu = l * (-inv2dx);
+        d2u = (c * (-2.0) + l) * inv2dx;          // sic: the reference divides this row by 2*dx
+    } else {
+        const v2d l = val(i - 1), r = val(i + 1);
+        cu = (r - l) * inv2dx;
+        d2u = (r - c * 2.0 + l) * invdx2;
+    }
+    const double x = -halfL + (double)(i + 1) * dx;
+    const double mu = mu_c + 0.5 * mu2 * x * x;
+    v2d f;
+    if (adjoint) f = cmul(v2d{nu_re, -nu_im}, cu) + cmul(v2d{ga_re, -ga_im}, d2u) + c * mu;
+    else f = cmul(v2d{-nu_re, -nu_im}, cu) + cmul(v2d{ga_re, ga_im}, d2u) + c * mu;
+    reinterpret_cast<v2d *>(kout)[i] = f;
+    v2d *av = reinterpret_cast<v2d *>(acc);
+    av[i] = (first ? uv[i] : av[i]) + f * b;
+}
+
 }  // namespace lk

@@ -124,3 +124,24 @@ class laplacian2d_linop_gpu(_engine_linop):
 
     def rmatvec(self, vec_in, vec_out) -> None:  # symmetric
         self._apply(_capi.LK_OP_N, vec_in, vec_out)
+
+
+class ginzburg_landau_linop_gpu(_engine_linop):
+    """Exponential propagator of the linearised complex Ginzburg-Landau equation over `tau`
+    (example/ginzburg_landau: `exponential_prop`, Ginzburg_Landau.f90:259-290), as `nsub` classical RK4
+    steps of the reference right-hand side (stencil + boundary rows, :126-136).  Defaults are the example's
+    constants (:23-33) with dx fixed at 200/513 and mu_2 rescaled by (200/L)^2 so that mu(x) keeps the
+    reference's range when n grows."""
+
+    def __init__(self, n: int, ctx: Context | None = None, tau: float = 0.01, nsub: int = 1,
+                 nu: complex = 2.0 + 0.2j, gamma: complex = 1.0 - 1.0j, mu_0: float = 0.38, c_mu: float = 0.2,
+                 mu_2: float | None = None, dx: float = 200.0 / 513.0):
+        super().__init__(ctx)
+        self.dtype, self.n = np.dtype(np.complex128), int(n)
+        L = dx * (n + 1)
+        self.mu_2 = -0.01 * (200.0 / L) ** 2 if mu_2 is None else mu_2
+        self.params = dict(n=self.n, dx=dx, tau=tau, nsub=nsub, nu=nu, gamma=gamma, mu_c=mu_0 - c_mu ** 2, mu2=self.mu_2)
+        nu_a = (C.c_double * 2)(nu.real, nu.imag)
+        ga_a = (C.c_double * 2)(gamma.real, gamma.imag)
+        _capi.check(self._lib.lk_linop_gl_create(self.ctx._h, self.n, float(dx), float(tau), int(nsub), nu_a, ga_a,
+                                                 float(mu_0 - c_mu ** 2), float(self.mu_2), C.byref(self._h)))

@@ -180,12 +180,14 @@ def gmres(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float
 
 # ------------------------------------------------------------------------------------------
 def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | None = None,
-         tolerance: float = rtol_dp, transpose: bool = False, write_intermediate: bool = False):
+         tolerance: float = rtol_dp, transpose: bool = False, write_intermediate: bool = False,
+         max_restarts: int | None = None):
     """Krylov-Schur eigensolver for the leading len(X) eigenpairs.
     src/IterativeSolvers/IterativeSolvers.fypp:972-1143.
     X (sequence / basis of nev vectors) receives the eigenvectors.
     Returns (eigvals[nev] complex, residuals[nev], info = number of Arnoldi steps).
-    (`write_intermediate` defaults to False here: the per-step text dump is file I/O outside the path.)"""
+    (`write_intermediate` defaults to False here: the per-step text dump is file I/O outside the path.
+    `max_restarts` is an engine extra: the reference loops until `nev` pairs converge, however long.)"""
     nev = len(X)
     kdim_ = 4 * nev if kdim is None else kdim                                      # :1023
     proto = X[0]
@@ -203,7 +205,11 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
     def median_selector(lam):                                                      # :1137-1142
         return np.abs(lam) > np.median(np.abs(lam))
 
+    restarts = 0
     while conv < nev:
+        if max_restarts is not None and restarts > max_restarts:
+            break
+        restarts += 1
         for k in range(kstart, kdim_ + 1):
             arnoldi(A, Xwrk, H, kstart=k, kend=k, transpose=transpose)            # :1059
             vecs, vals = eig(H[:k, :k])                                           # :1065

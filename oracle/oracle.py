@@ -210,6 +210,55 @@ class Lap5Op(_OpBase):
         return lib().ora_matvec_lap5_d, C.byref(self._s)
 
 
+class GLOp(_OpBase):
+    """Ginzburg-Landau propagator: nsub classical RK4 steps of the reference right-hand side
+    (example/ginzburg_landau/Ginzburg_Landau.f90:126-136, adjoint :170-179), numpy restatement."""
+
+    def __init__(self, n, dx, tau, nsub, nu, gamma, mu_c, mu2, adjoint=False):
+        self.n, self.dx, self.tau, self.nsub = n, dx, tau, nsub
+        self.nu, self.gamma, self.adjoint = nu, gamma, adjoint
+        L = dx * (n + 1)
+        x = -L / 2 + dx * np.arange(1, n + 1)                      # linspace(-L/2, L/2, n+2)(2:n+1)
+        self.mu = mu_c + 0.5 * mu2 * x * x
+
+        def _cb(_op, nn, xp, yp):
+            xin = np.ctypeslib.as_array(C.cast(xp, C.POINTER(C.c_double)), shape=(2 * nn,)).view(np.complex128)
+            yout = np.ctypeslib.as_array(C.cast(yp, C.POINTER(C.c_double)), shape=(2 * nn,)).view(np.complex128)
+            yout[:] = self.apply(xin)
+        self._cb = MATVEC_FN(_cb)
+
+    def rhs(self, u):
+        dx, n = self.dx, self.n
+        cu = np.empty_like(u)
+        d2u = np.empty_like(u)
+        cu[1:-1] = (u[2:] - u[:-2]) / (2 * dx)
+        d2u[1:-1] = (u[2:] - 2 * u[1:-1] + u[:-2]) / dx ** 2
+        cu[0] = u[1] / (2 * dx)
+        d2u[0] = (u[1] - 2 * u[0]) / dx ** 2
+        cu[-1] = -u[n - 2] / (2 * dx)
+        d2u[-1] = (-2 * u[n - 1] + u[n - 2]) / (2 * dx)            # sic, :131
+        if self.adjoint:
+            return np.conj(self.nu) * cu + np.conj(self.gamma) * d2u + self.mu * u
+        return -self.nu * cu + self.gamma * d2u + self.mu * u
+
+    def apply(self, u):
+        dt = self.tau / self.nsub
+        u = u.copy()
+        for _ in range(self.nsub):
+            k1 = self.rhs(u)
+            k2 = self.rhs(u + 0.5 * dt * k1)
+            k3 = self.rhs(u + 0.5 * dt * k2)
+            k4 = self.rhs(u + dt * k3)
+            u = u + dt / 6 * k1 + dt / 3 * k2 + dt / 3 * k3 + dt / 6 * k4
+        return u
+
+    def c_matvec(self):
+        return self._cb, None
+
+    def matvec(self, x, y):
+        y[:] = self.apply(x)
+
+
 class PyOp(_OpBase):
     """Any python callable f(x)->y as an operator (small cases only)."""
 

@@ -408,3 +408,105 @@ def test_arnoldi_full_size_properties(ctx, dtype, n, m):
     # Ritz values are those of a normal operator with spectrum on a known curve
     ritz = np.linalg.eigvals(H[:m, :m])
     assert (np.abs(ritz) >= 1.0 - 1e-9).all() and (np.abs(ritz) <= 2.0 + 1e-9).all()
+
+
+# ----------------------------------------------------------------------------- Ginzburg-Landau stepper (config 4)
+def _gl_pair(ctx, n, tau, nsub):
+    A = lk.ginzburg_landau_linop_gpu(n, ctx, tau=tau, nsub=nsub)
+    p = A.params
+    Ao = ora.GLOp(n, p["dx"], tau, nsub, p["nu"], p["gamma"], p["mu_c"], p["mu2"])
+    Aadj = ora.GLOp(n, p["dx"], tau, nsub, p["nu"], p["gamma"], p["mu_c"], p["mu2"], adjoint=True)
+    return A, Ao, Aadj
+
+
+@pytest.mark.parametrize("n,nsub", [(1, 1), (2, 1), (512, 1), (512, 3), (100_001, 2)])
+def test_ginzburg_landau_stepper_against_oracle(ctx, n, nsub):
+    A, Ao, Aadj = _gl_pair(ctx, n, 0.01 * nsub, nsub)
+    x = seeded(n, np.complex128, 13)
+    vx, vy = lk.dense_vector_gpu.from_array(x, ctx), lk.dense_vector_gpu(n, np.complex128, ctx)
+    A.apply_matvec(vx, vy)
+    ref = Ao.apply(x) if n > 1 else None
+    if n > 2:
+        assert np.abs(vy.to_array() - ref).max() <= 1e-13 * np.abs(ref).max()
+        A.apply_rmatvec(vx, vy)
+        refa = Aadj.apply(x)
+        assert np.abs(vy.to_array() - refa).max() <= 1e-13 * np.abs(refa).max()
+    assert np.isfinite(vy.to_array()).all() and np.array_equal(vx.to_array(), x)      # input untouched
+
+
+def test_eigs_ginzburg_landau_reference_size_against_oracle(ctx):
+    """The example's own size (nx = 512, nev = 8): leading eigenvalues of the propagator, engine vs oracle."""
+    n, nev, kdim = 512, 8, 64
+    A, Ao, _ = _gl_pair(ctx, n, 1.0, 40)
+    x0 = seeded(n, np.complex128, 13)
+    X = lk.krylov_basis_gpu(n, nev, np.complex128, ctx)
+    vals, res, info = lk.eigs(A, X, x0=lk.dense_vector_gpu.from_array(x0, ctx), kdim=kdim, tolerance=1e-10)
+    vo, ro, Vo, info_o = ora.eigs(Ao, x0, nev, kdim, 1e-10)
+    assert info == info_o
+    assert np.abs(vals - vo).max() <= 1e-9 * np.abs(vo).max()
+    V = X.download()
+    for i in range(nev):
+        assert np.linalg.norm(Ao.apply(V[:, i]) - vals[i] * V[:, i]) <= 1e-7 * abs(vals[i])
+
+
+def test_eigs_ginzburg_landau_full_size_properties(ctx):
+    """BASELINE config 4: complex(dp) n = 10^6, kdim = 128, nev = 8.  No oracle run at this size, and on a
+    domain this long the spectrum is too clustered for Krylov-Schur to converge in a test's time.  What is
+    checked is every step eigs takes: the 128-step Arnoldi factorisation A X_m = X_{m+1} H and X^H X = I,
+    the same relation after a krylov_schur restart, and that a bounded eigs run returns sorted Ritz values."""
+    n, nev, kdim = 1_000_000, 8, 128
+    A = lk.ginzburg_landau_linop_gpu(n, ctx, tau=1.0, nsub=40)
+    X = lk.krylov_basis_gpu(n, kdim + 1, np.complex128, ctx)
+    X[0].rand(True, seed=13)
+    H = np.zeros((kdim + 1, kdim), dtype=np.complex128, order="F")
+    assert lk.arnoldi(A, X, H) == 0
+    G = lk.Gram(X)
+    assert np.abs(G - np.eye(kdim + 1)).max() <= 1e-12
+
+    w = lk.dense_vector_gpu(n, np.complex128, ctx)
+
+    def relation_residual(ncols, j):
+        A.apply_matvec(X[j], w)
+        y = lk.linear_combination(X[:ncols + 1], np.ascontiguousarray(H[:ncols + 1, j]))
+        w.sub(y)
+        return w.norm()
+
+    for j in (0, 63, 127):
+        assert relation_residual(kdim, j) <= 1e-12 * np.abs(H[:, j]).max()
+    nsel = lk.krylov_schur(X, H, lambda lam: np.abs(lam) > np.median(np.abs(lam)))
+    assert 0 < nsel < kdim
+    Gs = lk.Gram(X[:nsel + 1])
+    assert np.abs(Gs - np.eye(nsel + 1)).max() <= 1e-12
+    for j in (0, nsel - 1):
+        assert relation_residual(nsel, j) <= 1e-11 * np.abs(H[:nsel + 1, :nsel]).max()
+
+    V = lk.krylov_basis_gpu(n, nev, np.complex128, ctx)
+    x0 = lk.dense_vector_gpu(n, np.complex128, ctx)
+    x0.rand(False, seed=13)
+    vals, res, info = lk.eigs(A, V, x0=x0, kdim=kdim, tolerance=1e-10, max_restarts=1)
+    assert info >= kdim and np.isfinite(vals).all() and np.isfinite(res).all()
+    assert (np.abs(vals[:-1]) >= np.abs(vals[1:]) - 1e-12).all()                       # sorted by |lambda| descending
+    assert np.abs(vals).max() <= 1.05 * np.exp(A.params["mu_c"] * A.params["tau"])   # Ritz values inside ~the numerical range
+
+
+def test_gmres_poisson_full_size_properties(ctx):
+    """BASELINE config 3 at full size: 5-point Laplacian, N = 4096 (n = 16.8 M), GMRES(30), maxiter = 2
+    (3 cycles of fixed work).  Properties: the recorded residual history equals the true residual
+    ||b - A x|| at every cycle end, and is non-increasing within a cycle."""
+    N = 4096
+    n = N * N
+    A = lk.laplacian2d_linop_gpu(N, ctx)
+    b = lk.dense_vector_gpu(n, np.float64, ctx); b.rand(False, seed=11)
+    x = lk.dense_vector_gpu(n, np.float64, ctx)
+    meta = lk.gmres_dp_metadata()
+    info = lk.gmres(A, b, x, rtol=1e-8, options=lk.gmres_dp_opts(kdim=30, maxiter=2), meta=meta)
+    assert info == -meta.n_iter and meta.n_outer == 3 and meta.n_inner == 90     # not converged: info = -n_iter
+    r = lk.dense_vector_gpu(n, np.float64, ctx)
+    A.apply_matvec(x, r); r.sub(b)
+    assert abs(r.norm() - meta.res[-1]) <= 1e-10 * meta.res[0]
+    res = np.array(meta.res)
+    assert res[-1] < res[0]
+    for c in range(3):                                                               # [init | 30 inner, outer] x 3
+        seg = res[1 + 31 * c: 1 + 31 * c + 30]
+        assert (np.diff(seg) <= 1e-12 * res[0]).all()
+        assert abs(res[1 + 31 * c + 30] - seg[-1]) <= 1e-8 * res[0]                  # least-squares vs true residual
