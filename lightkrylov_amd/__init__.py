@@ -16,7 +16,7 @@ from .vectors import (Gram, abstract_vector, axpby_basis, copy, dense_vector_gpu
                       krylov_basis_gpu, linear_combination, rand_basis, zero_basis)
 from .linops import (abstract_linop, dense_linop_gpu, diag_linop_gpu, ginzburg_landau_linop_gpu,
                      laplacian2d_linop_gpu)  # noqa: F401
-from .krylov import (arnoldi, double_gram_schmidt_step, is_orthonormal, krylov_schur, lanczos,  # noqa: F401
+from .krylov import (arnoldi, bidiagonalization, double_gram_schmidt_step, is_orthonormal, krylov_schur, lanczos,  # noqa: F401
                      orthogonalize_against_basis, qr)
 from .solvers import (apply_givens_rotation, eig, eigs, gmres, gmres_dp_metadata, gmres_dp_opts)  # noqa: F401
 

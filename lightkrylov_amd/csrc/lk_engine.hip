@@ -670,20 +670,35 @@ int lk_lincomb(lk_basis_t Bx, int k, const double *C, int q, lk_basis_t By, int 
         return fail(LK_ERR_INVALID, "Krylov basis X and combination matrix B have incompatible sizes.");
     lk_context_t c = Bx->ctx;
     const int ED = Bx->ed();
-    std::vector<double> neg((size_t)KMAX_FUSED * ED);
-    for (int j = 0; j < q; ++j) {
-        double *y = By->col(jy0 + j);
-        // Y(j)%zero(); then y <- y - X*(-C(:,j)) panel by panel
-        HIPCHK(hipMemsetAsync(y, 0, (size_t)By->n * ED * sizeof(double), c->stream));
+    const bool cp = Bx->dtype == LK_C128;
+    // the output columns must not be among the inputs (the reference writes into a fresh Xwrk / proj)
+    if (Bx->data == By->data && jy0 < k) return fail(LK_ERR_INVALID, "lk_lincomb: output columns alias the input basis");
+    // coefficients: one upload of the whole k x q block
+    LKCHK(ensure_scratch(c, (int64_t)k * q * ED));
+    HIPCHK(hipMemcpyAsync(c->scratch, C, (size_t)k * q * ED * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int QB = cp ? 8 : 16;
+    const int64_t tile_rows = 4 * 64 * (cp ? 1 : 2);
+    int64_t g = (Bx->n + tile_rows - 1) / tile_rows;
+    const int64_t cap = (int64_t)c->num_cu * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    for (int q0 = 0; q0 < q; q0 += QB) {
+        const int qn = (q - q0) < QB ? (q - q0) : QB;
         for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
             const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
-            for (int i = 0; i < kk * ED; ++i) neg[i] = -C[((size_t)j * k + c0) * ED + i];
-            HIPCHK(hipStreamSynchronize(c->stream));  // coef buffer reuse
-            HIPCHK(hipMemcpyAsync(c->coef, neg.data(), (size_t)kk * ED * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            LKCHK((sweep<true, false>(Bx, c0, kk, y, c->coef, c->red + 2 * RED_SECTION)));
+            const double *Cd = c->scratch + ((int64_t)q0 * k + c0) * ED;
+            ProfScope ps(c, "lincomb", (double)Bx->n * ED * 8.0 * (kk + qn));
+            if (cp)
+                hipLaunchKernelGGL((panel_gemm<true, 8, 8>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, kk,
+                                   By->col(jy0 + q0), By->ld, qn, Cd, (int64_t)k, Bx->n, c0 > 0 ? 1 : 0);
+            else
+                hipLaunchKernelGGL((panel_gemm<false, 8, 16>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, kk,
+                                   By->col(jy0 + q0), By->ld, qn, Cd, (int64_t)k, Bx->n, c0 > 0 ? 1 : 0);
+            HIPCHK(hipGetLastError());
         }
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // the host coefficient array may be released by the caller
+    if (c->prof) prof_collect(c);
     return LK_OK;
 }
 

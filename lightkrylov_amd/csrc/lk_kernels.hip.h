@@ -346,6 +346,69 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
     }
 }
 
+// Tall-skinny product Y(:, q0:q0+qn) (+)= X(:, :k) * C(:k, q0:q0+qn)  -- linear_combination_matrix
+// (AbstractVectors.fypp:605-643) as ONE pass over X per QB output columns instead of k*q axpbys.
+// Used by krylov_schur's basis update X <- X Z (BaseKrylov.fypp:816-824) and eigs' eigenvector
+// reconstruction (IterativeSolvers.fypp:1127-1132).  Each wave owns 64*ROWS rows and walks the k
+// columns in chunks of KC with QB accumulators per lane; the k x QB coefficient block sits in LDS
+// (wave-uniform broadcast reads).  Arithmetic intensity stays below 2 FMA/byte: still HBM-bound.
+template <bool CPLX, int KC, int QB>
+__global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, int64_t ldx, int k,
+                                                  double *__restrict__ Y, int64_t ldy, int qn,
+                                                  const double *__restrict__ Cdev, int64_t ldc, int64_t n,
+                                                  int accumulate) {
+    constexpr int ROWS = K<CPLX>::ROWS;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int WROWS = 64 * ROWS;
+    constexpr int KMAX = 128;
+    __shared__ v2d Cs[KMAX * QB * ED / 2 + 1];   // [k][QB] elements, row-major
+    double *Cd = reinterpret_cast<double *>(Cs);
+    for (int idx = threadIdx.x; idx < k * QB; idx += blockDim.x) {
+        const int j = idx / QB, qq = idx % QB;
+        for (int e = 0; e < ED; ++e)
+            Cd[(j * QB + qq) * ED + e] = (qq < qn) ? Cdev[((int64_t)qq * ldc + j) * ED + e] : 0.0;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tile_rows = 4 * (int64_t)WROWS;
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const int64_t xstride = ldx * ED, ystride = ldy * ED;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t r = t * tile_rows + (int64_t)wave * WROWS + (int64_t)lane * ROWS;
+        const bool full = (t + 1) * tile_rows <= n;
+        v2d acc[QB];
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) acc[qq] = v2d{0.0, 0.0};
+        for (int c0 = 0; c0 < k; c0 += KC) {
+            int nc = k - c0;
+            nc = nc > KC ? KC : nc;
+            v2d xv[KC];
+            load_cols<CPLX, KC>(X + (int64_t)c0 * xstride, xstride, r, n, full, nc, xv);
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) {
+                if (jj < nc) {
+#pragma unroll
+                    for (int qq = 0; qq < QB; ++qq) {
+                        if constexpr (CPLX) acc[qq] += cmul(xv[jj], Cs[(c0 + jj) * QB + qq]);
+                        else acc[qq] += xv[jj] * Cd[(c0 + jj) * QB + qq];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) {
+            if (qq < qn) {
+                double *yc = Y + (int64_t)qq * ystride;
+                v2d out = acc[qq];
+                if (accumulate) out += load_y<CPLX>(yc, r, n, full);
+                store_rows<CPLX>(yc, r, n, full, out);
+            }
+        }
+    }
+}
+
 // out[s] = sum_b partial[s*pstride + b], b < nblocks, fixed order: one wave per slot.
 __global__ __launch_bounds__(256) void finish_partials(const double *__restrict__ partial, int64_t pstride,
                                                        int nblocks, int nslots, double *__restrict__ out) {

@@ -234,6 +234,41 @@ def lanczos(A: abstract_linop, X, T: np.ndarray, kstart: int = 1, kend: int | No
     return info
 
 
+def bidiagonalization(A: abstract_linop, U, V, B: np.ndarray, kstart: int = 1, kend: int | None = None,
+                      tol: float = atol_dp) -> int:
+    """lanczos_bidiagonalization (Golub-Kahan): A V = U B, full re-orthogonalisation of both bases.
+    src/Krylov/golub_kahan.fypp:7-64.  U has kdim+1 vectors, V kdim(+1), B is (kdim+1, kdim)."""
+    kdim = len(U) - 1
+    kend = kdim if kend is None else kend
+    info = 0
+    gpu = isinstance(U, krylov_basis_gpu) and isinstance(V, krylov_basis_gpu)
+    for k in range(kstart, kend + 1):
+        A.apply_rmatvec(U[k - 1], V[k - 1])                                         # :27
+        norms: list = []
+        if k > 1:
+            double_gram_schmidt_step(V[k - 1], V[:k - 1], if_chk_orthonormal=False,  # :30-33
+                                     _norms=norms if gpu else None)
+        alpha = norms[2] if norms else V[k - 1].norm()                              # :36
+        B[k - 1, k - 1] = alpha
+        if abs(alpha) > tol:
+            V[k - 1].scal(1.0 / alpha)
+        else:
+            info = k
+            break
+        A.apply_matvec(V[k - 1], U[k])                                              # :45
+        norms = []
+        double_gram_schmidt_step(U[k], U[:k], if_chk_orthonormal=False,             # :48-49
+                                 _norms=norms if gpu else None)
+        beta = norms[2] if norms else U[k].norm()                                   # :52
+        B[k, k - 1] = beta
+        if abs(beta) > tol:
+            U[k].scal(1.0 / beta)
+        else:
+            info = k
+            break
+    return info
+
+
 # ------------------------------------------------------------------------------------------
 def _schur(Hm: np.ndarray):
     """stdlib `schur` = LAPACK gees without sorting (BaseKrylov.fypp:807)."""

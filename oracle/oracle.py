@@ -314,6 +314,34 @@ def lanczos(A: _OpBase, X: np.ndarray, T: np.ndarray, kstart: int = 1, kend: int
     return info
 
 
+def bidiagonalization(A: _OpBase, Ah: _OpBase, U: np.ndarray, V: np.ndarray, B: np.ndarray,
+                      tol: float = ATOL_DP) -> int:
+    """lanczos_bidiagonalization.  src/Krylov/golub_kahan.fypp:7-64.  `Ah` applies A^H (rmatvec)."""
+    kdim = U.shape[1] - 1
+    info = 0
+    for k in range(1, kdim + 1):
+        Ah.matvec(U[:, k - 1], V[:, k - 1])                                # :27
+        if k > 1:
+            double_gram_schmidt_step(V[:, k - 1], V[:, :k - 1])            # :30-33
+        alpha = norm(V[:, k - 1])
+        B[k - 1, k - 1] = alpha
+        if abs(alpha) > tol:
+            scal(V[:, k - 1], 1.0 / alpha)
+        else:
+            info = k
+            break
+        A.matvec(V[:, k - 1], U[:, k])                                     # :45
+        double_gram_schmidt_step(U[:, k], U[:, :k])                        # :48-49
+        beta = norm(U[:, k])
+        B[k, k - 1] = beta
+        if abs(beta) > tol:
+            scal(U[:, k], 1.0 / beta)
+        else:
+            info = k
+            break
+    return info
+
+
 # ----------------------------------------------------------------------------------------
 # small host LAPACK pieces (src/Utilities/submodule_utility_functions.fypp)
 # ----------------------------------------------------------------------------------------

@@ -116,7 +116,7 @@ def test_size_mismatch_is_an_error(ctx):
 # ----------------------------------------------------------------------------- basis helpers
 @pytest.mark.parametrize("dtype", KINDS)
 @pytest.mark.parametrize("n,k,p", [(1000, 1, 1), (1003, 7, 1), (4099, 16, 2), (4099, 17, 1), (20_001, 64, 1),
-                                   (20_001, 128, 1), (777, 130, 1), (5000, 200, 2)])
+                                   (20_001, 128, 1), (777, 130, 1), (5000, 200, 2), (3001, 100, 40), (2999, 128, 17)])
 def test_innerprod_lincomb_gram(ctx, dtype, n, k, p):
     X, Y = basis(n, k, dtype, 10), basis(n, p, dtype, 500)
     Bx = lk.krylov_basis_gpu(n, k, dtype, ctx); Bx.upload(X)
@@ -510,3 +510,28 @@ def test_gmres_poisson_full_size_properties(ctx):
         seg = res[1 + 31 * c: 1 + 31 * c + 30]
         assert (np.diff(seg) <= 1e-12 * res[0]).all()
         assert abs(res[1 + 31 * c + 30] - seg[-1]) <= 1e-8 * res[0]                  # least-squares vs true residual
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_bidiagonalization_against_oracle(ctx, dtype):
+    """lanczos_bidiagonalization (golub_kahan.fypp:7-64) on a dense operator: B vs oracle, A V = U B, bases orthonormal."""
+    n, kdim = 300, 40
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((n, n))
+    if np.dtype(dtype).kind == "c":
+        A = A + 1j * rng.standard_normal((n, n))
+    A = np.asfortranarray(A.astype(dtype))
+    u0 = seeded(n, dtype, 21); u0 /= np.linalg.norm(u0)
+    U = lk.krylov_basis_gpu(n, kdim + 1, dtype, ctx); U.upload(u0.reshape(-1, 1), 0)
+    V = lk.krylov_basis_gpu(n, kdim + 1, dtype, ctx)
+    B = np.zeros((kdim + 1, kdim), dtype=dtype, order="F")
+    assert lk.bidiagonalization(lk.dense_linop_gpu(A, ctx), U, V, B) == 0
+    Uo = np.zeros((n, kdim + 1), dtype=dtype, order="F"); Uo[:, 0] = u0
+    Vo = np.zeros((n, kdim + 1), dtype=dtype, order="F")
+    Bo = np.zeros((kdim + 1, kdim), dtype=dtype, order="F")
+    assert ora.bidiagonalization(ora.DenseOp(A), ora.DenseOp(np.asfortranarray(A.conj().T)), Uo, Vo, Bo) == 0
+    assert np.abs(B - Bo).max() <= 1e-11 * np.abs(Bo).max()
+    Ug, Vg = U.download(), V.download(0, kdim)
+    assert np.abs(A @ Vg - Ug @ B).max() <= 1e-11 * np.abs(B).max()
+    assert np.abs(Ug.conj().T @ Ug - np.eye(kdim + 1)).max() <= 1e-12
+    assert np.abs(Vg.conj().T @ Vg - np.eye(kdim)).max() <= 1e-12

@@ -167,3 +167,27 @@ def test_row_partition_covers_every_row_once():
             assert blocks[0][0] == 0 and sum(b[1] for b in blocks) == n
             for (r0, nl), (r1, _) in zip(blocks, blocks[1:]):
                 assert r0 + nl == r1 and nl % 2 == 0
+
+
+def test_generic_bidiagonalization_equals_oracle_and_strang_known_answer():
+    """test/TestKrylov.fypp:365-429 (A V = U B, orthonormal bases) and the Strang-matrix singular values
+    2 - 2 cos(i pi/(n+1)) of test/TestIterativeSolvers.fypp:444-452, 479-485 (svds' known answer)."""
+    n = 64
+    A = 2.0 * np.eye(n) - np.eye(n, k=1) - np.eye(n, k=-1)
+    u0 = seeded(n, np.float64, 21); u0 /= np.linalg.norm(u0)
+    U = list_basis(n, n + 1, np.float64); U[0].data[:] = u0
+    V = list_basis(n, n + 1, np.float64)
+    B = np.zeros((n + 1, n), order="F")
+    info = lk.bidiagonalization(oracle_dense_linop(A), U, V, B)
+    Uo = np.zeros((n, n + 1), order="F"); Uo[:, 0] = u0
+    Vo = np.zeros((n, n + 1), order="F")
+    Bo = np.zeros((n + 1, n), order="F")
+    assert info == ora.bidiagonalization(ora.DenseOp(A), ora.DenseOp(A.T.copy()), Uo, Vo, Bo)
+    k = info if info > 0 else n
+    np.testing.assert_allclose(B[:k, :k], Bo[:k, :k], rtol=1e-12, atol=1e-14)
+    sv = np.sort(np.linalg.svd(B[:k, :k], compute_uv=False))[::-1]
+    true = np.sort(np.array([2.0 - 2.0 * np.cos(i * np.pi / (n + 1)) for i in range(1, n + 1)]))[::-1]
+    assert k == n and np.abs(sv - true).max() < lk.rtol_dp
+    Um = np.stack([u.data for u in U[:k]], axis=1)
+    Vm = np.stack([v.data for v in V[:k]], axis=1)
+    assert np.abs(Um.T @ Um - np.eye(k)).max() < 1e-12 and np.abs(Vm.T @ Vm - np.eye(k)).max() < 1e-12
