@@ -20,4 +20,6 @@ from .krylov import (arnoldi, bidiagonalization, double_gram_schmidt_step, is_or
                      orthogonalize_against_basis, qr)
 from .solvers import (apply_givens_rotation, eig, eigs, gmres, gmres_dp_metadata, gmres_dp_opts)  # noqa: F401
 
+from .outputs import save_eigenspectrum, write_results  # noqa: F401
+
 __version__ = "0.1.0"

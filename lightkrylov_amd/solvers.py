@@ -15,6 +15,7 @@ from scipy.linalg import lapack as _lapack
 from .constants import atol_dp, rtol_dp
 from .krylov import arnoldi, double_gram_schmidt_step, krylov_schur
 from .linops import abstract_linop
+from .outputs import eigs_output, write_results
 from .vectors import abstract_vector, copy, dense_vector_gpu, krylov_basis_gpu, linear_combination, zero_basis
 
 
@@ -186,7 +187,8 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
     src/IterativeSolvers/IterativeSolvers.fypp:972-1143.
     X (sequence / basis of nev vectors) receives the eigenvectors.
     Returns (eigvals[nev] complex, residuals[nev], info = number of Arnoldi steps).
-    (`write_intermediate` defaults to False here: the per-step text dump is file I/O outside the path.
+    (`write_intermediate` defaults to False here -- the reference's default is .true. -- because the per-step
+    text dump is file I/O outside the path; when True it writes `eigs_output.txt` exactly like :1091.
     `max_restarts` is an engine extra: the reference loops until `nev` pairs converge, however long.)"""
     nev = len(X)
     kdim_ = 4 * nev if kdim is None else kdim                                      # :1023
@@ -227,6 +229,8 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                     res[i] = abs(beta * alpha)
             niter += 1
             conv = int(np.count_nonzero(res[:k] < tolerance))                      # :1087
+            if write_intermediate:
+                write_results(eigs_output, vals[:k], res[:k], tolerance)           # :1091 (sorts res(:k) in place)
             if conv >= nev:
                 break
         kstart = krylov_schur(Xwrk, H, median_selector) + 1                        # :1100

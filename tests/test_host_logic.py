@@ -191,3 +191,33 @@ def test_generic_bidiagonalization_equals_oracle_and_strang_known_answer():
     Um = np.stack([u.data for u in U[:k]], axis=1)
     Vm = np.stack([v.data for v in V[:k]], axis=1)
     assert np.abs(Um.T @ Um - np.eye(k)).max() < 1e-12 and np.abs(Vm.T @ Vm - np.eye(k)).max() < 1e-12
+
+
+def test_on_disk_outputs_follow_the_reference_layout(tmp_path, monkeypatch):
+    """write_results / save_eigenspectrum (IterativeSolvers.fypp:881-963): header, Fortran E16.9 columns,
+    sort by residual, n x 3 npy layout read back by example/ginzburg_landau/eigenplots.py."""
+    vals = np.array([1.5 - 0.25j, -2.0 + 0.0j, 0.001 + 3.0j])
+    res = np.array([1e-3, 1e-12, 5e-9])
+    f = tmp_path / "eigs_output.txt"
+    r2 = res.copy()
+    lk.write_results(str(f), vals, r2, 1e-8)
+    lines = f.read_text().splitlines()
+    assert lines[0] == "  Iter                Re                Im           modulus          residual  conv"
+    assert lines[1] == "     3  -0.200000000E+01   0.000000000E+00   0.200000000E+01   0.100000000E-11     T"
+    assert lines[2].endswith("0.500000000E-08     T") and lines[3].endswith("0.100000000E-02     F")
+    assert np.array_equal(r2, np.sort(res))                    # the reference sorts `res` in place
+    npy = tmp_path / "spectrum.npy"
+    lk.save_eigenspectrum(vals, res, str(npy))
+    arr = np.load(npy)
+    assert arr.shape == (3, 3) and np.array_equal(arr[:, 0], vals.real) and np.array_equal(arr[:, 2], res)
+    lk.save_eigenspectrum(vals.real, res, str(npy))
+    assert np.load(npy).shape == (3, 2)
+    # eigs(write_intermediate=True) writes eigs_output.txt in the working directory every step
+    monkeypatch.chdir(tmp_path)
+    n = 64
+    A = 0.37 * np.eye(n) + 0.61 * np.eye(n, k=1) - 0.61 * np.eye(n, k=-1)
+    X = list_basis(n, 2, np.float64)
+    lk.eigs(oracle_dense_linop(A), X, x0=oracle_vector(seeded(n, np.float64, 3)), kdim=20, tolerance=1e-8,
+            write_intermediate=True)
+    out = (tmp_path / "eigs_output.txt").read_text().splitlines()
+    assert out[0].split() == ["Iter", "Re", "Im", "modulus", "residual", "conv"] and len(out) >= 3
