@@ -1,0 +1,88 @@
+/* Plain-C client of the C ABI (no Python, no torch, no Fortran): proves the boundary is usable as a
+ * C library.  Runs a 16-step Arnoldi on a diagonal operator, checks orthonormality through lk_gram,
+ * the Arnoldi relation on the host, error paths, and wrap of caller-owned device memory.
+ * Built and run by tests/test_c_client.py (gcc + libamdhip64 for hipMalloc only). */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/lightkrylov_hip.h"
+
+/* minimal HIP prototypes so this file compiles with gcc (no hip headers needed) */
+extern int hipMalloc(void **p, size_t n);
+extern int hipFree(void *p);
+extern int hipMemset(void *p, int v, size_t n);
+
+#define CHECK(call)                                                                    \
+    do {                                                                               \
+        int rc_ = (call);                                                              \
+        if (rc_ != LK_OK) { printf("FAIL %s -> %d: %s\n", #call, rc_, lk_last_error()); return 1; } \
+    } while (0)
+#define EXPECT(cond)                                                                   \
+    do { if (!(cond)) { printf("FAIL expectation %s (line %d)\n", #cond, __LINE__); return 1; } } while (0)
+
+int main(void) {
+    const int64_t n = 50001; const int m = 16;
+    lk_context_t ctx; lk_basis_t X, W; lk_linop_t A;
+    CHECK(lk_init(0, NULL, &ctx));
+    EXPECT(lk_version() >= 100);
+
+    double *d = malloc(n * sizeof(double));
+    for (int64_t i = 0; i < n; ++i) d[i] = 1.0 + (double)i / (double)n;
+    CHECK(lk_basis_create(ctx, LK_F64, n, m + 1, &X));
+    CHECK(lk_vec_rand(X, 0, 7, 0, 1));
+    CHECK(lk_linop_diag_create(ctx, LK_F64, n, d, &A));
+    double *H = calloc((size_t)(m + 1) * m, sizeof(double));
+    int info = -99;
+    CHECK(lk_arnoldi(A, X, H, m + 1, 1, m, 1e-15, 0, &info));
+    EXPECT(info == 0);
+
+    /* orthonormality via lk_gram */
+    double *G = malloc((size_t)(m + 1) * (m + 1) * sizeof(double));
+    CHECK(lk_gram(X, m + 1, G));
+    double orth = 0;
+    for (int i = 0; i <= m; ++i) for (int j = 0; j <= m; ++j) {
+        double e = fabs(G[i + j * (m + 1)] - (i == j ? 1.0 : 0.0)); if (e > orth) orth = e; }
+    EXPECT(orth < 1e-13);
+
+    /* A X_m = X_{m+1} H on the host */
+    double *Xh = malloc((size_t)n * (m + 1) * sizeof(double));
+    CHECK(lk_basis_download(X, 0, m + 1, Xh, n));
+    double res = 0;
+    for (int j = 0; j < m; ++j) for (int64_t i = 0; i < n; i += 97) {
+        double s = d[i] * Xh[i + (size_t)j * n];
+        for (int l = 0; l <= m; ++l) s -= Xh[i + (size_t)l * n] * H[l + j * (m + 1)];
+        if (fabs(s) > res) res = fabs(s); }
+    EXPECT(res < 1e-13);
+
+    /* dot / norm / axpby through (basis, column) pairs */
+    double dd[2], nn;
+    CHECK(lk_vec_dot(X, 0, X, 1, dd)); EXPECT(fabs(dd[0]) < 1e-13);
+    CHECK(lk_vec_norm(X, 3, &nn)); EXPECT(fabs(nn - 1.0) < 1e-14);
+
+    /* caller-owned device memory: wrap, ld == n rounded to even, garbage beyond n_local is never read */
+    const int64_t ld = n + 1; void *dev = NULL;
+    EXPECT(hipMalloc(&dev, (size_t)ld * 2 * sizeof(double)) == 0);
+    EXPECT(hipMemset(dev, 0xFF, (size_t)ld * 2 * sizeof(double)) == 0);   /* NaN pattern everywhere */
+    CHECK(lk_basis_wrap(ctx, LK_F64, n, 2, ld, dev, &W));
+    CHECK(lk_vec_copy(W, 0, X, 0));
+    CHECK(lk_vec_copy(W, 1, X, 1));
+    double alpha = 2.0, beta = -1.0;
+    CHECK(lk_vec_axpby(&alpha, W, 0, &beta, W, 1));          /* W1 = 2 X0 - X1 */
+    CHECK(lk_vec_norm(W, 1, &nn)); EXPECT(fabs(nn - sqrt(5.0)) < 1e-13);
+    double h[1], norms[3]; int dinfo;
+    CHECK(lk_dgs(W, 1, W, 1, h, norms, 0, &dinfo));           /* orthogonalise W1 against W0 */
+    EXPECT(fabs(h[0] - 2.0) < 1e-13 && fabs(norms[2] - 1.0) < 1e-13 && dinfo == 0);
+
+    /* error convention: negative status + message, nothing aborts */
+    EXPECT(lk_vec_zero(X, m + 5) == LK_ERR_INVALID && strstr(lk_last_error(), "out of range"));
+    EXPECT(lk_dgs(X, 3, X, 1, h, norms, 0, &dinfo) == LK_ERR_INVALID);   /* y among the basis columns */
+    EXPECT(lk_basis_wrap(ctx, LK_F64, n, 2, n, (char *)dev + 8, &W) == LK_ERR_INVALID);  /* misaligned */
+    lk_basis_t Z; EXPECT(lk_basis_create(ctx, 7, n, 1, &Z) == LK_ERR_INVALID);
+    EXPECT(lk_arnoldi(A, X, H, m, 1, m, 1e-15, 0, &info) == LK_ERR_INVALID);  /* ldh too small */
+
+    lk_basis_destroy(W); hipFree(dev);
+    lk_linop_destroy(A); lk_basis_destroy(X); lk_finalize(ctx);
+    printf("C client ok: orth=%.2e relation=%.2e\n", orth, res);
+    return 0;
+}
