@@ -12,6 +12,7 @@
 extern int hipMalloc(void **p, size_t n);
 extern int hipFree(void *p);
 extern int hipMemset(void *p, int v, size_t n);
+extern int hipDeviceSynchronize(void);
 
 #define CHECK(call)                                                                    \
     do {                                                                               \
@@ -64,6 +65,7 @@ int main(void) {
     const int64_t ld = n + 1; void *dev = NULL;
     EXPECT(hipMalloc(&dev, (size_t)ld * 2 * sizeof(double)) == 0);
     EXPECT(hipMemset(dev, 0xFF, (size_t)ld * 2 * sizeof(double)) == 0);   /* NaN pattern everywhere */
+    EXPECT(hipDeviceSynchronize() == 0);   /* the memset runs on the null stream, the engine on its own */
     CHECK(lk_basis_wrap(ctx, LK_F64, n, 2, ld, dev, &W));
     CHECK(lk_vec_copy(W, 0, X, 0));
     CHECK(lk_vec_copy(W, 1, X, 1));
