@@ -82,8 +82,8 @@ int lk_set_allreduce(lk_context_t ctx, lk_allreduce_fn fn, void *user, int nrank
  * so that counter-based rand fills are identical for every partition. */
 int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
 /* tuning knobs (integers): "grid_mult" / "update_grid_mult" blocks per CU for the panel sweeps,
- * "prefetch" (sweep 2 register double-buffering), "stream_update" (barrier-free sweep 3),
- * "defer_store" (write y one tile late). */
+ * "stream_update" (barrier-free single-coefficient update sweep), "recompute_update" (two-pass DGS:
+ * sweep 2 keeps y' in registers and sweep 3 re-forms it, so y' is never written to HBM). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
 
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg).

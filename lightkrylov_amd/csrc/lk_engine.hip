@@ -60,10 +60,9 @@ struct lk_context_s {
     bool own_stream = false;
     int num_cu = 256;
     int grid_mult = 2;  // sweep blocks per CU
-    int prefetch = 0;   // sweep 2: issue the next tile's loads before the barrier (A/B: no gain)
-    int stream_update = 1;  // sweep 3 / lincomb: barrier-free streaming kernel
+    int stream_update = 1;     // single-coefficient update sweeps: barrier-free streaming kernel
     int update_grid_mult = 4;
-    int defer_store = 0; // sweeps 2/3: write y' one tile late, after the next tile's loads are issued (A/B: no gain)
+    int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     // reduction workspace
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
     double *red = nullptr;      // device results: 3 sections of (KMAX_FUSED+1)*2 doubles
@@ -214,19 +213,25 @@ SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n) {
 }
 
 // One sweep over columns [0,k) of X (k <= KMAX_FUSED) + finish into `out` (k+1 slots of ED doubles).
-template <bool CPLX, bool UPDATE, bool DOT>
+//   MODE 1: h = X^H y                       (DOT)
+//   MODE 2: y' = y - X hin ; h = X^H y'     (UPDATE+DOT), y' written only if `store`
+//   MODE 3: y' = y - X hin                  (UPDATE)
+//   MODE 4: y'' = (y - X hin) - X hin2      (UPDATE, two coefficient sets; pairs with MODE 2, store = 0)
+template <bool CPLX, int MODE>
 int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y, int64_t n, const double *hin,
-                 double *out) {
+                 const double *hin2, int store, double *out) {
     constexpr int KC = CPLX ? 8 : 16;
     constexpr int NW = CPLX ? 16 : 8;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr bool UPDATE = MODE != 1, DOT = MODE <= 2;
     static_assert(KC * NW == KMAX_FUSED, "fused capacity");
     SweepCfg s = sweep_cfg<CPLX, KC, NW>(c, k, n);
+    // ALGORITHMIC bytes of the three-sweep schedule: k+1 | k+2 | k+2 columns
     const double bytes = (double)n * ED * 8.0 * (k + 1 + (UPDATE ? 1 : 0));
     int nblocks = s.grid;
     {
-        ProfScope ps(c, !UPDATE ? "dgs_sweep1" : (DOT ? "dgs_sweep2" : "dgs_sweep3"), bytes);
-        if (UPDATE && !DOT && c->stream_update) {
+        ProfScope ps(c, MODE == 1 ? "dgs_sweep1" : (MODE == 2 ? "dgs_sweep2" : "dgs_sweep3"), bytes);
+        if (MODE == 3 && c->stream_update) {
             const int64_t tile_rows = (int64_t)NW * 64 * K<CPLX>::ROWS;
             int64_t g = (n + tile_rows - 1) / tile_rows;
             const int64_t cap = (int64_t)c->num_cu * c->update_grid_mult;
@@ -235,13 +240,10 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
             if (g < 1) g = 1;
             nblocks = (int)g;
             hipLaunchKernelGGL((panel_update<CPLX, KC, NW>), dim3(nblocks), dim3(NW * 64), 0, c->stream, X, ldx, k, y, n, hin,
-                               c->partial, (int64_t)MAX_GRID, c->defer_store);
-        } else if (UPDATE && DOT && c->prefetch) {
-            hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, UPDATE && DOT>), dim3(s.grid), dim3(NW * 64), 0, c->stream,
-                               X, ldx, k, y, n, hin, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, c->defer_store);
+                               c->partial, (int64_t)MAX_GRID);
         } else {
-            hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, false>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X, ldx,
-                               k, y, n, hin, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, c->defer_store);
+            hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
+                               ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, store);
         }
     }
     HIPCHK(hipGetLastError());
@@ -254,12 +256,19 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
     return allreduce(c, out + first, nslots);
 }
 
-template <bool UPDATE, bool DOT>
-int sweep(lk_basis_t Bx, int c0, int k, double *y, const double *hin, double *out) {
+template <int MODE>
+int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const double *hin2, int store, double *out) {
     lk_context_t c = Bx->ctx;
     const double *X = Bx->col(c0);
-    if (Bx->dtype == LK_C128) return launch_sweep<true, UPDATE, DOT>(c, X, Bx->ld, k, y, Bx->n, hin, out);
-    return launch_sweep<false, UPDATE, DOT>(c, X, Bx->ld, k, y, Bx->n, hin, out);
+    if (Bx->dtype == LK_C128) return launch_sweep<true, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+    return launch_sweep<false, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+}
+
+// legacy spelling used by the single-purpose callers: <UPDATE, DOT>
+template <bool UPDATE, bool DOT>
+int sweep(lk_basis_t Bx, int c0, int k, double *y, const double *hin, double *out) {
+    constexpr int MODE = !UPDATE ? 1 : (DOT ? 2 : 3);
+    return sweepm<MODE>(Bx, c0, k, y, hin, nullptr, 1, out);
 }
 
 int ensure_scratch(lk_context_t c, int64_t doubles) {
@@ -323,7 +332,10 @@ int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass) {
     double *r0 = c->red, *r1 = c->red + RED_SECTION, *r2 = c->red + 2 * RED_SECTION;
     if (k <= KMAX_FUSED) {
         LKCHK((sweep<false, true>(Bx, 0, k, y, nullptr, r0)));       // h1 = X^H y ; ||y||^2
-        if (two_pass) {
+        if (two_pass && c->recompute_update) {
+            LKCHK((sweepm<2>(Bx, 0, k, y, r0, nullptr, 0, r1)));     // y' = y - X h1 (registers only); h2 = X^H y'; ||y'||^2
+            LKCHK((sweepm<4>(Bx, 0, k, y, r0, r1, 1, r2)));          // y'' = (y - X h1) - X h2 ; ||y''||^2
+        } else if (two_pass) {
             LKCHK((sweep<true, true>(Bx, 0, k, y, r0, r1)));         // y' = y - X h1 ; h2 = X^H y' ; ||y'||^2
             LKCHK((sweep<true, false>(Bx, 0, k, y, r1, r2)));        // y'' = y' - X h2 ; ||y''||^2
         } else {
@@ -423,9 +435,8 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         c->grid_mult = value;
         return LK_OK;
     }
-    if (!strcmp(key, "prefetch")) { c->prefetch = value != 0; return LK_OK; }
     if (!strcmp(key, "stream_update")) { c->stream_update = value != 0; return LK_OK; }
-    if (!strcmp(key, "defer_store")) { c->defer_store = value != 0; return LK_OK; }
+    if (!strcmp(key, "recompute_update")) { c->recompute_update = value != 0; return LK_OK; }
     if (!strcmp(key, "update_grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "update_grid_mult must be in [1,16]");
         c->update_grid_mult = value;

@@ -132,17 +132,22 @@ __device__ __forceinline__ void store_rows(double *__restrict__ y, int64_t r, in
     }
 }
 
-// PREFETCH: the next tile's loads are issued BEFORE the current tile's LDS exchange + barrier, so
-// HBM requests stay in flight while the block synchronises (costs a second register tile).
-template <bool CPLX, int KC, int NW, bool UPDATE, bool DOT, bool PREFETCH>
+// TWO (sweep 3 of the two-pass DGS): two coefficient sets.  y' = y - X h1 is RE-formed from the
+// original y exactly as sweep 2 formed it (same wave split, same summation order), then
+// y'' = y' - X h2 is written.  That lets sweep 2 run with store = 0 (y' never goes to HBM): the
+// y' write was ~1% of sweep 2's bytes but cost it 5-13% (HBM read/write mixing).
+template <bool CPLX, int KC, int NW, bool UPDATE, bool DOT, bool TWO>
 __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict__ X, int64_t ldx, int k,
                                                         double *__restrict__ y, int64_t n,
                                                         const double *__restrict__ hin,
+                                                        const double *__restrict__ hin2,
                                                         double *__restrict__ partial, int64_t pstride,
-                                                        int WC, int kcw, int defer) {
+                                                        int WC, int kcw, int store) {
+    static_assert(!TWO || (UPDATE && !DOT), "TWO is the update-only sweep with two coefficient sets");
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;  // rows one wave covers per tile
+    constexpr int NU = TWO ? 2 : 1;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -154,18 +159,25 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     nc = nc > kcw ? kcw : nc;
     nc = nc < 0 ? 0 : nc;
 
-    __shared__ v2d u_lds[UPDATE ? 2 * NW * 64 : 1];
+    __shared__ v2d u_lds[UPDATE ? 2 * NU * NW * 64 : 1];
     __shared__ double red_lds[NW * (KC * ED + 1)];
 
     // projection coefficients of this wave's columns (wave-uniform)
-    v2d hc[KC];
+    v2d hc[KC], hc2[TWO ? KC : 1];
     if constexpr (UPDATE) {
 #pragma unroll
         for (int jj = 0; jj < KC; ++jj) {
             if (jj < nc) {
                 if constexpr (CPLX) hc[jj] = v2d{hin[2 * (c0 + jj)], hin[2 * (c0 + jj) + 1]};
                 else hc[jj] = v2d{hin[c0 + jj], 0.0};
-            } else hc[jj] = v2d{0.0, 0.0};
+                if constexpr (TWO) {
+                    if constexpr (CPLX) hc2[jj] = v2d{hin2[2 * (c0 + jj)], hin2[2 * (c0 + jj) + 1]};
+                    else hc2[jj] = v2d{hin2[c0 + jj], 0.0};
+                }
+            } else {
+                hc[jj] = v2d{0.0, 0.0};
+                if constexpr (TWO) hc2[jj] = v2d{0.0, 0.0};
+            }
         }
     }
 
@@ -181,52 +193,43 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     const int64_t roff = (int64_t)wr * WROWS + (int64_t)lane * ROWS;
     int buf = 0;
 
-    v2d xv[KC], xn[KC];
-    v2d yv, yn;
-    // Optional deferred store (`defer`): y'(t) is written one iteration late, right AFTER the next
-    // tile's loads have been issued (vmcnt retires in order, so a store issued before those loads must
-    // be acknowledged before the wave may touch the loaded tile).  Interleaved A/B on MI355X: within
-    // +-1% of the immediate store for every k and kind (tuning log) -- kept as a knob, off.
-    v2d ypend = v2d{0.0, 0.0};
-    int64_t rpend = 0;
-    bool fullpend = false, have_pend = false;
-    if constexpr (PREFETCH) {
-        const int64_t t0 = blockIdx.x;
-        if (t0 < ntiles) load_tile<CPLX, KC>(Xw, colstride, y, t0 * tile_rows + roff, n, (t0 + 1) * tile_rows <= n, nc, xv, yv);
-    }
-
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int64_t r = t * tile_rows + roff;        // first row of this lane
         const bool full = (t + 1) * tile_rows <= n;   // block-uniform
-        if constexpr (PREFETCH) {
-            const int64_t tn = t + gridDim.x;
-            if (tn < ntiles) load_tile<CPLX, KC>(Xw, colstride, y, tn * tile_rows + roff, n, (tn + 1) * tile_rows <= n, nc, xn, yn);
-        } else {
-            load_tile<CPLX, KC>(Xw, colstride, y, r, n, full, nc, xv, yv);
-        }
-        if constexpr (UPDATE) {
-            if (have_pend && wc == 0) store_rows<CPLX>(y, rpend, n, fullpend, ypend);
-        }
+        v2d xv[KC];
+        v2d yv;
+        load_tile<CPLX, KC>(Xw, colstride, y, r, n, full, nc, xv, yv);
 
         if constexpr (UPDATE) {
-            v2d u = v2d{0.0, 0.0};
+            v2d u = v2d{0.0, 0.0}, u2 = v2d{0.0, 0.0};
 #pragma unroll
             for (int jj = 0; jj < KC; ++jj) {
                 if constexpr (CPLX) u += cmul(xv[jj], hc[jj]);
                 else u += xv[jj] * hc[jj].x;
             }
+            if constexpr (TWO) {
+#pragma unroll
+                for (int jj = 0; jj < KC; ++jj) {
+                    if constexpr (CPLX) u2 += cmul(xv[jj], hc2[jj]);
+                    else u2 += xv[jj] * hc2[jj].x;
+                }
+            }
             if (WC > 1) {
-                v2d *ub = u_lds + buf * (NW * 64);
+                v2d *ub = u_lds + buf * (NU * NW * 64);
                 ub[wave * 64 + lane] = u;
+                if constexpr (TWO) ub[NW * 64 + wave * 64 + lane] = u2;
                 __syncthreads();
-                v2d s = v2d{0.0, 0.0};
+                v2d s = v2d{0.0, 0.0}, s2 = v2d{0.0, 0.0};
                 for (int w = 0; w < WC; ++w) s += ub[(wr * WC + w) * 64 + lane];
+                if constexpr (TWO)
+                    for (int w = 0; w < WC; ++w) s2 += ub[NW * 64 + (wr * WC + w) * 64 + lane];
                 u = s;
+                u2 = s2;
                 buf ^= 1;
             }
             yv -= u;
-            if (defer) { ypend = yv; rpend = r; fullpend = full; have_pend = true; }
-            else if (wc == 0) store_rows<CPLX>(y, r, n, full, yv);
+            if constexpr (TWO) yv -= u2;
+            if (store && wc == 0) store_rows<CPLX>(y, r, n, full, yv);
         }
         if constexpr (DOT) {
 #pragma unroll
@@ -236,15 +239,6 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
             }
         }
         if (wc == 0) nrm += yv.x * yv.x + yv.y * yv.y;
-        if constexpr (PREFETCH) {
-#pragma unroll
-            for (int jj = 0; jj < KC; ++jj) xv[jj] = xn[jj];
-            yv = yn;
-        }
-    }
-
-    if constexpr (UPDATE) {
-        if (have_pend && wc == 0) store_rows<CPLX>(y, rpend, n, fullpend, ypend);
     }
 
     // ---- block reduction: lanes (shuffle) -> waves sharing a column set (LDS) -> partial
@@ -292,7 +286,7 @@ template <bool CPLX, int KC, int NW>
 __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict__ X, int64_t ldx, int k,
                                                          double *__restrict__ y, int64_t n,
                                                          const double *__restrict__ hin,
-                                                         double *__restrict__ partial, int64_t pstride, int defer) {
+                                                         double *__restrict__ partial, int64_t pstride) {
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;
@@ -303,9 +297,6 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
     const int64_t colstride = ldx * ED;
     double nrm = 0.0;
     __shared__ double red_lds[NW];
-    v2d ypend = v2d{0.0, 0.0};   // deferred store, see panel_sweep
-    int64_t rpend = 0;
-    bool fullpend = false, have_pend = false;
 
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int64_t r = t * tile_rows + (int64_t)wave * WROWS + (int64_t)lane * ROWS;
@@ -317,10 +308,6 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
             nc = nc > KC ? KC : nc;
             v2d xv[KC];
             load_cols<CPLX, KC>(X + (int64_t)c0 * colstride, colstride, r, n, full, nc, xv);
-            if (c0 == 0 && have_pend) {
-                store_rows<CPLX>(y, rpend, n, fullpend, ypend);
-                have_pend = false;
-            }
 #pragma unroll
             for (int jj = 0; jj < KC; ++jj) {
                 if (jj < nc) {
@@ -330,11 +317,9 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
             }
         }
         yv -= u;
-        if (defer) { ypend = yv; rpend = r; fullpend = full; have_pend = true; }
-        else store_rows<CPLX>(y, r, n, full, yv);
+        store_rows<CPLX>(y, r, n, full, yv);
         nrm += yv.x * yv.x + yv.y * yv.y;
     }
-    if (have_pend) store_rows<CPLX>(y, rpend, n, fullpend, ypend);
     const double s = wave_sum(nrm);
     if (lane == 0) red_lds[wave] = s;
     __syncthreads();

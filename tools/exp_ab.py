@@ -12,11 +12,8 @@ B = lk.krylov_basis_gpu(n, kmax + 1, dtype, ctx)
 for j in range(kmax + 1):
     B[j].rand(True, seed=100 + j)
 variants = {
-    "A_immediate_barrier": dict(defer_store=0, stream_update=0, prefetch=0),
-    "B_defer_barrier": dict(defer_store=1, stream_update=0, prefetch=0),
-    "C_defer_stream": dict(defer_store=1, stream_update=1, prefetch=0),
-    "D_immediate_stream": dict(defer_store=0, stream_update=1, prefetch=0),
-    "E_defer_stream_prefetch": dict(defer_store=1, stream_update=1, prefetch=1),
+    "A_store_yprime": dict(recompute_update=0, stream_update=1),
+    "B_recompute_yprime": dict(recompute_update=1, stream_update=1),
 }
 def run(k, reps=3):
     ctx.profile_reset(); ctx.profile_enable(True)
