@@ -12,7 +12,7 @@ scaling: total work fixed), the only cross-rank traffic being the RCCL all-reduc
 reduction scalars after each sweep.  Inputs are generated in HBM before the timed region.
 
 Prints ONE JSON line on rank 0; `value` = Arnoldi iterations per second, whole job.
-  roofline   : the panel sweep kernels (lk::panel_sweep, lk::panel_update) -- algorithmic bytes s*n_local*(k+1|k+2)
+  roofline   : the panel sweep kernel (lk::panel_sweep, three instantiations) -- algorithmic bytes s*n_local*(k+1|k+2)
                per launch (s*n*(3k+5) per DGS) / HIP-event duration on the kernel's
                stream, averaged over every sweep launch of the timed region; peak = 8 TB/s HBM3E.
   cpu_baseline: the reference-schedule CPU oracle (oracle/, 1 thread, kind "port") timed on this
@@ -181,7 +181,7 @@ def main() -> None:
                 "all_reduce": "RCCL via torch.distributed" if dist is not None else "none (single rank)",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "lk::panel_sweep (DGS sweeps 1, 2) + lk::panel_update (sweep 3)",
+                "bound": "hbm", "kernel": "lk::panel_sweep, the three DGS sweeps (DOT | UPDATE+DOT, y' kept in registers | UPDATE with two coefficient sets)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "launches": int(n_sweeps), "avg_launch_ms": sweep_ms / max(n_sweeps, 1),
