@@ -1,0 +1,141 @@
+"""The row-sharded ENGINE path on ONE GPU: two contexts (= two ranks, each owning half the rows) driven by
+two threads of one process; the all-reduce hook the engine calls after every sweep is emulated with a
+thread barrier + a device-side sum of the two ranks' reduction buffers.  (RCCL itself refuses two ranks on
+one device; the real multi-GPU launch is the driver's.)  What this pins: every place the engine must
+all-reduce (h1, h2, the three norms, rand's normalisation), the partition-independent counter RNG
+(row0 offsets), and that a sharded Arnoldi / GMRES reproduces the single-context result."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import lightkrylov_amd as lk
+from lightkrylov_amd import _capi
+from lightkrylov_amd.context import _DevMem
+
+pytestmark = pytest.mark.gpu
+
+
+class _EmulatedGroup:
+    """Sum all-reduce between `nranks` threads; buffers live on the same device."""
+
+    def __init__(self, nranks):
+        import torch
+        self.torch = torch
+        self.n = nranks
+        self.barrier = threading.Barrier(nranks)
+        self.slots = [None] * nranks
+        self.calls = 0
+
+    def hook(self, rank, ctx):
+        torch = self.torch
+
+        def _cb(_user, dev_ptr, count, stream_ptr):
+            try:
+                ctx.sync_stream_only()
+                self.slots[rank] = torch.as_tensor(_DevMem(int(dev_ptr), int(count)), device="cuda:0")
+                self.barrier.wait(timeout=120)
+                if rank == 0:
+                    total = self.slots[0].clone()
+                    for r in range(1, self.n):
+                        total += self.slots[r]
+                    for r in range(self.n):
+                        self.slots[r].copy_(total)
+                    torch.cuda.synchronize()
+                    self.calls += 1
+                self.barrier.wait(timeout=120)
+                return 0
+            except Exception as exc:  # noqa: BLE001
+                print("emulated all-reduce failed:", repr(exc))
+                self.barrier.abort()
+                return 1
+        return _capi.ALLREDUCE_FN(_cb)
+
+
+def _sharded(n, nranks, body):
+    """Run body(rank, ctx, row0, n_local) on `nranks` threads with an emulated all-reduce; returns results."""
+    lib = _capi.load()
+    grp = _EmulatedGroup(nranks)
+    out, errs = [None] * nranks, []
+
+    def worker(rank):
+        try:
+            ctx = lk.Context(device=0, use_torch_stream=False)           # own stream per rank
+            ctx.sync_stream_only = lambda: _capi.check(lib.lk_sync(ctx._h))
+            cb = grp.hook(rank, ctx)
+            _capi.check(lib.lk_set_allreduce(ctx._h, cb, None, nranks, rank))
+            ctx._cb, ctx.nranks, ctx.rank = cb, nranks, rank
+            row0, nl = lk.row_partition(n, nranks, rank)
+            ctx.set_partition(row0, n)
+            out[rank] = body(rank, ctx, row0, nl)
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+            grp.barrier.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errs, errs
+    return out, grp
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_arnoldi_matches_single_context(ctx, dtype, nranks):
+    n, m = 300_003, 40
+
+    def dvals(row0, nl):
+        g = (row0 + np.arange(nl)) / n
+        d = 1.0 + g
+        return (d * np.exp(0.3j * g)).astype(dtype) if np.dtype(dtype).kind == "c" else d
+
+    def body(rank, c, row0, nl):
+        X = lk.krylov_basis_gpu(nl, m + 1, dtype, c)
+        X[0].rand(True, seed=7)                                   # global vector, partition independent
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        info = lk.arnoldi(lk.diag_linop_gpu(dvals(row0, nl), c), X, H)
+        return info, H, X.download()
+
+    res, grp = _sharded(n, nranks, body)
+    X1 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+    X1[0].rand(True, seed=7)
+    H1 = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.arnoldi(lk.diag_linop_gpu(dvals(0, n), ctx), X1, H1) == 0
+    assert grp.calls >= 3 * m                                      # >= 3 all-reduces per Arnoldi step
+    for info, H, _ in res:
+        assert info == 0
+        assert np.array_equal(H, res[0][1])                        # every rank holds the same H
+        for j in range(m):
+            assert np.abs(H[:, j] - H1[:, j]).max() <= 1e-13 * np.abs(H1[:, j]).max()
+    Xs = np.concatenate([r[2] for r in res], axis=0)               # stitch the row blocks back together
+    assert np.abs(Xs - X1.download()).max() <= 1e-12
+    assert np.abs(Xs.conj().T @ Xs - np.eye(m + 1)).max() <= 1e-12
+
+
+def test_sharded_blas1_and_gmres(ctx):
+    n = 200_001
+
+    def body(rank, c, row0, nl):
+        d = 2.0 + (row0 + np.arange(nl)) / n
+        b = lk.dense_vector_gpu(nl, np.float64, c); b.rand(False, seed=11)
+        w = lk.dense_vector_gpu(nl, np.float64, c); w.rand(False, seed=12)
+        dots = (b.dot(w), b.norm())
+        x = b.zeros_like()
+        meta = lk.gmres_dp_metadata()
+        info = lk.gmres(lk.diag_linop_gpu(d, c), b, x, rtol=1e-10, options=lk.gmres_dp_opts(kdim=15, maxiter=3), meta=meta)
+        return dots, info, np.array(meta.res), x.to_array()
+
+    res, _ = _sharded(n, 2, body)
+    d = 2.0 + np.arange(n) / n
+    b = lk.dense_vector_gpu(n, np.float64, ctx); b.rand(False, seed=11)
+    w = lk.dense_vector_gpu(n, np.float64, ctx); w.rand(False, seed=12)
+    x = b.zeros_like()
+    meta = lk.gmres_dp_metadata()
+    info = lk.gmres(lk.diag_linop_gpu(d, ctx), b, x, rtol=1e-10, options=lk.gmres_dp_opts(kdim=15, maxiter=3), meta=meta)
+    for dots, inf, hist, _ in res:
+        assert abs(dots[0] - b.dot(w)) <= 1e-12 * b.norm() * w.norm() and abs(dots[1] - b.norm()) <= 1e-12 * b.norm()
+        assert inf == info and len(hist) == len(meta.res)
+        assert np.abs(hist - np.array(meta.res)).max() <= 1e-12 * meta.res[0]
+    xs = np.concatenate([r[3] for r in res])
+    assert np.abs(xs - x.to_array()).max() <= 1e-12 * np.abs(x.to_array()).max()
