@@ -51,6 +51,13 @@ module lightkrylov_hip_c
             integer(c_int64_t), value :: row0, n_global
             integer(c_int) :: rc
         end function
+        function lk_set_tuning(ctx, key, val) bind(C, name="lk_set_tuning") result(rc)
+            import :: c_int, c_ptr, c_char
+            type(c_ptr), value :: ctx
+            character(kind=c_char), intent(in) :: key(*)
+            integer(c_int), value :: val
+            integer(c_int) :: rc
+        end function
         function lk_basis_create(ctx, dtype, n_local, ncols, B) bind(C, name="lk_basis_create") result(rc)
             import :: c_int, c_ptr, c_int64_t
             type(c_ptr), value :: ctx

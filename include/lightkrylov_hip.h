@@ -83,8 +83,18 @@ int lk_set_allreduce(lk_context_t ctx, lk_allreduce_fn fn, void *user, int nrank
 int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
 /* tuning knobs (integers): "grid_mult" / "update_grid_mult" blocks per CU for the panel sweeps,
  * "stream_update" (barrier-free single-coefficient update sweep), "recompute_update" (two-pass DGS:
- * sweep 2 keeps y' in registers and sweep 3 re-forms it, so y' is never written to HBM). */
+ * sweep 2 keeps y' in registers and sweep 3 re-forms it, so y' is never written to HBM), "lazy" (see
+ * lk_lazy_stats). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
+
+/* Lazy batching of the per-object path (tuning key "lazy", off by default).  When on, k consecutive
+ * lk_vec_dot(X, j, y) calls over the columns of one panel cost ONE sweep (the first call computes the whole
+ * run, the rest are memo hits) and consecutive lk_vec_axpby(a_j, X, j, 1, y) calls are queued and applied as
+ * ONE panel update when anything else touches the engine.  This is what turns the schedule an unchanged
+ * LightKrylov drives through the type-bound procedures (innerprod / linear_combination loops,
+ * AbstractVectors.fypp:672-674, 600-602) into fused traffic.  out4 = {dot memo hits, batched dot sweeps,
+ * queued axpbys, queue flushes}. */
+int lk_lazy_stats(lk_context_t ctx, int64_t *out4);
 
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg).
  * tags: "dgs_sweep1|2|3" (the three panel sweeps; "dgs_sweep*" sums them -- a trailing '*' is a

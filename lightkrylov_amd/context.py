@@ -102,6 +102,12 @@ class Context:
     def set_tuning(self, key: str, value: int) -> None:
         _capi.check(self._lib.lk_set_tuning(self._h, key.encode(), int(value)))
 
+    def lazy_stats(self):
+        """(dot memo hits, batched dot sweeps, queued axpbys, queue flushes) of the lazy per-object path."""
+        out = (C.c_int64 * 4)()
+        _capi.check(self._lib.lk_lazy_stats(self._h, out))
+        return tuple(out)
+
     def sync(self) -> None:
         _capi.check(self._lib.lk_sync(self._h))
 

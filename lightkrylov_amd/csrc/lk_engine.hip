@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -42,6 +44,9 @@ int fail(int code, const char *fmt, ...) {
         if (rc_ != LK_OK) return rc_; \
     } while (0)
 
+std::mutex g_ctx_mu;
+std::set<void *> g_live_ctx;   // lk_basis_destroy may run after lk_finalize (garbage collectors): never touch a dead context
+
 struct ProfRec {
     hipEvent_t e0, e1;
     std::string tag;
@@ -75,6 +80,25 @@ struct lk_context_s {
     void *allreduce_user = nullptr;
     int nranks = 1, rank = 0;
     int64_t row0 = 0, n_global = -1;  // this rank's row block [row0, row0 + n_local) of n_global rows
+    // lazy batching of the PER-OBJECT path (opt-in, tuning key "lazy"): what an unchanged LightKrylov drives
+    // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
+    int lazy = 0;
+    struct {
+        bool valid = false;
+        const double *xbase = nullptr;   // panel the memoised columns live in
+        const double *y = nullptr;       // the vector they were dotted with
+        int j0 = 0, cnt = 0;
+        std::vector<double> vals;
+    } memo;
+    struct {
+        bool active = false;
+        lk_basis_t Bx = nullptr, By = nullptr;
+        int j0 = 0, cnt = 0, jy = 0;
+        std::vector<double> coef;        // a_i, ED doubles each
+    } queue;
+    double *coef_host = nullptr;         // pinned staging for queued coefficients
+    hipEvent_t coef_ev = nullptr;        // completion of the last staging copy
+    int64_t lazy_stats[4] = {0, 0, 0, 0};  // dot memo hits, batched dot sweeps, queued axpbys, queue flushes
     // profiling
     bool prof = false;
     std::vector<ProfRec> prof_pending;
@@ -324,6 +348,29 @@ int scal_launch(lk_basis_t B, int j, double ar, double ai, const double *inv_sqr
     return LK_OK;
 }
 
+// ---- lazy batching of the per-object path --------------------------------------------------------------
+// Pending `y <- y + sum_i a_i X(:, j0+i)` (queued by consecutive lk_vec_axpby calls with beta == 1) is
+// applied as ONE panel update; every other ABI entry flushes it first, so no call ever observes a stale y.
+int lazy_flush(lk_context_t c) {
+    if (!c->queue.active) return LK_OK;
+    auto &q = c->queue;
+    q.active = false;
+    const int ED = q.Bx->ed();
+    if (c->coef_ev) HIPCHK(hipEventSynchronize(c->coef_ev));      // previous staging copy has left the pinned buffer
+    for (int i = 0; i < q.cnt * ED; ++i) c->coef_host[i] = -q.coef[i];   // the kernel computes y - X h
+    HIPCHK(hipMemcpyAsync(c->coef, c->coef_host, (size_t)q.cnt * ED * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->coef_ev, c->stream));
+    c->lazy_stats[3] += 1;
+    return sweepm<3>(q.Bx, q.j0, q.cnt, q.By->col(q.jy), c->coef, nullptr, 1, c->red + 2 * RED_SECTION);
+}
+
+// Called at the top of every ABI entry that reads or writes vector data.
+inline int lazy_enter(lk_context_t c, bool mutates) {
+    if (!c->lazy) return LK_OK;
+    if (mutates) c->memo.valid = false;
+    return lazy_flush(c);
+}
+
 // Core of double_gram_schmidt_step for one vector; results stay in c->red (device):
 //   section 0: h1[0..k), nrm2(y)    section 1: h2[0..k), nrm2(y')   section 2 (slot k): nrm2(y'')
 int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass) {
@@ -382,6 +429,13 @@ int lk_init(int device, void *stream, lk_context_t *ctx) {
     HIPCHK(hipMemsetAsync(c->red, 0, (size_t)3 * RED_SECTION * sizeof(double), c->stream));
     HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)3 * RED_SECTION * sizeof(double), hipHostMallocDefault));
     HIPCHK(hipMalloc((void **)&c->coef, (size_t)KMAX_FUSED * 2 * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&c->coef_host, (size_t)KMAX_FUSED * 2 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->coef_ev, c->stream));
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        g_live_ctx.insert(c);
+    }
     *ctx = c;
     return LK_OK;
 }
@@ -389,6 +443,12 @@ int lk_init(int device, void *stream, lk_context_t *ctx) {
 int lk_finalize(lk_context_t c) {
     if (!c) return LK_OK;
     (void)hipSetDevice(c->device);
+    (void)lazy_flush(c);
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        g_live_ctx.erase(c);
+    }
+
     (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -397,6 +457,8 @@ int lk_finalize(lk_context_t c) {
     if (c->coef) (void)hipFree(c->coef);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->red_host) (void)hipHostFree(c->red_host);
+    if (c->coef_host) (void)hipHostFree(c->coef_host);
+    if (c->coef_ev) (void)hipEventDestroy(c->coef_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LK_OK;
@@ -404,6 +466,7 @@ int lk_finalize(lk_context_t c) {
 
 int lk_sync(lk_context_t c) {
     if (!c) return fail(LK_ERR_INVALID, "lk_sync: null context");
+    LKCHK(lazy_enter(c, false));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->prof) prof_collect(c);
     return LK_OK;
@@ -436,6 +499,12 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "stream_update")) { c->stream_update = value != 0; return LK_OK; }
+    if (!strcmp(key, "lazy")) {
+        LKCHK(lazy_flush(c));
+        c->memo.valid = false;
+        c->lazy = value != 0;
+        return LK_OK;
+    }
     if (!strcmp(key, "recompute_update")) { c->recompute_update = value != 0; return LK_OK; }
     if (!strcmp(key, "update_grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "update_grid_mult must be in [1,16]");
@@ -478,6 +547,12 @@ int lk_profile_get(lk_context_t c, const char *tag, int64_t *count, double *tota
     return LK_OK;
 }
 
+int lk_lazy_stats(lk_context_t c, int64_t *out4) {
+    if (!c || !out4) return fail(LK_ERR_INVALID, "lk_lazy_stats: null argument");
+    for (int i = 0; i < 4; ++i) out4[i] = c->lazy_stats[i];
+    return LK_OK;
+}
+
 // ---- basis --------------------------------------------------------------------------------
 int lk_basis_create(lk_context_t c, int dtype, int64_t n_local, int ncols, lk_basis_t *B) {
     if (!c || !B) return fail(LK_ERR_INVALID, "lk_basis_create: null argument");
@@ -513,6 +588,13 @@ int lk_basis_wrap(lk_context_t c, int dtype, int64_t n_local, int ncols, int64_t
 
 int lk_basis_destroy(lk_basis_t B) {
     if (!B) return LK_OK;
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mu);
+        if (g_live_ctx.count(B->ctx)) {          // a queued update may still target / read this panel
+            (void)lazy_flush(B->ctx);
+            B->ctx->memo.valid = false;
+        }
+    }
     // hipFree waits for outstanding device work itself; the context may already be finalized.
     if (B->own && B->data) (void)hipFree(B->data);
     delete B;
@@ -533,6 +615,7 @@ int lk_basis_upload(lk_basis_t B, int col0, int ncols, const void *host, int64_t
     if (!B || !host) return fail(LK_ERR_INVALID, "lk_basis_upload: null argument");
     if (col0 < 0 || ncols < 0 || col0 + ncols > B->ncols || ldh < B->n) return fail(LK_ERR_INVALID, "lk_basis_upload: bad range");
     if (ncols == 0 || B->n == 0) return LK_OK;
+    LKCHK(lazy_enter(B->ctx, true));
     const size_t es = (size_t)B->ed() * sizeof(double);
     HIPCHK(hipMemcpy2DAsync(B->col(col0), (size_t)B->ld * es, host, (size_t)ldh * es, (size_t)B->n * es, ncols,
                             hipMemcpyHostToDevice, B->ctx->stream));
@@ -544,6 +627,7 @@ int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh
     if (!B || !host) return fail(LK_ERR_INVALID, "lk_basis_download: null argument");
     if (col0 < 0 || ncols < 0 || col0 + ncols > B->ncols || ldh < B->n) return fail(LK_ERR_INVALID, "lk_basis_download: bad range");
     if (ncols == 0 || B->n == 0) return LK_OK;
+    LKCHK(lazy_enter(B->ctx, false));
     const size_t es = (size_t)B->ed() * sizeof(double);
     HIPCHK(hipMemcpy2DAsync(host, (size_t)ldh * es, B->col(col0), (size_t)B->ld * es, (size_t)B->n * es, ncols,
                             hipMemcpyDeviceToHost, B->ctx->stream));
@@ -554,6 +638,7 @@ int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh
 // ---- vector TBPs ----------------------------------------------------------------------------
 int lk_vec_zero(lk_basis_t B, int j) {
     LKCHK(check_vec(B, j, "lk_vec_zero"));
+    LKCHK(lazy_enter(B->ctx, true));
     HIPCHK(hipMemsetAsync(B->col(j), 0, (size_t)B->n * B->ed() * sizeof(double), B->ctx->stream));
     return LK_OK;
 }
@@ -561,6 +646,7 @@ int lk_vec_zero(lk_basis_t B, int j) {
 int lk_vec_scal(lk_basis_t B, int j, const double *alpha) {
     LKCHK(check_vec(B, j, "lk_vec_scal"));
     if (!alpha) return fail(LK_ERR_INVALID, "lk_vec_scal: null alpha");
+    LKCHK(lazy_enter(B->ctx, true));
     return scal_launch(B, j, alpha[0], B->dtype == LK_C128 ? alpha[1] : 0.0, nullptr, 0.0);
 }
 
@@ -571,6 +657,28 @@ int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta,
     if (!alpha || !beta) return fail(LK_ERR_INVALID, "lk_vec_axpby: null scalar");
     lk_context_t c = Bx->ctx;
     const bool cp = Bx->dtype == LK_C128;
+    if (c->lazy) {
+        // y <- a X(:, jx) + 1 y with X a column of a multi-column panel: queue it (linear_combination's loop,
+        // AbstractVectors.fypp:600-602 / 637-642); consecutive columns onto the same y extend the queue.
+        const int ED = Bx->ed();
+        const bool unit_beta = beta[0] == 1.0 && (!cp || beta[1] == 0.0);
+        const bool y_in_range = (By->data == Bx->data) && jy == jx;
+        c->memo.valid = false;                                   // y is (about to be) modified
+        if (unit_beta && Bx->ncols > 1 && !y_in_range && Bx->col(jx) != By->col(jy)) {
+            auto &q = c->queue;
+            const bool extends = q.active && q.Bx == Bx && q.By == By && q.jy == jy && jx == q.j0 + q.cnt &&
+                                 q.cnt < KMAX_FUSED && !(By->data == Bx->data && jy == jx);
+            if (!extends) {
+                LKCHK(lazy_flush(c));
+                q.active = true; q.Bx = Bx; q.By = By; q.jy = jy; q.j0 = jx; q.cnt = 0; q.coef.clear();
+            }
+            for (int e = 0; e < ED; ++e) q.coef.push_back(alpha[e]);
+            q.cnt += 1;
+            c->lazy_stats[2] += 1;
+            return LK_OK;
+        }
+        LKCHK(lazy_flush(c));
+    }
     const int64_t nv = Bx->n * Bx->ed() / 2 + 1;
     ProfScope ps(c, "blas1", (double)Bx->n * Bx->ed() * 24.0);
     if (cp)
@@ -589,6 +697,32 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
     LKCHK(check_pair(Bx, By, "lk_vec_dot"));
     if (!out) return fail(LK_ERR_INVALID, "lk_vec_dot: null out");
     lk_context_t c = Bx->ctx;
+    LKCHK(lazy_enter(c, false));
+    if (c->lazy && Bx->ncols > 1) {
+        // innerprod's loop (AbstractVectors.fypp:672-674, 690-694) asks X(1)%dot(y), X(2)%dot(y), ...:
+        // the first miss computes the dots of the whole run of columns in ONE sweep, the rest are memo hits.
+        const int ED = Bx->ed();
+        auto &mm = c->memo;
+        const double *yp = By->col(jy);
+        if (mm.valid && mm.xbase == Bx->data && mm.y == yp && jx >= mm.j0 && jx < mm.j0 + mm.cnt) {
+            for (int e = 0; e < ED; ++e) out[e] = mm.vals[(size_t)(jx - mm.j0) * ED + e];
+            c->lazy_stats[0] += 1;
+            return LK_OK;
+        }
+        int jend = (By->data == Bx->data && jy > jx) ? jy : Bx->ncols;   // X(:k) vs y = X(k+1) in the same panel
+        int cnt = jend - jx;
+        if (cnt > KMAX_FUSED) cnt = KMAX_FUSED;
+        const bool y_inside = (By->data == Bx->data) && jy >= jx && jy < jx + cnt;
+        if (cnt >= 2 && !y_inside) {
+            LKCHK((sweepm<1>(Bx, jx, cnt, By->col(jy), nullptr, nullptr, 0, c->red)));
+            LKCHK(fetch(c, 0, 1));
+            mm.vals.assign(c->red_host, c->red_host + (size_t)cnt * ED);
+            mm.valid = true; mm.xbase = Bx->data; mm.y = yp; mm.j0 = jx; mm.cnt = cnt;
+            c->lazy_stats[1] += 1;
+            for (int e = 0; e < ED; ++e) out[e] = mm.vals[e];
+            return LK_OK;
+        }
+    }
     LKCHK(dot_device(Bx, jx, By, jy, c->red));
     LKCHK(fetch(c, 0, 1));
     out[0] = c->red_host[0];
@@ -600,6 +734,7 @@ int lk_vec_norm(lk_basis_t B, int j, double *out) {
     LKCHK(check_vec(B, j, "lk_vec_norm"));
     if (!out) return fail(LK_ERR_INVALID, "lk_vec_norm: null out");
     lk_context_t c = B->ctx;
+    LKCHK(lazy_enter(c, false));
     LKCHK(dot_device(B, j, B, j, c->red));
     LKCHK(fetch(c, 0, 1));
     // alpha = abs(self%dot(self)); alpha = sqrt(alpha)   AbstractVectors.fypp:431
@@ -618,6 +753,7 @@ int lk_vec_copy(lk_basis_t Bd, int jd, lk_basis_t Bs, int js) {
     LKCHK(check_vec(Bs, js, "lk_vec_copy(from)"));
     LKCHK(check_pair(Bd, Bs, "lk_vec_copy"));
     if (Bd->col(jd) == Bs->col(js)) return LK_OK;
+    LKCHK(lazy_enter(Bd->ctx, true));
     ProfScope ps(Bd->ctx, "blas1", (double)Bd->n * Bd->ed() * 16.0);
     HIPCHK(hipMemcpyAsync(Bd->col(jd), Bs->col(js), (size_t)Bd->n * Bd->ed() * sizeof(double), hipMemcpyDeviceToDevice,
                           Bd->ctx->stream));
@@ -627,6 +763,7 @@ int lk_vec_copy(lk_basis_t Bd, int jd, lk_basis_t Bs, int js) {
 int lk_vec_rand(lk_basis_t B, int j, uint64_t seed, int64_t row0, int ifnorm) {
     LKCHK(check_vec(B, j, "lk_vec_rand"));
     lk_context_t c = B->ctx;
+    LKCHK(lazy_enter(c, true));
     if (B->dtype == LK_C128)
         hipLaunchKernelGGL(k_rand<true>, dim3(blas1_grid(c, B->n)), dim3(256), 0, c->stream, B->col(j), B->n, seed, row0);
     else
@@ -645,6 +782,7 @@ int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M)
     LKCHK(check_pair(Bx, By, "lk_innerprod"));
     if (k < 1 || k > Bx->ncols || p < 1 || jy0 < 0 || jy0 + p > By->ncols) return fail(LK_ERR_INVALID, "lk_innerprod: bad range");
     lk_context_t c = Bx->ctx;
+    LKCHK(lazy_enter(c, false));
     const int ED = Bx->ed();
     for (int j = 0; j < p; ++j) {
         for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
@@ -680,6 +818,7 @@ int lk_lincomb(lk_basis_t Bx, int k, const double *C, int q, lk_basis_t By, int 
     if (k < 1 || k > Bx->ncols || q < 1 || jy0 < 0 || jy0 + q > By->ncols)
         return fail(LK_ERR_INVALID, "Krylov basis X and combination matrix B have incompatible sizes.");
     lk_context_t c = Bx->ctx;
+    LKCHK(lazy_enter(c, true));
     const int ED = Bx->ed();
     const bool cp = Bx->dtype == LK_C128;
     // the output columns must not be among the inputs (the reference writes into a fresh Xwrk / proj)
@@ -720,6 +859,7 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
     LKCHK(check_pair(Bx, By, "double_gram_schmidt_step"));
     if (k < 1 || k > Bx->ncols) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: k=%d out of range [1,%d]", k, Bx->ncols);
     lk_context_t c = Bx->ctx;
+    LKCHK(lazy_enter(c, true));
     const int ED = Bx->ed();
     double *y = By->col(jy);
     if (Bx == By && jy < k) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: y is one of the basis columns");
@@ -872,6 +1012,7 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
     LKCHK(check_pair(Bx, By, "lk_linop_apply"));
     if (Bx->dtype != op->dtype || Bx->n != op->n) return fail(LK_ERR_INVALID, "lk_linop_apply: operator/vector mismatch");
     lk_context_t c = op->ctx;
+    LKCHK(lazy_enter(c, true));
     const double *x = Bx->col(jx);
     double *y = By->col(jy);
     if (x == y) return fail(LK_ERR_INVALID, "lk_linop_apply: vec_in and vec_out alias");

@@ -535,3 +535,82 @@ def test_bidiagonalization_against_oracle(ctx, dtype):
     assert np.abs(A @ Vg - Ug @ B).max() <= 1e-11 * np.abs(B).max()
     assert np.abs(Ug.conj().T @ Ug - np.eye(kdim + 1)).max() <= 1e-12
     assert np.abs(Vg.conj().T @ Vg - np.eye(kdim)).max() <= 1e-12
+
+
+# ----------------------------------------------------------------------------- lazy per-object path
+@pytest.mark.parametrize("dtype", KINDS)
+def test_lazy_per_object_path_batches_the_reference_schedule(dtype):
+    """What an unchanged LightKrylov drives through the type-bound procedures: innerprod = k dots, then
+    linear_combination = k axpbys, twice per DGS.  With the engine's lazy mode the k dots cost ONE sweep and
+    the k axpbys ONE panel update, and the results equal the eager per-object path and the oracle."""
+    n, k = 50_001, 37
+    Q = orthonormal_basis(n, k, dtype, 3)
+    y0 = seeded(n, dtype, 77)
+    results = {}
+    for lazy in (0, 1):
+        c = lk.Context(device=0)
+        c.set_tuning("lazy", lazy)
+        B = lk.krylov_basis_gpu(n, k + 1, dtype, c)
+        B.upload(Q, 0); B.upload(y0.reshape(-1, 1), k)
+        X = [B[j] for j in range(k)]                       # python LIST of vectors => generic per-object path
+        beta = np.zeros(k, dtype=dtype)
+        info = lk.double_gram_schmidt_step(B[k], X, if_chk_orthonormal=False, beta=beta)
+        results[lazy] = (info, beta.copy(), B.download(k, 1)[:, 0], c.lazy_stats())
+        del X, B
+        c.close()
+    (i0, b0, y_eager, s0), (i1, b1, y_lazy, s1) = results[0], results[1]
+    assert s0 == (0, 0, 0, 0)
+    hits, sweeps, queued, flushes = s1
+    assert sweeps == 2 and hits == 2 * (k - 1)             # one batched sweep per pass, the other k-1 dots are memo hits
+    assert queued == 2 * k and flushes == 2                # k queued axpbys per pass, applied as one panel update each
+    yo = y0.copy()
+    ho, info_o = ora.double_gram_schmidt_step(yo, Q)
+    ynorm = np.linalg.norm(y0)
+    assert i0 == i1 == info_o
+    for b, yy in ((b0, y_eager), (b1, y_lazy)):
+        assert np.abs(b - ho).max() <= RTOL_RED * ynorm and np.abs(yy - yo).max() <= RTOL_RED * ynorm
+
+
+def test_lazy_mode_arnoldi_gmres_and_interleaved_calls_stay_correct():
+    """Lazy mode through whole solvers (generic per-object path) and with calls that must flush / invalidate:
+    a queued axpby followed by a read of y, a memo followed by a write to y, a write to a memoised column."""
+    n, m = 20_011, 24
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", 1)
+    d = 1.0 + np.arange(n) / n
+    A = lk.diag_linop_gpu(d, c)
+
+    class pyop(lk.abstract_linop):                        # python operator => python step loop
+        def matvec(self, vi, vo): A.matvec(vi, vo)
+    x0 = seeded(n, np.float64, 7); x0 /= np.linalg.norm(x0)
+    B = lk.krylov_basis_gpu(n, m + 1, np.float64, c); B.upload(x0.reshape(-1, 1), 0)
+    X = [B[j] for j in range(m + 1)]
+    H = np.zeros((m + 1, m), order="F")
+    assert lk.arnoldi(pyop(), X, H) == 0
+    Xo = np.zeros((n, m + 1), order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), order="F")
+    assert ora.arnoldi(ora.DiagOp(d), Xo, Ho) == 0
+    for j in range(m):
+        assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL_RED * np.abs(Ho[:, j]).max()
+    assert c.lazy_stats()[1] >= 2 * (m - 1)               # batched sweeps actually happened
+
+    # interleavings
+    P = lk.krylov_basis_gpu(n, 4, np.float64, c)
+    for j in range(4):
+        P[j].rand(False, seed=30 + j)
+    Ph = P.download()
+    y = lk.dense_vector_gpu.from_array(seeded(n, np.float64, 40), c)
+    yh = y.to_array()
+    y.axpby(2.0, P[0], 1.0); y.axpby(-3.0, P[1], 1.0)     # queued
+    assert abs(y.norm() - np.linalg.norm(yh + 2 * Ph[:, 0] - 3 * Ph[:, 1])) <= 1e-12 * np.linalg.norm(yh)   # norm flushes
+    d0 = P[0].dot(y); d1 = P[1].dot(y)                    # d1 is a memo hit
+    y.scal(0.5)                                           # write to y invalidates the memo
+    d0b = P[0].dot(y)
+    assert abs(d0b - 0.5 * d0) <= 1e-12 * abs(d0) and abs(d1 - Ph[:, 1] @ (yh + 2 * Ph[:, 0] - 3 * Ph[:, 1])) <= 1e-9
+    P[1].scal(2.0)                                        # write to a memoised column invalidates too
+    assert abs(P[1].dot(y) - 2.0 * 0.5 * d1) <= 1e-12 * abs(d1)
+    y.axpby(1.0, P[2], 1.0)                               # queued, then a non-unit beta forces eager order
+    y.axpby(1.0, P[3], 0.25)
+    ref = 0.25 * (0.5 * (yh + 2 * Ph[:, 0] - 3 * Ph[:, 1]) + Ph[:, 2]) + Ph[:, 3]
+    assert np.abs(y.to_array() - ref).max() <= 1e-13 * np.abs(ref).max()
+    c.close()
