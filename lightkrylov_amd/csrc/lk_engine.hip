@@ -295,6 +295,30 @@ int sweep(lk_basis_t Bx, int c0, int k, double *y, const double *hin, double *ou
     return sweepm<MODE>(Bx, c0, k, y, hin, nullptr, 1, out);
 }
 
+// M(:, q) = X(:, c0:c0+k)^H Y(:, jy0+q), q < pn <= 2, in one pass over X; results land in c->red as
+// [q][k+1][ED] (slot k of each q = ||Y_q||^2), all-reduced.
+int dots_p2(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int pn) {
+    lk_context_t c = Bx->ctx;
+    const bool cp = Bx->dtype == LK_C128;
+    const int ED = Bx->ed();
+    const int nslots = 2 * (k + 1) * ED;
+    SweepCfg s = cp ? sweep_cfg<true, 8, 16>(c, k, Bx->n) : sweep_cfg<false, 16, 8>(c, k, Bx->n);
+    {
+        ProfScope ps(c, "dots_p", (double)Bx->n * ED * 8.0 * (k + pn));
+        if (cp)
+            hipLaunchKernelGGL((panel_dot_p<true, 8, 16, 2>), dim3(s.grid), dim3(1024), 0, c->stream, Bx->col(c0), Bx->ld, k,
+                               By->col(jy0), By->ld, pn, Bx->n, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw);
+        else
+            hipLaunchKernelGGL((panel_dot_p<false, 16, 8, 2>), dim3(s.grid), dim3(512), 0, c->stream, Bx->col(c0), Bx->ld, k,
+                               By->col(jy0), By->ld, pn, Bx->n, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw);
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(finish_partials, dim3((nslots + 3) / 4), dim3(256), 0, c->stream, c->partial, (int64_t)MAX_GRID, s.grid,
+                       nslots, c->red);
+    HIPCHK(hipGetLastError());
+    return allreduce(c, c->red, nslots);
+}
+
 int ensure_scratch(lk_context_t c, int64_t doubles) {
     if (c->scratch_n >= doubles) return LK_OK;
     if (c->scratch) HIPCHK(hipFree(c->scratch));
@@ -424,7 +448,7 @@ int lk_init(int device, void *stream, lk_context_t *ctx) {
         HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         c->own_stream = true;
     }
-    HIPCHK(hipMalloc((void **)&c->partial, (size_t)RED_SECTION * MAX_GRID * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&c->partial, (size_t)2 * RED_SECTION * MAX_GRID * sizeof(double)));   // 2 y-columns per multi-RHS pass
     HIPCHK(hipMalloc((void **)&c->red, (size_t)3 * RED_SECTION * sizeof(double)));
     HIPCHK(hipMemsetAsync(c->red, 0, (size_t)3 * RED_SECTION * sizeof(double), c->stream));
     HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)3 * RED_SECTION * sizeof(double), hipHostMallocDefault));
@@ -784,12 +808,21 @@ int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M)
     lk_context_t c = Bx->ctx;
     LKCHK(lazy_enter(c, false));
     const int ED = Bx->ed();
-    for (int j = 0; j < p; ++j) {
+    for (int j = 0; j < p; j += 2) {
+        const int pn = (p - j) < 2 ? (p - j) : 2;
         for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
             const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
-            LKCHK((sweep<false, true>(Bx, c0, kk, By->col(jy0 + j), nullptr, c->red)));
-            LKCHK(fetch(c, 0, 1));
-            memcpy(M + ((size_t)j * k + c0) * ED, c->red_host, (size_t)kk * ED * sizeof(double));
+            if (pn == 1) {
+                LKCHK((sweep<false, true>(Bx, c0, kk, By->col(jy0 + j), nullptr, c->red)));
+                LKCHK(fetch(c, 0, 1));
+                memcpy(M + ((size_t)j * k + c0) * ED, c->red_host, (size_t)kk * ED * sizeof(double));
+            } else {                                   // two columns of Y per pass over X
+                LKCHK(dots_p2(Bx, c0, kk, By, jy0 + j, 2));
+                LKCHK(fetch(c, 0, 3));
+                for (int q = 0; q < 2; ++q)
+                    memcpy(M + ((size_t)(j + q) * k + c0) * ED, c->red_host + (size_t)q * (kk + 1) * ED,
+                           (size_t)kk * ED * sizeof(double));
+            }
         }
     }
     return LK_OK;
@@ -840,10 +873,10 @@ int lk_lincomb(lk_basis_t Bx, int k, const double *C, int q, lk_basis_t By, int 
             ProfScope ps(c, "lincomb", (double)Bx->n * ED * 8.0 * (kk + qn));
             if (cp)
                 hipLaunchKernelGGL((panel_gemm<true, 8, 8>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, kk,
-                                   By->col(jy0 + q0), By->ld, qn, Cd, (int64_t)k, Bx->n, c0 > 0 ? 1 : 0);
+                                   By->col(jy0 + q0), By->ld, qn, Cd, (int64_t)k, Bx->n, c0 > 0 ? 1 : 0, 1.0);
             else
                 hipLaunchKernelGGL((panel_gemm<false, 8, 16>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, kk,
-                                   By->col(jy0 + q0), By->ld, qn, Cd, (int64_t)k, Bx->n, c0 > 0 ? 1 : 0);
+                                   By->col(jy0 + q0), By->ld, qn, Cd, (int64_t)k, Bx->n, c0 > 0 ? 1 : 0, 1.0);
             HIPCHK(hipGetLastError());
         }
     }
@@ -923,11 +956,60 @@ int lk_dgs(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, double *norms
     return dgs_generic(Bx, k, By, jy, h, norms, flags, info, true);
 }
 
+// Y(:, jy0:jy0+qn) -= X(:, :k) * C, C = device coefficients laid out [q][ldc][ED] (what dots_p2 leaves in c->red)
+static int gemm_subtract(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int qn, const double *Cdev, int64_t ldc) {
+    lk_context_t c = Bx->ctx;
+    const bool cp = Bx->dtype == LK_C128;
+    const int64_t tile_rows = 4 * 64 * (cp ? 1 : 2);
+    int64_t g = (Bx->n + tile_rows - 1) / tile_rows;
+    const int64_t cap = (int64_t)c->num_cu * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    ProfScope ps(c, "lincomb", (double)Bx->n * Bx->ed() * 8.0 * (k + 2 * qn));
+    if (cp)
+        hipLaunchKernelGGL((panel_gemm<true, 8, 8>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(0), Bx->ld, k,
+                           By->col(jy0), By->ld, qn, Cdev, ldc, Bx->n, 1, -1.0);
+    else
+        hipLaunchKernelGGL((panel_gemm<false, 8, 16>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(0), Bx->ld, k,
+                           By->col(jy0), By->ld, qn, Cdev, ldc, Bx->n, 1, -1.0);
+    HIPCHK(hipGetLastError());
+    return LK_OK;
+}
+
 int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h, int *info) {
     if (!Bx || !By) return fail(LK_ERR_INVALID, "lk_dgs_block: null basis");
     if (p < 1 || jy0 < 0 || jy0 + p > By->ncols) return fail(LK_ERR_INVALID, "lk_dgs_block: bad column range");
     const int ED = Bx->ed();
     int inf = 0;
+    if (k >= 1 && k <= KMAX_FUSED && k <= Bx->ncols && p >= 2 && Bx->ctx == By->ctx && Bx->dtype == By->dtype &&
+        Bx->n == By->n && !(Bx->data == By->data && jy0 < k)) {
+        // panel x panel schedule, two columns of Y per pass over X:
+        //   H1 = X^H Y | Y -= X H1 | H2 = X^H Y | Y -= X H2      (DGS_basis_against_basis, gram_schmidt.fypp:59-105)
+        lk_context_t c = Bx->ctx;
+        LKCHK(lazy_enter(c, true));
+        for (int j = 0; j < p; j += 2) {
+            const int pn = (p - j) < 2 ? (p - j) : 2;
+            std::vector<double> h1((size_t)2 * (k + 1) * ED);
+            for (int pass = 0; pass < 2; ++pass) {
+                LKCHK(dots_p2(Bx, 0, k, By, jy0 + j, pn));
+                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, c->red, (int64_t)(k + 1)));
+                LKCHK(fetch(c, 0, 3));
+                const double *r = c->red_host;
+                for (int q = 0; q < pn; ++q) {
+                    const double nrm = std::sqrt(std::fabs(r[((size_t)q * (k + 1) + k) * ED]));
+                    if (pass == 1 && nrm < ATOL_DP) inf = j + q + 1;             // gram_schmidt.fypp:171-173 (pass 2 overwrites)
+                    if (nrm != nrm) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+                    for (int i = 0; i < k * ED; ++i) {
+                        const double v = r[(size_t)q * (k + 1) * ED + i];
+                        if (pass == 0) h1[(size_t)q * (k + 1) * ED + i] = v;
+                        else if (h) h[((size_t)(j + q) * k) * ED + i] = h1[(size_t)q * (k + 1) * ED + i] + v;   // :97
+                    }
+                }
+            }
+        }
+        if (info) *info = inf;
+        return LK_OK;
+    }
     for (int j = 0; j < p; ++j) {
         int ij = 0;
         LKCHK(dgs_generic(Bx, k, By, jy0 + j, h ? h + (size_t)j * k * ED : nullptr, nullptr, 0, &ij, true));

@@ -279,6 +279,89 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     }
 }
 
+// Multi-right-hand-side dots: M(:, q) = X(:, :k)^H Y(:, q) and ||Y(:, q)||^2 for P columns of Y in ONE pass
+// over X (innerprod_matrix, AbstractVectors.fypp:677-695; Gram; the dot sweeps of DGS_basis_against_basis,
+// gram_schmidt.fypp:59-105).  Same wave split as panel_sweep<DOT>; P accumulator sets per column.
+// partial layout: slot (q*(k+1) + j)*ED (+part), j = k is the norm slot of column q.
+template <bool CPLX, int KC, int NW, int P>
+__global__ __launch_bounds__(NW * 64) void panel_dot_p(const double *__restrict__ X, int64_t ldx, int k,
+                                                        const double *__restrict__ Y, int64_t ldy, int pn, int64_t n,
+                                                        double *__restrict__ partial, int64_t pstride, int WC, int kcw) {
+    constexpr int ROWS = K<CPLX>::ROWS;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int WROWS = 64 * ROWS;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wc = wave % WC, wr = wave / WC, WR = NW / WC;
+    const int c0 = wc * kcw;
+    int nc = k - c0;
+    nc = nc > kcw ? kcw : nc;
+    nc = nc < 0 ? 0 : nc;
+    constexpr int SLOTS = (KC * ED + 1) * P;
+    __shared__ double red_lds[NW * SLOTS];
+
+    v2d acc[P][KC];
+    double nrm[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        nrm[q] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) acc[q][jj] = v2d{0.0, 0.0};
+    }
+    const int64_t tile_rows = (int64_t)WR * WROWS;
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const double *Xw = X + (int64_t)c0 * ldx * ED;
+    const int64_t colstride = ldx * ED, ystride = ldy * ED;
+    const int64_t roff = (int64_t)wr * WROWS + (int64_t)lane * ROWS;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t r = t * tile_rows + roff;
+        const bool full = (t + 1) * tile_rows <= n;
+        v2d xv[KC], yv[P];
+        load_cols<CPLX, KC>(Xw, colstride, r, n, full, nc, xv);
+#pragma unroll
+        for (int q = 0; q < P; ++q) yv[q] = (q < pn) ? load_y<CPLX>(Y + q * ystride, r, n, full) : v2d{0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) {
+                if constexpr (CPLX) acc[q][jj] += cmulconj(xv[jj], yv[q]);
+                else acc[q][jj] += xv[jj] * yv[q];
+            }
+            if (wc == 0) nrm[q] += yv[q].x * yv[q].x + yv[q].y * yv[q].y;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        double *rl = red_lds + wave * SLOTS + q * (KC * ED + 1);
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) {
+            if constexpr (CPLX) {
+                double re = wave_sum(acc[q][jj].x), im = wave_sum(acc[q][jj].y);
+                if (lane == 0) { rl[2 * jj] = re; rl[2 * jj + 1] = im; }
+            } else {
+                double sm = wave_sum(acc[q][jj].x + acc[q][jj].y);
+                if (lane == 0) rl[jj] = sm;
+            }
+        }
+        double sn = wave_sum(nrm[q]);
+        if (lane == 0) rl[KC * ED] = sn;
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < P * (k + 1) * ED; idx += blockDim.x) {
+        const int q = idx / ((k + 1) * ED), rem = idx % ((k + 1) * ED);
+        const int j = rem / ED, part = rem % ED;
+        double sm = 0.0;
+        if (j < k) {
+            const int wcj = j / kcw, jj = j - wcj * kcw;
+            for (int w = 0; w < WR; ++w) sm += red_lds[(w * WC + wcj) * SLOTS + q * (KC * ED + 1) + jj * ED + part];
+        } else if (part == 0) {
+            for (int w = 0; w < WR; ++w) sm += red_lds[(w * WC) * SLOTS + q * (KC * ED + 1) + KC * ED];
+        }
+        partial[(int64_t)idx * pstride + blockIdx.x] = sm;
+    }
+}
+
 // Streaming update y <- y - X(:, :k) * hin with ||y_out||^2: no dots, so nothing has to stay in
 // registers and every wave can walk ALL k columns of its own rows in chunks of KC -- no LDS
 // exchange, no barrier in the loop.  Used for DGS sweep 3 and for linear_combination.
@@ -341,7 +424,7 @@ template <bool CPLX, int KC, int QB>
 __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, int64_t ldx, int k,
                                                   double *__restrict__ Y, int64_t ldy, int qn,
                                                   const double *__restrict__ Cdev, int64_t ldc, int64_t n,
-                                                  int accumulate) {
+                                                  int accumulate, double sign) {
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;
@@ -351,7 +434,7 @@ __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, 
     for (int idx = threadIdx.x; idx < k * QB; idx += blockDim.x) {
         const int j = idx / QB, qq = idx % QB;
         for (int e = 0; e < ED; ++e)
-            Cd[(j * QB + qq) * ED + e] = (qq < qn) ? Cdev[((int64_t)qq * ldc + j) * ED + e] : 0.0;
+            Cd[(j * QB + qq) * ED + e] = (qq < qn) ? sign * Cdev[((int64_t)qq * ldc + j) * ED + e] : 0.0;
     }
     __syncthreads();
 

@@ -614,3 +614,38 @@ def test_lazy_mode_arnoldi_gmres_and_interleaved_calls_stay_correct():
     ref = 0.25 * (0.5 * (yh + 2 * Ph[:, 0] - 3 * Ph[:, 1]) + Ph[:, 2]) + Ph[:, 3]
     assert np.abs(y.to_array() - ref).max() <= 1e-13 * np.abs(ref).max()
     c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("p", [2, 4, 5])
+def test_block_arnoldi_on_gpu_panels(ctx, dtype, p):
+    """Block Arnoldi (arnoldi.fypp:34-56 with blksize = p; test/TestKrylov.fypp:244-296): the block DGS runs as a
+    panel x panel schedule (two Y columns per pass over X).  A X = X+ H+ and X^H X = I; H against the oracle's
+    per-column DGS applied to the same block."""
+    n, kdim = 3001, 6
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    if np.dtype(dtype).kind == "c":
+        A = A + 1j * rng.standard_normal((n, n)) / np.sqrt(n)
+    A = np.asfortranarray(A.astype(dtype))
+    Q0, _ = np.linalg.qr(basis(n, p, dtype, 70))
+    X = lk.krylov_basis_gpu(n, (kdim + 1) * p, dtype, ctx)
+    X.upload(np.asfortranarray(Q0), 0)
+    H = np.zeros(((kdim + 1) * p, kdim * p), dtype=dtype, order="F")
+    assert lk.arnoldi(lk.dense_linop_gpu(A, ctx), X, H, blksize=p) == 0
+    Xg = X.download()
+    assert np.abs(A @ Xg[:, :kdim * p] - Xg @ H).max() <= 1e-12
+    assert np.abs(Xg.conj().T @ Xg - np.eye((kdim + 1) * p)).max() <= 1e-12
+    # block DGS coefficients vs the oracle on one block
+    Qb = np.asfortranarray(Xg[:, :2 * p])
+    Y = basis(n, p, dtype, 300)
+    B = lk.krylov_basis_gpu(n, 3 * p, dtype, ctx)
+    B.upload(Qb, 0); B.upload(Y, 2 * p)
+    beta = np.zeros((2 * p, p), dtype=dtype, order="F")
+    assert lk.double_gram_schmidt_step(B[2 * p:3 * p], B[:2 * p], False, beta) == 0
+    Yg = B.download(2 * p, p)
+    for j in range(p):
+        yo = Y[:, j].copy()
+        ho, _ = ora.double_gram_schmidt_step(yo, Qb)
+        assert np.abs(beta[:, j] - ho).max() <= RTOL_RED * np.linalg.norm(Y[:, j])
+        assert np.abs(Yg[:, j] - yo).max() <= RTOL_RED * np.linalg.norm(Y[:, j])
