@@ -34,13 +34,13 @@ module lightkrylov_gpu
     use lightkrylov_hip_c
     use LightKrylov_Constants, only: dp
     use LightKrylov_Logger, only: stop_error, type_error
-    use LightKrylov_AbstractVectors, only: abstract_vector_rdp
+    use LightKrylov_AbstractVectors, only: abstract_vector_rdp, abstract_vector_cdp
     use LightKrylov_AbstractLinops, only: abstract_linop_rdp
     implicit none
     private
     character(len=*), parameter :: this_module = 'LK_GPU'
 
-    public :: dense_vector_gpu_rdp, dense_linop_gpu_rdp
+    public :: dense_vector_gpu_rdp, dense_vector_gpu_cdp, dense_linop_gpu_rdp
     public :: lk_gpu_init, lk_gpu_finalize, lk_gpu_release_all, gpu_arnoldi_rdp
 
     type(c_ptr), save :: ctx = c_null_ptr
@@ -49,6 +49,7 @@ module lightkrylov_gpu
     type(c_ptr), allocatable, save :: pool(:)
     integer, save :: npool = 0
     integer, save :: slab_n = -1, slab_used = SLAB     ! row count of the open slab / columns already taken
+    integer(c_int), save :: slab_dtype = -1            ! kind of the open slab
 
     type, extends(abstract_vector_rdp) :: dense_vector_gpu_rdp
         integer :: n                        !! number of (local) rows; set by the user like dense_vector%n
@@ -65,6 +66,22 @@ module lightkrylov_gpu
         procedure, pass(self) :: get_size => gpu_get_size
         procedure, pass(self) :: upload => gpu_upload
         procedure, pass(self) :: download => gpu_download
+    end type
+
+    !> complex(dp) kind: same layout, interleaved (re, im) on the device (LK_C128)
+    type, extends(abstract_vector_cdp) :: dense_vector_gpu_cdp
+        integer :: n
+        type(c_ptr) :: buf
+        integer(c_int) :: col
+        integer(c_intptr_t) :: owner
+        integer :: magic
+    contains
+        procedure, pass(self) :: zero => gpuz_zero
+        procedure, pass(self) :: rand => gpuz_rand
+        procedure, pass(self) :: scal => gpuz_scal
+        procedure, pass(self) :: axpby => gpuz_axpby
+        procedure, pass(self) :: dot => gpuz_dot
+        procedure, pass(self) :: get_size => gpuz_get_size
     end type
 
     !> dense_linop on the device (AbstractLinops.fypp:265-271, 608-660)
@@ -108,26 +125,34 @@ contains
         if (rc /= LK_OK) call stop_error(lk_error_message(), this_module, procedure)
     end subroutine
 
+    !> Next free column of the open slab of kind `dtype` and `n` rows (a new slab when full or mismatching).
+    subroutine take_column(n, dtype, sl, col)
+        integer, intent(in) :: n
+        integer(c_int), intent(in) :: dtype
+        type(c_ptr), intent(out) :: sl
+        integer(c_int), intent(out) :: col
+        type(c_ptr), allocatable :: grown(:)
+        if (slab_used >= SLAB .or. slab_n /= n .or. slab_dtype /= dtype) then
+            call chk(lk_basis_create(ctx, dtype, int(n, c_int64_t), int(SLAB, c_int), sl), 'take_column')
+            if (npool == size(pool)) then
+                allocate (grown(2*npool)); grown(:npool) = pool; call move_alloc(grown, pool)
+            end if
+            npool = npool + 1; pool(npool) = sl
+            slab_n = n; slab_dtype = dtype; slab_used = 0
+        end if
+        sl = pool(npool); col = int(slab_used, c_int); slab_used = slab_used + 1
+    end subroutine
+
     !> Make sure `self` owns a private device vector; keep=.true. preserves the current contents.
     subroutine bind(self, keep)
         class(dense_vector_gpu_rdp), intent(inout), target :: self
         logical, intent(in) :: keep
         type(c_ptr) :: fresh, old
         integer(c_int) :: fresh_col, old_col
-        type(c_ptr), allocatable :: grown(:)
         logical :: live
         live = (self%magic == MAGIC)
         if (live .and. self%owner == transfer(c_loc(self%n), self%owner)) return
-        ! next free column of the open slab (a new slab when it is full or the size differs)
-        if (slab_used >= SLAB .or. slab_n /= self%n) then
-            call chk(lk_basis_create(ctx, LK_F64, int(self%n, c_int64_t), int(SLAB, c_int), fresh), 'bind')
-            if (npool == size(pool)) then
-                allocate (grown(2*npool)); grown(:npool) = pool; call move_alloc(grown, pool)
-            end if
-            npool = npool + 1; pool(npool) = fresh
-            slab_n = self%n; slab_used = 0
-        end if
-        fresh = pool(npool); fresh_col = int(slab_used, c_int); slab_used = slab_used + 1
+        call take_column(self%n, LK_F64, fresh, fresh_col)
         if (live .and. keep) then
             old = self%buf; old_col = self%col
             call chk(lk_vec_copy(fresh, fresh_col, old, old_col), 'bind')
@@ -208,6 +233,84 @@ contains
         real(dp), intent(out), target :: x(:)
         call chk(lk_basis_download(self%buf, self%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'download')
     end subroutine
+
+    ! ---- complex(dp) kind ---------------------------------------------------------------------
+    subroutine bindz(self, keep)
+        class(dense_vector_gpu_cdp), intent(inout), target :: self
+        logical, intent(in) :: keep
+        type(c_ptr) :: fresh, old
+        integer(c_int) :: fresh_col, old_col
+        logical :: live
+        live = (self%magic == MAGIC)
+        if (live .and. self%owner == transfer(c_loc(self%n), self%owner)) return
+        call take_column(self%n, LK_C128, fresh, fresh_col)
+        if (live .and. keep) then
+            old = self%buf; old_col = self%col
+            call chk(lk_vec_copy(fresh, fresh_col, old, old_col), 'bind')
+        end if
+        self%buf = fresh; self%col = fresh_col
+        self%owner = transfer(c_loc(self%n), self%owner); self%magic = MAGIC
+    end subroutine
+
+    subroutine gpuz_zero(self)
+        class(dense_vector_gpu_cdp), intent(inout) :: self
+        call bindz(self, .false.)
+        call chk(lk_vec_zero(self%buf, self%col), 'zero')
+    end subroutine
+
+    subroutine gpuz_rand(self, ifnorm)
+        class(dense_vector_gpu_cdp), intent(inout) :: self
+        logical, optional, intent(in) :: ifnorm
+        integer(c_int) :: nrm
+        integer(c_int64_t), save :: seed = 1000001
+        nrm = 0; if (present(ifnorm)) nrm = merge(1_c_int, 0_c_int, ifnorm)
+        call bindz(self, .false.)
+        seed = seed + 1
+        call chk(lk_vec_rand(self%buf, self%col, seed, 0_c_int64_t, nrm), 'rand')
+    end subroutine
+
+    subroutine gpuz_scal(self, alpha)
+        class(dense_vector_gpu_cdp), intent(inout) :: self
+        complex(dp), intent(in) :: alpha
+        call bindz(self, .true.)
+        call chk(lk_vec_scal(self%buf, self%col, [real(alpha, dp), aimag(alpha)]), 'scal')
+    end subroutine
+
+    subroutine gpuz_axpby(alpha, vec, beta, self)
+        complex(dp), intent(in) :: alpha, beta
+        class(abstract_vector_cdp), intent(in) :: vec
+        class(dense_vector_gpu_cdp), intent(inout) :: self
+        select type (vec)
+        type is (dense_vector_gpu_cdp)
+            if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'axpby')
+            call bindz(self, beta /= (0.0_dp, 0.0_dp))
+            call chk(lk_vec_axpby([real(alpha, dp), aimag(alpha)], vec%buf, vec%col, [real(beta, dp), aimag(beta)], &
+                                  self%buf, self%col), 'axpby')
+        class default
+            call type_error('vec', 'dense_vector_gpu_cdp', 'IN', this_module, 'axpby')
+        end select
+    end subroutine
+
+    function gpuz_dot(self, vec) result(alpha)
+        class(dense_vector_gpu_cdp), intent(in) :: self
+        class(abstract_vector_cdp), intent(in) :: vec
+        complex(dp) :: alpha
+        real(c_double) :: res(2)
+        alpha = (0.0_dp, 0.0_dp)
+        select type (vec)
+        type is (dense_vector_gpu_cdp)
+            call chk(lk_vec_dot(self%buf, self%col, vec%buf, vec%col, res), 'dot')   ! conj on self, like dotc
+            alpha = cmplx(res(1), res(2), kind=dp)
+        class default
+            call type_error('vec', 'dense_vector_gpu_cdp', 'IN', this_module, 'dot')
+        end select
+    end function
+
+    function gpuz_get_size(self) result(n)
+        class(dense_vector_gpu_cdp), intent(in) :: self
+        integer :: n
+        n = self%n
+    end function
 
     ! ---- dense_linop on the device -----------------------------------------------------------
     subroutine apply_dense(self, trans, vec_in, vec_out, procedure)

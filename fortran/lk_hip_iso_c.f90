@@ -58,6 +58,20 @@ module lightkrylov_hip_c
             integer(c_int), value :: val
             integer(c_int) :: rc
         end function
+        function lk_lazy_stats(ctx, out4) bind(C, name="lk_lazy_stats") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), intent(out) :: out4(4)
+            integer(c_int) :: rc
+        end function
+        function lk_orthogonalize(Bx, k, By, jy, h, info) bind(C, name="lk_orthogonalize") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: Bx, By
+            integer(c_int), value :: k, jy
+            real(c_double), intent(out) :: h(*)
+            integer(c_int), intent(out) :: info
+            integer(c_int) :: rc
+        end function
         function lk_basis_create(ctx, dtype, n_local, ncols, B) bind(C, name="lk_basis_create") result(rc)
             import :: c_int, c_ptr, c_int64_t
             type(c_ptr), value :: ctx

@@ -12,6 +12,10 @@ program test_iso_c
     real(c_double) :: H(m + 1, m), G, orth, nrm
     integer(c_int) :: rc, info
     integer :: i, j, k
+    ! lazy per-object pass
+    type(c_ptr) :: Z
+    real(c_double) :: hl(m), hf(m), d2(2), ny_lazy, ny_fused, one(1), ai(1), mone(1)
+    integer(c_int64_t) :: st(4)
 
     rc = lk_init(0_c_int, c_null_ptr, ctx); call chk(rc, 'lk_init')
     do i = 1, n
@@ -41,6 +45,38 @@ program test_iso_c
     print '(A,ES24.16)', 'Hlast ', H(m + 1, m)
     print '(A,ES12.4)', 'orth ', orth
     print '(A,ES24.16)', 'norm_last ', nrm
+    ! ---- the reference's per-object schedule (innerprod loop, then linear_combination loop, then sub:
+    !      gram_schmidt.fypp:141-145 through AbstractVectors.fypp:672-674, 600-602) driven from Fortran with
+    !      the engine in lazy mode: m dots must cost ONE sweep, m axpbys ONE panel update.
+    one = 1.0d0; mone = -1.0d0
+    rc = lk_set_tuning(ctx, 'lazy'//c_null_char, 1_c_int); call chk(rc, 'lk_set_tuning')
+    rc = lk_basis_create(ctx, LK_F64, int(n, c_int64_t), int(m + 3, c_int), Z); call chk(rc, 'lk_basis_create(Z)')
+    do j = 0, m - 1
+        rc = lk_vec_copy(Z, int(j, c_int), X, int(j, c_int)); call chk(rc, 'lk_vec_copy')
+    end do
+    rc = lk_vec_rand(Z, int(m, c_int), 99_c_int64_t, 0_c_int64_t, 0_c_int); call chk(rc, 'lk_vec_rand')      ! y
+    rc = lk_vec_copy(Z, int(m + 2, c_int), Z, int(m, c_int)); call chk(rc, 'lk_vec_copy')                     ! y copy for the fused call
+    do j = 0, m - 1                                                                                          ! innerprod
+        rc = lk_vec_dot(Z, int(j, c_int), Z, int(m, c_int), d2); call chk(rc, 'lk_vec_dot')
+        hl(j + 1) = d2(1)
+    end do
+    rc = lk_vec_zero(Z, int(m + 1, c_int)); call chk(rc, 'lk_vec_zero')                                      ! proj
+    do j = 0, m - 1                                                                                          ! linear_combination
+        ai(1) = hl(j + 1)
+        rc = lk_vec_axpby(ai, Z, int(j, c_int), one, Z, int(m + 1, c_int)); call chk(rc, 'lk_vec_axpby')
+    end do
+    rc = lk_vec_axpby(mone, Z, int(m + 1, c_int), one, Z, int(m, c_int)); call chk(rc, 'lk_vec_axpby(sub)')  ! y%sub(proj)
+    rc = lk_vec_norm(Z, int(m, c_int), ny_lazy); call chk(rc, 'lk_vec_norm')
+    rc = lk_lazy_stats(ctx, st); call chk(rc, 'lk_lazy_stats')
+    rc = lk_orthogonalize(Z, int(m, c_int), Z, int(m + 2, c_int), hf, info); call chk(rc, 'lk_orthogonalize')
+    rc = lk_vec_norm(Z, int(m + 2, c_int), ny_fused); call chk(rc, 'lk_vec_norm')
+    print '(A,I0)', 'lazy_hits ', st(1)
+    print '(A,I0)', 'lazy_sweeps ', st(2)
+    print '(A,I0)', 'lazy_queued ', st(3)
+    print '(A,I0)', 'lazy_flushes ', st(4)
+    print '(A,ES12.4)', 'lazy_h_err ', maxval(abs(hl - hf))
+    print '(A,ES12.4)', 'lazy_y_err ', abs(ny_lazy - ny_fused)
+    rc = lk_basis_destroy(Z)
     rc = lk_linop_destroy(A)
     rc = lk_basis_destroy(X)
     rc = lk_finalize(ctx)
