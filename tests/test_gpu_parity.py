@@ -649,3 +649,33 @@ def test_block_arnoldi_on_gpu_panels(ctx, dtype, p):
         ho, _ = ora.double_gram_schmidt_step(yo, Qb)
         assert np.abs(beta[:, j] - ho).max() <= RTOL_RED * np.linalg.norm(Y[:, j])
         assert np.abs(Yg[:, j] - yo).max() <= RTOL_RED * np.linalg.norm(Y[:, j])
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_dgs_randomised_shapes_against_oracle(ctx, dtype):
+    """60 seeded random (n, k) pairs, ragged everywhere: tile tails, k around the wave-split boundaries
+    (8/16/32/64/128), k > n impossible cases clipped, fused and wide (k > 128) paths, normalise flag."""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 9000)]))
+        k = int(min(n, rng.choice([rng.integers(1, 10), rng.integers(10, 70), rng.integers(70, 150)])))
+        Q = orthonormal_basis(n, k, dtype, 1000 + case)
+        y = seeded(n, dtype, 5000 + case)
+        B = lk.krylov_basis_gpu(n, k + 1, dtype, ctx)
+        B.upload(Q, 0); B.upload(y.reshape(-1, 1), k)
+        beta = np.zeros(k, dtype=dtype)
+        norms: list = []
+        info = lk.double_gram_schmidt_step(B[k], B[:k], False, beta, _normalize=bool(case % 2), _norms=norms)
+        yo = y.copy()
+        ho, info_o = ora.double_gram_schmidt_step(yo, Q)
+        ynorm = np.linalg.norm(y)
+        assert info == info_o, (case, n, k)
+        assert np.abs(beta - ho).max() <= RTOL_RED * ynorm, (case, n, k)
+        yg = B.download(k, 1)[:, 0]
+        nyo = np.linalg.norm(yo)
+        assert abs(norms[2] - nyo) <= RTOL_RED * ynorm, (case, n, k)
+        if case % 2 and nyo >= lk.atol_dp:
+            if nyo > 1e-10 * ynorm:                       # direction is meaningful only when y is not (numerically) in span(Q)
+                assert np.abs(yg - yo / nyo).max() <= 1e-9, (case, n, k)
+        else:
+            assert np.abs(yg - yo).max() <= RTOL_RED * ynorm, (case, n, k)
