@@ -192,7 +192,14 @@ class dense_vector_gpu(abstract_vector):
         _capi.check(self._lib.lk_vec_zero(self.basis._h, self.col))
 
     def rand(self, ifnorm: bool = False, seed: int | None = None) -> None:
-        s = self._seed if seed is None else seed
+        if seed is None:
+            # every un-seeded call draws a fresh stream (the reference's random_number does): a per-context
+            # counter keeps runs reproducible and identical on every rank of a sharded vector
+            ctx = self.basis.ctx
+            ctx._rand_calls = getattr(ctx, "_rand_calls", 0) + 1
+            s = self._seed + 7919 * ctx._rand_calls
+        else:
+            s = seed
         _capi.check(self._lib.lk_vec_rand(self.basis._h, self.col, C.c_uint64(s),
                                           C.c_int64(getattr(self.basis.ctx, "row0", 0)), 1 if ifnorm else 0))
 
@@ -326,6 +333,6 @@ def rand_basis(X, ifnorm: bool = False) -> None:
     """:725-730"""
     for j, x in enumerate([X] if isinstance(X, abstract_vector) else X):
         if isinstance(x, dense_vector_gpu):
-            x.rand(ifnorm, seed=x._seed + 1000003 * (j + 1))
+            x.rand(ifnorm)
         else:
             x.rand(ifnorm)

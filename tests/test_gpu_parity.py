@@ -679,3 +679,20 @@ def test_dgs_randomised_shapes_against_oracle(ctx, dtype):
                 assert np.abs(yg - yo / nyo).max() <= 1e-9, (case, n, k)
         else:
             assert np.abs(yg - yo).max() <= RTOL_RED * ynorm, (case, n, k)
+
+
+def test_unseeded_rand_draws_fresh_vectors_and_qr_survives_colinear_columns(ctx):
+    """rand() without a seed must not repeat itself (the reference's random_number does not), otherwise
+    qr_no_pivoting's replacement of two colinear columns (qr.fypp:146-162) would re-create a colinear pair."""
+    n = 4001
+    a = lk.dense_vector_gpu(n, np.float64, ctx); b = lk.dense_vector_gpu(n, np.float64, ctx)
+    a.rand(); b.rand()
+    assert abs(a.dot(b)) < 0.2 * a.norm() * b.norm()
+    v = seeded(n, np.float64, 1)
+    v /= 4 * np.linalg.norm(v)          # residual of a colinear column is ~eps*||column||: keep it below atol_dp = 1e-15
+    Q = lk.krylov_basis_gpu(n, 4, np.float64, ctx)
+    Q.upload(np.asfortranarray(np.stack([v, 2 * v, -v, seeded(n, np.float64, 2)], axis=1)))
+    R = np.zeros((4, 4), order="F")
+    assert lk.qr(Q, R) == 2 and R[1, 1] == 0.0 and R[2, 2] == 0.0
+    Qg = Q.download()
+    assert np.abs(Qg.T @ Qg - np.eye(4)).max() < 1e-12
