@@ -336,3 +336,87 @@ def rand_basis(X, ifnorm: bool = False) -> None:
             x.rand(ifnorm)
         else:
             x.rand(ifnorm)
+
+
+def verify_vector_axioms(x: abstract_vector, ntrials: int = 100, tolerance: float = 10.0 ** (-14), seed: int = 0) -> bool:
+    """Conformance harness for a user vector type: the eight vector-space axiom blocks of
+    AbstractVectors.fypp:733-927, `ntrials` random trials each, absolute tolerance 10^-(precision-1) on the norm
+    of the defect (the reference's default).  Returns True when every trial of every block passes."""
+    rng = np.random.default_rng(seed)
+    cplx = np.dtype(getattr(x, "dtype", np.float64)).kind == "c"
+
+    def new():
+        v = x.zeros_like()
+        v.rand()
+        return v
+
+    def clone(u):
+        v = u.zeros_like()
+        copy(v, u)
+        return v
+
+    def scalar():
+        return complex(rng.random(), rng.random()) if cplx else float(rng.random())
+
+    for _ in range(ntrials):
+        # addition: associativity ("addition_distributivity", :756-779)
+        u, v, w = new(), new(), new()
+        wrk1, wrk2 = clone(v), clone(v)
+        wrk1.add(w); wrk2.add(u)
+        u.add(wrk1); w.add(wrk2)
+        u.sub(w)
+        if not u.norm() <= tolerance:
+            return False
+        # addition: commutativity (:781-797)
+        u, v = new(), new()
+        w = clone(v)
+        v.add(u); u.add(w)
+        u.sub(v)
+        if not u.norm() <= tolerance:
+            return False
+        # additive identity (:799-813)
+        u = new()
+        v = clone(u)
+        z = u.zeros_like(); z.zero()
+        u.add(z); u.sub(v)
+        if not u.norm() <= tolerance:
+            return False
+        # additive inverse (:815-826)
+        u = new()
+        v = clone(u)
+        u.sub(v)
+        if not u.norm() <= tolerance:
+            return False
+        # scaling identity (:828-842)
+        u = new()
+        v = clone(u)
+        v.scal(1.0); u.sub(v)
+        if not u.norm() <= tolerance:
+            return False
+        # scaling compatibility a(bu) = (ab)u (:844-868)
+        a, b = scalar(), scalar()
+        u = x.zeros_like(); u.rand(True)
+        v = clone(u)
+        v.scal(b); v.scal(a); u.scal(a * b)
+        u.sub(v)
+        if not u.norm() <= tolerance:
+            return False
+        # distributivity a(u+v) = au + av (:870-893)
+        a = scalar()
+        u, v = new(), new()
+        w = clone(u)
+        w.add(v); w.scal(a)
+        u.scal(a); v.scal(a); v.add(u)
+        v.sub(w)
+        if not v.norm() <= tolerance:
+            return False
+        # distributivity (a+b)u = au + bu through axpby (:895-921)
+        a, b = scalar(), scalar()
+        u = new()
+        v = clone(u)
+        v.axpby(a, u, b)
+        u.scal(a + b)
+        v.sub(u)
+        if not v.norm() <= tolerance:
+            return False
+    return True

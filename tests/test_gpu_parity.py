@@ -696,3 +696,10 @@ def test_unseeded_rand_draws_fresh_vectors_and_qr_survives_colinear_columns(ctx)
     assert lk.qr(Q, R) == 2 and R[1, 1] == 0.0 and R[2, 2] == 0.0
     Qg = Q.download()
     assert np.abs(Qg.T @ Qg - np.eye(4)).max() < 1e-12
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_dense_vector_gpu_passes_the_reference_axiom_harness(ctx, dtype):
+    """verify_vector_axioms on the GPU type, the reference's own conformance check for user vector types
+    (AbstractVectors.fypp:733-927; test/TestVectors.fypp:50-60): test_size = 128, 100 trials, tolerance 1e-14."""
+    assert lk.verify_vector_axioms(lk.dense_vector_gpu(128, dtype, ctx), ntrials=100)

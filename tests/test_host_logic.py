@@ -221,3 +221,18 @@ def test_on_disk_outputs_follow_the_reference_layout(tmp_path, monkeypatch):
             write_intermediate=True)
     out = (tmp_path / "eigs_output.txt").read_text().splitlines()
     assert out[0].split() == ["Iter", "Re", "Im", "modulus", "residual", "conv"] and len(out) >= 3
+
+
+def test_verify_vector_axioms_harness_accepts_a_good_type_and_rejects_a_broken_one():
+    """AbstractVectors.fypp:733-927 / test/TestVectors.fypp:50-60 (test_size = 128)."""
+    good = oracle_vector(np.zeros(128))
+    assert lk.verify_vector_axioms(good, ntrials=20)
+    assert lk.verify_vector_axioms(oracle_vector(np.zeros(128, dtype=np.complex128)), ntrials=20)
+
+    class broken(oracle_vector):                       # axpby that forgets beta
+        def zeros_like(self):
+            return broken(np.zeros_like(self.data))
+
+        def axpby(self, alpha, vec, beta):
+            self.data[:] = alpha * vec.data + self.data
+    assert not lk.verify_vector_axioms(broken(np.zeros(128)), ntrials=5)
