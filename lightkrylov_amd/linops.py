@@ -50,6 +50,69 @@ class abstract_linop:
             self.matvec_counter = 0
 
 
+# ---- composite operators built on the vector contract only (AbstractLinops.fypp; generated .f90 lines cited) ----
+class Id(abstract_linop):
+    """Identity: `copy(vec_out, vec_in)`.  AbstractLinops.f90:350-357, 974-980"""
+
+    def matvec(self, vec_in, vec_out) -> None:
+        from .vectors import copy
+        copy(vec_out, vec_in)
+
+    rmatvec = matvec
+
+
+class scaled_linop(abstract_linop):
+    """B = sigma A (the adjoint is scaled by sigma too, NOT conj(sigma), like the reference).
+    AbstractLinops.f90:395-403, 1011-1025"""
+
+    def __init__(self, A: abstract_linop, sigma):
+        super().__init__()
+        self.A, self.sigma = A, sigma
+
+    def matvec(self, vec_in, vec_out) -> None:
+        self.A.apply_matvec(vec_in, vec_out)
+        vec_out.scal(self.sigma)
+
+    def rmatvec(self, vec_in, vec_out) -> None:
+        self.A.apply_rmatvec(vec_in, vec_out)
+        vec_out.scal(self.sigma)
+
+
+class axpby_linop(abstract_linop):
+    """C = alpha op(A) + beta op(B).  AbstractLinops.f90:451-459, 1125-1191"""
+
+    def __init__(self, A: abstract_linop, B: abstract_linop, alpha=1.0, beta=1.0, transA: bool = False, transB: bool = False):
+        super().__init__()
+        self.A, self.B, self.alpha, self.beta, self.transA, self.transB = A, B, alpha, beta, transA, transB
+
+    def _apply(self, vec_in, vec_out, adjoint: bool) -> None:
+        wrk = vec_in.zeros_like()
+        wrk.zero()
+        (self.A.apply_rmatvec if self.transA != adjoint else self.A.apply_matvec)(vec_in, wrk)
+        (self.B.apply_rmatvec if self.transB != adjoint else self.B.apply_matvec)(vec_in, vec_out)
+        vec_out.axpby(self.alpha, wrk, self.beta)                  # y = alpha*w + beta*y
+
+    def matvec(self, vec_in, vec_out) -> None:
+        self._apply(vec_in, vec_out, False)
+
+    def rmatvec(self, vec_in, vec_out) -> None:
+        self._apply(vec_in, vec_out, True)
+
+
+class adjoint_linop(abstract_linop):
+    """matvec and rmatvec of A switched (does not compute an adjoint).  AbstractLinops.f90:155-163, 1372-1386"""
+
+    def __init__(self, A: abstract_linop):
+        super().__init__()
+        self.A = A
+
+    def matvec(self, vec_in, vec_out) -> None:
+        self.A.apply_rmatvec(vec_in, vec_out)
+
+    def rmatvec(self, vec_in, vec_out) -> None:
+        self.A.apply_matvec(vec_in, vec_out)
+
+
 class _engine_linop(abstract_linop):
     """An operator implemented by a kernel of the HIP engine."""
 

@@ -236,3 +236,30 @@ def test_verify_vector_axioms_harness_accepts_a_good_type_and_rejects_a_broken_o
         def axpby(self, alpha, vec, beta):
             self.data[:] = alpha * vec.data + self.data
     assert not lk.verify_vector_axioms(broken(np.zeros(128)), ntrials=5)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_composite_linops(dtype):
+    """Id / scaled / axpby / adjoint operators against matrix formulas (test/TestLinops.fypp:186-420)."""
+    n = 40
+    rng = np.random.default_rng(6)
+    cplx = np.dtype(dtype).kind == "c"
+    mk = lambda: (rng.standard_normal((n, n)) + (1j * rng.standard_normal((n, n)) if cplx else 0)).astype(dtype)  # noqa: E731
+    A, B = mk(), mk()
+    x = seeded(n, dtype, 1)
+    vin = oracle_vector(x.copy())
+    out = oracle_vector(np.zeros(n, dtype=dtype))
+    opA, opB = oracle_dense_linop(A), oracle_dense_linop(B)
+    sigma, al, be = (0.7 - 0.2j, 1.5 + 0.5j, -0.25j) if cplx else (0.7, 1.5, -0.25)
+
+    lk.Id().apply_matvec(vin, out); np.testing.assert_array_equal(out.data, x)
+    S = lk.scaled_linop(opA, sigma)
+    S.apply_matvec(vin, out); np.testing.assert_allclose(out.data, sigma * (A @ x), rtol=1e-13)
+    S.apply_rmatvec(vin, out); np.testing.assert_allclose(out.data, sigma * (A.conj().T @ x), rtol=1e-13)
+    Cop = lk.axpby_linop(opA, opB, al, be, transA=False, transB=True)
+    Cop.apply_matvec(vin, out); np.testing.assert_allclose(out.data, al * (A @ x) + be * (B.conj().T @ x), rtol=1e-12)
+    Cop.apply_rmatvec(vin, out); np.testing.assert_allclose(out.data, al * (A.conj().T @ x) + be * (B @ x), rtol=1e-12)
+    T = lk.adjoint_linop(opA)
+    T.apply_matvec(vin, out); np.testing.assert_allclose(out.data, A.conj().T @ x, rtol=1e-13)
+    T.apply_rmatvec(vin, out); np.testing.assert_allclose(out.data, A @ x, rtol=1e-13)
+    assert opA.matvec_counter == 3 and opA.rmatvec_counter == 3 and T.matvec_counter == 1
