@@ -83,6 +83,12 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_distributed.py): several ranks on ONE device with the gloo backend, which
+    # all-reduces CUDA tensors through the host -- exercises the multi-process sharded path where RCCL cannot
+    # (RCCL refuses two ranks on one GPU).  Never set by the driver.
+    backend = os.environ.get("LK_DIST_BACKEND", "nccl")
+    if "LK_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["LK_FORCE_DEVICE"])
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -93,7 +99,10 @@ def main() -> None:
     if world > 1 or "RANK" in os.environ:      # under torch.distributed.run: RCCL path even for one rank
         import torch.distributed as dist  # noqa: PLW0621
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     ctx = lk.Context(device=local_rank)
     if dist is not None:
@@ -178,7 +187,7 @@ def main() -> None:
                             f"m={m}, one step = one m-step factorisation",
                 "n_global": n, "n_local": n_local, "m": m, "parallelism": f"row-shard x{world} (RCCL all-reduce of <=129 scalars/sweep)",
                 "info": int(info), "H_fro": float(np.linalg.norm(H)), "H_last_subdiag": float(abs(H[m, m - 1])),
-                "all_reduce": "RCCL via torch.distributed" if dist is not None else "none (single rank)",
+                "all_reduce": (("RCCL" if backend == "nccl" else backend) + " via torch.distributed") if dist is not None else "none (single rank)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": "lk::panel_sweep, the three DGS sweeps (DOT | UPDATE+DOT, y' kept in registers | UPDATE with two coefficient sets)",

@@ -21,8 +21,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(cmd):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(cmd, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
@@ -39,3 +39,18 @@ def test_single_rank_rccl_path_is_bit_identical():
     assert dist["config"]["H_last_subdiag"] == plain["config"]["H_last_subdiag"]
     assert dist["config"]["info"] == plain["config"]["info"] == 0
     assert dist["n_gpus"] == 1 and dist["roofline"]["launches"] == plain["roofline"]["launches"]
+
+
+def test_two_processes_sharing_one_gpu_reproduce_the_single_process_factorisation():
+    """True multi-process row sharding (torch.distributed.run, 2 ranks, both on device 0) with the gloo backend
+    standing in for RCCL: every sweep's partial h / norm is all-reduced between the processes.  The
+    factorisation must match the single-process one to rounding (partial sums are combined in another order)."""
+    args = ["--rows", "3000001", "--kdim", "20", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    plain = _run([sys.executable, "bench.py", "--gpus", "1"] + args)
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + args,
+               LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
+    assert two["n_gpus"] == 2 and two["config"]["all_reduce"].startswith("gloo")
+    assert two["config"]["n_local"] == 1500000 and two["config"]["info"] == 0
+    assert abs(two["config"]["H_fro"] - plain["config"]["H_fro"]) <= 1e-13 * plain["config"]["H_fro"]
+    assert abs(two["config"]["H_last_subdiag"] - plain["config"]["H_last_subdiag"]) <= 1e-12 * plain["config"]["H_last_subdiag"]
