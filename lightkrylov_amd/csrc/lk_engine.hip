@@ -67,6 +67,7 @@ struct lk_context_s {
     int grid_mult = 2;  // sweep blocks per CU
     int stream_update = 1;     // single-coefficient update sweeps: barrier-free streaming kernel
     int update_grid_mult = 4;
+    int stream_two = 0;        // sweep 3 with two coefficient sets: barrier-free streaming kernel instead of the LDS/barrier one
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     // reduction workspace
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
@@ -255,7 +256,7 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
     int nblocks = s.grid;
     {
         ProfScope ps(c, MODE == 1 ? "dgs_sweep1" : (MODE == 2 ? "dgs_sweep2" : "dgs_sweep3"), bytes);
-        if (MODE == 3 && c->stream_update) {
+        if ((MODE == 3 && c->stream_update) || (MODE == 4 && c->stream_two)) {
             const int64_t tile_rows = (int64_t)NW * 64 * K<CPLX>::ROWS;
             int64_t g = (n + tile_rows - 1) / tile_rows;
             const int64_t cap = (int64_t)c->num_cu * c->update_grid_mult;
@@ -263,8 +264,8 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
             if (g > MAX_GRID) g = MAX_GRID;
             if (g < 1) g = 1;
             nblocks = (int)g;
-            hipLaunchKernelGGL((panel_update<CPLX, KC, NW>), dim3(nblocks), dim3(NW * 64), 0, c->stream, X, ldx, k, y, n, hin,
-                               c->partial, (int64_t)MAX_GRID);
+            hipLaunchKernelGGL((panel_update<CPLX, KC, NW, MODE == 4>), dim3(nblocks), dim3(NW * 64), 0, c->stream, X, ldx, k, y,
+                               n, hin, hin2, c->partial, (int64_t)MAX_GRID);
         } else {
             hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
                                ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, store);
@@ -529,7 +530,9 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         c->lazy = value != 0;
         return LK_OK;
     }
+    if (!strcmp(key, "stream_two")) { c->stream_two = value != 0; return LK_OK; }
     if (!strcmp(key, "recompute_update")) { c->recompute_update = value != 0; return LK_OK; }
+    if (!strcmp(key, "stream_two")) { c->stream_two = value != 0; return LK_OK; }
     if (!strcmp(key, "update_grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "update_grid_mult must be in [1,16]");
         c->update_grid_mult = value;

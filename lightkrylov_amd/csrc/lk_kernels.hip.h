@@ -365,10 +365,11 @@ __global__ __launch_bounds__(NW * 64) void panel_dot_p(const double *__restrict_
 // Streaming update y <- y - X(:, :k) * hin with ||y_out||^2: no dots, so nothing has to stay in
 // registers and every wave can walk ALL k columns of its own rows in chunks of KC -- no LDS
 // exchange, no barrier in the loop.  Used for DGS sweep 3 and for linear_combination.
-template <bool CPLX, int KC, int NW>
+template <bool CPLX, int KC, int NW, bool TWO>
 __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict__ X, int64_t ldx, int k,
                                                          double *__restrict__ y, int64_t n,
                                                          const double *__restrict__ hin,
+                                                         const double *__restrict__ hin2,
                                                          double *__restrict__ partial, int64_t pstride) {
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int64_t r = t * tile_rows + (int64_t)wave * WROWS + (int64_t)lane * ROWS;
         const bool full = (t + 1) * tile_rows <= n;
-        v2d u = v2d{0.0, 0.0};
+        v2d u = v2d{0.0, 0.0}, u2 = v2d{0.0, 0.0};
         v2d yv = load_y<CPLX>(y, r, n, full);
         for (int c0 = 0; c0 < k; c0 += KC) {
             int nc = k - c0;
@@ -396,10 +397,15 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
                 if (jj < nc) {
                     if constexpr (CPLX) u += cmul(xv[jj], v2d{hin[2 * (c0 + jj)], hin[2 * (c0 + jj) + 1]});
                     else u += xv[jj] * hin[c0 + jj];
+                    if constexpr (TWO) {
+                        if constexpr (CPLX) u2 += cmul(xv[jj], v2d{hin2[2 * (c0 + jj)], hin2[2 * (c0 + jj) + 1]});
+                        else u2 += xv[jj] * hin2[c0 + jj];
+                    }
                 }
             }
         }
         yv -= u;
+        if constexpr (TWO) yv -= u2;      // y'' = (y - X h1) - X h2
         store_rows<CPLX>(y, r, n, full, yv);
         nrm += yv.x * yv.x + yv.y * yv.y;
     }

@@ -12,8 +12,8 @@ B = lk.krylov_basis_gpu(n, kmax + 1, dtype, ctx)
 for j in range(kmax + 1):
     B[j].rand(True, seed=100 + j)
 variants = {
-    "A_store_yprime": dict(recompute_update=0, stream_update=1),
-    "B_recompute_yprime": dict(recompute_update=1, stream_update=1),
+    "A_sweep3_barrier_two": dict(recompute_update=1, stream_two=0),
+    "B_sweep3_stream_two": dict(recompute_update=1, stream_two=1),
 }
 def run(k, reps=3):
     ctx.profile_reset(); ctx.profile_enable(True)
