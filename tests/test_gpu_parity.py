@@ -703,3 +703,38 @@ def test_dense_vector_gpu_passes_the_reference_axiom_harness(ctx, dtype):
     """verify_vector_axioms on the GPU type, the reference's own conformance check for user vector types
     (AbstractVectors.fypp:733-927; test/TestVectors.fypp:50-60): test_size = 128, 100 trials, tolerance 1e-14."""
     assert lk.verify_vector_axioms(lk.dense_vector_gpu(128, dtype, ctx), ntrials=100)
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_arnoldi_and_gmres_with_transpose(ctx, dtype):
+    """`transpose=.true.` (arnoldi.fypp:39-43, gmres.fypp:134-165): the factorisation / solve of A^H, through the
+    engine's fused loop (rmatvec kernel) and through the python loop, against the oracle run on A^H."""
+    n, m = 400, 25
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((n, n)) / np.sqrt(n) + 2.0 * np.eye(n)
+    if np.dtype(dtype).kind == "c":
+        A = A + 1j * rng.standard_normal((n, n)) / np.sqrt(n)
+    A = np.asfortranarray(A.astype(dtype))
+    AH = np.asfortranarray(A.conj().T)
+    x0 = seeded(n, dtype, 3); x0 /= np.linalg.norm(x0)
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.arnoldi(ora.DenseOp(AH), Xo, Ho) == 0
+    op = lk.dense_linop_gpu(A, ctx)
+
+    class wrapped(lk.abstract_linop):
+        def matvec(self, vi, vo): op.matvec(vi, vo)
+        def rmatvec(self, vi, vo): op.rmatvec(vi, vo)
+    for A_ in (op, wrapped()):
+        X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X.upload(x0.reshape(-1, 1), 0)
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        assert lk.arnoldi(A_, X, H, transpose=True) == 0
+        assert A_.rmatvec_counter == m and A_.matvec_counter == 0
+        for j in range(m):
+            assert np.abs(H[:, j] - Ho[:, j]).max() <= 1e-11 * np.abs(Ho[:, j]).max()
+    b = seeded(n, dtype, 4)
+    x = lk.dense_vector_gpu(n, dtype, ctx)
+    info = lk.gmres(op, lk.dense_vector_gpu.from_array(b, ctx), x, rtol=1e-10, transpose=True,
+                    options=lk.gmres_dp_opts(kdim=40, maxiter=5))
+    assert info > 0
+    assert np.linalg.norm(AH @ x.to_array() - b) <= 1e-9 * np.linalg.norm(b)
