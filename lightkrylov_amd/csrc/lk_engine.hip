@@ -69,6 +69,8 @@ struct lk_context_s {
     int update_grid_mult = 4;
     int stream_two = 0;        // sweep 3 with two coefficient sets: barrier-free streaming kernel instead of the LDS/barrier one
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
+    int store_policy = 0;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
+    int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     // reduction workspace
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
     double *red = nullptr;      // device results: 3 sections of (KMAX_FUSED+1)*2 doubles
@@ -265,10 +267,11 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
             if (g < 1) g = 1;
             nblocks = (int)g;
             hipLaunchKernelGGL((panel_update<CPLX, KC, NW, MODE == 4>), dim3(nblocks), dim3(NW * 64), 0, c->stream, X, ldx, k, y,
-                               n, hin, hin2, c->partial, (int64_t)MAX_GRID);
+                               n, hin, hin2, c->partial, (int64_t)MAX_GRID, c->store_policy);
         } else {
+            const int st = store ? (1 | (c->store_policy << 1) | (c->store_split ? 8 : 0)) : 0;
             hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
-                               ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, store);
+                               ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st);
         }
     }
     HIPCHK(hipGetLastError());
@@ -532,7 +535,12 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     }
     if (!strcmp(key, "stream_two")) { c->stream_two = value != 0; return LK_OK; }
     if (!strcmp(key, "recompute_update")) { c->recompute_update = value != 0; return LK_OK; }
-    if (!strcmp(key, "stream_two")) { c->stream_two = value != 0; return LK_OK; }
+    if (!strcmp(key, "store_policy")) {
+        if (value < 0 || value > 3) return fail(LK_ERR_INVALID, "store_policy must be in [0,3]");
+        c->store_policy = value;
+        return LK_OK;
+    }
+    if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "update_grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "update_grid_mult must be in [1,16]");
         c->update_grid_mult = value;

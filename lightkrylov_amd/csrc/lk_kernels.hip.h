@@ -120,10 +120,23 @@ __device__ __forceinline__ void load_tile(const double *__restrict__ Xw, int64_t
     load_cols<CPLX, KC>(Xw, colstride, r, n, full, nc, xv);
 }
 
+// 16-byte store with an explicit gfx950 cache policy.  `policy` is block-uniform:
+//   0 plain (write-back, line stays in the XCD's L2)   1 nt (streaming hint)
+//   2 sc1 / 3 sc0 sc1 (write-through: the line leaves L2 in issue order instead of at eviction time)
+__device__ __forceinline__ void store16(v2d *p, v2d v, int policy) {
+    switch (policy) {
+    case 1: __builtin_nontemporal_store(v, p); break;
+    case 2: asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); break;
+    case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); break;
+    default: *p = v;
+    }
+}
+
 template <bool CPLX>
-__device__ __forceinline__ void store_rows(double *__restrict__ y, int64_t r, int64_t n, bool full, v2d yv) {
+__device__ __forceinline__ void store_rows(double *__restrict__ y, int64_t r, int64_t n, bool full, v2d yv,
+                                           int policy = 0) {
     if (full) {
-        *reinterpret_cast<v2d *>(y + r * K<CPLX>::ELEM_DOUBLES) = yv;
+        store16(reinterpret_cast<v2d *>(y + r * K<CPLX>::ELEM_DOUBLES), yv, policy);
     } else if constexpr (CPLX) {
         if (r < n) *reinterpret_cast<v2d *>(y + r * 2) = yv;
     } else {
@@ -229,7 +242,18 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
             }
             yv -= u;
             if constexpr (TWO) yv -= u2;
-            if (store && wc == 0) store_rows<CPLX>(y, r, n, full, yv);
+            // `store`: 0 = keep y' in registers; otherwise bit 0 set, bits 1-2 = cache policy of the 16-B
+            // store, bit 3 = every wave of the column split stores its own 64/WC-lane slice of the rows
+            // (instead of the wc == 0 wave storing all 64 lanes).
+            if (store) {
+                const int pol = (store >> 1) & 3;
+                if (store & 8) {
+                    const int per = 64 / WC;
+                    if (lane / per == wc) store_rows<CPLX>(y, r, n, full, yv, pol);
+                } else if (wc == 0) {
+                    store_rows<CPLX>(y, r, n, full, yv, pol);
+                }
+            }
         }
         if constexpr (DOT) {
 #pragma unroll
@@ -370,7 +394,7 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
                                                          double *__restrict__ y, int64_t n,
                                                          const double *__restrict__ hin,
                                                          const double *__restrict__ hin2,
-                                                         double *__restrict__ partial, int64_t pstride) {
+                                                         double *__restrict__ partial, int64_t pstride, int policy) {
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;
@@ -406,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
         }
         yv -= u;
         if constexpr (TWO) yv -= u2;      // y'' = (y - X h1) - X h2
-        store_rows<CPLX>(y, r, n, full, yv);
+        store_rows<CPLX>(y, r, n, full, yv, policy);
         nrm += yv.x * yv.x + yv.y * yv.y;
     }
     const double s = wave_sum(nrm);
@@ -623,10 +647,10 @@ __global__ __launch_bounds__(256) void k_diag_linspace(double d0, double dstep, 
     v2d *yv = reinterpret_cast<v2d *>(y);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         const double g = (double)(row0 + 2 * i);
-        v2d dd = v2d{d0 + dstep * g, d0 + dstep * (g + 1.0)};
+        v2d dd = v2d{fma(dstep, g, d0), fma(dstep, g + 1.0, d0)};   // ONE rounding per d_i (oracle: DiagLinOp)
         yv[i] = dd * xv[i];
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = (d0 + dstep * (double)(row0 + n - 1)) * x[n - 1];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(dstep, (double)(row0 + n - 1), d0) * x[n - 1];
 }
 
 // y = A x, A n x n column-major.  Block = 4 waves x 64 rows; wave w sums columns j == w (mod 4).

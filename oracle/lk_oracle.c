@@ -20,6 +20,9 @@
  */
 #include <complex.h>
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,6 +31,30 @@
 #define ORA_ATOL_DP 1.0e-15
 
 typedef void (*ora_matvec_fn)(void *op, int64_t n, const void *x, void *y);
+
+/* Threads used by the *_fast entry points and the element-wise operators.  Default 1: the
+ * reference has no threading, and bench.py's reference-schedule cpu_baseline leg relies on that.
+ * Raising it never changes a result (see lk_oracle_fast.inc). */
+static int ora_nthreads = 1;
+void ora_set_threads(int nt)
+{
+    if (nt < 1) nt = 1;
+#ifdef _OPENMP
+    if (nt > omp_get_max_threads()) nt = omp_get_max_threads();
+#else
+    nt = 1;
+#endif
+    ora_nthreads = nt;
+}
+int ora_get_threads(void) { return ora_nthreads; }
+int ora_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 static inline uint64_t splitmix64(uint64_t z)
 {
@@ -55,6 +82,7 @@ static inline double _Complex fill_z(uint64_t seed, uint64_t i)
 #define REALPART(x) (x)
 #define FILLVAL(seed, i) fill_d(seed, i)
 #include "lk_oracle_body.inc"
+#include "lk_oracle_fast.inc"
 #undef T
 #undef FN
 #undef CONJ
@@ -71,7 +99,10 @@ static inline double _Complex fill_z(uint64_t seed, uint64_t i)
 #define ISZERO(x) (creal(x) == 0.0 && cimag(x) == 0.0)
 #define REALPART(x) creal(x)
 #define FILLVAL(seed, i) fill_z(seed, i)
+#define ORA_KIND_COMPLEX 1
 #include "lk_oracle_body.inc"
+#include "lk_oracle_fast.inc"
+#undef ORA_KIND_COMPLEX
 #undef T
 #undef FN
 #undef CONJ
@@ -91,12 +122,26 @@ void ora_matvec_diag_d(void *op, int64_t n, const void *x, void *y)
 {
     const double *d = (const double *)((ora_diag_op *)op)->d;
     const double *xx = (const double *)x; double *yy = (double *)y;
+#pragma omp parallel for schedule(static) num_threads(ora_nthreads) if (ora_nthreads > 1)
     for (int64_t i = 0; i < n; ++i) yy[i] = d[i] * xx[i];
+}
+
+/* diagonal operator generated on the fly: d_i = fma(dstep, row0 + i, d0) -- ONE rounding, the same
+ * expression the engine's k_diag_linspace evaluates (BASELINE configs 2 and 5: d0 = 1, dstep = 1/n). */
+typedef struct { double d0, dstep; int64_t row0; } ora_diaglin_op;
+__attribute__((target("fma")))
+void ora_matvec_diaglin_d(void *op, int64_t n, const void *x, void *y)
+{
+    const ora_diaglin_op *o = (const ora_diaglin_op *)op;
+    const double *xx = (const double *)x; double *yy = (double *)y;
+#pragma omp parallel for schedule(static) num_threads(ora_nthreads) if (ora_nthreads > 1)
+    for (int64_t i = 0; i < n; ++i) yy[i] = __builtin_fma(o->dstep, (double)(o->row0 + i), o->d0) * xx[i];
 }
 void ora_matvec_diag_z(void *op, int64_t n, const void *x, void *y)
 {
     const double _Complex *d = (const double _Complex *)((ora_diag_op *)op)->d;
     const double _Complex *xx = (const double _Complex *)x; double _Complex *yy = (double _Complex *)y;
+#pragma omp parallel for schedule(static) num_threads(ora_nthreads) if (ora_nthreads > 1)
     for (int64_t i = 0; i < n; ++i) yy[i] = d[i] * xx[i];
 }
 

@@ -36,7 +36,7 @@ MATVEC_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p)
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liblk_oracle.so")
-    src = [os.path.join(_HERE, f) for f in ("lk_oracle.c", "lk_oracle_body.inc")]
+    src = [os.path.join(_HERE, f) for f in ("lk_oracle.c", "lk_oracle_body.inc", "lk_oracle_fast.inc")]
     if force or not os.path.exists(so) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in src
     ):
@@ -53,7 +53,24 @@ def lib():
             getattr(_LIB, "ora_orthogonalize" + sfx).restype = C.c_int
             getattr(_LIB, "ora_dgs" + sfx).restype = C.c_int
             getattr(_LIB, "ora_arnoldi" + sfx).restype = C.c_int
+            getattr(_LIB, "ora_dgs_fast" + sfx).restype = C.c_int
+            getattr(_LIB, "ora_arnoldi_fast" + sfx).restype = C.c_int
+            getattr(_LIB, "ora_norm_mode" + sfx).restype = C.c_double
     return _LIB
+
+
+SEQUENTIAL, COMPENSATED = 0, 1          # dot modes of the *_fast entry points (lk_oracle_fast.inc)
+
+
+def set_threads(nt: int) -> int:
+    """Threads for the ``fast=True`` paths and the element-wise operators (default 1 = the
+    reference).  Never changes a result in SEQUENTIAL mode.  Returns the value in effect."""
+    lib().ora_set_threads(C.c_int(int(nt)))
+    return int(lib().ora_get_threads())
+
+
+def max_threads() -> int:
+    return int(lib().ora_max_threads())
 
 
 def _sfx(a: np.ndarray) -> str:
@@ -141,14 +158,25 @@ def orthogonalize_against_basis(y: np.ndarray, X: np.ndarray):
     return h, int(info)
 
 
-def double_gram_schmidt_step(y: np.ndarray, X: np.ndarray):
-    """Returns (beta = h1 + h2, info).  y is updated in place.  gram_schmidt.fypp:12-57"""
+def double_gram_schmidt_step(y: np.ndarray, X: np.ndarray, fast: bool = False, mode: int = SEQUENTIAL):
+    """Returns (beta = h1 + h2, info).  y is updated in place.  gram_schmidt.fypp:12-57.
+    fast=True: the multi-threaded evaluation of the same schedule (bit-identical in SEQUENTIAL mode)."""
     k = X.shape[1]
     h = np.zeros(max(k, 1), dtype=X.dtype)
     wrk = np.zeros(max(k, 1), dtype=X.dtype)
-    info = getattr(lib(), "ora_dgs" + _sfx(X))(
-        C.c_int64(X.shape[0]), C.c_int(k), _p(X), C.c_int64(_ld(X)), _p(y), _p(h), _p(wrk))
+    if fast or mode != SEQUENTIAL:
+        info = getattr(lib(), "ora_dgs_fast" + _sfx(X))(
+            C.c_int64(X.shape[0]), C.c_int(k), _p(X), C.c_int64(_ld(X)), _p(y), _p(h), _p(wrk), C.c_int(mode))
+    else:
+        info = getattr(lib(), "ora_dgs" + _sfx(X))(
+            C.c_int64(X.shape[0]), C.c_int(k), _p(X), C.c_int64(_ld(X)), _p(y), _p(h), _p(wrk))
     return h[:k], int(info)
+
+
+def dot_mode(x: np.ndarray, y: np.ndarray, mode: int):
+    out = np.zeros(1, dtype=x.dtype)
+    getattr(lib(), "ora_dot_mode" + _sfx(x))(C.c_int64(x.size), _p(x), _p(y), _p(out), C.c_int(mode))
+    return out[0]
 
 
 def fill_counter(x: np.ndarray, seed: int, i0: int = 0) -> None:
@@ -188,6 +216,21 @@ class DiagOp(_OpBase):
 
     def c_matvec(self):
         return getattr(lib(), "ora_matvec_diag" + _sfx(self.d)), C.byref(self._s)
+
+
+class _DiagLinStruct(C.Structure):
+    _fields_ = [("d0", C.c_double), ("dstep", C.c_double), ("row0", C.c_int64)]
+
+
+class DiagLinOp(_OpBase):
+    """d_i = fma(dstep, row0 + i, d0), generated on the fly (no n-sized array): the operator of
+    BASELINE configs 2 and 5 exactly as the engine's diag_linop_gpu(d0=, dstep=) evaluates it."""
+
+    def __init__(self, d0: float, dstep: float, row0: int = 0):
+        self._s = _DiagLinStruct(d0, dstep, row0)
+
+    def c_matvec(self):
+        return lib().ora_matvec_diaglin_d, C.byref(self._s)
 
 
 class DenseOp(_OpBase):
@@ -281,12 +324,18 @@ class PyOp(_OpBase):
 # Krylov factorisations
 # ----------------------------------------------------------------------------------------
 def arnoldi(A: _OpBase, X: np.ndarray, H: np.ndarray, kstart: int = 1, kend: int | None = None,
-            tol: float = ATOL_DP, rand_seed: int = 12345) -> int:
-    """arnoldi (blksize 1).  src/Krylov/arnoldi.fypp:8-76.  X: (n, m+1) F-order, H: (m+1, m) F-order."""
+            tol: float = ATOL_DP, rand_seed: int = 12345, fast: bool = False, mode: int = SEQUENTIAL) -> int:
+    """arnoldi (blksize 1).  src/Krylov/arnoldi.fypp:8-76.  X: (n, m+1) F-order, H: (m+1, m) F-order.
+    fast=True runs the multi-threaded evaluation (set_threads), bit-identical in SEQUENTIAL mode;
+    mode=COMPENSATED uses twice-working-precision dots (not the reference's arithmetic)."""
     m = X.shape[1] - 1
     kend = m if kend is None else kend
     fn, op = A.c_matvec()
     fnp = C.cast(fn, C.c_void_p)
+    if fast or mode != SEQUENTIAL:
+        return int(getattr(lib(), "ora_arnoldi_fast" + _sfx(X))(
+            C.c_int64(X.shape[0]), C.c_int(m), _p(X), C.c_int64(_ld(X)), _p(H), C.c_int64(H.shape[0]),
+            C.c_int(kstart), C.c_int(kend), C.c_double(tol), fnp, op, C.c_uint64(rand_seed), C.c_int(mode)))
     info = getattr(lib(), "ora_arnoldi" + _sfx(X))(
         C.c_int64(X.shape[0]), C.c_int(m), _p(X), C.c_int64(_ld(X)), _p(H), C.c_int64(H.shape[0]),
         C.c_int(kstart), C.c_int(kend), C.c_double(tol), fnp, op, C.c_uint64(rand_seed))
