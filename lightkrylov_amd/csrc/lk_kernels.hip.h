@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void k_diag_linspace(double d0, double dstep, 
     v2d *yv = reinterpret_cast<v2d *>(y);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         const double g = (double)(row0 + 2 * i);
-        v2d dd = v2d{fma(dstep, g, d0), fma(dstep, g + 1.0, d0)};   // ONE rounding per d_i (oracle: DiagLinOp)
+        v2d dd = v2d{fma(dstep, g, d0), fma(dstep, g + 1.0, d0)};   // ONE rounding per d_i
         yv[i] = dd * xv[i];
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(dstep, (double)(row0 + n - 1), d0) * x[n - 1];
