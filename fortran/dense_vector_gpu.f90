@@ -1,62 +1,74 @@
-!> LightKrylov plugin: `dense_vector_gpu_rdp` / `dense_linop_gpu_rdp` extend LightKrylov's
-!> `abstract_vector_rdp` / `abstract_linop_rdp` (src/AbstractTypes/AbstractVectors.fypp:295-381,
-!> src/AbstractTypes/AbstractLinops.fypp:58-87) on top of the C ABI in
-!> include/lightkrylov_hip.h, so that `arnoldi`, `gmres`, `eigs`, ... of an UNCHANGED LightKrylov
-!> run their O(n) work on the MI355X.
+!> LightKrylov plugin: `dense_vector_gpu_{rdp,cdp}` extend LightKrylov's `abstract_vector_{rdp,cdp}`
+!> (src/AbstractTypes/AbstractVectors.fypp:295-381) and `linop_gpu_{rdp,cdp}` / `dense_linop_gpu_{rdp,cdp}` extend
+!> `abstract_linop_{rdp,cdp}` (src/AbstractTypes/AbstractLinops.fypp:58-87, 265-271) on top of the C ABI in
+!> include/lightkrylov_hip.h, so that `arnoldi`, `gmres`, `eigs`, ... of an UNCHANGED LightKrylov run their O(n)
+!> work on the MI355X.
 !>
-!> Build: compile AFTER LightKrylov's own modules (needs LightKrylov + fortran-lang/stdlib; this
-!> image has neither stdlib nor fpm, so this file is NOT compiled by __graft_entry__.build(); the
-!> ISO_C_BINDING layer it relies on, fortran/lk_hip_iso_c.f90, is compiled and run on the GPU by
-!> tests/test_fortran_binding.py).  See INTEGRATION.md for the fpm stanza.
+!> Build: after LightKrylov's own modules (LightKrylov + fortran-lang/stdlib; see INTEGRATION.md).  In this
+!> repository tools/check_plugin.sh compiles and links it against the reference's real module interfaces and
+!> executes the object-semantics logic below on the host (build container only).
 !>
-!> Object semantics (probed with flang 22, SURVEY.md Appendix B).  The reference creates vectors by
-!> sourced allocation (`allocate(V(kdim+1), source=b)`, gmres.fypp:110-113; IterativeSolvers.fypp:1032),
-!> which BIT-COPIES components with no hook, by polymorphic assignment (`wrk = V(k)`, gmres.fypp:155)
-!> and by passing to `intent(out)` dummies (`matvec`'s vec_out, `copy`'s out).  Hence:
-!>   * the device handle is a plain `type(c_ptr)` component WITHOUT default initialisation and the
-!>     type has NO `final` procedure (an intent(out) dummy then keeps its buffer; nothing is freed
-!>     behind our back; bit-copies cannot double free);
-!>   * every handle remembers the address of the Fortran object that owns it (`owner`).  A mutating
-!>     call through an object whose address differs from `owner` has found a bit-copy: it takes a
-!>     fresh device vector first (copying the contents only if the operation reads them);
-!>   * device memory is reclaimed explicitly with `lk_gpu_release_all()` after a solver call (the
-!>     reference never frees vectors explicitly either; it relies on automatic deallocation).
-!> Lazy batching.  Device vectors are carved as CONSECUTIVE COLUMNS of shared slabs (panels of SLAB
-!> columns), in the order objects are first written -- which for `allocate(V(kdim+1), source=b);
-!> call zero_basis(V)` is V(1), V(2), ... -- and the engine runs in "lazy" mode (lk_lazy_stats in the
-!> header): the k calls `X(i)%dot(y)` of `innerprod` cost one panel sweep and the k calls
-!> `y%axpby(a_i, X(i), 1)` of `linear_combination` one panel update, so the UNCHANGED reference gets
-!> fused traffic (measured through the same per-object call pattern from Python: 2.7-4.6x over eager).
-!> The fully fused three-sweep DGS is reached from Fortran through `lk_dgs` / `lk_arnoldi` on a panel
-!> (`gpu_arnoldi_rdp` below).
+!> Object semantics.  LightKrylov creates vectors by sourced allocation (`allocate(V(kdim+1), source=b)`,
+!> gmres.fypp:110-113; IterativeSolvers.fypp:1032) -- a BIT COPY with no user hook --, by intrinsic polymorphic
+!> assignment (`wrk = V(k)`, gmres.fypp:155; `p = r`, CG.fypp:116) and by passing to `intent(out)` dummies
+!> (`matvec`'s vec_out, `copy`'s out), and it never frees a vector explicitly.  Hence:
+!>   * device storage is a COLUMN of a pool slab (lk_pool_* in the header), registered to an OWNER TAG = the address
+!>     of the handle component inside the Fortran object.  The type has no `final`; nothing is freed behind the
+!>     object's back and bit copies cannot double free.
+!>   * the handle is default-initialised (unbound).  An `intent(out)` dummy is reset by the compiler on entry; its
+!>     first write re-acquires by tag and gets the SAME column back, so `matvec(V(k), V(k+1))` stays in place.
+!>   * a mutating call through an object whose address differs from the handle's `owner` has found a bit copy: it
+!>     takes a column of its own first (copying the contents only if the operation reads them).
+!>   * intrinsic assignment invokes the handle's defined `assignment(=)`: a DEEP copy, so `p = r` followed by
+!>     writes to `r` leaves `p` alone (the CG update pattern).
+!>   * an object that appears at the address of a dead one inherits its column: temporaries such as
+!>     `linear_combination`'s `y` (allocated twice per Gram-Schmidt pass, AbstractVectors.fypp:595-598) cost no new
+!>     device memory per call.  `lk_gpu_release_all()` returns everything after a solver call.
+!>   Limit: a sourced copy shares its source's column until it is first written through.  Every sourced allocation
+!>   in LightKrylov's Krylov layer and solvers is followed by `zero()` / `zero_basis()` or an overwrite (gmres.fypp:
+!>   110-115, IterativeSolvers.fypp:1032-1034, AbstractVectors.fypp:595-598, 628-630, qr.fypp:186); user code that
+!>   needs an independent copy should assign (`y = x`), not source-allocate.
+!> Lazy batching.  Columns are handed out in the order objects are first written -- V(1), V(2), ... for
+!> `allocate(V(kdim+1), source=b); call zero_basis(V)` -- and the engine runs in "lazy" mode (lk_lazy_stats): the
+!> k calls `X(i)%dot(y)` of `innerprod` cost one panel sweep and the k calls `y%axpby(a_i, X(i), 1)` of
+!> `linear_combination` one panel update.  The fully fused three-sweep DGS is reached through `gpu_arnoldi_rdp`.
 module lightkrylov_gpu
     use, intrinsic :: iso_c_binding
     use lightkrylov_hip_c
     use LightKrylov_Constants, only: dp
     use LightKrylov_Logger, only: stop_error, type_error
     use LightKrylov_AbstractVectors, only: abstract_vector_rdp, abstract_vector_cdp
-    use LightKrylov_AbstractLinops, only: abstract_linop_rdp
+    use LightKrylov_AbstractLinops, only: abstract_linop_rdp, abstract_linop_cdp
     implicit none
     private
     character(len=*), parameter :: this_module = 'LK_GPU'
 
-    public :: dense_vector_gpu_rdp, dense_vector_gpu_cdp, dense_linop_gpu_rdp
-    public :: lk_gpu_init, lk_gpu_finalize, lk_gpu_release_all, gpu_arnoldi_rdp
+    public :: dense_vector_gpu_rdp, dense_vector_gpu_cdp, dense_vector_gpu
+    public :: linop_gpu_rdp, linop_gpu_cdp, dense_linop_gpu_rdp, dense_linop_gpu_cdp
+    public :: dense_linop_gpu, diag_linop_gpu, diag_linspace_linop_gpu, laplacian2d_linop_gpu, ginzburg_landau_linop_gpu
+    public :: lk_gpu_init, lk_gpu_finalize, lk_gpu_release_all, lk_gpu_context, lk_gpu_pool_stats
+    public :: lk_gpu_set_partition, lk_gpu_comm_unique_id, lk_gpu_comm_init
+    public :: gpu_arnoldi_rdp
 
     type(c_ptr), save :: ctx = c_null_ptr
-    ! slabs (panels of SLAB columns) handed out since the last release; vectors are columns of a slab
-    integer, parameter :: SLAB = 160
-    type(c_ptr), allocatable, save :: pool(:)
-    integer, save :: npool = 0
-    integer, save :: slab_n = -1, slab_used = SLAB     ! row count of the open slab / columns already taken
-    integer(c_int), save :: slab_dtype = -1            ! kind of the open slab
+    integer(c_int64_t), save :: part_row0 = 0          ! first global row of this rank's block (lk_gpu_set_partition)
+
+    !> Device storage of one vector: a column of a pool slab.  Defined assignment = deep copy.
+    type :: gpu_handle
+        type(c_ptr) :: buf = c_null_ptr                !! slab (panel) handle
+        integer(c_int) :: col = -1                     !! this vector's column in the slab
+        integer(c_int) :: dtype = -1
+        integer(c_int64_t) :: n = -1
+        integer(c_intptr_t) :: owner = 0               !! address of the handle this column is registered to
+    contains
+        procedure, private :: handle_assign
+        generic :: assignment(=) => handle_assign
+    end type
 
     type, extends(abstract_vector_rdp) :: dense_vector_gpu_rdp
-        integer :: n                        !! number of (local) rows; set by the user like dense_vector%n
-        type(c_ptr) :: buf                  !! slab (panel) handle; NO default init, NO final (see above)
-        integer(c_int) :: col               !! this vector's column in the slab
-        integer(c_intptr_t) :: owner        !! loc() of the object this handle was bound to
-        integer :: magic                    !! = MAGIC once `buf` is a live handle
+        integer :: n                        !! number of (local) rows; set by the user like dense_vector%n (no default
+                                            !! initialisation, like dense_vector: an intent(out) dummy keeps its size)
+        type(gpu_handle) :: h
     contains
         procedure, pass(self) :: zero => gpu_zero
         procedure, pass(self) :: rand => gpu_rand
@@ -71,10 +83,7 @@ module lightkrylov_gpu
     !> complex(dp) kind: same layout, interleaved (re, im) on the device (LK_C128)
     type, extends(abstract_vector_cdp) :: dense_vector_gpu_cdp
         integer :: n
-        type(c_ptr) :: buf
-        integer(c_int) :: col
-        integer(c_intptr_t) :: owner
-        integer :: magic
+        type(gpu_handle) :: h
     contains
         procedure, pass(self) :: zero => gpuz_zero
         procedure, pass(self) :: rand => gpuz_rand
@@ -82,40 +91,89 @@ module lightkrylov_gpu
         procedure, pass(self) :: axpby => gpuz_axpby
         procedure, pass(self) :: dot => gpuz_dot
         procedure, pass(self) :: get_size => gpuz_get_size
+        procedure, pass(self) :: upload => gpuz_upload
+        procedure, pass(self) :: download => gpuz_download
     end type
 
-    !> dense_linop on the device (AbstractLinops.fypp:265-271, 608-660)
-    type, extends(abstract_linop_rdp) :: dense_linop_gpu_rdp
+    !> Any engine operator (lk_linop_*) behind LightKrylov's abstract_linop: matvec / rmatvec = lk_linop_apply N / H.
+    type, extends(abstract_linop_rdp) :: linop_gpu_rdp
         type(c_ptr) :: op = c_null_ptr
     contains
-        procedure, pass(self) :: matvec => gpu_dense_matvec
-        procedure, pass(self) :: rmatvec => gpu_dense_rmatvec
+        procedure, pass(self) :: matvec => gpu_matvec_rdp
+        procedure, pass(self) :: rmatvec => gpu_rmatvec_rdp
+    end type
+    type, extends(abstract_linop_cdp) :: linop_gpu_cdp
+        type(c_ptr) :: op = c_null_ptr
+    contains
+        procedure, pass(self) :: matvec => gpu_matvec_cdp
+        procedure, pass(self) :: rmatvec => gpu_rmatvec_cdp
+    end type
+    !> dense_linop on the device (AbstractLinops.fypp:265-271, 608-660), both double-precision kinds
+    type, extends(linop_gpu_rdp) :: dense_linop_gpu_rdp
+    end type
+    type, extends(linop_gpu_cdp) :: dense_linop_gpu_cdp
     end type
 
-    integer, parameter :: MAGIC = 1263225675
+    !> dense_vector_gpu(x): the counterpart of the reference's dense_vector(x) constructor (AbstractVectors.fypp:469-474)
+    interface dense_vector_gpu
+        module procedure dense_vector_gpu_from_rdp, dense_vector_gpu_from_cdp
+    end interface
+    interface dense_linop_gpu
+        module procedure dense_linop_gpu_from_rdp, dense_linop_gpu_from_cdp
+    end interface
+    interface diag_linop_gpu
+        module procedure diag_linop_gpu_from_rdp, diag_linop_gpu_from_cdp
+    end interface
 
 contains
 
+    ! ---- context -----------------------------------------------------------------------------------------
     subroutine lk_gpu_init(device)
         integer, intent(in) :: device
         call chk(lk_init(int(device, c_int), c_null_ptr, ctx), 'lk_gpu_init')
         call chk(lk_set_tuning(ctx, 'lazy'//c_null_char, 1_c_int), 'lk_gpu_init')
-        allocate (pool(64)); npool = 0; slab_n = -1; slab_used = SLAB
+        part_row0 = 0
     end subroutine
 
+    function lk_gpu_context() result(c)
+        type(c_ptr) :: c
+        c = ctx
+    end function
+
+    !> returns every pool column (all vectors become unbound; their next write re-acquires)
     subroutine lk_gpu_release_all()
-        integer :: i
-        integer(c_int) :: rc
-        do i = 1, npool
-            rc = lk_basis_destroy(pool(i))
-        end do
-        npool = 0; slab_n = -1; slab_used = SLAB
+        call chk(lk_pool_release_all(ctx), 'lk_gpu_release_all')
     end subroutine
 
     subroutine lk_gpu_finalize()
         integer(c_int) :: rc
-        call lk_gpu_release_all()
         rc = lk_finalize(ctx); ctx = c_null_ptr
+    end subroutine
+
+    !> out4 = slabs, columns ever carved, columns currently registered, acquisitions served by re-use
+    subroutine lk_gpu_pool_stats(out4)
+        integer(c_int64_t), intent(out) :: out4(4)
+        call chk(lk_pool_stats(ctx, out4), 'lk_gpu_pool_stats')
+    end subroutine
+
+    !> this rank owns global rows [row0, row0 + n_local) of n_global (row-sharded run, one process per GPU)
+    subroutine lk_gpu_set_partition(row0, n_global)
+        integer(c_int64_t), intent(in) :: row0, n_global
+        call chk(lk_set_partition(ctx, row0, n_global), 'lk_gpu_set_partition')
+        part_row0 = row0
+    end subroutine
+
+    !> rank 0: 128 opaque bytes to broadcast (MPI_Bcast) before every rank calls lk_gpu_comm_init
+    subroutine lk_gpu_comm_unique_id(id)
+        character(kind=c_char), intent(out) :: id(128)
+        call chk(lk_comm_get_unique_id(id), 'lk_gpu_comm_unique_id')
+    end subroutine
+
+    !> collective: native RCCL sum all-reduce for every dot / norm / Gram-Schmidt coefficient from now on
+    subroutine lk_gpu_comm_init(nranks, rank, id)
+        integer, intent(in) :: nranks, rank
+        character(kind=c_char), intent(in) :: id(128)
+        call chk(lk_comm_init_rank(ctx, int(nranks, c_int), int(rank, c_int), id), 'lk_gpu_comm_init')
     end subroutine
 
     subroutine chk(rc, procedure)
@@ -125,46 +183,91 @@ contains
         if (rc /= LK_OK) call stop_error(lk_error_message(), this_module, procedure)
     end subroutine
 
-    !> Next free column of the open slab of kind `dtype` and `n` rows (a new slab when full or mismatching).
-    subroutine take_column(n, dtype, sl, col)
-        integer, intent(in) :: n
+    ! ---- handle ----------------------------------------------------------------------------------------------
+    !> .true. when `h` is registered to the object it sits in (not a bit copy, not stale) with this shape
+    logical function handle_is_own(h, dtype, n) result(own)
+        type(gpu_handle), intent(in), target :: h
         integer(c_int), intent(in) :: dtype
-        type(c_ptr), intent(out) :: sl
-        integer(c_int), intent(out) :: col
-        type(c_ptr), allocatable :: grown(:)
-        if (slab_used >= SLAB .or. slab_n /= n .or. slab_dtype /= dtype) then
-            call chk(lk_basis_create(ctx, dtype, int(n, c_int64_t), int(SLAB, c_int), sl), 'take_column')
-            if (npool == size(pool)) then
-                allocate (grown(2*npool)); grown(:npool) = pool; call move_alloc(grown, pool)
-            end if
-            npool = npool + 1; pool(npool) = sl
-            slab_n = n; slab_dtype = dtype; slab_used = 0
-        end if
-        sl = pool(npool); col = int(slab_used, c_int); slab_used = slab_used + 1
-    end subroutine
+        integer(c_int64_t), intent(in) :: n
+        integer(c_intptr_t) :: tag, reg
+        own = .false.
+        if (.not. c_associated(h%buf)) return
+        tag = transfer(c_loc(h), tag)
+        if (h%owner /= tag .or. h%dtype /= dtype .or. h%n /= n) return
+        call chk(lk_pool_owner(ctx, h%buf, h%col, reg), 'handle_is_own')
+        own = (reg == tag)
+    end function
 
-    !> Make sure `self` owns a private device vector; keep=.true. preserves the current contents.
-    subroutine bind(self, keep)
-        class(dense_vector_gpu_rdp), intent(inout), target :: self
+    !> .true. when `h` points at a registered pool column (own or shared): safe to read
+    logical function handle_is_readable(h) result(ok)
+        type(gpu_handle), intent(in) :: h
+        integer(c_intptr_t) :: reg
+        ok = .false.
+        if (.not. c_associated(h%buf)) return
+        call chk(lk_pool_owner(ctx, h%buf, h%col, reg), 'handle_is_readable')
+        ok = (reg /= 0)
+    end function
+
+    !> Make `h` own a column of shape (dtype, n); keep=.true. preserves what it could read before.
+    subroutine handle_bind(h, dtype, n, keep)
+        type(gpu_handle), intent(inout), target :: h
+        integer(c_int), intent(in) :: dtype
+        integer(c_int64_t), intent(in) :: n
         logical, intent(in) :: keep
-        type(c_ptr) :: fresh, old
+        type(c_ptr) :: fresh, old_buf
         integer(c_int) :: fresh_col, old_col
-        logical :: live
-        live = (self%magic == MAGIC)
-        if (live .and. self%owner == transfer(c_loc(self%n), self%owner)) return
-        call take_column(self%n, LK_F64, fresh, fresh_col)
-        if (live .and. keep) then
-            old = self%buf; old_col = self%col
-            call chk(lk_vec_copy(fresh, fresh_col, old, old_col), 'bind')
+        integer(c_intptr_t) :: tag
+        logical :: copy_old
+        if (n <= 0) call stop_error('vector size not set (set %n or upload first)', this_module, 'bind')
+        if (handle_is_own(h, dtype, n)) return
+        copy_old = .false.
+        if (keep .and. h%dtype == dtype .and. h%n == n) copy_old = handle_is_readable(h)
+        old_buf = h%buf; old_col = h%col
+        tag = transfer(c_loc(h), tag)
+        call chk(lk_pool_acquire(ctx, dtype, n, tag, fresh, fresh_col), 'bind')
+        if (copy_old) then
+            if (.not. (c_associated(fresh, old_buf) .and. fresh_col == old_col)) &
+                call chk(lk_vec_copy(fresh, fresh_col, old_buf, old_col), 'bind')
         end if
-        self%buf = fresh; self%col = fresh_col
-        self%owner = transfer(c_loc(self%n), self%owner); self%magic = MAGIC
+        h%buf = fresh; h%col = fresh_col; h%dtype = dtype; h%n = n; h%owner = tag
     end subroutine
 
+    !> defined assignment of the handle component = DEEP COPY (intrinsic assignment `wrk = V(k)`, `p = r`)
+    subroutine handle_assign(lhs, rhs)
+        class(gpu_handle), intent(inout), target :: lhs
+        class(gpu_handle), intent(in) :: rhs
+        if (.not. c_associated(rhs%buf)) then          ! unbound source: unbound copy
+            lhs%buf = c_null_ptr; lhs%col = -1; lhs%dtype = rhs%dtype; lhs%n = rhs%n; lhs%owner = 0
+            return
+        end if
+        if (.not. handle_is_readable(rhs)) then        ! stale source (pool released): nothing to copy
+            lhs%buf = c_null_ptr; lhs%col = -1; lhs%dtype = rhs%dtype; lhs%n = rhs%n; lhs%owner = 0
+            return
+        end if
+        select type (lhs)
+        type is (gpu_handle)
+            call handle_bind(lhs, rhs%dtype, rhs%n, .false.)
+        end select
+        if (.not. (c_associated(lhs%buf, rhs%buf) .and. lhs%col == rhs%col)) &
+            call chk(lk_vec_copy(lhs%buf, lhs%col, rhs%buf, rhs%col), 'assignment(=)')
+    end subroutine
+
+    function dense_vector_gpu_from_rdp(x) result(vec)
+        real(dp), intent(in) :: x(:)
+        type(dense_vector_gpu_rdp) :: vec
+        call vec%upload(x)
+    end function
+    function dense_vector_gpu_from_cdp(x) result(vec)
+        complex(dp), intent(in) :: x(:)
+        type(dense_vector_gpu_cdp) :: vec
+        call vec%upload(x)
+    end function
+
+    ! ---- real(dp) kind ---------------------------------------------------------------------------------------
     subroutine gpu_zero(self)
         class(dense_vector_gpu_rdp), intent(inout) :: self
-        call bind(self, .false.)
-        call chk(lk_vec_zero(self%buf, self%col), 'zero')
+        call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), .false.)
+        call chk(lk_vec_zero(self%h%buf, self%h%col), 'zero')
     end subroutine
 
     subroutine gpu_rand(self, ifnorm)
@@ -173,16 +276,16 @@ contains
         integer(c_int) :: nrm
         integer(c_int64_t), save :: seed = 1
         nrm = 0; if (present(ifnorm)) nrm = merge(1_c_int, 0_c_int, ifnorm)
-        call bind(self, .false.)
+        call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), .false.)
         seed = seed + 1
-        call chk(lk_vec_rand(self%buf, self%col, seed, 0_c_int64_t, nrm), 'rand')
+        call chk(lk_vec_rand(self%h%buf, self%h%col, seed, part_row0, nrm), 'rand')
     end subroutine
 
     subroutine gpu_scal(self, alpha)
         class(dense_vector_gpu_rdp), intent(inout) :: self
         real(dp), intent(in) :: alpha
-        call bind(self, .true.)
-        call chk(lk_vec_scal(self%buf, self%col, [alpha]), 'scal')
+        call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), .true.)
+        call chk(lk_vec_scal(self%h%buf, self%h%col, [alpha]), 'scal')
     end subroutine
 
     subroutine gpu_axpby(alpha, vec, beta, self)
@@ -190,10 +293,14 @@ contains
         class(abstract_vector_rdp), intent(in) :: vec
         class(dense_vector_gpu_rdp), intent(inout) :: self
         select type (vec)
-        type is (dense_vector_gpu_rdp)
+        class is (dense_vector_gpu_rdp)
+            ! no storage yet (fresh object, or an intent(out) dummy such as copy's `out`): adopt vec's size, like
+            ! dense_axpby's `if (.not. allocated(self%data)) allocate(self%data(m))` (AbstractVectors.fypp:521-524)
+            if (.not. c_associated(self%h%buf)) self%n = vec%n
             if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'axpby')
-            call bind(self, beta /= 0.0_dp)      ! beta == 0: old contents are not read (true axpby)
-            call chk(lk_vec_axpby([alpha], vec%buf, vec%col, [beta], self%buf, self%col), 'axpby')
+            if (.not. handle_is_readable(vec%h)) call stop_error("vec holds no data", this_module, 'axpby')
+            call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), beta /= 0.0_dp)   ! beta == 0: old contents are not read
+            call chk(lk_vec_axpby([alpha], vec%h%buf, vec%h%col, [beta], self%h%buf, self%h%col), 'axpby')
         class default
             call type_error('vec', 'dense_vector_gpu_rdp', 'IN', this_module, 'axpby')
         end select
@@ -206,8 +313,11 @@ contains
         real(c_double) :: res(2)
         alpha = 0.0_dp
         select type (vec)
-        type is (dense_vector_gpu_rdp)
-            call chk(lk_vec_dot(self%buf, self%col, vec%buf, vec%col, res), 'dot')
+        class is (dense_vector_gpu_rdp)
+            if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'dot')
+            if (.not. (handle_is_readable(self%h) .and. handle_is_readable(vec%h))) &
+                call stop_error("vector holds no data", this_module, 'dot')
+            call chk(lk_vec_dot(self%h%buf, self%h%col, vec%h%buf, vec%h%col, res), 'dot')
             alpha = res(1)
         class default
             call type_error('vec', 'dense_vector_gpu_rdp', 'IN', this_module, 'dot')
@@ -224,38 +334,22 @@ contains
         class(dense_vector_gpu_rdp), intent(inout) :: self
         real(dp), intent(in), target :: x(:)
         self%n = size(x)
-        call bind(self, .false.)
-        call chk(lk_basis_upload(self%buf, self%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'upload')
+        call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), .false.)
+        call chk(lk_basis_upload(self%h%buf, self%h%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'upload')
     end subroutine
 
     subroutine gpu_download(self, x)
         class(dense_vector_gpu_rdp), intent(in) :: self
         real(dp), intent(out), target :: x(:)
-        call chk(lk_basis_download(self%buf, self%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'download')
+        if (.not. handle_is_readable(self%h)) call stop_error("vector holds no data", this_module, 'download')
+        call chk(lk_basis_download(self%h%buf, self%h%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'download')
     end subroutine
 
-    ! ---- complex(dp) kind ---------------------------------------------------------------------
-    subroutine bindz(self, keep)
-        class(dense_vector_gpu_cdp), intent(inout), target :: self
-        logical, intent(in) :: keep
-        type(c_ptr) :: fresh, old
-        integer(c_int) :: fresh_col, old_col
-        logical :: live
-        live = (self%magic == MAGIC)
-        if (live .and. self%owner == transfer(c_loc(self%n), self%owner)) return
-        call take_column(self%n, LK_C128, fresh, fresh_col)
-        if (live .and. keep) then
-            old = self%buf; old_col = self%col
-            call chk(lk_vec_copy(fresh, fresh_col, old, old_col), 'bind')
-        end if
-        self%buf = fresh; self%col = fresh_col
-        self%owner = transfer(c_loc(self%n), self%owner); self%magic = MAGIC
-    end subroutine
-
+    ! ---- complex(dp) kind ------------------------------------------------------------------------------------
     subroutine gpuz_zero(self)
         class(dense_vector_gpu_cdp), intent(inout) :: self
-        call bindz(self, .false.)
-        call chk(lk_vec_zero(self%buf, self%col), 'zero')
+        call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), .false.)
+        call chk(lk_vec_zero(self%h%buf, self%h%col), 'zero')
     end subroutine
 
     subroutine gpuz_rand(self, ifnorm)
@@ -264,16 +358,16 @@ contains
         integer(c_int) :: nrm
         integer(c_int64_t), save :: seed = 1000001
         nrm = 0; if (present(ifnorm)) nrm = merge(1_c_int, 0_c_int, ifnorm)
-        call bindz(self, .false.)
+        call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), .false.)
         seed = seed + 1
-        call chk(lk_vec_rand(self%buf, self%col, seed, 0_c_int64_t, nrm), 'rand')
+        call chk(lk_vec_rand(self%h%buf, self%h%col, seed, part_row0, nrm), 'rand')
     end subroutine
 
     subroutine gpuz_scal(self, alpha)
         class(dense_vector_gpu_cdp), intent(inout) :: self
         complex(dp), intent(in) :: alpha
-        call bindz(self, .true.)
-        call chk(lk_vec_scal(self%buf, self%col, [real(alpha, dp), aimag(alpha)]), 'scal')
+        call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), .true.)
+        call chk(lk_vec_scal(self%h%buf, self%h%col, [real(alpha, dp), aimag(alpha)]), 'scal')
     end subroutine
 
     subroutine gpuz_axpby(alpha, vec, beta, self)
@@ -281,11 +375,13 @@ contains
         class(abstract_vector_cdp), intent(in) :: vec
         class(dense_vector_gpu_cdp), intent(inout) :: self
         select type (vec)
-        type is (dense_vector_gpu_cdp)
+        class is (dense_vector_gpu_cdp)
+            if (.not. c_associated(self%h%buf)) self%n = vec%n
             if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'axpby')
-            call bindz(self, beta /= (0.0_dp, 0.0_dp))
-            call chk(lk_vec_axpby([real(alpha, dp), aimag(alpha)], vec%buf, vec%col, [real(beta, dp), aimag(beta)], &
-                                  self%buf, self%col), 'axpby')
+            if (.not. handle_is_readable(vec%h)) call stop_error("vec holds no data", this_module, 'axpby')
+            call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), beta /= (0.0_dp, 0.0_dp))
+            call chk(lk_vec_axpby([real(alpha, dp), aimag(alpha)], vec%h%buf, vec%h%col, [real(beta, dp), aimag(beta)], &
+                                  self%h%buf, self%h%col), 'axpby')
         class default
             call type_error('vec', 'dense_vector_gpu_cdp', 'IN', this_module, 'axpby')
         end select
@@ -298,8 +394,11 @@ contains
         real(c_double) :: res(2)
         alpha = (0.0_dp, 0.0_dp)
         select type (vec)
-        type is (dense_vector_gpu_cdp)
-            call chk(lk_vec_dot(self%buf, self%col, vec%buf, vec%col, res), 'dot')   ! conj on self, like dotc
+        class is (dense_vector_gpu_cdp)
+            if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'dot')
+            if (.not. (handle_is_readable(self%h) .and. handle_is_readable(vec%h))) &
+                call stop_error("vector holds no data", this_module, 'dot')
+            call chk(lk_vec_dot(self%h%buf, self%h%col, vec%h%buf, vec%h%col, res), 'dot')   ! conj on self, like dotc
             alpha = cmplx(res(1), res(2), kind=dp)
         class default
             call type_error('vec', 'dense_vector_gpu_cdp', 'IN', this_module, 'dot')
@@ -312,20 +411,36 @@ contains
         n = self%n
     end function
 
-    ! ---- dense_linop on the device -----------------------------------------------------------
-    subroutine apply_dense(self, trans, vec_in, vec_out, procedure)
-        class(dense_linop_gpu_rdp), intent(inout) :: self
+    subroutine gpuz_upload(self, x)
+        class(dense_vector_gpu_cdp), intent(inout) :: self
+        complex(dp), intent(in), target :: x(:)
+        self%n = size(x)
+        call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), .false.)
+        call chk(lk_basis_upload(self%h%buf, self%h%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'upload')
+    end subroutine
+
+    subroutine gpuz_download(self, x)
+        class(dense_vector_gpu_cdp), intent(in) :: self
+        complex(dp), intent(out), target :: x(:)
+        if (.not. handle_is_readable(self%h)) call stop_error("vector holds no data", this_module, 'download')
+        call chk(lk_basis_download(self%h%buf, self%h%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'download')
+    end subroutine
+
+    ! ---- operators ---------------------------------------------------------------------------------------------
+    subroutine apply_rdp(op, trans, vec_in, vec_out, procedure)
+        type(c_ptr), intent(in) :: op
         integer(c_int), intent(in) :: trans
         class(abstract_vector_rdp), intent(in) :: vec_in
-        class(abstract_vector_rdp), intent(out) :: vec_out     ! intent(out): components keep their bits (no default init)
+        class(abstract_vector_rdp), intent(inout) :: vec_out   ! the TBP's intent(out) dummy has already been reset
         character(len=*), intent(in) :: procedure
         select type (vec_in)
-        type is (dense_vector_gpu_rdp)
+        class is (dense_vector_gpu_rdp)
             select type (vec_out)
-            type is (dense_vector_gpu_rdp)
+            class is (dense_vector_gpu_rdp)
+                if (.not. handle_is_readable(vec_in%h)) call stop_error("vec_in holds no data", this_module, procedure)
                 vec_out%n = vec_in%n
-                call bind(vec_out, .false.)
-                call chk(lk_linop_apply(self%op, trans, vec_in%buf, vec_in%col, vec_out%buf, vec_out%col), procedure)
+                call handle_bind(vec_out%h, LK_F64, int(vec_out%n, c_int64_t), .false.)
+                call chk(lk_linop_apply(op, trans, vec_in%h%buf, vec_in%h%col, vec_out%h%buf, vec_out%h%col), procedure)
             class default
                 call type_error('vec_out', 'dense_vector_gpu_rdp', 'OUT', this_module, procedure)
             end select
@@ -334,19 +449,98 @@ contains
         end select
     end subroutine
 
-    subroutine gpu_dense_matvec(self, vec_in, vec_out)
-        class(dense_linop_gpu_rdp), intent(inout) :: self
-        class(abstract_vector_rdp), intent(in) :: vec_in
-        class(abstract_vector_rdp), intent(out) :: vec_out
-        call apply_dense(self, LK_OP_N, vec_in, vec_out, 'matvec')
+    subroutine apply_cdp(op, trans, vec_in, vec_out, procedure)
+        type(c_ptr), intent(in) :: op
+        integer(c_int), intent(in) :: trans
+        class(abstract_vector_cdp), intent(in) :: vec_in
+        class(abstract_vector_cdp), intent(inout) :: vec_out
+        character(len=*), intent(in) :: procedure
+        select type (vec_in)
+        class is (dense_vector_gpu_cdp)
+            select type (vec_out)
+            class is (dense_vector_gpu_cdp)
+                if (.not. handle_is_readable(vec_in%h)) call stop_error("vec_in holds no data", this_module, procedure)
+                vec_out%n = vec_in%n
+                call handle_bind(vec_out%h, LK_C128, int(vec_out%n, c_int64_t), .false.)
+                call chk(lk_linop_apply(op, trans, vec_in%h%buf, vec_in%h%col, vec_out%h%buf, vec_out%h%col), procedure)
+            class default
+                call type_error('vec_out', 'dense_vector_gpu_cdp', 'OUT', this_module, procedure)
+            end select
+        class default
+            call type_error('vec_in', 'dense_vector_gpu_cdp', 'IN', this_module, procedure)
+        end select
     end subroutine
 
-    subroutine gpu_dense_rmatvec(self, vec_in, vec_out)
-        class(dense_linop_gpu_rdp), intent(inout) :: self
+    subroutine gpu_matvec_rdp(self, vec_in, vec_out)
+        class(linop_gpu_rdp), intent(inout) :: self
         class(abstract_vector_rdp), intent(in) :: vec_in
         class(abstract_vector_rdp), intent(out) :: vec_out
-        call apply_dense(self, LK_OP_H, vec_in, vec_out, 'rmatvec')
+        call apply_rdp(self%op, LK_OP_N, vec_in, vec_out, 'matvec')
     end subroutine
+    subroutine gpu_rmatvec_rdp(self, vec_in, vec_out)
+        class(linop_gpu_rdp), intent(inout) :: self
+        class(abstract_vector_rdp), intent(in) :: vec_in
+        class(abstract_vector_rdp), intent(out) :: vec_out
+        call apply_rdp(self%op, LK_OP_H, vec_in, vec_out, 'rmatvec')
+    end subroutine
+    subroutine gpu_matvec_cdp(self, vec_in, vec_out)
+        class(linop_gpu_cdp), intent(inout) :: self
+        class(abstract_vector_cdp), intent(in) :: vec_in
+        class(abstract_vector_cdp), intent(out) :: vec_out
+        call apply_cdp(self%op, LK_OP_N, vec_in, vec_out, 'matvec')
+    end subroutine
+    subroutine gpu_rmatvec_cdp(self, vec_in, vec_out)
+        class(linop_gpu_cdp), intent(inout) :: self
+        class(abstract_vector_cdp), intent(in) :: vec_in
+        class(abstract_vector_cdp), intent(out) :: vec_out
+        call apply_cdp(self%op, LK_OP_H, vec_in, vec_out, 'rmatvec')
+    end subroutine
+
+    ! constructors: the operator lives in the engine; the Fortran object holds its handle
+    function dense_linop_gpu_from_rdp(A) result(L)
+        real(dp), intent(in), target :: A(:, :)
+        type(dense_linop_gpu_rdp) :: L
+        call chk(lk_linop_dense_create(ctx, LK_F64, int(size(A, 1), c_int64_t), c_loc(A), int(size(A, 1), c_int64_t), L%op), &
+                 'dense_linop_gpu')
+    end function
+    function dense_linop_gpu_from_cdp(A) result(L)
+        complex(dp), intent(in), target :: A(:, :)
+        type(dense_linop_gpu_cdp) :: L
+        call chk(lk_linop_dense_create(ctx, LK_C128, int(size(A, 1), c_int64_t), c_loc(A), int(size(A, 1), c_int64_t), L%op), &
+                 'dense_linop_gpu')
+    end function
+    function diag_linop_gpu_from_rdp(d) result(L)
+        real(dp), intent(in), target :: d(:)
+        type(linop_gpu_rdp) :: L
+        call chk(lk_linop_diag_create(ctx, LK_F64, int(size(d), c_int64_t), c_loc(d), L%op), 'diag_linop_gpu')
+    end function
+    function diag_linop_gpu_from_cdp(d) result(L)
+        complex(dp), intent(in), target :: d(:)
+        type(linop_gpu_cdp) :: L
+        call chk(lk_linop_diag_create(ctx, LK_C128, int(size(d), c_int64_t), c_loc(d), L%op), 'diag_linop_gpu')
+    end function
+    !> d_i = d0 + dstep*(row0 + i), generated on the device (row-sharded runs pass this rank's row0)
+    function diag_linspace_linop_gpu(n_local, row0, d0, dstep) result(L)
+        integer(c_int64_t), intent(in) :: n_local, row0
+        real(dp), intent(in) :: d0, dstep
+        type(linop_gpu_rdp) :: L
+        call chk(lk_linop_diag_linspace_create(ctx, n_local, row0, d0, dstep, L%op), 'diag_linspace_linop_gpu')
+    end function
+    !> 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2
+    function laplacian2d_linop_gpu(N) result(L)
+        integer, intent(in) :: N
+        type(linop_gpu_rdp) :: L
+        call chk(lk_linop_lap5_create(ctx, int(N, c_int64_t), L%op), 'laplacian2d_linop_gpu')
+    end function
+    !> fixed-step RK4 propagator of the linearised Ginzburg-Landau operator (example/ginzburg_landau/Ginzburg_Landau.f90:126-136)
+    function ginzburg_landau_linop_gpu(n, dx, tau, nsub, nu, gamma, mu_c, mu2) result(L)
+        integer, intent(in) :: n, nsub
+        real(dp), intent(in) :: dx, tau, mu_c, mu2
+        complex(dp), intent(in) :: nu, gamma
+        type(linop_gpu_cdp) :: L
+        call chk(lk_linop_gl_create(ctx, int(n, c_int64_t), dx, tau, int(nsub, c_int), [real(nu, dp), aimag(nu)], &
+                                    [real(gamma, dp), aimag(gamma)], mu_c, mu2, L%op), 'ginzburg_landau_linop_gpu')
+    end function
 
     ! ---- fused path from Fortran: the whole Arnoldi step loop inside the engine ----------------
     !> Same contract as LightKrylov's `arnoldi` (src/Krylov/arnoldi.fypp:8-76) for an engine operator

@@ -184,6 +184,113 @@ module lightkrylov_hip_c
             type(c_ptr), intent(out) :: op
             integer(c_int) :: rc
         end function
+        function lk_context_info(ctx, device, stream) bind(C, name="lk_context_info") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), intent(out) :: device
+            type(c_ptr), intent(out) :: stream
+            integer(c_int) :: rc
+        end function
+        !> native RCCL all-reduce: rank 0 fills id(128) and ships it (e.g. MPI_Bcast); every rank then calls
+        !> lk_comm_init_rank (collective).
+        function lk_comm_get_unique_id(id) bind(C, name="lk_comm_get_unique_id") result(rc)
+            import :: c_int, c_char
+            character(kind=c_char), intent(out) :: id(128)
+            integer(c_int) :: rc
+        end function
+        function lk_comm_init_rank(ctx, nranks, rank, id) bind(C, name="lk_comm_init_rank") result(rc)
+            import :: c_int, c_ptr, c_char
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: nranks, rank
+            character(kind=c_char), intent(in) :: id(128)
+            integer(c_int) :: rc
+        end function
+        function lk_comm_destroy(ctx) bind(C, name="lk_comm_destroy") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int) :: rc
+        end function
+        function lk_pool_acquire(ctx, dtype, n_local, owner_tag, slab, col) bind(C, name="lk_pool_acquire") result(rc)
+            import :: c_int, c_ptr, c_int64_t, c_intptr_t
+            type(c_ptr), value :: ctx
+            integer(c_int), value :: dtype
+            integer(c_int64_t), value :: n_local
+            integer(c_intptr_t), value :: owner_tag
+            type(c_ptr), intent(out) :: slab
+            integer(c_int), intent(out) :: col
+            integer(c_int) :: rc
+        end function
+        function lk_pool_owner(ctx, slab, col, owner_tag) bind(C, name="lk_pool_owner") result(rc)
+            import :: c_int, c_ptr, c_intptr_t
+            type(c_ptr), value :: ctx, slab
+            integer(c_int), value :: col
+            integer(c_intptr_t), intent(out) :: owner_tag
+            integer(c_int) :: rc
+        end function
+        function lk_pool_release(ctx, slab, col) bind(C, name="lk_pool_release") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx, slab
+            integer(c_int), value :: col
+            integer(c_int) :: rc
+        end function
+        function lk_pool_release_all(ctx) bind(C, name="lk_pool_release_all") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int) :: rc
+        end function
+        function lk_pool_stats(ctx, out4) bind(C, name="lk_pool_stats") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), intent(out) :: out4(4)
+            integer(c_int) :: rc
+        end function
+        function lk_vec_size(B, n_local) bind(C, name="lk_vec_size") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: B
+            integer(c_int64_t), intent(out) :: n_local
+            integer(c_int) :: rc
+        end function
+        function lk_gram(Bx, k, G) bind(C, name="lk_gram") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: Bx
+            integer(c_int), value :: k
+            real(c_double), intent(out) :: G(*)
+            integer(c_int) :: rc
+        end function
+        function lk_dgs_block(Bx, k, By, jy0, p, h, info) bind(C, name="lk_dgs_block") result(rc)
+            import :: c_int, c_ptr, c_double
+            type(c_ptr), value :: Bx, By
+            integer(c_int), value :: k, jy0, p
+            real(c_double), intent(out) :: h(*)
+            integer(c_int), intent(out) :: info
+            integer(c_int) :: rc
+        end function
+        function lk_linop_diag_linspace_create(ctx, n_local, row0, d0, dstep, op) &
+            bind(C, name="lk_linop_diag_linspace_create") result(rc)
+            import :: c_int, c_ptr, c_int64_t, c_double
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), value :: n_local, row0
+            real(c_double), value :: d0, dstep
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
+        function lk_linop_lap5_create(ctx, N, op) bind(C, name="lk_linop_lap5_create") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), value :: N
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
+        function lk_linop_gl_create(ctx, n, dx, tau, nsub, nu, gamma, mu_c, mu2, op) bind(C, name="lk_linop_gl_create") result(rc)
+            import :: c_int, c_ptr, c_int64_t, c_double
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), value :: n
+            real(c_double), value :: dx, tau, mu_c, mu2
+            integer(c_int), value :: nsub
+            real(c_double), intent(in) :: nu(2), gamma(2)
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
         function lk_linop_destroy(op) bind(C, name="lk_linop_destroy") result(rc)
             import :: c_int, c_ptr
             type(c_ptr), value :: op

@@ -78,6 +78,22 @@ int lk_init(int device, void *stream, lk_context_t *ctx);
 int lk_finalize(lk_context_t ctx);
 int lk_sync(lk_context_t ctx);
 int lk_set_allreduce(lk_context_t ctx, lk_allreduce_fn fn, void *user, int nranks, int rank);
+/* device ordinal and hipStream_t the context runs on (either pointer may be NULL). */
+int lk_context_info(lk_context_t ctx, int *device, void **stream);
+
+/* Native RCCL all-reduce (one process per GPU; backend "nccl" of the reference-side launchers IS RCCL on
+ * ROCm).  Rank 0 calls lk_comm_get_unique_id and ships the LK_COMM_ID_BYTES opaque bytes to every rank by
+ * whatever out-of-band channel the host program has (MPI_Bcast in a Fortran/MPI host, the torch.distributed
+ * store in bench.py); every rank then calls lk_comm_init_rank (collective: ncclCommInitRank on the context's
+ * device), which installs ncclAllReduce(ncclDouble, ncclSum) on the context's stream as the engine's
+ * reduction hook -- the <= 129 (258 complex) scalars of each sweep are reduced in place in device memory.
+ * The reference itself has no collective (paper/paper.md:35,97,101: "the user's job inside dot").
+ * librccl is dlopen'ed on first use.  lk_comm_destroy (or lk_finalize) releases the communicator. */
+#define LK_COMM_ID_BYTES 128
+int lk_comm_get_unique_id(void *id_out);
+int lk_comm_init_rank(lk_context_t ctx, int nranks, int rank, const void *id);
+int lk_comm_destroy(lk_context_t ctx);
+
 /* row block owned by this rank: global rows [row0, row0 + n_local) of n_global; only used
  * so that counter-based rand fills are identical for every partition. */
 int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
@@ -120,6 +136,29 @@ int lk_basis_info(lk_basis_t B, int *dtype, int64_t *n_local, int *ncols, int64_
  * dimension ldh (elements).  Synchronous. */
 int lk_basis_upload(lk_basis_t B, int col0, int ncols, const void *host, int64_t ldh);
 int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh);
+
+/* ---- column pool: device storage for hosts that own vectors OBJECT BY OBJECT ---------
+ * LightKrylov creates vectors one object at a time, by sourced allocation, polymorphic assignment and
+ * intent(out) dummies, and never frees them explicitly (AbstractVectors.fypp:595-598, gmres.fypp:110-115,155;
+ * SURVEY 8b "Ownership").  A plugin type therefore cannot own device memory through allocate/final; it asks
+ * this pool for a COLUMN of a shared slab (a panel of `pool_slab_cols` columns, tuning key, default 160) keyed
+ * by an owner tag -- the address of the Fortran object:
+ *   lk_pool_acquire  returns the column already registered to `owner_tag` (an object that reappears at the
+ *                    address of a dead one re-uses its column: temporaries such as linear_combination's `proj`
+ *                    cost no new memory per call), else the lowest released column, else the next column of the
+ *                    open slab, so `allocate(V(k), source=b); call zero_basis(V)` lands in consecutive columns
+ *                    of one panel and the lazy per-object path (lk_lazy_stats) can batch it;
+ *   lk_pool_owner    tag a column is registered to (0: free or not a pool column; `slab` is validated
+ *                    against the pool before it is dereferenced, so stale handles are safe to ask about);
+ *   lk_pool_release  returns one column; lk_pool_release_all destroys every slab (after a solver call);
+ *   lk_pool_stats    out4 = {slabs, columns ever carved, columns currently registered, acquisitions served by
+ *                    re-use}. */
+int lk_pool_acquire(lk_context_t ctx, int dtype, int64_t n_local, uint64_t owner_tag, lk_basis_t *slab,
+                    int *col);
+int lk_pool_owner(lk_context_t ctx, lk_basis_t slab, int col, uint64_t *owner_tag);
+int lk_pool_release(lk_context_t ctx, lk_basis_t slab, int col);
+int lk_pool_release_all(lk_context_t ctx);
+int lk_pool_stats(lk_context_t ctx, int64_t *out4);
 
 /* ---- abstract_vector type-bound procedures (AbstractVectors.fypp:295-381) ------------ */
 

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "liblightkrylov_hip.so")
 LK_F64, LK_C128 = 0, 1
 LK_DGS_NORMALIZE = 1
 LK_OP_N, LK_OP_H = 0, 1
+LK_COMM_ID_BYTES = 128
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
@@ -33,6 +34,10 @@ SIGNATURES = {
     "lk_finalize": (_int, [_p]),
     "lk_sync": (_int, [_p]),
     "lk_set_allreduce": (_int, [_p, ALLREDUCE_FN, _p, _int, _int]),
+    "lk_context_info": (_int, [_p, _ip, _pp]),
+    "lk_comm_get_unique_id": (_int, [_p]),
+    "lk_comm_init_rank": (_int, [_p, _int, _int, _p]),
+    "lk_comm_destroy": (_int, [_p]),
     "lk_set_partition": (_int, [_p, _i64, _i64]),
     "lk_set_tuning": (_int, [_p, C.c_char_p, _int]),
     "lk_lazy_stats": (_int, [_p, C.POINTER(_i64)]),
@@ -45,6 +50,11 @@ SIGNATURES = {
     "lk_basis_info": (_int, [_p, _ip, C.POINTER(_i64), _ip, C.POINTER(_i64), _pp]),
     "lk_basis_upload": (_int, [_p, _int, _int, _p, _i64]),
     "lk_basis_download": (_int, [_p, _int, _int, _p, _i64]),
+    "lk_pool_acquire": (_int, [_p, _int, _i64, C.c_uint64, _pp, _ip]),
+    "lk_pool_owner": (_int, [_p, _p, _int, C.POINTER(C.c_uint64)]),
+    "lk_pool_release": (_int, [_p, _p, _int]),
+    "lk_pool_release_all": (_int, [_p]),
+    "lk_pool_stats": (_int, [_p, C.POINTER(_i64)]),
     "lk_vec_zero": (_int, [_p, _int]),
     "lk_vec_rand": (_int, [_p, _int, C.c_uint64, _i64, _int]),
     "lk_vec_scal": (_int, [_p, _int, _dp]),

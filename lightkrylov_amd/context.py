@@ -95,6 +95,41 @@ class Context:
         self._cb = _capi.ALLREDUCE_FN(_allreduce)
         _capi.check(self._lib.lk_set_allreduce(self._h, self._cb, None, self.nranks, self.rank))
 
+    # -- multi-GPU, native: ncclAllReduce issued by the library itself (no interpreter in the path) ------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: a fresh RCCL unique id (LK_COMM_ID_BYTES opaque bytes) to ship to every rank."""
+        buf = C.create_string_buffer(_capi.LK_COMM_ID_BYTES)
+        _capi.check(_capi.load().lk_comm_get_unique_id(buf))
+        return buf.raw
+
+    def init_native_comm(self, nranks: int, rank: int, unique_id: bytes) -> None:
+        """Collective over the `nranks` processes sharing a row-sharded basis: ncclCommInitRank on this
+        context's device; afterwards every sweep's reduction scalars are summed by ncclAllReduce on the
+        context's stream (lk_comm_init_rank)."""
+        if len(unique_id) != _capi.LK_COMM_ID_BYTES:
+            raise ValueError("unique_id must be LK_COMM_ID_BYTES bytes")
+        buf = C.create_string_buffer(unique_id, _capi.LK_COMM_ID_BYTES)
+        _capi.check(self._lib.lk_comm_init_rank(self._h, int(nranks), int(rank), buf))
+        self.nranks, self.rank = int(nranks), int(rank)
+        self._cb = None
+
+    def init_native_comm_from_process_group(self, pg=None) -> None:
+        """Bootstrap the native communicator through an existing torch.distributed group: rank 0's unique id
+        is broadcast over `pg` (torch only carries the 128 bootstrap bytes; the data path is the library's)."""
+        import torch
+        import torch.distributed as dist
+        nranks, rank = dist.get_world_size(pg), dist.get_rank(pg)
+        payload = [self.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(payload, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg,
+                                   device=torch.device(f"cuda:{self.device}") if dist.get_backend(pg) == "nccl" else None)
+        self.init_native_comm(nranks, rank, payload[0])
+        self._pg = pg
+
+    def destroy_native_comm(self) -> None:
+        _capi.check(self._lib.lk_comm_destroy(self._h))
+        self.nranks, self.rank = 1, 0
+
     def set_partition(self, row0: int, n_global: int) -> None:
         _capi.check(self._lib.lk_set_partition(self._h, int(row0), int(n_global)))
         self.row0, self.n_global = int(row0), int(n_global)

@@ -1,6 +1,6 @@
 // lk_engine.hip -- host side of the C ABI declared in include/lightkrylov_hip.h.
 // HIP only: there is no CPU code path in this library.
-#include "../../include/lightkrylov_hip.h"
+#include "lk_internal.h"
 #include "lk_kernels.hip.h"
 
 #include <cmath>
@@ -23,13 +23,7 @@ constexpr int MAX_GRID = 4096;       // upper bound on sweep blocks (partial buf
 
 thread_local char g_err[512] = "";
 
-int fail(int code, const char *fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
+#define fail lk_fail_
 
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
@@ -59,6 +53,14 @@ struct ProfAcc {
 
 }  // namespace
 
+extern "C" int lk_fail_(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 struct lk_context_s {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -67,6 +69,7 @@ struct lk_context_s {
     int grid_mult = 2;  // sweep blocks per CU
     int stream_update = 1;     // single-coefficient update sweeps: barrier-free streaming kernel
     int update_grid_mult = 4;
+    int gemm_grid_mult = 4;    // panel_gemm blocks per CU
     int stream_two = 0;        // sweep 3 with two coefficient sets: barrier-free streaming kernel instead of the LDS/barrier one
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 0;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
@@ -102,6 +105,17 @@ struct lk_context_s {
     double *coef_host = nullptr;         // pinned staging for queued coefficients
     hipEvent_t coef_ev = nullptr;        // completion of the last staging copy
     int64_t lazy_stats[4] = {0, 0, 0, 0};  // dot memo hits, batched dot sweeps, queued axpbys, queue flushes
+    // column pool (lk_pool_*): slabs handed out to per-object hosts
+    struct PoolSlab {
+        lk_basis_t B = nullptr;
+        int used = 0;                          // columns carved so far
+        std::vector<uint64_t> owner;           // owner tag per column (0 = free)
+    };
+    std::vector<PoolSlab> pool;
+    std::map<uint64_t, std::pair<int, int>> pool_by_tag;   // owner tag -> (slab index, column)
+    std::set<std::pair<int, int>> pool_free;                // released columns, lowest first
+    int pool_slab_cols = 160;
+    int64_t pool_stats[2] = {0, 0};            // columns ever carved, acquisitions served by re-use
     // profiling
     bool prof = false;
     std::vector<ProfRec> prof_pending;
@@ -116,6 +130,8 @@ struct lk_basis_s {
     int ncols;
     double *data;
     bool own;
+    int hwm = 0;   // columns [0, hwm) have been written through the ABI (lazy dot batches never sweep beyond it)
+    void touch(int j, int cnt = 1) { if (j + cnt > hwm) hwm = j + cnt; }
     int ed() const { return dtype == LK_C128 ? 2 : 1; }
     double *col(int j) const { return data + (int64_t)j * ld * ed(); }
 };
@@ -141,6 +157,8 @@ struct lk_linop_s {
 namespace {
 
 constexpr int RED_SECTION = (KMAX_FUSED + 1) * 2;  // doubles per result section
+constexpr int RED_SECTIONS = 3;                     // h1 | h2 | ||y''||^2 (multi-RHS sweeps use them as one flat buffer)
+constexpr int PARTIAL_SECTIONS = 2;                 // per-block partials: 2 y-columns per multi-RHS pass
 
 // ---- profiling helpers ----------------------------------------------------------------
 struct ProfScope {
@@ -184,6 +202,20 @@ void prof_collect(lk_context_t c) {
     }
     c->prof_pending.clear();
 }
+
+// Every ABI entry that touches the device runs on the CONTEXT's device, whatever the caller's current device is
+// (a process may hold contexts on several GPUs, or torch may have switched the current device).
+struct DevGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DevGuard(lk_context_t c) {
+        if (!c) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~DevGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 inline int blas1_grid(lk_context_t c, int64_t nvec) {
     int64_t g = (nvec + 255) / 256;
@@ -244,6 +276,8 @@ SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n) {
 //   MODE 2: y' = y - X hin ; h = X^H y'     (UPDATE+DOT), y' written only if `store`
 //   MODE 3: y' = y - X hin                  (UPDATE)
 //   MODE 4: y'' = (y - X hin) - X hin2      (UPDATE, two coefficient sets; pairs with MODE 2, store = 0)
+// out == nullptr (update-only modes): the norm of the result is not wanted -- no finish kernel, and above all NO
+// all-reduce (the lazy flush runs at rank-dependent times; a collective there could mismatch across ranks).
 template <bool CPLX, int MODE>
 int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y, int64_t n, const double *hin,
                  const double *hin2, int store, double *out) {
@@ -275,6 +309,7 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
         }
     }
     HIPCHK(hipGetLastError());
+    if (!out) return LK_OK;
     // slots: DOT -> 0..k*ED-1 valid; norm at slot k*ED.  Without DOT only the norm slot is defined.
     const int first = DOT ? 0 : k * ED;
     const int nslots = (k + 1) * ED - first;
@@ -330,6 +365,47 @@ int ensure_scratch(lk_context_t c, int64_t doubles) {
     c->scratch_n = 0;
     HIPCHK(hipMalloc((void **)&c->scratch, (size_t)doubles * sizeof(double)));
     c->scratch_n = doubles;
+    return LK_OK;
+}
+
+// ---- tall-skinny product launcher (panel_gemm) -------------------------------------------------------------
+constexpr int GEMM_QB = 16;       // accumulators (output columns) per lane
+constexpr int GEMM_NQG = 4;       // output-column groups per block (= waves per block)
+
+inline int64_t gemm_packed_doubles(int k, int q, int ED) {
+    return (int64_t)((q + GEMM_QB - 1) / GEMM_QB) * k * GEMM_QB * ED;
+}
+
+// Y(:, jy0 : jy0+q) (+)= sign * X(:, c0 : c0+k) * C, C = DEVICE coefficients, column-major k x q with leading dimension
+// ldc (elements).  `pack` = device workspace of gemm_packed_doubles(k, q, ED) doubles.  One pass over X per 64 outputs.
+int gemm_launch(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, const double *Cdev, int64_t ldc, double sign,
+                int accumulate, double *pack) {
+    lk_context_t c = Bx->ctx;
+    const bool cp = Bx->dtype == LK_C128;
+    const int ED = Bx->ed();
+    const int total = (int)gemm_packed_doubles(k, q, ED);
+    hipLaunchKernelGGL(pack_coef, dim3((total + 255) / 256 > 64 ? 64 : (total + 255) / 256), dim3(256), 0, c->stream, Cdev, ldc, k, q,
+                       GEMM_QB, ED, sign, pack);
+    HIPCHK(hipGetLastError());
+    for (int q0 = 0; q0 < q; q0 += GEMM_QB * GEMM_NQG) {
+        const int qn = (q - q0) < GEMM_QB * GEMM_NQG ? (q - q0) : GEMM_QB * GEMM_NQG;
+        const int groups = (qn + GEMM_QB - 1) / GEMM_QB;
+        const int QGB = groups <= 1 ? 1 : (groups == 2 ? 2 : 4);
+        const int64_t tile_rows = (int64_t)(4 / QGB) * 64 * (cp ? 1 : 2);
+        int64_t g = (Bx->n + tile_rows - 1) / tile_rows;
+        const int64_t cap = (int64_t)c->num_cu * c->gemm_grid_mult;
+        if (g > cap) g = cap;
+        if (g < 1) g = 1;
+        const double *Cp = pack + (int64_t)(q0 / GEMM_QB) * k * GEMM_QB * ED;
+        ProfScope ps(c, "lincomb", (double)Bx->n * ED * 8.0 * (k + qn * (accumulate ? 2 : 1)));
+        if (cp)
+            hipLaunchKernelGGL((panel_gemm<true, 4, GEMM_QB>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, k,
+                               By->col(jy0 + q0), By->ld, qn, Cp, Bx->n, accumulate, QGB);
+        else
+            hipLaunchKernelGGL((panel_gemm<false, 8, GEMM_QB>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, k,
+                               By->col(jy0 + q0), By->ld, qn, Cp, Bx->n, accumulate, QGB);
+        HIPCHK(hipGetLastError());
+    }
     return LK_OK;
 }
 
@@ -389,7 +465,7 @@ int lazy_flush(lk_context_t c) {
     HIPCHK(hipMemcpyAsync(c->coef, c->coef_host, (size_t)q.cnt * ED * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->coef_ev, c->stream));
     c->lazy_stats[3] += 1;
-    return sweepm<3>(q.Bx, q.j0, q.cnt, q.By->col(q.jy), c->coef, nullptr, 1, c->red + 2 * RED_SECTION);
+    return sweepm<3>(q.Bx, q.j0, q.cnt, q.By->col(q.jy), c->coef, nullptr, 1, nullptr);   // norm unused: no collective
 }
 
 // Called at the top of every ABI entry that reads or writes vector data.
@@ -443,23 +519,35 @@ int lk_init(int device, void *stream, lk_context_t *ctx) {
     HIPCHK(hipSetDevice(device));
     lk_context_t c = new lk_context_s();
     c->device = device;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
-    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (stream) {
-        c->stream = (hipStream_t)stream;
-    } else {
-        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        c->own_stream = true;
+    // any failure below releases what was acquired so far (lk_finalize tolerates a half-built context)
+    auto body = [&]() -> int {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (stream) {
+            c->stream = (hipStream_t)stream;
+        } else {
+            HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->own_stream = true;
+        }
+        HIPCHK(hipMalloc((void **)&c->partial, (size_t)PARTIAL_SECTIONS * RED_SECTION * MAX_GRID * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&c->red, (size_t)RED_SECTIONS * RED_SECTION * sizeof(double)));
+        HIPCHK(hipMemsetAsync(c->red, 0, (size_t)RED_SECTIONS * RED_SECTION * sizeof(double), c->stream));
+        HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)RED_SECTIONS * RED_SECTION * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&c->coef, (size_t)KMAX_FUSED * 2 * sizeof(double)));
+        HIPCHK(hipHostMalloc((void **)&c->coef_host, (size_t)KMAX_FUSED * 2 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->coef_ev, c->stream));
+        return LK_OK;
+    };
+    const int rc_init = body();
+    if (rc_init != LK_OK) {
+        char keep[sizeof(g_err)];
+        memcpy(keep, g_err, sizeof(keep));
+        (void)lk_finalize(c);
+        memcpy(g_err, keep, sizeof(keep));
+        return rc_init;
     }
-    HIPCHK(hipMalloc((void **)&c->partial, (size_t)2 * RED_SECTION * MAX_GRID * sizeof(double)));   // 2 y-columns per multi-RHS pass
-    HIPCHK(hipMalloc((void **)&c->red, (size_t)3 * RED_SECTION * sizeof(double)));
-    HIPCHK(hipMemsetAsync(c->red, 0, (size_t)3 * RED_SECTION * sizeof(double), c->stream));
-    HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)3 * RED_SECTION * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipMalloc((void **)&c->coef, (size_t)KMAX_FUSED * 2 * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&c->coef_host, (size_t)KMAX_FUSED * 2 * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(c->coef_ev, c->stream));
     {
         std::lock_guard<std::mutex> lock(g_ctx_mu);
         g_live_ctx.insert(c);
@@ -468,16 +556,25 @@ int lk_init(int device, void *stream, lk_context_t *ctx) {
     return LK_OK;
 }
 
+int lk_context_info(lk_context_t c, int *device, void **stream) {
+    if (!c) return fail(LK_ERR_INVALID, "lk_context_info: null context");
+    if (device) *device = c->device;
+    if (stream) *stream = (void *)c->stream;
+    return LK_OK;
+}
+
 int lk_finalize(lk_context_t c) {
     if (!c) return LK_OK;
-    (void)hipSetDevice(c->device);
-    (void)lazy_flush(c);
+    DevGuard dev_guard(c);
+    (void)lk_pool_release_all(c);
+    (void)lk_comm_destroy(c);
+    if (c->stream) (void)lazy_flush(c);
     {
         std::lock_guard<std::mutex> lock(g_ctx_mu);
         g_live_ctx.erase(c);
     }
 
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     prof_collect(c);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->partial) (void)hipFree(c->partial);
@@ -487,13 +584,14 @@ int lk_finalize(lk_context_t c) {
     if (c->red_host) (void)hipHostFree(c->red_host);
     if (c->coef_host) (void)hipHostFree(c->coef_host);
     if (c->coef_ev) (void)hipEventDestroy(c->coef_ev);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LK_OK;
 }
 
 int lk_sync(lk_context_t c) {
     if (!c) return fail(LK_ERR_INVALID, "lk_sync: null context");
+    DevGuard dev_guard(c);
     LKCHK(lazy_enter(c, false));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->prof) prof_collect(c);
@@ -541,6 +639,16 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
+    if (!strcmp(key, "pool_slab_cols")) {
+        if (value < 2 || value > 4096) return fail(LK_ERR_INVALID, "pool_slab_cols must be in [2,4096]");
+        c->pool_slab_cols = value;
+        return LK_OK;
+    }
+    if (!strcmp(key, "gemm_grid_mult")) {
+        if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "gemm_grid_mult must be in [1,16]");
+        c->gemm_grid_mult = value;
+        return LK_OK;
+    }
     if (!strcmp(key, "update_grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "update_grid_mult must be in [1,16]");
         c->update_grid_mult = value;
@@ -551,6 +659,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
 
 int lk_profile_enable(lk_context_t c, int on) {
     if (!c) return fail(LK_ERR_INVALID, "null context");
+    DevGuard dev_guard(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
     c->prof = on != 0;
@@ -558,6 +667,7 @@ int lk_profile_enable(lk_context_t c, int on) {
 }
 int lk_profile_reset(lk_context_t c) {
     if (!c) return fail(LK_ERR_INVALID, "null context");
+    DevGuard dev_guard(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
     c->prof_acc.clear();
@@ -565,6 +675,7 @@ int lk_profile_reset(lk_context_t c) {
 }
 int lk_profile_get(lk_context_t c, const char *tag, int64_t *count, double *total_ms, double *total_bytes) {
     if (!c || !tag) return fail(LK_ERR_INVALID, "null argument");
+    DevGuard dev_guard(c);
     HIPCHK(hipStreamSynchronize(c->stream));
     prof_collect(c);
     ProfAcc a;
@@ -591,6 +702,7 @@ int lk_lazy_stats(lk_context_t c, int64_t *out4) {
 // ---- basis --------------------------------------------------------------------------------
 int lk_basis_create(lk_context_t c, int dtype, int64_t n_local, int ncols, lk_basis_t *B) {
     if (!c || !B) return fail(LK_ERR_INVALID, "lk_basis_create: null argument");
+    DevGuard dev_guard(c);
     if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "lk_basis_create: bad dtype %d", dtype);
     if (n_local < 0 || ncols < 1) return fail(LK_ERR_INVALID, "lk_basis_create: bad shape %lld x %d", (long long)n_local, ncols);
     if (n_local > 2147483647LL) return fail(LK_ERR_INVALID, "lk_basis_create: n_local exceeds get_size's default integer");
@@ -617,6 +729,7 @@ int lk_basis_wrap(lk_context_t c, int dtype, int64_t n_local, int ncols, int64_t
     if (dtype == LK_F64 && (ld & 1) && ncols > 1) return fail(LK_ERR_INVALID, "lk_basis_wrap: ld must be even for LK_F64");
     lk_basis_t b = new lk_basis_s();
     b->ctx = c; b->dtype = dtype; b->n = n_local; b->ld = ld; b->ncols = ncols; b->own = false; b->data = (double *)dev_ptr;
+    b->hwm = ncols;   // caller-owned memory: every column may hold data
     *B = b;
     return LK_OK;
 }
@@ -648,9 +761,11 @@ int lk_basis_info(lk_basis_t B, int *dtype, int64_t *n_local, int *ncols, int64_
 
 int lk_basis_upload(lk_basis_t B, int col0, int ncols, const void *host, int64_t ldh) {
     if (!B || !host) return fail(LK_ERR_INVALID, "lk_basis_upload: null argument");
+    DevGuard dev_guard(B->ctx);
     if (col0 < 0 || ncols < 0 || col0 + ncols > B->ncols || ldh < B->n) return fail(LK_ERR_INVALID, "lk_basis_upload: bad range");
     if (ncols == 0 || B->n == 0) return LK_OK;
     LKCHK(lazy_enter(B->ctx, true));
+    B->touch(col0, ncols);
     const size_t es = (size_t)B->ed() * sizeof(double);
     HIPCHK(hipMemcpy2DAsync(B->col(col0), (size_t)B->ld * es, host, (size_t)ldh * es, (size_t)B->n * es, ncols,
                             hipMemcpyHostToDevice, B->ctx->stream));
@@ -660,6 +775,7 @@ int lk_basis_upload(lk_basis_t B, int col0, int ncols, const void *host, int64_t
 
 int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh) {
     if (!B || !host) return fail(LK_ERR_INVALID, "lk_basis_download: null argument");
+    DevGuard dev_guard(B->ctx);
     if (col0 < 0 || ncols < 0 || col0 + ncols > B->ncols || ldh < B->n) return fail(LK_ERR_INVALID, "lk_basis_download: bad range");
     if (ncols == 0 || B->n == 0) return LK_OK;
     LKCHK(lazy_enter(B->ctx, false));
@@ -670,28 +786,135 @@ int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh
     return LK_OK;
 }
 
+// ---- column pool ---------------------------------------------------------------------------
+static int pool_find_slab(lk_context_t c, lk_basis_t slab) {
+    for (size_t i = 0; i < c->pool.size(); ++i)
+        if (c->pool[i].B == slab) return (int)i;
+    return -1;
+}
+
+int lk_pool_acquire(lk_context_t c, int dtype, int64_t n_local, uint64_t tag, lk_basis_t *slab, int *col) {
+    if (!c || !slab || !col) return fail(LK_ERR_INVALID, "lk_pool_acquire: null argument");
+    if (tag == 0) return fail(LK_ERR_INVALID, "lk_pool_acquire: owner tag 0 is reserved for 'free'");
+    DevGuard dev_guard(c);
+    auto matches = [&](int si) { return c->pool[si].B->dtype == dtype && c->pool[si].B->n == n_local; };
+    auto it = c->pool_by_tag.find(tag);
+    if (it != c->pool_by_tag.end()) {
+        const int si = it->second.first, cj = it->second.second;
+        if (matches(si)) {                                   // the object that lived at this address is gone: re-use
+            *slab = c->pool[si].B; *col = cj;
+            c->pool_stats[1] += 1;
+            return LK_OK;
+        }
+        c->pool[si].owner[cj] = 0;                            // other shape: give the old column back
+        c->pool_free.insert({si, cj});
+        c->pool_by_tag.erase(it);
+    }
+    for (auto f = c->pool_free.begin(); f != c->pool_free.end(); ++f) {
+        if (!matches(f->first)) continue;
+        const int si = f->first, cj = f->second;
+        c->pool_free.erase(f);
+        c->pool[si].owner[cj] = tag;
+        c->pool_by_tag[tag] = {si, cj};
+        *slab = c->pool[si].B; *col = cj;
+        c->pool_stats[1] += 1;
+        return LK_OK;
+    }
+    int si = -1;
+    for (int i = (int)c->pool.size() - 1; i >= 0; --i)
+        if (matches(i) && c->pool[i].used < c->pool[i].B->ncols) { si = i; break; }
+    if (si < 0) {
+        // new slab: pool_slab_cols columns, fewer when that would take more than a quarter of the free memory
+        int ncols = c->pool_slab_cols;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double colbytes = (double)(n_local > 0 ? n_local : 1) * (dtype == LK_C128 ? 16.0 : 8.0);
+            const double fit = 0.25 * (double)free_b / colbytes;
+            if (fit < ncols) ncols = fit < 8.0 ? 8 : (int)fit;
+        }
+        lk_context_s::PoolSlab ps;
+        LKCHK(lk_basis_create(c, dtype, n_local, ncols, &ps.B));
+        ps.owner.assign((size_t)ncols, 0);
+        c->pool.push_back(ps);
+        si = (int)c->pool.size() - 1;
+    }
+    auto &ps = c->pool[si];
+    const int cj = ps.used++;
+    ps.owner[cj] = tag;
+    c->pool_by_tag[tag] = {si, cj};
+    c->pool_stats[0] += 1;
+    *slab = ps.B; *col = cj;
+    return LK_OK;
+}
+
+int lk_pool_owner(lk_context_t c, lk_basis_t slab, int col, uint64_t *tag) {
+    if (!c || !tag) return fail(LK_ERR_INVALID, "lk_pool_owner: null argument");
+    *tag = 0;
+    const int si = pool_find_slab(c, slab);
+    if (si < 0 || col < 0 || col >= c->pool[si].used) return LK_OK;
+    *tag = c->pool[si].owner[col];
+    return LK_OK;
+}
+
+int lk_pool_release(lk_context_t c, lk_basis_t slab, int col) {
+    if (!c) return fail(LK_ERR_INVALID, "lk_pool_release: null context");
+    const int si = pool_find_slab(c, slab);
+    if (si < 0 || col < 0 || col >= c->pool[si].used) return fail(LK_ERR_INVALID, "lk_pool_release: not a pool column");
+    const uint64_t tag = c->pool[si].owner[col];
+    if (tag == 0) return LK_OK;
+    c->pool_by_tag.erase(tag);
+    c->pool[si].owner[col] = 0;
+    c->pool_free.insert({si, col});
+    return LK_OK;
+}
+
+int lk_pool_release_all(lk_context_t c) {
+    if (!c) return LK_OK;
+    DevGuard dev_guard(c);
+    for (auto &ps : c->pool) (void)lk_basis_destroy(ps.B);
+    c->pool.clear();
+    c->pool_by_tag.clear();
+    c->pool_free.clear();
+    return LK_OK;
+}
+
+int lk_pool_stats(lk_context_t c, int64_t *out4) {
+    if (!c || !out4) return fail(LK_ERR_INVALID, "lk_pool_stats: null argument");
+    out4[0] = (int64_t)c->pool.size();
+    out4[1] = c->pool_stats[0];
+    out4[2] = (int64_t)c->pool_by_tag.size();
+    out4[3] = c->pool_stats[1];
+    return LK_OK;
+}
+
 // ---- vector TBPs ----------------------------------------------------------------------------
 int lk_vec_zero(lk_basis_t B, int j) {
     LKCHK(check_vec(B, j, "lk_vec_zero"));
+    DevGuard dev_guard(B->ctx);
     LKCHK(lazy_enter(B->ctx, true));
+    B->touch(j);
     HIPCHK(hipMemsetAsync(B->col(j), 0, (size_t)B->n * B->ed() * sizeof(double), B->ctx->stream));
     return LK_OK;
 }
 
 int lk_vec_scal(lk_basis_t B, int j, const double *alpha) {
     LKCHK(check_vec(B, j, "lk_vec_scal"));
+    DevGuard dev_guard(B->ctx);
     if (!alpha) return fail(LK_ERR_INVALID, "lk_vec_scal: null alpha");
     LKCHK(lazy_enter(B->ctx, true));
+    B->touch(j);
     return scal_launch(B, j, alpha[0], B->dtype == LK_C128 ? alpha[1] : 0.0, nullptr, 0.0);
 }
 
 int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta, lk_basis_t By, int jy) {
     LKCHK(check_vec(Bx, jx, "lk_vec_axpby(vec)"));
     LKCHK(check_vec(By, jy, "lk_vec_axpby(self)"));
+    DevGuard dev_guard(Bx->ctx);
     LKCHK(check_pair(Bx, By, "lk_vec_axpby"));
     if (!alpha || !beta) return fail(LK_ERR_INVALID, "lk_vec_axpby: null scalar");
     lk_context_t c = Bx->ctx;
     const bool cp = Bx->dtype == LK_C128;
+    By->touch(jy);
     if (c->lazy) {
         // y <- a X(:, jx) + 1 y with X a column of a multi-column panel: queue it (linear_combination's loop,
         // AbstractVectors.fypp:600-602 / 637-642); consecutive columns onto the same y extend the queue.
@@ -729,6 +952,7 @@ int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta,
 int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
     LKCHK(check_vec(Bx, jx, "lk_vec_dot(self)"));
     LKCHK(check_vec(By, jy, "lk_vec_dot(vec)"));
+    DevGuard dev_guard(Bx->ctx);
     LKCHK(check_pair(Bx, By, "lk_vec_dot"));
     if (!out) return fail(LK_ERR_INVALID, "lk_vec_dot: null out");
     lk_context_t c = Bx->ctx;
@@ -744,7 +968,9 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
             c->lazy_stats[0] += 1;
             return LK_OK;
         }
-        int jend = (By->data == Bx->data && jy > jx) ? jy : Bx->ncols;   // X(:k) vs y = X(k+1) in the same panel
+        // X(:k) vs y = X(k+1) in the same panel; otherwise the run of columns ever written (slab panels are mostly
+        // unused columns: sweeping them would cost up to 128/k times the eager traffic)
+        int jend = (By->data == Bx->data && jy > jx) ? jy : (Bx->hwm < Bx->ncols ? Bx->hwm : Bx->ncols);
         int cnt = jend - jx;
         if (cnt > KMAX_FUSED) cnt = KMAX_FUSED;
         const bool y_inside = (By->data == Bx->data) && jy >= jx && jy < jx + cnt;
@@ -767,6 +993,7 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
 
 int lk_vec_norm(lk_basis_t B, int j, double *out) {
     LKCHK(check_vec(B, j, "lk_vec_norm"));
+    DevGuard dev_guard(B->ctx);
     if (!out) return fail(LK_ERR_INVALID, "lk_vec_norm: null out");
     lk_context_t c = B->ctx;
     LKCHK(lazy_enter(c, false));
@@ -786,9 +1013,11 @@ int lk_vec_size(lk_basis_t B, int64_t *n_local) {
 int lk_vec_copy(lk_basis_t Bd, int jd, lk_basis_t Bs, int js) {
     LKCHK(check_vec(Bd, jd, "lk_vec_copy(out)"));
     LKCHK(check_vec(Bs, js, "lk_vec_copy(from)"));
+    DevGuard dev_guard(Bd->ctx);
     LKCHK(check_pair(Bd, Bs, "lk_vec_copy"));
     if (Bd->col(jd) == Bs->col(js)) return LK_OK;
     LKCHK(lazy_enter(Bd->ctx, true));
+    Bd->touch(jd);
     ProfScope ps(Bd->ctx, "blas1", (double)Bd->n * Bd->ed() * 16.0);
     HIPCHK(hipMemcpyAsync(Bd->col(jd), Bs->col(js), (size_t)Bd->n * Bd->ed() * sizeof(double), hipMemcpyDeviceToDevice,
                           Bd->ctx->stream));
@@ -797,8 +1026,10 @@ int lk_vec_copy(lk_basis_t Bd, int jd, lk_basis_t Bs, int js) {
 
 int lk_vec_rand(lk_basis_t B, int j, uint64_t seed, int64_t row0, int ifnorm) {
     LKCHK(check_vec(B, j, "lk_vec_rand"));
+    DevGuard dev_guard(B->ctx);
     lk_context_t c = B->ctx;
     LKCHK(lazy_enter(c, true));
+    B->touch(j);
     if (B->dtype == LK_C128)
         hipLaunchKernelGGL(k_rand<true>, dim3(blas1_grid(c, B->n)), dim3(256), 0, c->stream, B->col(j), B->n, seed, row0);
     else
@@ -814,6 +1045,7 @@ int lk_vec_rand(lk_basis_t B, int j, uint64_t seed, int64_t row0, int ifnorm) {
 // ---- basis helpers ---------------------------------------------------------------------------
 int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M) {
     if (!Bx || !By || !M) return fail(LK_ERR_INVALID, "lk_innerprod: null argument");
+    DevGuard dev_guard(Bx->ctx);
     LKCHK(check_pair(Bx, By, "lk_innerprod"));
     if (k < 1 || k > Bx->ncols || p < 1 || jy0 < 0 || jy0 + p > By->ncols) return fail(LK_ERR_INVALID, "lk_innerprod: bad range");
     lk_context_t c = Bx->ctx;
@@ -858,39 +1090,21 @@ int lk_gram(lk_basis_t Bx, int k, double *G) {
 
 int lk_lincomb(lk_basis_t Bx, int k, const double *C, int q, lk_basis_t By, int jy0) {
     if (!Bx || !By || !C) return fail(LK_ERR_INVALID, "lk_lincomb: null argument");
+    DevGuard dev_guard(Bx->ctx);
     LKCHK(check_pair(Bx, By, "lk_lincomb"));
     if (k < 1 || k > Bx->ncols || q < 1 || jy0 < 0 || jy0 + q > By->ncols)
         return fail(LK_ERR_INVALID, "Krylov basis X and combination matrix B have incompatible sizes.");
     lk_context_t c = Bx->ctx;
     LKCHK(lazy_enter(c, true));
     const int ED = Bx->ed();
-    const bool cp = Bx->dtype == LK_C128;
+    By->touch(jy0, q);
     // the output columns must not be among the inputs (the reference writes into a fresh Xwrk / proj)
     if (Bx->data == By->data && jy0 < k) return fail(LK_ERR_INVALID, "lk_lincomb: output columns alias the input basis");
-    // coefficients: one upload of the whole k x q block
-    LKCHK(ensure_scratch(c, (int64_t)k * q * ED));
-    HIPCHK(hipMemcpyAsync(c->scratch, C, (size_t)k * q * ED * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    const int QB = cp ? 8 : 16;
-    const int64_t tile_rows = 4 * 64 * (cp ? 1 : 2);
-    int64_t g = (Bx->n + tile_rows - 1) / tile_rows;
-    const int64_t cap = (int64_t)c->num_cu * 8;
-    if (g > cap) g = cap;
-    if (g < 1) g = 1;
-    for (int q0 = 0; q0 < q; q0 += QB) {
-        const int qn = (q - q0) < QB ? (q - q0) : QB;
-        for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
-            const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
-            const double *Cd = c->scratch + ((int64_t)q0 * k + c0) * ED;
-            ProfScope ps(c, "lincomb", (double)Bx->n * ED * 8.0 * (kk + qn));
-            if (cp)
-                hipLaunchKernelGGL((panel_gemm<true, 8, 8>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, kk,
-                                   By->col(jy0 + q0), By->ld, qn, Cd, (int64_t)k, Bx->n, c0 > 0 ? 1 : 0, 1.0);
-            else
-                hipLaunchKernelGGL((panel_gemm<false, 8, 16>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, kk,
-                                   By->col(jy0 + q0), By->ld, qn, Cd, (int64_t)k, Bx->n, c0 > 0 ? 1 : 0, 1.0);
-            HIPCHK(hipGetLastError());
-        }
-    }
+    // coefficients: one upload of the whole k x q block, repacked on the device for the kernel's scalar loads
+    const int64_t raw = (int64_t)k * q * ED;
+    LKCHK(ensure_scratch(c, raw + gemm_packed_doubles(k, q, ED)));
+    HIPCHK(hipMemcpyAsync(c->scratch, C, (size_t)raw * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    LKCHK(gemm_launch(Bx, 0, k, By, jy0, q, c->scratch, (int64_t)k, 1.0, 0, c->scratch + raw));
     HIPCHK(hipStreamSynchronize(c->stream));   // the host coefficient array may be released by the caller
     if (c->prof) prof_collect(c);
     return LK_OK;
@@ -899,6 +1113,7 @@ int lk_lincomb(lk_basis_t Bx, int k, const double *C, int q, lk_basis_t By, int 
 static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, double *norms, int flags, int *info,
                        bool two_pass) {
     if (!Bx || !By) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: null basis");
+    DevGuard dev_guard(Bx->ctx);
     LKCHK(check_vec(By, jy, "double_gram_schmidt_step(y)"));
     LKCHK(check_pair(Bx, By, "double_gram_schmidt_step"));
     if (k < 1 || k > Bx->ncols) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: k=%d out of range [1,%d]", k, Bx->ncols);
@@ -906,7 +1121,10 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
     LKCHK(lazy_enter(c, true));
     const int ED = Bx->ed();
     double *y = By->col(jy);
-    if (Bx == By && jy < k) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: y is one of the basis columns");
+    {   // y must not lie inside the device range of X(:, :k) -- compared by address, so a wrapped view of the same panel counts
+        const double *x0 = Bx->col(0), *x1 = Bx->col(k - 1) + Bx->n * ED;
+        if (y + Bx->n * ED > x0 && y < x1) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: y is one of the basis columns");
+    }
     double n0 = 0, n1 = 0, n2 = 0;
     ProfScope ps(c, "dgs", (double)Bx->n * ED * 8.0 * (two_pass ? (3.0 * k + 5.0) : (2.0 * k + 3.0)));
     if (k <= KMAX_FUSED) {
@@ -967,28 +1185,16 @@ int lk_dgs(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, double *norms
     return dgs_generic(Bx, k, By, jy, h, norms, flags, info, true);
 }
 
-// Y(:, jy0:jy0+qn) -= X(:, :k) * C, C = device coefficients laid out [q][ldc][ED] (what dots_p2 leaves in c->red)
+// Y(:, jy0:jy0+qn) -= X(:, :k) * C, C = device coefficients laid out [q][ldc][ED] (what the multi-RHS dot sweep leaves in c->red)
 static int gemm_subtract(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int qn, const double *Cdev, int64_t ldc) {
     lk_context_t c = Bx->ctx;
-    const bool cp = Bx->dtype == LK_C128;
-    const int64_t tile_rows = 4 * 64 * (cp ? 1 : 2);
-    int64_t g = (Bx->n + tile_rows - 1) / tile_rows;
-    const int64_t cap = (int64_t)c->num_cu * 8;
-    if (g > cap) g = cap;
-    if (g < 1) g = 1;
-    ProfScope ps(c, "lincomb", (double)Bx->n * Bx->ed() * 8.0 * (k + 2 * qn));
-    if (cp)
-        hipLaunchKernelGGL((panel_gemm<true, 8, 8>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(0), Bx->ld, k,
-                           By->col(jy0), By->ld, qn, Cdev, ldc, Bx->n, 1, -1.0);
-    else
-        hipLaunchKernelGGL((panel_gemm<false, 8, 16>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(0), Bx->ld, k,
-                           By->col(jy0), By->ld, qn, Cdev, ldc, Bx->n, 1, -1.0);
-    HIPCHK(hipGetLastError());
-    return LK_OK;
+    LKCHK(ensure_scratch(c, gemm_packed_doubles(k, qn, Bx->ed())));
+    return gemm_launch(Bx, 0, k, By, jy0, qn, Cdev, ldc, -1.0, 1, c->scratch);
 }
 
 int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h, int *info) {
     if (!Bx || !By) return fail(LK_ERR_INVALID, "lk_dgs_block: null basis");
+    DevGuard dev_guard(Bx->ctx);
     if (p < 1 || jy0 < 0 || jy0 + p > By->ncols) return fail(LK_ERR_INVALID, "lk_dgs_block: bad column range");
     const int ED = Bx->ed();
     int inf = 0;
@@ -1033,13 +1239,15 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
 // ---- operators ------------------------------------------------------------------------------------
 int lk_linop_diag_create(lk_context_t c, int dtype, int64_t n_local, const void *d_host, lk_linop_t *op) {
     if (!c || !d_host || !op) return fail(LK_ERR_INVALID, "lk_linop_diag_create: null argument");
+    DevGuard dev_guard(c);
     if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "bad dtype");
     lk_linop_t o = new lk_linop_s();
     o->ctx = c; o->kind = OP_DIAG; o->dtype = dtype; o->n = n_local;
     const size_t bytes = (size_t)(n_local + 2) * (dtype == LK_C128 ? 2 : 1) * sizeof(double);
     hipError_t e = hipMalloc((void **)&o->dev, bytes);
     if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
-    HIPCHK(hipMemcpy(o->dev, d_host, (size_t)n_local * (dtype == LK_C128 ? 2 : 1) * sizeof(double), hipMemcpyHostToDevice));
+    e = hipMemcpy(o->dev, d_host, (size_t)n_local * (dtype == LK_C128 ? 2 : 1) * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(o->dev); delete o; return fail(LK_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e)); }
     *op = o;
     return LK_OK;
 }
@@ -1054,6 +1262,7 @@ int lk_linop_diag_linspace_create(lk_context_t c, int64_t n_local, int64_t row0,
 
 int lk_linop_dense_create(lk_context_t c, int dtype, int64_t n, const void *A_host, int64_t lda, lk_linop_t *op) {
     if (!c || !A_host || !op) return fail(LK_ERR_INVALID, "lk_linop_dense_create: null argument");
+    DevGuard dev_guard(c);
     if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "bad dtype");
     if (lda < n) return fail(LK_ERR_INVALID, "lda < n");
     if (c->nranks > 1) return fail(LK_ERR_INVALID, "dense_linop is single-rank only");
@@ -1062,7 +1271,8 @@ int lk_linop_dense_create(lk_context_t c, int dtype, int64_t n, const void *A_ho
     const size_t es = (dtype == LK_C128 ? 2 : 1) * sizeof(double);
     hipError_t e = hipMalloc((void **)&o->dev, (size_t)n * n * es + 16);
     if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
-    HIPCHK(hipMemcpy2D(o->dev, (size_t)n * es, A_host, (size_t)lda * es, (size_t)n * es, n, hipMemcpyHostToDevice));
+    e = hipMemcpy2D(o->dev, (size_t)n * es, A_host, (size_t)lda * es, (size_t)n * es, n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(o->dev); delete o; return fail(LK_ERR_HIP, "hipMemcpy2D failed: %s", hipGetErrorString(e)); }
     *op = o;
     return LK_OK;
 }
@@ -1079,6 +1289,7 @@ int lk_linop_lap5_create(lk_context_t c, int64_t N, lk_linop_t *op) {
 int lk_linop_gl_create(lk_context_t c, int64_t n, double dx, double tau, int nsub, const double *nu, const double *gamma,
                        double mu_c, double mu2, lk_linop_t *op) {
     if (!c || !op || !nu || !gamma || n < 1 || nsub < 1 || !(dx > 0.0)) return fail(LK_ERR_INVALID, "lk_linop_gl_create: bad argument");
+    DevGuard dev_guard(c);
     if (c->nranks > 1) return fail(LK_ERR_INVALID, "Ginzburg-Landau operator is single-rank only");
     lk_linop_t o = new lk_linop_s();
     o->ctx = c; o->kind = OP_GL; o->dtype = LK_C128; o->n = n; o->tau = tau; o->nsub = nsub;
@@ -1100,6 +1311,7 @@ int lk_linop_destroy(lk_linop_t op) {
 
 int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t By, int jy) {
     if (!op) return fail(LK_ERR_INVALID, "lk_linop_apply: null operator");
+    DevGuard dev_guard(op->ctx);
     LKCHK(check_vec(Bx, jx, "lk_linop_apply(vec_in)"));
     LKCHK(check_vec(By, jy, "lk_linop_apply(vec_out)"));
     LKCHK(check_pair(Bx, By, "lk_linop_apply"));
@@ -1109,6 +1321,7 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
     const double *x = Bx->col(jx);
     double *y = By->col(jy);
     if (x == y) return fail(LK_ERR_INVALID, "lk_linop_apply: vec_in and vec_out alias");
+    By->touch(jy);
     const bool cp = op->dtype == LK_C128;
     const int64_t n = op->n;
     const int64_t nv = n * Bx->ed() / 2 + 1;

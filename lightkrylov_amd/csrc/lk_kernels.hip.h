@@ -444,66 +444,102 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
     }
 }
 
-// Tall-skinny product Y(:, q0:q0+qn) (+)= X(:, :k) * C(:k, q0:q0+qn)  -- linear_combination_matrix
-// (AbstractVectors.fypp:605-643) as ONE pass over X per QB output columns instead of k*q axpbys.
-// Used by krylov_schur's basis update X <- X Z (BaseKrylov.fypp:816-824) and eigs' eigenvector
-// reconstruction (IterativeSolvers.fypp:1127-1132).  Each wave owns 64*ROWS rows and walks the k
-// columns in chunks of KC with QB accumulators per lane; the k x QB coefficient block sits in LDS
-// (wave-uniform broadcast reads).  Arithmetic intensity stays below 2 FMA/byte: still HBM-bound.
+// Tall-skinny product Y(:, :qn) (+)= X(:, :k) * C  -- linear_combination_matrix (AbstractVectors.fypp:605-643)
+// in ONE pass over X for up to NQG*QB output columns, instead of k*q axpbys.  Used by krylov_schur's basis update
+// X <- X Z (BaseKrylov.fypp:816-824), eigs' eigenvector reconstruction (IterativeSolvers.fypp:1127-1132), the
+// GMRES solution update (gmres.fypp:201) and the block Gram-Schmidt update.
+//
+// FP64-FMA bound for the complex kind (8 k q flop per 16 (k+q) bytes), balanced for the real kind, so the design
+// goal is back-to-back v_fma_f64 issue: lanes run along rows (16 B per lane), every lane keeps QB accumulators in
+// VGPRs, and the coefficients are WAVE-UNIFORM: they come in through scalar loads (SGPRs feed the FMA directly --
+// no LDS, no VGPR broadcast).  The 4 waves of a block split the output columns QGB ways (QGB = 1, 2, 4 groups of
+// QB) and the rows 4/QGB ways; waves of one block that share rows read the same X lines at the same time, so
+// X leaves HBM once (the repeats are L1/L2 hits).
+// Cp: coefficients packed by the host as [group g][column j < k][qq < QB][ED], zero padded, sign folded in.
+// acc[qq] += X(r, j0 + jj) * C(j0 + jj, qq) for NCOL consecutive columns; GUARD = element-wise guarded loads
+// (ragged last tile).  cj points at the packed coefficients of column j0 (uniform -> scalar loads).
+template <bool CPLX, int NCOL, int QB, bool GUARD>
+__device__ __forceinline__ void gemm_cols(const double *__restrict__ Xj, int64_t xstride, int64_t r, int64_t n,
+                                          const double *__restrict__ cj, v2d (&acc)[QB]) {
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    v2d xv[NCOL];
+    load_cols<CPLX, NCOL>(Xj, xstride, r, n, !GUARD, NCOL, xv);
+#pragma unroll
+    for (int jj = 0; jj < NCOL; ++jj) {
+        const double *__restrict__ c = cj + jj * (QB * ED);
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) {
+            if constexpr (CPLX) {                                   // 4 FMAs, coefficient operands in SGPRs
+                const double cr = c[2 * qq], ci = c[2 * qq + 1];
+                acc[qq].x = fma(xv[jj].x, cr, acc[qq].x);
+                acc[qq].x = fma(-xv[jj].y, ci, acc[qq].x);
+                acc[qq].y = fma(xv[jj].x, ci, acc[qq].y);
+                acc[qq].y = fma(xv[jj].y, cr, acc[qq].y);
+            } else {
+                const double cr = c[qq];
+                acc[qq].x = fma(xv[jj].x, cr, acc[qq].x);
+                acc[qq].y = fma(xv[jj].y, cr, acc[qq].y);
+            }
+        }
+    }
+}
+
 template <bool CPLX, int KC, int QB>
 __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, int64_t ldx, int k,
                                                   double *__restrict__ Y, int64_t ldy, int qn,
-                                                  const double *__restrict__ Cdev, int64_t ldc, int64_t n,
-                                                  int accumulate, double sign) {
+                                                  const double *__restrict__ Cp, int64_t n, int accumulate, int QGB) {
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;
-    constexpr int KMAX = 128;
-    __shared__ v2d Cs[KMAX * QB * ED / 2 + 1];   // [k][QB] elements, row-major
-    double *Cd = reinterpret_cast<double *>(Cs);
-    for (int idx = threadIdx.x; idx < k * QB; idx += blockDim.x) {
-        const int j = idx / QB, qq = idx % QB;
-        for (int e = 0; e < ED; ++e)
-            Cd[(j * QB + qq) * ED + e] = (qq < qn) ? sign * Cdev[((int64_t)qq * ldc + j) * ED + e] : 0.0;
-    }
-    __syncthreads();
-
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t tile_rows = 4 * (int64_t)WROWS;
+    const int qg = wave % QGB, rs = wave / QGB, RS = 4 / QGB;
+    const int q0 = qg * QB;
+    int nq = qn - q0;
+    nq = nq > QB ? QB : nq;
+    if (nq <= 0) return;                                     // no barrier in this kernel
+    const double *__restrict__ Cw = Cp + (int64_t)qg * k * (QB * ED);
+    const int tile_rows = RS * WROWS;
     const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
     const int64_t xstride = ldx * ED, ystride = ldy * ED;
+    const int kfast = (k / KC) * KC;
     for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int64_t r = t * tile_rows + (int64_t)wave * WROWS + (int64_t)lane * ROWS;
+        const int64_t r = t * tile_rows + (int64_t)rs * WROWS + (int64_t)lane * ROWS;
         const bool full = (t + 1) * tile_rows <= n;
         v2d acc[QB];
 #pragma unroll
         for (int qq = 0; qq < QB; ++qq) acc[qq] = v2d{0.0, 0.0};
-        for (int c0 = 0; c0 < k; c0 += KC) {
-            int nc = k - c0;
-            nc = nc > KC ? KC : nc;
-            v2d xv[KC];
-            load_cols<CPLX, KC>(X + (int64_t)c0 * xstride, xstride, r, n, full, nc, xv);
-#pragma unroll
-            for (int jj = 0; jj < KC; ++jj) {
-                if (jj < nc) {
-#pragma unroll
-                    for (int qq = 0; qq < QB; ++qq) {
-                        if constexpr (CPLX) acc[qq] += cmul(xv[jj], Cs[(c0 + jj) * QB + qq]);
-                        else acc[qq] += xv[jj] * Cd[(c0 + jj) * QB + qq];
-                    }
-                }
-            }
+        if (full) {
+            for (int c0 = 0; c0 < kfast; c0 += KC)
+                gemm_cols<CPLX, KC, QB, false>(X + (int64_t)c0 * xstride, xstride, r, n, Cw + (int64_t)c0 * (QB * ED), acc);
+            for (int c0 = kfast; c0 < k; ++c0)
+                gemm_cols<CPLX, 1, QB, false>(X + (int64_t)c0 * xstride, xstride, r, n, Cw + (int64_t)c0 * (QB * ED), acc);
+        } else {
+            for (int c0 = 0; c0 < k; ++c0)
+                gemm_cols<CPLX, 1, QB, true>(X + (int64_t)c0 * xstride, xstride, r, n, Cw + (int64_t)c0 * (QB * ED), acc);
         }
 #pragma unroll
         for (int qq = 0; qq < QB; ++qq) {
-            if (qq < qn) {
-                double *yc = Y + (int64_t)qq * ystride;
+            if (qq < nq) {
+                double *yc = Y + (int64_t)(q0 + qq) * ystride;
                 v2d out = acc[qq];
                 if (accumulate) out += load_y<CPLX>(yc, r, n, full);
                 store_rows<CPLX>(yc, r, n, full, out);
             }
         }
+    }
+}
+
+// repack device coefficients laid out [q][ldc][ED] (column-major k x q block, e.g. the sections finish_partials
+// leaves in the reduction buffer) into panel_gemm's [group][j][qq][ED] layout with a sign and zero padding.
+__global__ __launch_bounds__(256) void pack_coef(const double *__restrict__ C, int64_t ldc, int k, int q, int QB, int ED,
+                                                 double sign, double *__restrict__ Cp) {
+    const int ngroups = (q + QB - 1) / QB;
+    const int total = ngroups * k * QB * ED;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int e = idx % ED, qq = (idx / ED) % QB, j = (idx / (ED * QB)) % k, g = idx / (ED * QB * k);
+        const int qcol = g * QB + qq;
+        Cp[idx] = (qcol < q) ? sign * C[((int64_t)qcol * ldc + j) * ED + e] : 0.0;
     }
 }
 

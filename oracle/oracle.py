@@ -56,6 +56,7 @@ def lib():
             getattr(_LIB, "ora_dgs_fast" + sfx).restype = C.c_int
             getattr(_LIB, "ora_arnoldi_fast" + sfx).restype = C.c_int
             getattr(_LIB, "ora_norm_mode" + sfx).restype = C.c_double
+            getattr(_LIB, "ora_arnoldi_fused" + sfx).restype = C.c_int
     return _LIB
 
 
@@ -340,6 +341,16 @@ def arnoldi(A: _OpBase, X: np.ndarray, H: np.ndarray, kstart: int = 1, kend: int
         C.c_int64(X.shape[0]), C.c_int(m), _p(X), C.c_int64(_ld(X)), _p(H), C.c_int64(H.shape[0]),
         C.c_int(kstart), C.c_int(kend), C.c_double(tol), fnp, op, C.c_uint64(rand_seed))
     return int(info)
+
+
+def arnoldi_fused_allcores(A: _OpBase, X: np.ndarray, H: np.ndarray, tol: float = ATOL_DP) -> int:
+    """NOT the reference's arithmetic and never a checker: the engine's three-sweep fused CGS2 schedule on
+    the host cores (set_threads), timed by bench.py as the all-core leg of cpu_baseline."""
+    m = X.shape[1] - 1
+    fn, op = A.c_matvec()
+    return int(getattr(lib(), "ora_arnoldi_fused" + _sfx(X))(
+        C.c_int64(X.shape[0]), C.c_int(m), _p(X), C.c_int64(_ld(X)), _p(H), C.c_int64(H.shape[0]),
+        C.c_double(tol), C.cast(fn, C.c_void_p), op))
 
 
 def lanczos(A: _OpBase, X: np.ndarray, T: np.ndarray, kstart: int = 1, kend: int | None = None,
