@@ -15,7 +15,15 @@ program test_iso_c
     ! lazy per-object pass
     type(c_ptr) :: Z
     real(c_double) :: hl(m), hf(m), d2(2), ny_lazy, ny_fused, one(1), ai(1), mone(1)
-    integer(c_int64_t) :: st(4)
+    integer(c_int64_t) :: st(4), ps0(4), ps1(4)
+    ! complex(dp) pass + column pool
+    type(c_ptr) :: Xz, Az, slab, slab2
+    complex(c_double_complex), target :: dz(n), x0z(n)
+    complex(c_double_complex) :: Hz(m + 1, m)
+    real(c_double) :: hb(2*m), nrm3(3), a2(2), b2(2), dres(2)
+    integer(c_int) :: col, col2, cols(m + 1)
+    integer(c_intptr_t) :: tag
+    integer :: it
 
     rc = lk_init(0_c_int, c_null_ptr, ctx); call chk(rc, 'lk_init')
     do i = 1, n
@@ -77,10 +85,74 @@ program test_iso_c
     print '(A,ES12.4)', 'lazy_h_err ', maxval(abs(hl - hf))
     print '(A,ES12.4)', 'lazy_y_err ', abs(ny_lazy - ny_fused)
     rc = lk_basis_destroy(Z)
+    rc = lk_set_tuning(ctx, 'lazy'//c_null_char, 0_c_int); call chk(rc, 'lk_set_tuning')
+
+    ! ---- complex(dp) kind through the same binding: Arnoldi with a complex diagonal operator (the python test
+    !      recomputes this case with the oracle and compares the printed entries)
+    do i = 1, n
+        dz(i) = cmplx(1.0d0 + real(i - 1, c_double)/real(n, c_double), 0.25d0*sin(real(i, c_double)), kind=c_double_complex)
+        x0z(i) = cmplx(sin(real(i, c_double)), cos(real(2*i, c_double)), kind=c_double_complex)
+    end do
+    x0z = x0z/sqrt(sum(abs(x0z)**2))
+    rc = lk_basis_create(ctx, LK_C128, int(n, c_int64_t), int(m + 1, c_int), Xz); call chk(rc, 'lk_basis_create(z)')
+    rc = lk_basis_upload(Xz, 0_c_int, 1_c_int, c_loc(x0z), int(n, c_int64_t)); call chk(rc, 'lk_basis_upload(z)')
+    rc = lk_linop_diag_create(ctx, LK_C128, int(n, c_int64_t), c_loc(dz), Az); call chk(rc, 'lk_linop_diag_create(z)')
+    Hz = (0.0d0, 0.0d0)
+    call arnoldi_z(Az, Xz, Hz, info)
+    print '(A,I0)', 'z_info ', info
+    print '(A,ES24.16)', 'z_H11_re ', real(Hz(1, 1))
+    print '(A,ES24.16)', 'z_H11_im ', aimag(Hz(1, 1))
+    print '(A,ES24.16)', 'z_H12_re ', real(Hz(1, 2))
+    print '(A,ES24.16)', 'z_H12_im ', aimag(Hz(1, 2))
+    print '(A,ES24.16)', 'z_Hlast ', real(Hz(m + 1, m))
+    rc = lk_linop_destroy(Az)
+    rc = lk_basis_destroy(Xz)
+
+    ! ---- column pool, driven the way the LightKrylov plugin drives it (fortran/dense_vector_gpu.f90): V(1..m+1)
+    !      acquired in order land in consecutive columns of ONE slab; 200 emulated Gram-Schmidt passes, each of which
+    !      "allocates" its two temporaries (linear_combination's y, AbstractVectors.fypp:595-598) at two recurring
+    !      addresses, must not carve a single new column.
+    do j = 1, m + 1
+        tag = int(4096 + 64*j, c_intptr_t)
+        rc = lk_pool_acquire(ctx, LK_F64, int(n, c_int64_t), tag, slab, cols(j)); call chk(rc, 'lk_pool_acquire')
+        rc = lk_vec_rand(slab, cols(j), int(500 + j, c_int64_t), 0_c_int64_t, 1_c_int); call chk(rc, 'lk_vec_rand(pool)')
+    end do
+    rc = lk_pool_stats(ctx, ps0); call chk(rc, 'lk_pool_stats')
+    one = 1.0d0; mone = -1.0d0
+    do it = 1, 200
+        tag = int(900000 + 64*mod(it, 2), c_intptr_t)                     ! proj of pass 1 / pass 2
+        rc = lk_pool_acquire(ctx, LK_F64, int(n, c_int64_t), tag, slab2, col2); call chk(rc, 'lk_pool_acquire(proj)')
+        rc = lk_vec_zero(slab2, col2); call chk(rc, 'lk_vec_zero(proj)')
+        do j = 1, m
+            rc = lk_vec_dot(slab, cols(j), slab, cols(m + 1), d2); call chk(rc, 'lk_vec_dot(pool)')
+            ai(1) = d2(1)
+            rc = lk_vec_axpby(ai, slab, cols(j), one, slab2, col2); call chk(rc, 'lk_vec_axpby(pool)')
+        end do
+        rc = lk_vec_axpby(mone, slab2, col2, one, slab, cols(m + 1)); call chk(rc, 'lk_vec_axpby(pool sub)')
+    end do
+    rc = lk_pool_stats(ctx, ps1); call chk(rc, 'lk_pool_stats')
+    print '(A,I0)', 'pool_consecutive ', merge(1, 0, all(cols == [(j - 1, j=1, m + 1)]))
+    print '(A,I0)', 'pool_slabs ', ps1(1)
+    print '(A,I0)', 'pool_carved_before ', ps0(2)
+    print '(A,I0)', 'pool_carved_after ', ps1(2)
+    print '(A,I0)', 'pool_reused ', ps1(4)
+    rc = lk_vec_dot(slab, cols(1), slab, cols(m + 1), d2); call chk(rc, 'lk_vec_dot(final)')
+    print '(A,ES12.4)', 'pool_orth_resid ', abs(d2(1))
+    rc = lk_pool_release_all(ctx); call chk(rc, 'lk_pool_release_all')
     rc = lk_linop_destroy(A)
     rc = lk_basis_destroy(X)
     rc = lk_finalize(ctx)
 contains
+    !> lk_arnoldi takes the Hessenberg array as interleaved doubles; a complex(dp) Fortran array IS that layout
+    subroutine arnoldi_z(Aop, Xb, Hc, inf)
+        type(c_ptr), intent(in) :: Aop, Xb
+        complex(c_double_complex), intent(inout), target :: Hc(:, :)
+        integer(c_int), intent(out) :: inf
+        real(c_double), pointer :: Hr(:)
+        call c_f_pointer(c_loc(Hc), Hr, [2*size(Hc)])
+        rc = lk_arnoldi(Aop, Xb, Hr, int(size(Hc, 1), c_int64_t), 1_c_int, int(size(Hc, 2), c_int), 1.0d-15, 0_c_int, inf)
+        call chk(rc, 'lk_arnoldi(z)')
+    end subroutine
     subroutine chk(rc, what)
         integer(c_int), intent(in) :: rc
         character(len=*), intent(in) :: what

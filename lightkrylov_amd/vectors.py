@@ -331,11 +331,8 @@ def axpby_basis(alpha, X: Sequence[abstract_vector], beta, Y: Sequence[abstract_
 
 def rand_basis(X, ifnorm: bool = False) -> None:
     """:725-730"""
-    for j, x in enumerate([X] if isinstance(X, abstract_vector) else X):
-        if isinstance(x, dense_vector_gpu):
-            x.rand(ifnorm)
-        else:
-            x.rand(ifnorm)
+    for x in ([X] if isinstance(X, abstract_vector) else X):
+        x.rand(ifnorm)
 
 
 def verify_vector_axioms(x: abstract_vector, ntrials: int = 100, tolerance: float = 10.0 ** (-14), seed: int = 0) -> bool:

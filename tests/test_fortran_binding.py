@@ -43,3 +43,22 @@ def test_fortran_host_program_runs_arnoldi_on_the_gpu():
     # norm reads y: 9 queued, 2 flushes; same coefficients and same vector as the fused single-pass call
     assert (vals["lazy_sweeps"], vals["lazy_hits"], vals["lazy_queued"], vals["lazy_flushes"]) == (1, 7, 9, 2)
     assert vals["lazy_h_err"] < 1e-13 and vals["lazy_y_err"] < 1e-13
+    # complex(dp) pass: the same case through the oracle
+    from oracle import oracle as ora
+    n, m = 1000, 8
+    i = np.arange(1, n + 1, dtype=np.float64)
+    dz = (1.0 + (i - 1) / n) + 0.25j * np.sin(i)
+    x0 = np.sin(i) + 1j * np.cos(2 * i)
+    x0 /= np.sqrt(np.sum(np.abs(x0) ** 2))
+    Xo = np.zeros((n, m + 1), dtype=np.complex128, order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), dtype=np.complex128, order="F")
+    assert ora.arnoldi(ora.DiagOp(dz.astype(np.complex128)), Xo, Ho) == 0 and vals["z_info"] == 0
+    got11, got12 = complex(vals["z_H11_re"], vals["z_H11_im"]), complex(vals["z_H12_re"], vals["z_H12_im"])
+    assert abs(got11 - Ho[0, 0]) <= 1e-12 * abs(Ho[0, 0])           # libm sin/cos of the two hosts may differ by an ulp
+    assert abs(got12 - Ho[0, 1]) <= 1e-12 * np.abs(Ho[:, 1]).max()
+    assert abs(vals["z_Hlast"] - Ho[m, m - 1].real) <= 1e-12 * abs(Ho[m, m - 1])
+    # column pool driven like the LightKrylov plugin: consecutive columns in one slab, and 200 emulated Gram-Schmidt
+    # passes with recurring temporaries carve nothing new
+    assert vals["pool_consecutive"] == 1 and vals["pool_slabs"] == 1
+    assert vals["pool_carved_before"] == m + 1 and vals["pool_carved_after"] == m + 3
+    assert vals["pool_reused"] >= 198 and vals["pool_orth_resid"] < 1e-10

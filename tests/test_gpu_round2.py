@@ -1,0 +1,264 @@
+"""GPU tests added in round 2 (all through the C ABI): the small gaps the round-1 review listed (axpby_basis /
+rand_basis, Lanczos T against the oracle, on-disk outputs from a GPU eigs), the new entry points (native RCCL
+communicator, column pool, one-pass panel_gemm shapes) and the invariance of results under the store-policy knobs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import lightkrylov_amd as lk
+from lightkrylov_amd import _capi
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+KINDS = [np.float64, np.complex128]
+
+
+def seeded(n, dtype, seed):
+    x = np.empty(n, dtype=dtype)
+    ora.fill_counter(x, seed)
+    return x
+
+
+def basis(n, k, dtype, seed):
+    X = np.empty((n, k), dtype=dtype, order="F")
+    for j in range(k):
+        ora.fill_counter(X[:, j], seed + j)
+    return X
+
+
+# ----------------------------------------------------------------------------- a9: basis helpers
+@pytest.mark.parametrize("dtype", KINDS)
+def test_axpby_basis_and_rand_basis(ctx, dtype):
+    """axpby_basis / rand_basis / zero_basis are elemental wrappers over the TBPs (AbstractVectors.fypp:697-730)."""
+    n, k = 5003, 5
+    a, b = (0.37 - 1.2j, -1.5 + 0.25j) if np.dtype(dtype).kind == "c" else (0.37, -1.5)
+    Xh, Yh = basis(n, k, dtype, 10), basis(n, k, dtype, 40)
+    X = lk.krylov_basis_gpu(n, k, dtype, ctx); X.upload(Xh)
+    Y = lk.krylov_basis_gpu(n, k, dtype, ctx); Y.upload(Yh)
+    lk.axpby_basis(a, X, b, Y)                                # Y(i) <- a X(i) + b Y(i)
+    ref = Yh.copy(order="F")
+    for j in range(k):
+        ora.axpby(a, Xh[:, j], b, ref[:, j])                  # the reference's scal-then-axpy
+    np.testing.assert_allclose(Y.download(), ref, rtol=4e-15, atol=4e-15)
+    # rand_basis: every column a fresh, reproducible stream; ifnorm=True normalises each
+    c2 = lk.Context(device=0)
+    R1 = lk.krylov_basis_gpu(n, k, dtype, ctx)
+    ctx._rand_calls = 0
+    lk.rand_basis(R1, ifnorm=True)
+    A1 = R1.download()
+    assert np.allclose(np.linalg.norm(A1, axis=0), 1.0, rtol=0, atol=1e-14)
+    for i in range(k):
+        for j in range(i + 1, k):
+            assert not np.array_equal(A1[:, i], A1[:, j])
+    R2 = lk.krylov_basis_gpu(n, k, dtype, c2)
+    lk.rand_basis(R2, ifnorm=True)                            # same call sequence on a fresh context: same draws
+    assert np.array_equal(R2.download(), A1)
+    # un-normalised draws are the shared counter generator
+    v = lk.dense_vector_gpu(n, dtype, ctx)
+    lk.rand_basis(v)
+    assert np.abs(v.to_array()).max() <= np.sqrt(2.0)
+    lk.zero_basis(R1)
+    assert not R1.download().any()
+    c2.close()
+
+
+# ----------------------------------------------------------------------------- a17: Lanczos T vs oracle
+@pytest.mark.parametrize("dtype", KINDS)
+def test_lanczos_tridiagonal_matches_the_oracle(ctx, dtype):
+    """lanczos_tridiagonalization (lanczos.fypp:7-64) on a dense symmetric / Hermitian operator: every entry of T
+    against the oracle's restatement, normwise 1e-12 per column."""
+    n, m = 3001, 40
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    if np.dtype(dtype).kind == "c":
+        A = A + 1j * rng.standard_normal((n, n)) / np.sqrt(n)
+    A = np.asfortranarray(((A + A.conj().T) / 2 + np.diag(np.linspace(1.0, 3.0, n))).astype(dtype))
+    x0 = seeded(n, dtype, 21); x0 /= np.linalg.norm(x0)
+    X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X.upload(x0.reshape(-1, 1), 0)
+    T = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.lanczos(lk.dense_linop_gpu(A, ctx), X, T) == 0
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
+    To = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.lanczos(ora.DenseOp(A), Xo, To) == 0
+    for j in range(m):
+        assert np.abs(T[:, j] - To[:, j]).max() <= 1e-11 * np.abs(To[:, j]).max()      # dense gemv order differs too
+    # the diagonal-operator variant isolates the path (no gemv): 1e-12
+    d = (1.0 + np.arange(n) / n).astype(dtype)
+    X.upload(np.zeros((n, m + 1), dtype=dtype)); X.upload(x0.reshape(-1, 1), 0)
+    T[...] = 0
+    assert lk.lanczos(lk.diag_linop_gpu(d, ctx), X, T) == 0
+    Xo[...] = 0; Xo[:, 0] = x0; To[...] = 0
+    assert ora.lanczos(ora.DiagOp(d), Xo, To) == 0
+    for j in range(m):
+        assert np.abs(T[:, j] - To[:, j]).max() <= 1e-12 * np.abs(To[:, j]).max()
+    G = lk.Gram(X[:m + 1])
+    assert np.abs(G - np.eye(m + 1)).max() < 1e-12
+
+
+# ----------------------------------------------------------------------------- f4: on-disk outputs from the GPU
+def test_eigs_on_gpu_writes_the_reference_outputs(ctx, tmp_path, monkeypatch):
+    """eigs(write_intermediate=.true.) dumps eigs_output.txt every Arnoldi step (IterativeSolvers.fypp:1091, 899-922)
+    and save_eigenspectrum writes the n x 3 .npy eigenplots.py reads (:944-963) -- here from GPU vectors."""
+    monkeypatch.chdir(tmp_path)
+    n, nev = 400, 4
+    A = 0.37 * np.eye(n) + 0.61 * np.eye(n, k=1) - 0.61 * np.eye(n, k=-1)
+    A[np.arange(4), np.arange(4)] += np.array([3.0, 2.5, 2.0, 1.5])
+    X = lk.krylov_basis_gpu(n, nev, np.float64, ctx)
+    x0 = lk.dense_vector_gpu.from_array(seeded(n, np.float64, 3), ctx)
+    lam, res, info = lk.eigs(lk.dense_linop_gpu(A, ctx), X, x0=x0, kdim=40, tolerance=1e-9, write_intermediate=True)
+    assert info > 0 and (res < 1e-9).all()
+    true = np.linalg.eigvals(A)
+    true = true[np.argsort(-np.abs(true))][:nev]
+    assert np.abs(np.sort_complex(lam) - np.sort_complex(true)).max() < 1e-8
+    out = (tmp_path / "eigs_output.txt").read_text().splitlines()
+    assert out[0].split() == ["Iter", "Re", "Im", "modulus", "residual", "conv"]
+    assert len(out) >= nev + 1 and out[1].split()[-1] == "T"
+    lk.save_eigenspectrum(lam, res, str(tmp_path / "spectrum.npy"))
+    arr = np.load(tmp_path / "spectrum.npy")
+    assert arr.shape == (nev, 3) and np.array_equal(arr[:, 0], lam.real) and np.array_equal(arr[:, 2], res)
+    # eigenvectors really are eigenvectors: |A v - lam v| small
+    V = X.download()
+    for i in range(nev):
+        if abs(lam[i].imag) < 1e-12:
+            assert np.linalg.norm(A @ V[:, i] - lam[i].real * V[:, i]) < 1e-7
+
+
+# ----------------------------------------------------------------------------- native RCCL communicator
+def _arnoldi_h(ctx, n=400_003, m=12):
+    X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
+    A = lk.diag_linop_gpu(n_local=n, row0=0, d0=1.0, dstep=1.0 / n, ctx=ctx)
+    H = np.zeros((m + 1, m), order="F")
+    X[0].rand(True, seed=7)
+    assert lk.arnoldi(A, X, H) == 0
+    return H, X.download()
+
+
+def test_native_rccl_single_rank_is_bit_identical():
+    """lk_comm_init_rank with a 1-rank communicator: every sweep's scalars go through ncclAllReduce on the engine's
+    stream; the sum over one rank is the identity, so H and the basis must be bit-identical to the run without it."""
+    plain = lk.Context(device=0)
+    H0, X0 = _arnoldi_h(plain)
+    plain.close()
+    c = lk.Context(device=0)
+    uid = lk.Context.comm_unique_id()
+    assert len(uid) == _capi.LK_COMM_ID_BYTES and any(uid)
+    c.init_native_comm(1, 0, uid)
+    H1, X1 = _arnoldi_h(c)
+    with pytest.raises(_capi.LightKrylovHipError, match="already has a communicator"):
+        c.init_native_comm(1, 0, uid)
+    c.destroy_native_comm()
+    H2, _ = _arnoldi_h(c)                      # and back
+    c.close()
+    assert H1.tobytes() == H0.tobytes() and X1.tobytes() == X0.tobytes() and H2.tobytes() == H0.tobytes()
+
+
+# ----------------------------------------------------------------------------- column pool
+def test_column_pool_contract(ctx):
+    lib = _capi.load()
+    st = (C.c_int64 * 4)()
+
+    def stats():
+        _capi.check(lib.lk_pool_stats(ctx._h, st))
+        return tuple(st)
+
+    def acquire(dtype, n, tag):
+        slab, col = C.c_void_p(), C.c_int()
+        _capi.check(lib.lk_pool_acquire(ctx._h, dtype, n, C.c_uint64(tag), C.byref(slab), C.byref(col)))
+        return slab.value, col.value
+
+    def owner(slab, col):
+        t = C.c_uint64()
+        _capi.check(lib.lk_pool_owner(ctx._h, C.c_void_p(slab), col, C.byref(t)))
+        return t.value
+
+    _capi.check(lib.lk_pool_release_all(ctx._h))
+    ctx.set_tuning("pool_slab_cols", 8)
+    base = stats()
+    n = 1000
+    cols = [acquire(_capi.LK_F64, n, 0x1000 + 64 * i) for i in range(10)]      # 10 objects: 8 + 2 over two slabs
+    assert [c for _s, c in cols[:8]] == list(range(8)) and len({s for s, _c in cols[:8]}) == 1   # consecutive, one slab
+    assert cols[8][0] != cols[0][0] and cols[8][1] == 0
+    assert stats()[0] - base[0] == 2 and stats()[2] == 10
+    assert acquire(_capi.LK_F64, n, 0x1000 + 64 * 3) == cols[3]                 # same address again: same column
+    assert owner(*cols[3]) == 0x1000 + 64 * 3 and owner(cols[0][0], 77) == 0 and owner(0xdead0, 0) == 0
+    _capi.check(lib.lk_pool_release(ctx._h, C.c_void_p(cols[5][0]), cols[5][1]))
+    _capi.check(lib.lk_pool_release(ctx._h, C.c_void_p(cols[2][0]), cols[2][1]))
+    assert owner(*cols[2]) == 0
+    assert acquire(_capi.LK_F64, n, 0x9000) == cols[2]                          # lowest released column first
+    assert acquire(_capi.LK_F64, n, 0x9040) == cols[5]
+    zslab, zcol = acquire(_capi.LK_C128, n, 0x1000)                             # other kind at a known address: new slab,
+    assert zslab not in {s for s, _c in cols} and owner(*cols[0]) == 0          # and the old column is given back
+    # the columns are real device vectors
+    B = lk.krylov_basis_gpu(n, 8, np.float64, ctx, _handle=C.c_void_p(cols[1][0]))
+    B._owner = B                                                                # not ours to destroy
+    v = lk.dense_vector_gpu(_basis=B, _col=cols[1][1])
+    v.rand(True, seed=3)
+    assert abs(v.norm() - 1.0) < 1e-14
+    B._h = C.c_void_p()
+    _capi.check(lib.lk_pool_release_all(ctx._h))
+    assert stats()[0] == 0 and stats()[2] == 0
+    ctx.set_tuning("pool_slab_cols", 160)
+
+
+# ----------------------------------------------------------------------------- K9 shapes of the one-pass panel_gemm
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("n,k,q", [(1, 1, 1), (130, 3, 2), (4097, 128, 64), (2051, 200, 70), (1023, 33, 17),
+                                   (777, 129, 65), (5000, 16, 48), (3000, 7, 16)])
+def test_linear_combination_matrix_shapes(ctx, dtype, n, k, q):
+    """linear_combination_matrix (AbstractVectors.fypp:605-643): Y = X C for every split of the output columns
+    over the kernel's column groups (q <= 16, 32, 64, > 64), k beyond one register chunk, ragged row tiles."""
+    X, Cm = basis(n, k, dtype, 10), basis(k, q, dtype, 900)
+    Bx = lk.krylov_basis_gpu(n, k, dtype, ctx); Bx.upload(X)
+    Y = lk.linear_combination(Bx, Cm).download()
+    ref = X @ Cm
+    scale = np.abs(X).max() * np.abs(Cm).max() * k
+    assert np.abs(Y - ref).max() <= 4e-15 * scale
+    for j in {0, q - 1, q // 2}:                                       # and against the reference's k-axpby schedule
+        r = ora.linear_combination(X, np.ascontiguousarray(Cm[:, j]))
+        assert np.abs(Y[:, j] - r).max() <= 1e-13 * max(np.abs(r).max(), 1e-300) * max(1, k) ** 0.5
+
+
+# ----------------------------------------------------------------------------- tuning knobs never change results
+@pytest.mark.parametrize("dtype", KINDS)
+def test_store_policy_knobs_are_result_invariant(dtype):
+    """The cache policy of the y'' store (plain / nt / sc1 / sc0 sc1) and the lane-split store only change HOW the same
+    bytes are written: coefficients and vector must be bit-identical."""
+    c = lk.Context(device=0)
+    n, k = 300_007, 37
+    Xh, yh = basis(n, k, dtype, 50), seeded(n, dtype, 99)
+    Q, _ = np.linalg.qr(Xh)
+    B = lk.krylov_basis_gpu(n, k + 1, dtype, c)
+    out = []
+    for pol, split in ((0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (1, 1)):
+        c.set_tuning("store_policy", pol); c.set_tuning("store_split", split)
+        B.upload(np.asfortranarray(Q)); B.upload(yh.reshape(-1, 1), k)
+        h = np.zeros(k, dtype=dtype)
+        lk.double_gram_schmidt_step(B[k], B[:k], False, h)
+        out.append((h.tobytes(), B.download(k, 1).tobytes()))
+    assert all(o == out[0] for o in out[1:])
+    c.close()
+
+
+def test_lazy_dot_batch_stops_at_the_columns_ever_written(ctx):
+    """A slab-like panel with 160 columns of which 5 hold vectors: X(i)%dot(y) with y in ANOTHER panel must sweep 5
+    columns, not 128 (the batch is capped by the panel's high-water mark)."""
+    n = 200_001
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", 1)
+    P = lk.krylov_basis_gpu(n, 160, np.float64, c)
+    Xh = basis(n, 5, np.float64, 7)
+    P.upload(Xh, 0)
+    y = lk.dense_vector_gpu.from_array(seeded(n, np.float64, 70), c)
+    c.profile_reset(); c.profile_enable(True)
+    got = [P[i].dot(y) for i in range(5)]
+    c.sync()
+    cnt, _ms, by = c.profile_get("dgs_sweep1")
+    c.profile_enable(False)
+    hits, sweeps, _q, _f = c.lazy_stats()
+    assert (sweeps, hits) == (1, 4) and cnt == 1
+    assert by == pytest.approx(8.0 * n * (5 + 1))            # 5 columns + y, not 128 + 1
+    ref = ora.innerprod(Xh, y.to_array())
+    assert np.abs(np.array(got) - ref).max() <= 1e-12 * np.linalg.norm(Xh[:, 0]) * np.linalg.norm(y.to_array())
+    c.close()
