@@ -1,6 +1,7 @@
 """The RCCL all-reduce plumbing on a real GPU: bench.py under torch.distributed.run with ONE rank goes
-through init_process_group("nccl"), the ctypes callback, the zero-copy tensor view of the engine's
-reduction buffer and dist.all_reduce on the engine's stream.  With one rank the sum is the identity, so
+through init_process_group("nccl") and the library's own communicator (lk_comm_init_rank: ncclAllReduce issued
+by liblightkrylov_hip on its stream), or -- LK_NATIVE_RCCL=0 -- through the ctypes callback, the zero-copy
+tensor view of the engine's reduction buffer and dist.all_reduce on the engine's stream.  With one rank the sum is the identity, so
 the factorisation must be bit-identical to the run without a process group.  (N > 1 GPUs are the
 driver's to launch; the N > 1 host logic is covered on CPU by tests/test_distributed_gloo.py.)"""
 import json
@@ -34,11 +35,16 @@ def test_single_rank_rccl_path_is_bit_identical():
     plain = _run([sys.executable, "bench.py"] + args)
     dist = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
                  "127.0.0.1", "--master-port", str(_free_port()), "bench.py"] + args)
-    assert plain["config"]["all_reduce"].startswith("none") and dist["config"]["all_reduce"].startswith("RCCL")
+    assert plain["config"]["all_reduce"].startswith("none") and dist["config"]["all_reduce"].startswith("RCCL native")
     assert dist["config"]["H_fro"] == plain["config"]["H_fro"]
     assert dist["config"]["H_last_subdiag"] == plain["config"]["H_last_subdiag"]
     assert dist["config"]["info"] == plain["config"]["info"] == 0
     assert dist["n_gpus"] == 1 and dist["roofline"]["launches"] == plain["roofline"]["launches"]
+    # the older route (torch.distributed.all_reduce through the ctypes callback) stays selectable and identical
+    cb = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), "bench.py"] + args, LK_NATIVE_RCCL="0")
+    assert cb["config"]["all_reduce"] == "RCCL via torch.distributed callback"
+    assert cb["config"]["H_fro"] == plain["config"]["H_fro"] and cb["config"]["H_last_subdiag"] == plain["config"]["H_last_subdiag"]
 
 
 def test_two_processes_sharing_one_gpu_reproduce_the_single_process_factorisation():

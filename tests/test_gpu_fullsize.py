@@ -1,0 +1,107 @@
+"""Parity at the sizes the metric is quoted on (north_star: Hessenberg entries and Ritz values within 1e-12).
+
+* BASELINE configs[4] / bench.py's workload -- n = 10^8 real(dp), m = 128, diagonal-linspace operator, counter-RNG
+  x0 -- against tests/golden/arnoldi_diaglin_n100000000_m128_rdp.npz: H of the oracle in SEQUENTIAL mode (= the
+  reference's arithmetic: per-primitive BLAS-1, left-to-right sums; 424 s on 128 host threads of the GPU box, produced
+  by tools/fullsize_parity.py) and in COMPENSATED mode (twice-working-precision dots), which separates the
+  reference's own summation rounding from the engine's error.
+* configs[1] -- n = 10^7, m = 64 -- against its fixture AND against a live multi-threaded oracle run (~20 s).
+Plus size-independent properties: orthonormality of the basis (lk_gram), the Arnoldi relation on row samples.
+Tolerance (floating point, stated per assert): 1e-12 normwise per column of H / relative per Ritz value."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lightkrylov_amd as lk
+from lightkrylov_amd import _capi
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-12
+
+
+def colerr(A, B):
+    return max(np.abs(A[:, j] - B[:, j]).max() / np.abs(B[:, j]).max() for j in range(B.shape[1]))
+
+
+def ritz(H):
+    m = H.shape[1]
+    w = np.linalg.eigvals(H[:m, :m])
+    return w[np.argsort(w.real, kind="stable")]
+
+
+def row_sample(X, r0, rows):
+    """rows [r0, r0+rows) of every column of a device panel (a wrapped sub-panel view; r0 even keeps 16-B alignment)."""
+    _dt, _n, nc, ld, ptr = X.info()
+    h = C.c_void_p()
+    _capi.check(X._lib.lk_basis_wrap(X.ctx._h, _capi.LK_F64, rows, nc, ld, C.c_void_p(ptr + 8 * r0), C.byref(h)))
+    out = np.empty((rows, nc), order="F")
+    _capi.check(X._lib.lk_basis_download(h, 0, nc, out.ctypes.data_as(C.c_void_p), rows))
+    X._lib.lk_basis_destroy(h)
+    return out
+
+
+def run_engine(ctx, n, m):
+    X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
+    A = lk.diag_linop_gpu(n_local=n, row0=0, d0=1.0, dstep=1.0 / n, ctx=ctx)        # exactly bench.py's operator
+    H = np.zeros((m + 1, m), order="F")
+    X[0].rand(True, seed=7)                                                          # exactly bench.py's x0
+    assert lk.arnoldi(A, X, H) == 0
+    return X, H
+
+
+def check_properties(X, H, n, m):
+    G = lk.Gram(X[:m + 1])
+    assert np.abs(G - np.eye(m + 1)).max() <= TOL, "basis not orthonormal at 1e-12"
+    for r0 in (0, (n // 3) & ~1, n - 50_000):                                        # A X_m = X_{m+1} H on row samples
+        Xs = row_sample(X, r0, 50_000)
+        i = np.arange(r0, r0 + 50_000, dtype=np.float64)
+        dvals = 1.0 + i / n
+        assert np.abs(dvals[:, None] * Xs[:, :m] - Xs @ H).max() <= 1e-12
+    w = ritz(H)
+    assert np.abs(w.imag).max() <= 1e-12 and w.real.min() >= 1.0 - 1e-9 and w.real.max() <= 2.0 + 1e-9
+
+
+def test_metric_size_parity_n1e8_m128(ctx):
+    """THE metric workload: engine vs the committed oracle fixture, 1e-12 on H columns and on Ritz values."""
+    z = np.load(os.path.join(GOLD, "arnoldi_diaglin_n100000000_m128_rdp.npz"))
+    meta = json.loads(str(z["meta"]))
+    n, m = meta["n"], meta["m"]
+    assert (n, m) == (100_000_000, 128)
+    X, H = run_engine(ctx, n, m)
+    e_seq, e_comp = colerr(H, z["H_seq"]), colerr(H, z["H_comp"])
+    r_seq = np.max(np.abs(ritz(H) - ritz(z["H_seq"])) / np.abs(ritz(z["H_seq"])))
+    r_comp = np.max(np.abs(ritz(H) - ritz(z["H_comp"])) / np.abs(ritz(z["H_comp"])))
+    print(f"n=1e8 m=128: |dH| vs sequential {e_seq:.2e}, vs compensated {e_comp:.2e}; Ritz {r_seq:.2e} / {r_comp:.2e}; "
+          f"reference-side rounding (seq vs comp) {meta['seq_vs_comp_H']:.2e}")
+    assert e_seq <= TOL, f"H vs the reference's arithmetic: {e_seq:.3e}"
+    assert r_seq <= TOL, f"Ritz values vs the reference's arithmetic: {r_seq:.3e}"
+    assert e_comp <= 1e-13 and r_comp <= TOL          # against exact-ish dots the engine is an order tighter still
+    check_properties(X, H, n, m)
+
+
+def test_config2_full_size_against_live_oracle_and_fixture(ctx):
+    """configs[1]: n = 10^7, m = 64.  The oracle runs HERE, multi-threaded (bit-identical to its 1-thread self,
+    tests/test_oracle_fast.py), and must reproduce the committed fixture bit for bit; the engine matches both."""
+    z = np.load(os.path.join(GOLD, "arnoldi_diaglin_n10000000_m64_rdp.npz"))
+    n, m = 10_000_000, 64
+    X, H = run_engine(ctx, n, m)
+    assert colerr(H, z["H_seq"]) <= TOL and colerr(H, z["H_comp"]) <= 1e-13
+    assert np.max(np.abs(ritz(H) - ritz(z["H_seq"])) / np.abs(ritz(z["H_seq"]))) <= TOL
+    check_properties(X, H, n, m)
+    del X
+    ora.set_threads(ora.max_threads())
+    try:
+        Xo = np.zeros((n, m + 1), order="F")
+        ora.fill_counter(Xo[:, 0], 7)
+        ora.scal(Xo[:, 0], 1.0 / ora.norm(Xo[:, 0]))
+        Ho = np.zeros((m + 1, m), order="F")
+        assert ora.arnoldi(ora.DiagLinOp(1.0, 1.0 / n), Xo, Ho, fast=True) == 0
+    finally:
+        ora.set_threads(1)
+    assert Ho.tobytes() == np.asfortranarray(z["H_seq"]).tobytes(), "live oracle differs from the committed fixture"
+    assert colerr(H, Ho) <= TOL
