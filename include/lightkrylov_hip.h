@@ -97,10 +97,13 @@ int lk_comm_destroy(lk_context_t ctx);
 /* row block owned by this rank: global rows [row0, row0 + n_local) of n_global; only used
  * so that counter-based rand fills are identical for every partition. */
 int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
-/* tuning knobs (integers): "grid_mult" / "update_grid_mult" blocks per CU for the panel sweeps,
- * "stream_update" (barrier-free single-coefficient update sweep), "recompute_update" (two-pass DGS:
- * sweep 2 keeps y' in registers and sweep 3 re-forms it, so y' is never written to HBM), "lazy" (see
- * lk_lazy_stats). */
+/* tuning knobs (integers): "grid_mult" / "update_grid_mult" / "gemm_grid_mult" blocks per CU for the panel kernels;
+ * "stream_update" (barrier-free single-coefficient update sweep); "recompute_update" (two-pass DGS: sweep 2 keeps y'
+ * in registers and sweep 3 re-forms it, so y' is never written to HBM); "store_policy" (cache policy of the sweeps'
+ * 16-byte y store: 0 plain, 1 nt, 2 sc1 = write-through [default], 3 sc0 sc1) and "store_split"; "async_arnoldi"
+ * (default 1: lk_arnoldi enqueues all steps with a device-side breakdown flag, one host synchronisation per call; 0:
+ * one host round trip per step); "pool_slab_cols" (columns per pool slab); "lazy" (see lk_lazy_stats).  None of them
+ * changes a result bit (tests/test_gpu_round2.py). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
 
 /* Lazy batching of the per-object path (tuning key "lazy", off by default).  When on, k consecutive

@@ -70,9 +70,10 @@ struct lk_context_s {
     int stream_update = 1;     // single-coefficient update sweeps: barrier-free streaming kernel
     int update_grid_mult = 4;
     int gemm_grid_mult = 4;    // panel_gemm blocks per CU
+    int gemm_mfma = 1;         // tall-skinny product on the FP64 matrix cores (0: FP64 VALU kernel)
     int stream_two = 0;        // sweep 3 with two coefficient sets: barrier-free streaming kernel instead of the LDS/barrier one
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
-    int store_policy = 0;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
+    int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     // reduction workspace
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
@@ -105,6 +106,16 @@ struct lk_context_s {
     double *coef_host = nullptr;         // pinned staging for queued coefficients
     hipEvent_t coef_ev = nullptr;        // completion of the last staging copy
     int64_t lazy_stats[4] = {0, 0, 0, 0};  // dot memo hits, batched dot sweeps, queued axpbys, queue flushes
+    // asynchronous Arnoldi pipeline (lk_arnoldi): per-step result slots + device-side breakdown flag
+    int *stop_dev = nullptr;               // device int: 0, or the step that asked every later step to stop
+    int *stop_host = nullptr;              // pinned mirror
+    bool guard_on = false;                 // launches carry the guard only inside an asynchronous batch
+    int guard_step = 0;
+    double *step_red = nullptr;            // device: nsteps x RED_SECTIONS x RED_SECTION doubles
+    double *step_red_host = nullptr;       // pinned mirror
+    int step_red_cap = 0;                  // steps the two buffers hold
+    int async_arnoldi = 1;                 // tuning key: 0 = one host round trip per step (the round-1 schedule)
+    Guard guard() const { return Guard{guard_on ? stop_dev : nullptr, guard_step}; }
     // column pool (lk_pool_*): slabs handed out to per-object hosts
     struct PoolSlab {
         lk_basis_t B = nullptr;
@@ -301,11 +312,11 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
             if (g < 1) g = 1;
             nblocks = (int)g;
             hipLaunchKernelGGL((panel_update<CPLX, KC, NW, MODE == 4>), dim3(nblocks), dim3(NW * 64), 0, c->stream, X, ldx, k, y,
-                               n, hin, hin2, c->partial, (int64_t)MAX_GRID, c->store_policy);
+                               n, hin, hin2, c->partial, (int64_t)MAX_GRID, c->store_policy, c->guard());
         } else {
             const int st = store ? (1 | (c->store_policy << 1) | (c->store_split ? 8 : 0)) : 0;
             hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
-                               ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st);
+                               ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st, c->guard());
         }
     }
     HIPCHK(hipGetLastError());
@@ -373,13 +384,16 @@ constexpr int GEMM_QB = 16;       // accumulators (output columns) per lane
 constexpr int GEMM_NQG = 4;       // output-column groups per block (= waves per block)
 
 inline int64_t gemm_packed_doubles(int k, int q, int ED) {
-    return (int64_t)((q + GEMM_QB - 1) / GEMM_QB) * k * GEMM_QB * ED;
+    const int64_t valu = (int64_t)((q + GEMM_QB - 1) / GEMM_QB) * k * GEMM_QB * ED;
+    const int QBm = ED == 2 ? 8 : 16;                                  // MFMA layout: [groups][k/4][NA][64]
+    const int64_t mfma = (int64_t)((q + QBm - 1) / QBm + 8) * ((KMAX_FUSED + 3) / 4) * 64;   // +8: a launch stages NG whole groups
+    return valu > mfma ? valu : mfma;
 }
 
 // Y(:, jy0 : jy0+q) (+)= sign * X(:, c0 : c0+k) * C, C = DEVICE coefficients, column-major k x q with leading dimension
 // ldc (elements).  `pack` = device workspace of gemm_packed_doubles(k, q, ED) doubles.  One pass over X per 64 outputs.
-int gemm_launch(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, const double *Cdev, int64_t ldc, double sign,
-                int accumulate, double *pack) {
+int gemm_launch_valu(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, const double *Cdev, int64_t ldc, double sign,
+                     int accumulate, double *pack) {
     lk_context_t c = Bx->ctx;
     const bool cp = Bx->dtype == LK_C128;
     const int ED = Bx->ed();
@@ -407,6 +421,72 @@ int gemm_launch(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, con
         HIPCHK(hipGetLastError());
     }
     return LK_OK;
+}
+
+// MFMA path: k-chunks of 128 columns (one LDS image of the coefficient tiles per launch), NG output groups per launch
+// (64 output columns per pass over X for either kind).
+template <bool CPLX, int NG>
+int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *Y, int64_t ldy, int qn, const double *Cp, int64_t n,
+                  int accumulate) {
+    const int nt = (kk + 3) / 4;
+    const size_t lds = (size_t)NG * nt * 64 * sizeof(double);
+    if (lds > 48 * 1024)                         // more than the default dynamic-LDS limit needs the opt-in (gfx950: 160 KB per workgroup)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    constexpr int tile_rows = 8 * 2 * (CPLX ? 16 : 32);
+    int64_t g = (n + tile_rows - 1) / tile_rows;
+    const int64_t cap = (int64_t)c->num_cu * (NG >= 8 ? 1 : (NG >= 4 && CPLX ? 2 : c->gemm_grid_mult));
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate);
+    HIPCHK(hipGetLastError());
+    return LK_OK;
+}
+
+int gemm_launch_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, const double *Cdev, int64_t ldc, double sign,
+                     int accumulate, double *pack) {
+    lk_context_t c = Bx->ctx;
+    const bool cp = Bx->dtype == LK_C128;
+    const int ED = Bx->ed();
+    const int QB = cp ? 8 : 16, NGMAX = cp ? 8 : 4;
+    for (int kc = 0; kc < k; kc += KMAX_FUSED) {
+        const int kk = (k - kc) < KMAX_FUSED ? (k - kc) : KMAX_FUSED;
+        const int nt = (kk + 3) / 4;
+        const int ngroups = (q + QB - 1) / QB;
+        const int total = ngroups * nt * 64;
+        hipLaunchKernelGGL(pack_coef_mfma, dim3((total + 255) / 256 > 64 ? 64 : (total + 255) / 256), dim3(256), 0, c->stream,
+                           Cdev + (int64_t)kc * ED, ldc, kk, q, cp ? 1 : 0, sign, pack);
+        HIPCHK(hipGetLastError());
+        const int acc = (accumulate || kc > 0) ? 1 : 0;
+        for (int g0 = 0; g0 < ngroups; g0 += NGMAX) {
+            const int groups = (ngroups - g0) < NGMAX ? (ngroups - g0) : NGMAX;
+            const int qn = (q - g0 * QB) < groups * QB ? (q - g0 * QB) : groups * QB;
+            const double *Cp = pack + (int64_t)g0 * nt * 64;
+            const double *Xp = Bx->col(c0 + kc);
+            double *Yp = By->col(jy0 + g0 * QB);
+            ProfScope ps(c, "lincomb", (double)Bx->n * ED * 8.0 * (kk + qn * (acc ? 2 : 1)));
+            int rc;
+            if (cp) {
+                if (groups <= 1) rc = gemm_mfma_one<true, 1>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+                else if (groups == 2) rc = gemm_mfma_one<true, 2>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+                else if (groups <= 4) rc = gemm_mfma_one<true, 4>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+                else rc = gemm_mfma_one<true, 8>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+            } else {
+                if (groups <= 1) rc = gemm_mfma_one<false, 1>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+                else if (groups == 2) rc = gemm_mfma_one<false, 2>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+                else rc = gemm_mfma_one<false, 4>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+            }
+            LKCHK(rc);
+        }
+    }
+    return LK_OK;
+}
+
+int gemm_launch(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, const double *Cdev, int64_t ldc, double sign,
+                int accumulate, double *pack) {
+    // the MFMA kernel needs >= 2 useful output groups to beat the VALU one's one-wave-per-16-outputs layout on tiny q
+    if (Bx->ctx->gemm_mfma && q >= 2) return gemm_launch_mfma(Bx, c0, k, By, jy0, q, Cdev, ldc, sign, accumulate, pack);
+    return gemm_launch_valu(Bx, c0, k, By, jy0, q, Cdev, ldc, sign, accumulate, pack);
 }
 
 int dot_device(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out_dev) {
@@ -438,16 +518,17 @@ int fetch(lk_context_t c, int section0, int nsections) {
     return LK_OK;
 }
 
-int scal_launch(lk_basis_t B, int j, double ar, double ai, const double *inv_sqrt_of, double tol) {
+int scal_launch(lk_basis_t B, int j, double ar, double ai, const double *inv_sqrt_of, double tol, int *stop_out = nullptr,
+                double tol_break = 0.0) {
     lk_context_t c = B->ctx;
     const int64_t nv = B->n * B->ed() / 2 + 1;
     ProfScope ps(c, "blas1", (double)B->n * B->ed() * 16.0);
     if (B->dtype == LK_C128)
         hipLaunchKernelGGL(k_scal<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, B->col(j), B->n, ar, ai,
-                           inv_sqrt_of, tol);
+                           inv_sqrt_of, tol, c->guard(), stop_out, tol_break);
     else
         hipLaunchKernelGGL(k_scal<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, B->col(j), B->n, ar, ai,
-                           inv_sqrt_of, tol);
+                           inv_sqrt_of, tol, c->guard(), stop_out, tol_break);
     HIPCHK(hipGetLastError());
     return LK_OK;
 }
@@ -477,24 +558,23 @@ inline int lazy_enter(lk_context_t c, bool mutates) {
 
 // Core of double_gram_schmidt_step for one vector; results stay in c->red (device):
 //   section 0: h1[0..k), nrm2(y)    section 1: h2[0..k), nrm2(y')   section 2 (slot k): nrm2(y'')
-int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass) {
+int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass, double *red_base = nullptr) {
     lk_context_t c = Bx->ctx;
-    const int ED = Bx->ed();
-    double *r0 = c->red, *r1 = c->red + RED_SECTION, *r2 = c->red + 2 * RED_SECTION;
+    double *base = red_base ? red_base : c->red;
+    double *r0 = base, *r1 = base + RED_SECTION, *r2 = base + 2 * RED_SECTION;
     if (k <= KMAX_FUSED) {
-        LKCHK((sweep<false, true>(Bx, 0, k, y, nullptr, r0)));       // h1 = X^H y ; ||y||^2
+        LKCHK((sweepm<1>(Bx, 0, k, y, nullptr, nullptr, 1, r0)));    // h1 = X^H y ; ||y||^2
         if (two_pass && c->recompute_update) {
             LKCHK((sweepm<2>(Bx, 0, k, y, r0, nullptr, 0, r1)));     // y' = y - X h1 (registers only); h2 = X^H y'; ||y'||^2
             LKCHK((sweepm<4>(Bx, 0, k, y, r0, r1, 1, r2)));          // y'' = (y - X h1) - X h2 ; ||y''||^2
         } else if (two_pass) {
-            LKCHK((sweep<true, true>(Bx, 0, k, y, r0, r1)));         // y' = y - X h1 ; h2 = X^H y' ; ||y'||^2
-            LKCHK((sweep<true, false>(Bx, 0, k, y, r1, r2)));        // y'' = y' - X h2 ; ||y''||^2
+            LKCHK((sweepm<2>(Bx, 0, k, y, r0, nullptr, 1, r1)));     // y' = y - X h1 ; h2 = X^H y' ; ||y'||^2
+            LKCHK((sweepm<3>(Bx, 0, k, y, r1, nullptr, 1, r2)));     // y'' = y' - X h2 ; ||y''||^2
         } else {
-            LKCHK((sweep<true, false>(Bx, 0, k, y, r0, r1)));        // y' = y - X h1 ; ||y'||^2
+            LKCHK((sweepm<3>(Bx, 0, k, y, r0, nullptr, 1, r1)));     // y' = y - X h1 ; ||y'||^2
         }
         return LK_OK;
     }
-    (void)ED;
     return fail(LK_ERR_INVALID, "internal: dgs_device called with k=%d > %d", k, KMAX_FUSED);
 }
 
@@ -536,6 +616,9 @@ int lk_init(int device, void *stream, lk_context_t *ctx) {
         HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)RED_SECTIONS * RED_SECTION * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **)&c->coef, (size_t)KMAX_FUSED * 2 * sizeof(double)));
         HIPCHK(hipHostMalloc((void **)&c->coef_host, (size_t)KMAX_FUSED * 2 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&c->stop_dev, sizeof(int)));
+        HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
+        HIPCHK(hipHostMalloc((void **)&c->stop_host, sizeof(int), hipHostMallocDefault));
         HIPCHK(hipEventCreateWithFlags(&c->coef_ev, hipEventDisableTiming));
         HIPCHK(hipEventRecord(c->coef_ev, c->stream));
         return LK_OK;
@@ -584,6 +667,10 @@ int lk_finalize(lk_context_t c) {
     if (c->red_host) (void)hipHostFree(c->red_host);
     if (c->coef_host) (void)hipHostFree(c->coef_host);
     if (c->coef_ev) (void)hipEventDestroy(c->coef_ev);
+    if (c->stop_dev) (void)hipFree(c->stop_dev);
+    if (c->stop_host) (void)hipHostFree(c->stop_host);
+    if (c->step_red) (void)hipFree(c->step_red);
+    if (c->step_red_host) (void)hipHostFree(c->step_red_host);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LK_OK;
@@ -639,11 +726,13 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
+    if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }
     if (!strcmp(key, "pool_slab_cols")) {
         if (value < 2 || value > 4096) return fail(LK_ERR_INVALID, "pool_slab_cols must be in [2,4096]");
         c->pool_slab_cols = value;
         return LK_OK;
     }
+    if (!strcmp(key, "gemm_mfma")) { c->gemm_mfma = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "gemm_grid_mult must be in [1,16]");
         c->gemm_grid_mult = value;
@@ -1328,19 +1417,19 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
     ProfScope ps(c, "matvec", 0.0);
     switch (op->kind) {
     case OP_DIAG:
-        if (cp) hipLaunchKernelGGL(k_diag<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->dev, x, y, n, trans == LK_OP_H);
-        else hipLaunchKernelGGL(k_diag<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->dev, x, y, n, 0);
+        if (cp) hipLaunchKernelGGL(k_diag<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->dev, x, y, n, trans == LK_OP_H, c->guard());
+        else hipLaunchKernelGGL(k_diag<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->dev, x, y, n, 0, c->guard());
         break;
     case OP_DIAG_LIN:
-        hipLaunchKernelGGL(k_diag_linspace, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->d0, op->dstep, op->row0, x, y, n);
+        hipLaunchKernelGGL(k_diag_linspace, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->d0, op->dstep, op->row0, x, y, n, c->guard());
         break;
     case OP_DENSE:
         if (trans == LK_OP_N) {
-            if (cp) hipLaunchKernelGGL(k_gemv_n<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y);
-            else hipLaunchKernelGGL(k_gemv_n<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y);
+            if (cp) hipLaunchKernelGGL(k_gemv_n<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y, c->guard());
+            else hipLaunchKernelGGL(k_gemv_n<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y, c->guard());
         } else {
-            if (cp) hipLaunchKernelGGL(k_gemv_h<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y);
-            else hipLaunchKernelGGL(k_gemv_h<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y);
+            if (cp) hipLaunchKernelGGL(k_gemv_h<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y, c->guard());
+            else hipLaunchKernelGGL(k_gemv_h<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y, c->guard());
         }
         break;
     case OP_GL: {
@@ -1352,10 +1441,10 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
         const int adj = trans == LK_OP_H;
         const double *uin = x;
         for (int sstep = 0; sstep < op->nsub; ++sstep) {
-            double *uout = (sstep == op->nsub - 1) ? y : ((uin == us) ? y : us);
-            if (uout == uin) uout = (uin == y) ? us : y;
+            // outputs alternate between the work vector and y so that the LAST sub-step lands in y
+            double *uout = ((op->nsub - 1 - sstep) % 2 == 0) ? y : us;
 #define GL_STAGE(KPREV, A, KOUT, B, FIRST) \
-            hipLaunchKernelGGL(k_gl_stage, dim3(grid), dim3(256), 0, c->stream, uin, KPREV, A, KOUT, uout, B, FIRST, n, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], adj)
+            hipLaunchKernelGGL(k_gl_stage, dim3(grid), dim3(256), 0, c->stream, uin, KPREV, A, KOUT, uout, B, FIRST, n, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], adj, c->guard())
             GL_STAGE((const double *)nullptr, 0.0, ka, dt / 6.0, 1);
             GL_STAGE((const double *)ka, 0.5 * dt, kb, dt / 3.0, 0);
             GL_STAGE((const double *)kb, 0.5 * dt, ka, dt / 3.0, 0);
@@ -1363,14 +1452,13 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
 #undef GL_STAGE
             uin = uout;
         }
-        if (uin != y) HIPCHK(hipMemcpyAsync(y, uin, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         break;
     }
     case OP_LAP5: {
         const int64_t N = op->N;
         const double s = (double)(N + 1) * (double)(N + 1);
         dim3 grid((unsigned)((N / 2 + 1 + 255) / 256), (unsigned)N);
-        hipLaunchKernelGGL(k_lap5, grid, dim3(256), 0, c->stream, x, y, N, s);
+        hipLaunchKernelGGL(k_lap5, grid, dim3(256), 0, c->stream, x, y, N, s, c->guard());
         break;
     }
     }
@@ -1379,40 +1467,133 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
 }
 
 // ---- Arnoldi -----------------------------------------------------------------------------------------
+// One step on the host-synchronous schedule (one round trip per step): used for k > KMAX_FUSED and with
+// async_arnoldi = 0.  Returns through *stop: 0 continue, 1 loop must exit (info set).
+static int arnoldi_step_sync(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int k, double tol, int trans, std::vector<double> &h,
+                             int *info, int *stop) {
+    const int ED = X->ed();
+    *stop = 0;
+    LKCHK(lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, k - 1, X, k));          // arnoldi.fypp:39-47
+    double norms[3];
+    int dinfo = 0;
+    LKCHK(lk_dgs(X, k, X, k, h.data(), norms, LK_DGS_NORMALIZE, &dinfo));          // arnoldi.fypp:50-55
+    double *Hk = H + (size_t)(k - 1) * ldh * ED;
+    memcpy(Hk, h.data(), (size_t)k * ED * sizeof(double));
+    const double beta = norms[2];
+    Hk[(size_t)k * ED] = 0.0;
+    if (ED == 2) Hk[(size_t)k * ED + 1] = 0.0;
+    if (beta < ATOL_DP) {
+        // qr_no_pivoting, colinear column: R(1,1) = 0, rand, re-normalise   qr.fypp:146-162
+        LKCHK(lk_vec_rand(X, k, 0x5EEDull + (uint64_t)k, X->ctx->row0, 1));
+    } else {
+        Hk[(size_t)k * ED] = beta;
+    }
+    if (std::fabs(Hk[(size_t)k * ED]) < tol) {                                     // arnoldi.fypp:58-71
+        *info = k;
+        *stop = 1;
+    }
+    return LK_OK;
+}
+
+static int ensure_step_buffers(lk_context_t c, int nsteps) {
+    if (c->step_red_cap >= nsteps) return LK_OK;
+    if (c->step_red) HIPCHK(hipFree(c->step_red));
+    if (c->step_red_host) HIPCHK(hipHostFree(c->step_red_host));
+    c->step_red = nullptr; c->step_red_host = nullptr; c->step_red_cap = 0;
+    const size_t bytes = (size_t)nsteps * RED_SECTIONS * RED_SECTION * sizeof(double);
+    HIPCHK(hipMalloc((void **)&c->step_red, bytes));
+    HIPCHK(hipHostMalloc((void **)&c->step_red_host, bytes, hipHostMallocDefault));
+    c->step_red_cap = nsteps;
+    return LK_OK;
+}
+
+// Steps [k0, k1] (all <= KMAX_FUSED) enqueued back to back with NO host round trip: operator, three fused sweeps and
+// the normalise of step s write their reduction results into step slot s - k0; the normalise kernel raises the device
+// stop flag on breakdown (||y''|| < max(tol, atol_dp)) or NaN, which turns every kernel of a later step into a
+// no-op.  One D2H copy + one synchronisation per batch.  *done = last step whose results are valid.
+static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, double tol, int trans, int *done) {
+    lk_context_t c = X->ctx;
+    const int nsteps = k1 - k0 + 1;
+    LKCHK(ensure_step_buffers(c, nsteps));
+    HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
+    const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
+    const int ED = X->ed();
+    c->guard_on = true;
+    int rc = LK_OK;
+    for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
+        c->guard_step = k;
+        double *slot = c->step_red + (size_t)(k - k0) * RED_SECTIONS * RED_SECTION;
+        rc = lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, k - 1, X, k);
+        if (rc != LK_OK) break;
+        ProfScope ps(c, "dgs", (double)X->n * ED * 8.0 * (3.0 * k + 5.0));
+        rc = dgs_device(X, k, X->col(k), true, slot);
+        if (rc != LK_OK) break;
+        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * RED_SECTION + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
+    }
+    c->guard_on = false;
+    c->guard_step = 0;
+    LKCHK(rc);
+    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)nsteps * RED_SECTIONS * RED_SECTION * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->stop_host, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    const int stop_step = *c->stop_host;
+    *done = stop_step ? stop_step : k1;
+    return LK_OK;
+}
+
 int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend, double tol, int trans, int *info) {
     if (!A || !X || !H || !info) return fail(LK_ERR_INVALID, "lk_arnoldi: null argument");
     const int kdim = X->ncols - 1;                               // arnoldi.fypp:26 (p = 1)
     if (kdim < 1) return fail(LK_ERR_INVALID, "lk_arnoldi: basis needs at least 2 columns");
     if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_arnoldi: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
     if (ldh < kdim + 1) return fail(LK_ERR_INVALID, "lk_arnoldi: ldh too small");
+    lk_context_t c = X->ctx;
+    DevGuard dev_guard(c);
     const int ED = X->ed();
     *info = 0;
     std::vector<double> h((size_t)kdim * ED);
-    for (int k = kstart; k <= kend; ++k) {
-        // matvec X(k) -> X(k+1)                                   arnoldi.fypp:39-47
-        LKCHK(lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, k - 1, X, k));
-        // DGS with beta = H(:k, k), normalise folded in            arnoldi.fypp:50-55
-        double norms[3];
-        int dinfo = 0;
-        LKCHK(lk_dgs(X, k, X, k, h.data(), norms, LK_DGS_NORMALIZE, &dinfo));
-        double *Hk = H + (size_t)(k - 1) * ldh * ED;
-        memcpy(Hk, h.data(), (size_t)k * ED * sizeof(double));
-        double beta = norms[2];
-        if (beta < ATOL_DP) {
-            // qr_no_pivoting, colinear column: R(1,1) = 0, rand, re-normalise   qr.fypp:146-162
-            Hk[(size_t)k * ED] = 0.0;
-            if (ED == 2) Hk[(size_t)k * ED + 1] = 0.0;
-            LKCHK(lk_vec_rand(X, k, 0x5EEDull + (uint64_t)k, X->ctx->row0, 1));
-            beta = 0.0;
-        } else {
-            Hk[(size_t)k * ED] = beta;
-            if (ED == 2) Hk[(size_t)k * ED + 1] = 0.0;
+    int k = kstart;
+    while (k <= kend) {
+        int stop = 0;
+        if (!c->async_arnoldi || k > KMAX_FUSED || k == kend) {
+            // single step, wide basis, or the round-1 schedule: one host round trip per step
+            LKCHK(arnoldi_step_sync(A, X, H, ldh, k, tol, trans, h, info, &stop));
+            if (stop) break;
+            ++k;
+            continue;
         }
-        // breakdown test   arnoldi.fypp:58-71
-        if (std::fabs(Hk[(size_t)k * ED]) < tol) {
-            *info = k;
-            break;
+        const int k1 = kend < KMAX_FUSED ? kend : KMAX_FUSED;
+        LKCHK(lazy_enter(c, true));
+        int done = 0;
+        LKCHK(arnoldi_batch_async(A, X, k, k1, tol, trans, &done));
+        const bool stopped_early = *c->stop_host != 0;
+        for (int s = k; s <= done; ++s) {
+            const double *slot = c->step_red_host + (size_t)(s - k) * RED_SECTIONS * RED_SECTION;
+            const double *r0 = slot, *r1 = slot + RED_SECTION, *r2 = slot + 2 * RED_SECTION;
+            double *Hk = H + (size_t)(s - 1) * ldh * ED;
+            for (int i = 0; i < s * ED; ++i) Hk[i] = r0[i] + r1[i];                 // gram_schmidt.fypp:49
+            const double beta = std::sqrt(std::fabs(r2[s * ED]));
+            if (beta != beta) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+            Hk[(size_t)s * ED] = 0.0;
+            if (ED == 2) Hk[(size_t)s * ED + 1] = 0.0;
+            if (beta < ATOL_DP) {
+                // colinear column (the device left y'' unnormalised and stopped): R(1,1) = 0, rand, re-normalise  qr.fypp:146-162
+                LKCHK(lk_vec_rand(X, s, 0x5EEDull + (uint64_t)s, c->row0, 1));
+            } else {
+                Hk[(size_t)s * ED] = beta;
+            }
+            if (std::fabs(Hk[(size_t)s * ED]) < tol) {                              // arnoldi.fypp:58-71
+                *info = s;
+                stop = 1;
+                break;
+            }
         }
+        if (stop) break;
+        // a stop the reference would NOT have taken (tol below atol_dp with a colinear column): resume after it
+        k = done + 1;
+        (void)stopped_early;
     }
     return LK_OK;
 }

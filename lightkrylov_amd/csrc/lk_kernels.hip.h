@@ -36,6 +36,20 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Early-exit guard of the ASYNCHRONOUS Arnoldi pipeline (lk_arnoldi enqueues every step without waiting for the
+// host): when step s finds an invariant subspace / a colinear vector / a NaN, its normalise kernel records
+// *stop_step = s; every kernel of a LATER step returns at once, so the basis beyond the breakdown stays untouched
+// exactly as the reference leaves it (arnoldi.fypp:58-71).  stop_step == nullptr: no guard (synchronous callers).
+struct Guard {
+    const int *stop_step;
+    int step;
+};
+__device__ __forceinline__ bool stopped(Guard g) {
+    if (!g.stop_step) return false;
+    const int s = *g.stop_step;          // uniform (scalar) load
+    return s != 0 && s < g.step;
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -155,8 +169,9 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
                                                         const double *__restrict__ hin,
                                                         const double *__restrict__ hin2,
                                                         double *__restrict__ partial, int64_t pstride,
-                                                        int WC, int kcw, int store) {
+                                                        int WC, int kcw, int store, Guard guard) {
     static_assert(!TWO || (UPDATE && !DOT), "TWO is the update-only sweep with two coefficient sets");
+    if (stopped(guard)) return;
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;  // rows one wave covers per tile
@@ -394,7 +409,9 @@ __global__ __launch_bounds__(NW * 64) void panel_update(const double *__restrict
                                                          double *__restrict__ y, int64_t n,
                                                          const double *__restrict__ hin,
                                                          const double *__restrict__ hin2,
-                                                         double *__restrict__ partial, int64_t pstride, int policy) {
+                                                         double *__restrict__ partial, int64_t pstride, int policy,
+                                                         Guard guard) {
+    if (stopped(guard)) return;
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;
@@ -530,6 +547,164 @@ __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, 
     }
 }
 
+// ---- FP64-MFMA tall-skinny product --------------------------------------------------------------------------------
+// Same contract as panel_gemm for k <= 128, on the matrix cores: v_mfma_f64_16x16x4_f64 computes D(16x16) += A(16x4) B(4x16)
+// with lane l holding A[i = l&15][kk = l>>4], B[kk = l>>4][j = l&15] and D[i = (l>>4) + 4 reg][j = l&15]
+// (cdna_hip_programming.md, "f64 MFMA does NOT use the f32 maps").  Here i = OUTPUT column, j = ROW of the panel,
+// kk = basis column within a 4-column step, i.e. D^T = C^T X^T.
+//   * the A operands (coefficient tiles, one per output group of 16 and k-step) are staged ONCE per block in LDS and read
+//     back per MFMA (512 B per wave instruction, lane-indexed: conflict free);
+//   * the B operand is this wave's OWN rows of X, 16 bytes per lane, prefetched U k-steps ahead: every wave of the block
+//     streams different rows (8 independent streams per CU), and X leaves HBM exactly once;
+//   * every wave keeps the accumulators of ALL NG output groups of its rows in registers (NG x 2 row groups independent
+//     MFMA chains).
+//   real kind   : a lane loads rows (2j, 2j+1) of column 4t+kk and feeds the even rows to one accumulator and the odd rows
+//                 to another (32 rows per row group, 16 outputs per group).
+//   complex kind: a group is 8 complex outputs as 16 real ones (n < 8: Re, n >= 8: Im).  A lane loads (re, im) of row j of
+//                 column 4t+kk; the re parts multiply the tile [Cr | Ci], the im parts the tile [-Ci | Cr], which is the
+//                 first tile with lanes n <-> n^8 swapped and one half negated, so only [Cr | Ci] is stored.
+// Cp: coefficient tiles packed per lane by pack_coef_mfma: [group][k-step t][64 lanes].
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <bool CPLX, int NG>
+__global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict__ X, int64_t ldx, int k,
+                                                       double *__restrict__ Y, int64_t ldy, int qn,
+                                                       const double *__restrict__ Cp, int64_t n, int accumulate) {
+    constexpr int QB = CPLX ? 8 : 16;            // output columns per group
+    constexpr int RG = CPLX ? 16 : 32;           // rows per row group (one MFMA N extent; x2 rows per lane for real)
+    constexpr int NACC = CPLX ? 1 : 2;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int U = 4;                         // k-steps of X in flight per wave: 2 U loads of 16 B per lane
+    extern __shared__ double tiles[];            // [NG][nt][64]
+    const int nt = (k + 3) >> 2;
+    for (int i = threadIdx.x; i < NG * nt * 64; i += blockDim.x) tiles[i] = Cp[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kk = lane >> 4, j = lane & 15;
+    const double sgn = (lane & 8) ? 1.0 : -1.0;  // complex second tile: [-Ci | Cr] from [Cr | Ci]
+    const int64_t xstride = ldx * ED, ystride = ldy * ED;
+    constexpr int tile_rows = 8 * 2 * RG;        // 8 waves x two row groups
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const double *__restrict__ Xl = X + (int64_t)kk * xstride;      // this lane's column within a k-step
+    const bool kfast = (k & 3) == 0;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * tile_rows + (int64_t)wave * (2 * RG) + (CPLX ? j : 2 * j), r1 = r0 + RG;
+        const bool fast = kfast && (tile + 1) * tile_rows <= n;
+        v4d acc[NG][2][NACC];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                for (int e = 0; e < NACC; ++e) acc[g][g2][e] = v4d{0.0, 0.0, 0.0, 0.0};
+
+        for (int t0 = 0; t0 < nt; t0 += U) {
+            v2d x[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u;
+                x[u][0] = v2d{0.0, 0.0};
+                x[u][1] = v2d{0.0, 0.0};
+                if (t < nt) {
+                    const double *__restrict__ xc = Xl + (int64_t)(4 * t) * xstride;
+                    if (fast) {
+                        x[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xc + r0 * ED));
+                        x[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xc + r1 * ED));
+                    } else if ((4 * t + kk) < k) {
+                        x[u][0] = load_y<CPLX>(xc, r0, n, false);
+                        x[u][1] = load_y<CPLX>(xc, r1, n, false);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u;
+                if (t < nt) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const double a0 = tiles[(g * nt + t) * 64 + lane];
+                        if constexpr (CPLX) {
+                            const double a1 = tiles[(g * nt + t) * 64 + (lane ^ 8)] * sgn;
+#pragma unroll
+                            for (int g2 = 0; g2 < 2; ++g2)
+                                acc[g][g2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x[u][g2].x, acc[g][g2][0], 0, 0, 0);
+#pragma unroll
+                            for (int g2 = 0; g2 < 2; ++g2)
+                                acc[g][g2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x[u][g2].y, acc[g][g2][0], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int g2 = 0; g2 < 2; ++g2) {
+                                acc[g][g2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x[u][g2].x, acc[g][g2][0], 0, 0, 0);
+                                acc[g][g2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x[u][g2].y, acc[g][g2][1], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // D[n = kk + 4 reg][row j] of group g
+        const bool full = (tile + 1) * tile_rows <= n;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int64_t r = g2 ? r1 : r0;
+                if constexpr (CPLX) {
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {              // complex output kk + 4 h2: (Re, Im) = regs (h2, h2 + 2)
+                        const int qq = g * QB + kk + 4 * h2;
+                        if (qq < qn) {
+                            double *yc = Y + (int64_t)qq * ystride;
+                            v2d out = v2d{acc[g][g2][0][h2], acc[g][g2][0][h2 + 2]};
+                            if (accumulate) out += load_y<CPLX>(yc, r, n, full);
+                            store_rows<CPLX>(yc, r, n, full, out);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {           // real output kk + 4 reg: rows (2j, 2j+1) = (even, odd acc)
+                        const int qq = g * QB + kk + 4 * reg;
+                        if (qq < qn) {
+                            double *yc = Y + (int64_t)qq * ystride;
+                            v2d out = v2d{acc[g][g2][0][reg], acc[g][g2][1][reg]};
+                            if (accumulate) out += load_y<CPLX>(yc, r, n, full);
+                            store_rows<CPLX>(yc, r, n, full, out);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// per-lane coefficient tiles of panel_gemm_mfma from device coefficients laid out [q][ldc][ED] (column-major k x q):
+// Cp[(g * nt + t) * 64 + lane] = A-operand value of lane (kk = lane>>4, n = lane&15) of group g for k-step t.
+__global__ __launch_bounds__(256) void pack_coef_mfma(const double *__restrict__ C, int64_t ldc, int k, int q, int cplx,
+                                                      double sign, double *__restrict__ Cp) {
+    const int QB = cplx ? 8 : 16, ED = cplx ? 2 : 1;
+    const int ngroups = (q + QB - 1) / QB, nt = (k + 3) >> 2;
+    const int total = ngroups * nt * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, t = (idx >> 6) % nt, g = idx / (64 * nt);
+        const int kk = lane >> 4, nn = lane & 15;
+        const int col = 4 * t + kk;
+        double v = 0.0;
+        if (col < k) {
+            if (!cplx) {
+                const int qq = g * QB + nn;
+                if (qq < q) v = sign * C[(int64_t)qq * ldc + col];
+            } else {
+                const int qq = g * QB + (nn & 7);                  // [Cr | Ci]
+                if (qq < q) v = sign * C[((int64_t)qq * ldc + col) * ED + (nn < 8 ? 0 : 1)];
+            }
+        }
+        Cp[idx] = v;
+    }
+}
+
 // repack device coefficients laid out [q][ldc][ED] (column-major k x q block, e.g. the sections finish_partials
 // leaves in the reduction buffer) into panel_gemm's [group][j][qq][ED] layout with a sign and zero padding.
 __global__ __launch_bounds__(256) void pack_coef(const double *__restrict__ C, int64_t ldc, int k, int q, int QB, int ED,
@@ -561,11 +736,15 @@ __global__ __launch_bounds__(256) void finish_partials(const double *__restrict_
 // =====================================================================================
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_scal(double *__restrict__ x, int64_t n, double ar, double ai,
-                                              const double *__restrict__ inv_sqrt_of, double tol) {
+                                              const double *__restrict__ inv_sqrt_of, double tol, Guard guard,
+                                              int *__restrict__ stop_out, double tol_break) {
     // inv_sqrt_of != NULL: alpha = 1/sqrt(|*inv_sqrt_of|) read on the device (fused normalise);
     // skipped (alpha = 1) when the norm is below tol so the host can take the breakdown path.
+    // stop_out != NULL (asynchronous Arnoldi): a norm below tol_break, or a NaN, stops every LATER step.
+    if (stopped(guard)) return;
     if (inv_sqrt_of) {
         const double nr = sqrt(fabs(*inv_sqrt_of));
+        if (stop_out && blockIdx.x == 0 && threadIdx.x == 0 && !(nr >= tol_break)) *stop_out = guard.step;
         if (!(nr >= tol)) return;
         ar = 1.0 / nr;
         ai = 0.0;
@@ -659,7 +838,8 @@ __global__ __launch_bounds__(256) void k_rand(double *__restrict__ x, int64_t n,
 // =====================================================================================
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_diag(const double *__restrict__ d, const double *__restrict__ x,
-                                              double *__restrict__ y, int64_t n, int conj_d) {
+                                              double *__restrict__ y, int64_t n, int conj_d, Guard guard) {
+    if (stopped(guard)) return;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     const int64_t nd = n * ED, nv = nd / 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -676,7 +856,8 @@ __global__ __launch_bounds__(256) void k_diag(const double *__restrict__ d, cons
 
 __global__ __launch_bounds__(256) void k_diag_linspace(double d0, double dstep, int64_t row0,
                                                        const double *__restrict__ x, double *__restrict__ y,
-                                                       int64_t n) {
+                                                       int64_t n, Guard guard) {
+    if (stopped(guard)) return;
     const int64_t nv = n / 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const v2d *xv = reinterpret_cast<const v2d *>(x);
@@ -692,7 +873,8 @@ __global__ __launch_bounds__(256) void k_diag_linspace(double d0, double dstep, 
 // y = A x, A n x n column-major.  Block = 4 waves x 64 rows; wave w sums columns j == w (mod 4).
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_gemv_n(const double *__restrict__ A, int64_t lda, int64_t n,
-                                                const double *__restrict__ x, double *__restrict__ y) {
+                                                const double *__restrict__ x, double *__restrict__ y, Guard guard) {
+    if (stopped(guard)) return;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -721,7 +903,8 @@ __global__ __launch_bounds__(256) void k_gemv_n(const double *__restrict__ A, in
 // y = A^H x: one wave per column j, lanes over rows.
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_gemv_h(const double *__restrict__ A, int64_t lda, int64_t n,
-                                                const double *__restrict__ x, double *__restrict__ y) {
+                                                const double *__restrict__ x, double *__restrict__ y, Guard guard) {
+    if (stopped(guard)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 4 + wave;
     if (j >= n) return;
@@ -745,7 +928,8 @@ __global__ __launch_bounds__(256) void k_gemv_h(const double *__restrict__ A, in
 // 5-point Laplacian, N x N grid, Dirichlet, scale s = (N+1)^2.  One thread per 2 grid points
 // along the fast index; neighbours come from L1/L2 (each row is re-used by 3 stencil rows).
 __global__ __launch_bounds__(256) void k_lap5(const double *__restrict__ u, double *__restrict__ v, int64_t N,
-                                              double s) {
+                                              double s, Guard guard) {
+    if (stopped(guard)) return;
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     const int64_t j = blockIdx.y;
     if (i >= N) return;
@@ -772,7 +956,8 @@ __global__ __launch_bounds__(256) void k_gl_stage(const double *__restrict__ u, 
                                                   double a, double *__restrict__ kout, double *__restrict__ acc,
                                                   double b, int first, int64_t n, double dx, double halfL,
                                                   double nu_re, double nu_im, double ga_re, double ga_im,
-                                                  double mu_c, double mu2, int adjoint) {
+                                                  double mu_c, double mu2, int adjoint, Guard guard) {
+    if (stopped(guard)) return;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 0-based; reference index i+1
     if (i >= n) return;
     const v2d *uv = reinterpret_cast<const v2d *>(u);

@@ -262,3 +262,41 @@ def test_lazy_dot_batch_stops_at_the_columns_ever_written(ctx):
     ref = ora.innerprod(Xh, y.to_array())
     assert np.abs(np.array(got) - ref).max() <= 1e-12 * np.linalg.norm(Xh[:, 0]) * np.linalg.norm(y.to_array())
     c.close()
+
+
+# ----------------------------------------------------------------------------- asynchronous Arnoldi pipeline
+@pytest.mark.parametrize("dtype", KINDS)
+def test_async_arnoldi_equals_the_step_by_step_schedule(dtype):
+    """lk_arnoldi enqueues all steps with a device-side breakdown flag (one synchronisation per call).  Same kernels,
+    same order, same inputs as the one-round-trip-per-step schedule: H and the basis must be bit-identical, with and
+    without a breakdown, and the columns beyond a breakdown must stay untouched (arnoldi.fypp:58-71)."""
+    c = lk.Context(device=0)
+    n, m = 250_003, 40
+    g = np.arange(n) / n
+    d = (1.0 + g).astype(dtype) if np.dtype(dtype).kind == "f" else ((1.0 + g) * np.exp(1j * g)).astype(dtype)
+    out = {}
+    for mode in (0, 1):
+        c.set_tuning("async_arnoldi", mode)
+        X = lk.krylov_basis_gpu(n, m + 1, dtype, c)
+        X[0].rand(True, seed=7)
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        assert lk.arnoldi(lk.diag_linop_gpu(d, c), X, H) == 0
+        out[mode] = (H.tobytes(), X.download().tobytes())
+    assert out[0] == out[1]
+    # invariant subspace after 6 steps: operator with 6 distinct eigenvalues
+    d6 = (1.0 + (np.arange(n) % 6)).astype(dtype)
+    res = {}
+    for mode in (0, 1):
+        c.set_tuning("async_arnoldi", mode)
+        X = lk.krylov_basis_gpu(n, m + 1, dtype, c)
+        X[0].rand(True, seed=9)
+        marker = seeded(n, dtype, 123)
+        for j in range(7, m + 1):
+            X.upload(marker.reshape(-1, 1), j)            # whatever sits beyond the breakdown must survive
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        info = lk.arnoldi(lk.diag_linop_gpu(d6, c), X, H, tol=1e-10)
+        res[mode] = (info, H.tobytes(), X.download().tobytes())
+        assert info == 6
+        assert np.array_equal(X.download(m, 1)[:, 0], marker) and np.array_equal(X.download(7, 1)[:, 0], marker)
+    assert res[0] == res[1]
+    c.close()
