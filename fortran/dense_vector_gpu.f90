@@ -526,20 +526,36 @@ contains
         type(linop_gpu_rdp) :: L
         call chk(lk_linop_diag_linspace_create(ctx, n_local, row0, d0, dstep, L%op), 'diag_linspace_linop_gpu')
     end function
-    !> 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2
-    function laplacian2d_linop_gpu(N) result(L)
+    !> 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2.  Row-sharded runs pass the grid lines this rank
+    !> owns (j0 = first line, 0-based; nj = number of lines): one line is exchanged with each neighbouring rank per matvec.
+    function laplacian2d_linop_gpu(N, j0, nj) result(L)
         integer, intent(in) :: N
+        integer, optional, intent(in) :: j0, nj
         type(linop_gpu_rdp) :: L
-        call chk(lk_linop_lap5_create(ctx, int(N, c_int64_t), L%op), 'laplacian2d_linop_gpu')
+        if (present(j0) .and. present(nj)) then
+            call chk(lk_linop_lap5_create_sharded(ctx, int(N, c_int64_t), int(j0, c_int64_t), int(nj, c_int64_t), L%op), &
+                     'laplacian2d_linop_gpu')
+        else
+            call chk(lk_linop_lap5_create(ctx, int(N, c_int64_t), L%op), 'laplacian2d_linop_gpu')
+        end if
     end function
-    !> fixed-step RK4 propagator of the linearised Ginzburg-Landau operator (example/ginzburg_landau/Ginzburg_Landau.f90:126-136)
-    function ginzburg_landau_linop_gpu(n, dx, tau, nsub, nu, gamma, mu_c, mu2) result(L)
+    !> fixed-step RK4 propagator of the linearised Ginzburg-Landau operator (example/ginzburg_landau/Ginzburg_Landau.f90:126-136);
+    !> n = GLOBAL size; row-sharded runs pass this rank's block (row0 0-based, n_local): one point per RK4 stage goes to each
+    !> neighbouring rank.
+    function ginzburg_landau_linop_gpu(n, dx, tau, nsub, nu, gamma, mu_c, mu2, row0, n_local) result(L)
         integer, intent(in) :: n, nsub
         real(dp), intent(in) :: dx, tau, mu_c, mu2
         complex(dp), intent(in) :: nu, gamma
+        integer, optional, intent(in) :: row0, n_local
         type(linop_gpu_cdp) :: L
-        call chk(lk_linop_gl_create(ctx, int(n, c_int64_t), dx, tau, int(nsub, c_int), [real(nu, dp), aimag(nu)], &
-                                    [real(gamma, dp), aimag(gamma)], mu_c, mu2, L%op), 'ginzburg_landau_linop_gpu')
+        if (present(row0) .and. present(n_local)) then
+            call chk(lk_linop_gl_create_sharded(ctx, int(n, c_int64_t), int(row0, c_int64_t), int(n_local, c_int64_t), dx, tau, &
+                                                int(nsub, c_int), [real(nu, dp), aimag(nu)], [real(gamma, dp), aimag(gamma)], &
+                                                mu_c, mu2, L%op), 'ginzburg_landau_linop_gpu')
+        else
+            call chk(lk_linop_gl_create(ctx, int(n, c_int64_t), dx, tau, int(nsub, c_int), [real(nu, dp), aimag(nu)], &
+                                        [real(gamma, dp), aimag(gamma)], mu_c, mu2, L%op), 'ginzburg_landau_linop_gpu')
+        end if
     end function
 
     ! ---- fused path from Fortran: the whole Arnoldi step loop inside the engine ----------------

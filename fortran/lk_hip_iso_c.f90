@@ -274,6 +274,30 @@ module lightkrylov_hip_c
             type(c_ptr), intent(out) :: op
             integer(c_int) :: rc
         end function
+        function lk_linop_lap5_create_sharded(ctx, N, j0, nj, op) bind(C, name="lk_linop_lap5_create_sharded") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), value :: N, j0, nj
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
+        function lk_linop_gl_create_sharded(ctx, n_global, row0, n_local, dx, tau, nsub, nu, gamma, mu_c, mu2, op) &
+            bind(C, name="lk_linop_gl_create_sharded") result(rc)
+            import :: c_int, c_ptr, c_int64_t, c_double
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), value :: n_global, row0, n_local
+            real(c_double), value :: dx, tau, mu_c, mu2
+            integer(c_int), value :: nsub
+            real(c_double), intent(in) :: nu(2), gamma(2)
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
+        function lk_set_halo_exchange(ctx, fn, user) bind(C, name="lk_set_halo_exchange") result(rc)
+            import :: c_int, c_ptr, c_funptr
+            type(c_ptr), value :: ctx, user
+            type(c_funptr), value :: fn
+            integer(c_int) :: rc
+        end function
         function lk_linop_lap5_create(ctx, N, op) bind(C, name="lk_linop_lap5_create") result(rc)
             import :: c_int, c_ptr, c_int64_t
             type(c_ptr), value :: ctx

@@ -94,6 +94,15 @@ int lk_comm_get_unique_id(void *id_out);
 int lk_comm_init_rank(lk_context_t ctx, int nranks, int rank, const void *id);
 int lk_comm_destroy(lk_context_t ctx);
 
+/* Nearest-neighbour exchange between consecutive ranks of the row partition, needed only by stencil operators
+ * (5-point Laplacian: one grid line; Ginzburg-Landau: one point): `count` doubles at device address send_lo go to
+ * rank-1 and send_hi to rank+1; recv_lo is filled with rank-1's send_hi, recv_hi with rank+1's send_lo; a NULL pair
+ * means "no neighbour on that side".  Ordered on `stream`.  lk_comm_init_rank installs the native one
+ * (ncclSend / ncclRecv in one group); lk_set_halo_exchange lets a host bring its own (MPI_Sendrecv, tests). */
+typedef int (*lk_halo_fn)(void *user, const void *send_lo, const void *send_hi, void *recv_lo, void *recv_hi,
+                          int64_t count, void *stream);
+int lk_set_halo_exchange(lk_context_t ctx, lk_halo_fn fn, void *user);
+
 /* row block owned by this rank: global rows [row0, row0 + n_local) of n_global; only used
  * so that counter-based rand fills are identical for every partition. */
 int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
@@ -232,16 +241,24 @@ int lk_linop_diag_linspace_create(lk_context_t ctx, int64_t n_local, int64_t row
 int lk_linop_dense_create(lk_context_t ctx, int dtype, int64_t n, const void *A_host, int64_t lda,
                           lk_linop_t *op);
 /* 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (BASELINE config 3).
- * F64, single-rank only. */
+ * F64; whole grid on one rank (row-sharded: the _sharded variant below). */
 int lk_linop_lap5_create(lk_context_t ctx, int64_t N, lk_linop_t *op);
+/* row-sharded: this rank owns grid lines [j0, j0 + nj), i.e. vector rows [j0*N, (j0+nj)*N); the neighbouring
+ * ranks' boundary lines arrive through the halo exchange (one line of N doubles each way per application). */
+int lk_linop_lap5_create_sharded(lk_context_t ctx, int64_t N, int64_t j0, int64_t nj, lk_linop_t *op);
 /* Exponential-propagator stand-in of the Ginzburg-Landau example (BASELINE config 4): y = Phi_tau x,
  * Phi_tau = `nsub` classical RK4 steps of the linearised complex GL right-hand side with the reference's
  * stencil and boundary rows (example/ginzburg_landau/Ginzburg_Landau.f90:126-136; LK_OP_H uses the adjoint
  * right-hand side, :170-179).  x_i = -L/2 + i*dx, L = dx*(n+1); mu_i = mu_c + (mu2/2) x_i^2.
- * nu, gamma: 2 doubles each.  LK_C128, single-rank only.  (The reference integrates with rklib's adaptive
+ * nu, gamma: 2 doubles each.  LK_C128; whole domain on one rank (row-sharded: the _sharded variant).  (The reference integrates with rklib's adaptive
  * rks54, an un-vendored dependency; a fixed-step RK4 is used by oracle and engine alike.) */
 int lk_linop_gl_create(lk_context_t ctx, int64_t n, double dx, double tau, int nsub, const double *nu,
                        const double *gamma, double mu_c, double mu2, lk_linop_t *op);
+/* row-sharded: this rank owns rows [row0, row0 + n_local) of n_global; every RK4 stage exchanges one point with each
+ * neighbouring rank through the halo exchange. */
+int lk_linop_gl_create_sharded(lk_context_t ctx, int64_t n_global, int64_t row0, int64_t n_local, double dx,
+                               double tau, int nsub, const double *nu, const double *gamma, double mu_c,
+                               double mu2, lk_linop_t *op);
 int lk_linop_destroy(lk_linop_t op);
 /* apply_matvec / apply_rmatvec: y(:, jy) = op(A) x(:, jx).  AbstractLinops.fypp:391-424 */
 int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t By, int jy);

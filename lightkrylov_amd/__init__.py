@@ -15,7 +15,7 @@ from .context import Context, default_context, row_partition  # noqa: F401
 from .vectors import (Gram, abstract_vector, axpby_basis, copy, dense_vector_gpu, innerprod,  # noqa: F401
                       krylov_basis_gpu, linear_combination, rand_basis, verify_vector_axioms, zero_basis)
 from .linops import (Id, abstract_linop, adjoint_linop, axpby_linop, scaled_linop, dense_linop_gpu, diag_linop_gpu, ginzburg_landau_linop_gpu,
-                     laplacian2d_linop_gpu)  # noqa: F401
+                     grid_partition, laplacian2d_linop_gpu)  # noqa: F401
 from .krylov import (arnoldi, bidiagonalization, double_gram_schmidt_step, is_orthonormal, krylov_schur, lanczos,  # noqa: F401
                      orthogonalize_against_basis, qr)
 from .solvers import (apply_givens_rotation, eig, eigs, gmres, gmres_dp_metadata, gmres_dp_opts)  # noqa: F401

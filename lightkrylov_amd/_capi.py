@@ -18,6 +18,7 @@ LK_OP_N, LK_OP_H = 0, 1
 LK_COMM_ID_BYTES = 128
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 _p = C.c_void_p
 _pp = C.POINTER(C.c_void_p)
@@ -34,6 +35,7 @@ SIGNATURES = {
     "lk_finalize": (_int, [_p]),
     "lk_sync": (_int, [_p]),
     "lk_set_allreduce": (_int, [_p, ALLREDUCE_FN, _p, _int, _int]),
+    "lk_set_halo_exchange": (_int, [_p, HALO_FN, _p]),
     "lk_context_info": (_int, [_p, _ip, _pp]),
     "lk_comm_get_unique_id": (_int, [_p]),
     "lk_comm_init_rank": (_int, [_p, _int, _int, _p]),
@@ -73,6 +75,8 @@ SIGNATURES = {
     "lk_linop_diag_linspace_create": (_int, [_p, _i64, _i64, C.c_double, C.c_double, _pp]),
     "lk_linop_dense_create": (_int, [_p, _int, _i64, _p, _i64, _pp]),
     "lk_linop_lap5_create": (_int, [_p, _i64, _pp]),
+    "lk_linop_lap5_create_sharded": (_int, [_p, _i64, _i64, _i64, _pp]),
+    "lk_linop_gl_create_sharded": (_int, [_p, _i64, _i64, _i64, C.c_double, C.c_double, _int, _dp, _dp, C.c_double, C.c_double, _pp]),
     "lk_linop_gl_create": (_int, [_p, _i64, C.c_double, C.c_double, _int, _dp, _dp, C.c_double, C.c_double, _pp]),
     "lk_linop_destroy": (_int, [_p]),
     "lk_linop_apply": (_int, [_p, _int, _p, _int, _p, _int]),

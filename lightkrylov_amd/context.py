@@ -130,6 +130,12 @@ class Context:
         _capi.check(self._lib.lk_comm_destroy(self._h))
         self.nranks, self.rank = 1, 0
 
+    def set_halo_exchange(self, fn) -> None:
+        """Install a host-provided nearest-neighbour exchange (`_capi.HALO_FN`) for the stencil operators; the native
+        communicator installs its own (ncclSend / ncclRecv)."""
+        self._halo_cb = fn
+        _capi.check(self._lib.lk_set_halo_exchange(self._h, fn, None))
+
     def set_partition(self, row0: int, n_global: int) -> None:
         _capi.check(self._lib.lk_set_partition(self._h, int(row0), int(n_global)))
         self.row0, self.n_global = int(row0), int(n_global)

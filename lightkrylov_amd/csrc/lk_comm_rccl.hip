@@ -28,11 +28,15 @@ struct Rccl {
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
 };
 static_assert(sizeof(ncclUniqueId) == LK_COMM_ID_BYTES, "LK_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
 Rccl g_rccl;
 std::mutex g_mu;
-struct CommState { ncclComm_t comm; };
+struct CommState { ncclComm_t comm; int nranks, rank; };
 std::map<lk_context_t, CommState *> g_comms;
 
 int load_rccl() {
@@ -50,7 +54,12 @@ int load_rccl() {
     g_rccl.comm_destroy = (decltype(g_rccl.comm_destroy))dlsym(h, "ncclCommDestroy");
     g_rccl.all_reduce = (decltype(g_rccl.all_reduce))dlsym(h, "ncclAllReduce");
     g_rccl.error_string = (decltype(g_rccl.error_string))dlsym(h, "ncclGetErrorString");
-    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce)
+    g_rccl.send = (decltype(g_rccl.send))dlsym(h, "ncclSend");
+    g_rccl.recv = (decltype(g_rccl.recv))dlsym(h, "ncclRecv");
+    g_rccl.group_start = (decltype(g_rccl.group_start))dlsym(h, "ncclGroupStart");
+    g_rccl.group_end = (decltype(g_rccl.group_end))dlsym(h, "ncclGroupEnd");
+    if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce || !g_rccl.send ||
+        !g_rccl.recv || !g_rccl.group_start || !g_rccl.group_end)
         return lk_fail_(LK_ERR_COMM, "lk_comm: librccl lacks a required symbol");
     g_rccl.handle = h;
     return LK_OK;
@@ -61,6 +70,19 @@ const char *errstr(ncclResult_t rc) { return g_rccl.error_string ? g_rccl.error_
 int rccl_sum(void *user, void *dev_buf, int64_t count, void *stream) {
     CommState *st = (CommState *)user;
     return g_rccl.all_reduce(dev_buf, dev_buf, (size_t)count, ncclDouble, ncclSum, st->comm, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+}
+
+// one grid line / one point to and from the ranks that own the neighbouring row blocks
+int rccl_halo(void *user, const void *send_lo, const void *send_hi, void *recv_lo, void *recv_hi, int64_t count, void *stream) {
+    CommState *st = (CommState *)user;
+    hipStream_t s = (hipStream_t)stream;
+    bool ok = g_rccl.group_start() == ncclSuccess;
+    if (send_lo && st->rank > 0) ok = ok && g_rccl.send(send_lo, (size_t)count, ncclDouble, st->rank - 1, st->comm, s) == ncclSuccess;
+    if (recv_lo && st->rank > 0) ok = ok && g_rccl.recv(recv_lo, (size_t)count, ncclDouble, st->rank - 1, st->comm, s) == ncclSuccess;
+    if (send_hi && st->rank + 1 < st->nranks) ok = ok && g_rccl.send(send_hi, (size_t)count, ncclDouble, st->rank + 1, st->comm, s) == ncclSuccess;
+    if (recv_hi && st->rank + 1 < st->nranks) ok = ok && g_rccl.recv(recv_hi, (size_t)count, ncclDouble, st->rank + 1, st->comm, s) == ncclSuccess;
+    ok = (g_rccl.group_end() == ncclSuccess) && ok;
+    return ok ? 0 : 1;
 }
 
 }  // namespace
@@ -95,8 +117,9 @@ int lk_comm_init_rank(lk_context_t ctx, int nranks, int rank, const void *id) {
     ncclComm_t comm = nullptr;
     const ncclResult_t nrc = g_rccl.comm_init_rank(&comm, nranks, uid, rank);
     if (nrc != ncclSuccess) return lk_fail_(LK_ERR_COMM, "ncclCommInitRank(%d/%d) failed: %s", rank, nranks, errstr(nrc));
-    CommState *st = new CommState{comm};
+    CommState *st = new CommState{comm, nranks, rank};
     rc = lk_set_allreduce(ctx, rccl_sum, st, nranks, rank);
+    if (rc == LK_OK) rc = lk_set_halo_exchange(ctx, rccl_halo, st);
     if (rc != LK_OK) {
         (void)g_rccl.comm_destroy(comm);
         delete st;
@@ -113,6 +136,7 @@ int lk_comm_destroy(lk_context_t ctx) {
     if (it == g_comms.end()) return LK_OK;
     (void)lk_sync(ctx);
     (void)lk_set_allreduce(ctx, nullptr, nullptr, 1, 0);
+    (void)lk_set_halo_exchange(ctx, nullptr, nullptr);
     const ncclResult_t nrc = g_rccl.comm_destroy(it->second->comm);
     delete it->second;
     g_comms.erase(it);

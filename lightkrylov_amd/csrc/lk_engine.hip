@@ -85,6 +85,8 @@ struct lk_context_s {
     // communication
     lk_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
+    lk_halo_fn halo = nullptr;
+    void *halo_user = nullptr;
     int nranks = 1, rank = 0;
     int64_t row0 = 0, n_global = -1;  // this rank's row block [row0, row0 + n_local) of n_global rows
     // lazy batching of the PER-OBJECT path (opt-in, tuning key "lazy"): what an unchanged LightKrylov drives
@@ -163,6 +165,12 @@ struct lk_linop_s {
     double tau = 0;
     int nsub = 1;
     double *wk = nullptr; // 3 work vectors (k_a, k_b, u_sub)
+    // row-sharded stencil operators
+    int64_t NJ = 0;            // lap5: grid lines held by this rank
+    int64_t n_global = 0;      // GL: global rows
+    bool has_lo = false, has_hi = false;   // a neighbouring rank below / above this block
+    double *halo = nullptr;    // lap5: 2 N doubles (line from rank-1 | line from rank+1); GL: 4 doubles
+    double *edges = nullptr;   // GL: this rank's two edge values (send buffer), 4 doubles
 };
 
 namespace {
@@ -1366,32 +1374,68 @@ int lk_linop_dense_create(lk_context_t c, int dtype, int64_t n, const void *A_ho
     return LK_OK;
 }
 
-int lk_linop_lap5_create(lk_context_t c, int64_t N, lk_linop_t *op) {
-    if (!c || !op || N < 1) return fail(LK_ERR_INVALID, "lk_linop_lap5_create: bad argument");
-    if (c->nranks > 1) return fail(LK_ERR_INVALID, "lap5 operator is single-rank only");
+static int halo_exchange(lk_context_t c, const double *send_lo, const double *send_hi, double *recv_lo, double *recv_hi, int64_t count) {
+    if (!c->halo) return fail(LK_ERR_COMM, "row-sharded stencil operator but no halo exchange installed (lk_comm_init_rank / lk_set_halo_exchange)");
+    const int rc = c->halo(c->halo_user, send_lo, send_hi, recv_lo, recv_hi, count, (void *)c->stream);
+    if (rc != 0) return fail(LK_ERR_COMM, "halo exchange callback returned %d", rc);
+    return LK_OK;
+}
+
+int lk_set_halo_exchange(lk_context_t c, lk_halo_fn fn, void *user) {
+    if (!c) return fail(LK_ERR_INVALID, "lk_set_halo_exchange: null context");
+    c->halo = fn;
+    c->halo_user = user;
+    return LK_OK;
+}
+
+int lk_linop_lap5_create_sharded(lk_context_t c, int64_t N, int64_t j0, int64_t nj, lk_linop_t *op) {
+    if (!c || !op || N < 1 || j0 < 0 || nj < 1 || j0 + nj > N) return fail(LK_ERR_INVALID, "lk_linop_lap5_create: bad argument");
+    DevGuard dev_guard(c);
     lk_linop_t o = new lk_linop_s();
-    o->ctx = c; o->kind = OP_LAP5; o->dtype = LK_F64; o->n = N * N; o->N = N;
+    o->ctx = c; o->kind = OP_LAP5; o->dtype = LK_F64; o->n = nj * N; o->N = N; o->NJ = nj;
+    o->has_lo = j0 > 0; o->has_hi = j0 + nj < N;
+    if (o->has_lo || o->has_hi) {
+        hipError_t e = hipMalloc((void **)&o->halo, (size_t)2 * N * sizeof(double));
+        if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    }
+    *op = o;
+    return LK_OK;
+}
+
+int lk_linop_lap5_create(lk_context_t c, int64_t N, lk_linop_t *op) {
+    if (c && c->nranks > 1) return fail(LK_ERR_INVALID, "lap5 over several ranks: use lk_linop_lap5_create_sharded (grid lines per rank)");
+    return lk_linop_lap5_create_sharded(c, N, 0, N, op);
+}
+
+int lk_linop_gl_create_sharded(lk_context_t c, int64_t n_global, int64_t row0, int64_t n_local, double dx, double tau, int nsub,
+                               const double *nu, const double *gamma, double mu_c, double mu2, lk_linop_t *op) {
+    if (!c || !op || !nu || !gamma || n_global < 1 || n_local < 1 || row0 < 0 || row0 + n_local > n_global || nsub < 1 || !(dx > 0.0))
+        return fail(LK_ERR_INVALID, "lk_linop_gl_create: bad argument");
+    DevGuard dev_guard(c);
+    lk_linop_t o = new lk_linop_s();
+    o->ctx = c; o->kind = OP_GL; o->dtype = LK_C128; o->n = n_local; o->tau = tau; o->nsub = nsub;
+    o->row0 = row0; o->n_global = n_global;
+    o->has_lo = row0 > 0; o->has_hi = row0 + n_local < n_global;
+    o->gl[0] = dx; o->gl[1] = 0.5 * dx * (double)(n_global + 1);   // L = dx (n+1), x = linspace(-L/2, L/2, n+2)
+    o->gl[2] = nu[0]; o->gl[3] = nu[1]; o->gl[4] = gamma[0]; o->gl[5] = gamma[1]; o->gl[6] = mu_c; o->gl[7] = mu2;
+    hipError_t e = hipMalloc((void **)&o->wk, ((size_t)3 * n_local * 2 + 8) * sizeof(double));
+    if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    o->halo = o->wk + (size_t)6 * n_local;      // 4 doubles
+    o->edges = o->halo + 4;                     // 4 doubles
+    (void)hipMemsetAsync(o->halo, 0, 8 * sizeof(double), c->stream);
     *op = o;
     return LK_OK;
 }
 
 int lk_linop_gl_create(lk_context_t c, int64_t n, double dx, double tau, int nsub, const double *nu, const double *gamma,
                        double mu_c, double mu2, lk_linop_t *op) {
-    if (!c || !op || !nu || !gamma || n < 1 || nsub < 1 || !(dx > 0.0)) return fail(LK_ERR_INVALID, "lk_linop_gl_create: bad argument");
-    DevGuard dev_guard(c);
-    if (c->nranks > 1) return fail(LK_ERR_INVALID, "Ginzburg-Landau operator is single-rank only");
-    lk_linop_t o = new lk_linop_s();
-    o->ctx = c; o->kind = OP_GL; o->dtype = LK_C128; o->n = n; o->tau = tau; o->nsub = nsub;
-    o->gl[0] = dx; o->gl[1] = 0.5 * dx * (double)(n + 1);   // L = dx (n+1), x = linspace(-L/2, L/2, n+2)
-    o->gl[2] = nu[0]; o->gl[3] = nu[1]; o->gl[4] = gamma[0]; o->gl[5] = gamma[1]; o->gl[6] = mu_c; o->gl[7] = mu2;
-    hipError_t e = hipMalloc((void **)&o->wk, (size_t)3 * n * 2 * sizeof(double));
-    if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
-    *op = o;
-    return LK_OK;
+    if (c && c->nranks > 1) return fail(LK_ERR_INVALID, "Ginzburg-Landau operator over several ranks: use lk_linop_gl_create_sharded");
+    return lk_linop_gl_create_sharded(c, n, 0, n, dx, tau, nsub, nu, gamma, mu_c, mu2, op);
 }
 
 int lk_linop_destroy(lk_linop_t op) {
     if (!op) return LK_OK;
+    if (op->kind == OP_LAP5 && op->halo) (void)hipFree(op->halo);
     if (op->wk) (void)hipFree(op->wk);
     if (op->dev) (void)hipFree(op->dev);  // synchronises; the context may already be finalized
     delete op;
@@ -1443,8 +1487,18 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
         for (int sstep = 0; sstep < op->nsub; ++sstep) {
             // outputs alternate between the work vector and y so that the LAST sub-step lands in y
             double *uout = ((op->nsub - 1 - sstep) % 2 == 0) ? y : us;
-#define GL_STAGE(KPREV, A, KOUT, B, FIRST) \
-            hipLaunchKernelGGL(k_gl_stage, dim3(grid), dim3(256), 0, c->stream, uin, KPREV, A, KOUT, uout, B, FIRST, n, g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], adj, c->guard())
+            const bool sharded = op->has_lo || op->has_hi;
+            const double *halo = sharded ? op->halo : nullptr;
+#define GL_STAGE(KPREV, A, KOUT, B, FIRST)                                                                                    \
+            do {                                                                                                                   \
+                if (sharded) {   /* the stage needs v = u + a*kprev one point beyond either end of this rank's block */          \
+                    hipLaunchKernelGGL(k_gl_edges, dim3(1), dim3(64), 0, c->stream, uin, KPREV, A, n, op->edges, c->guard());      \
+                    LKCHK(halo_exchange(c, op->has_lo ? op->edges : nullptr, op->has_hi ? op->edges + 2 : nullptr,                \
+                                        op->has_lo ? op->halo : nullptr, op->has_hi ? op->halo + 2 : nullptr, 2));               \
+                }                                                                                                                  \
+                hipLaunchKernelGGL(k_gl_stage, dim3(grid), dim3(256), 0, c->stream, uin, KPREV, A, KOUT, uout, B, FIRST, n, g[0], g[1], \
+                                   g[2], g[3], g[4], g[5], g[6], g[7], adj, op->row0, op->n_global, halo, c->guard());            \
+            } while (0)
             GL_STAGE((const double *)nullptr, 0.0, ka, dt / 6.0, 1);
             GL_STAGE((const double *)ka, 0.5 * dt, kb, dt / 3.0, 0);
             GL_STAGE((const double *)kb, 0.5 * dt, ka, dt / 3.0, 0);
@@ -1455,10 +1509,18 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
         break;
     }
     case OP_LAP5: {
-        const int64_t N = op->N;
+        const int64_t N = op->N, NJ = op->NJ;
         const double s = (double)(N + 1) * (double)(N + 1);
-        dim3 grid((unsigned)((N / 2 + 1 + 255) / 256), (unsigned)N);
-        hipLaunchKernelGGL(k_lap5, grid, dim3(256), 0, c->stream, x, y, N, s, c->guard());
+        const double *lo = nullptr, *hi = nullptr;
+        if (op->has_lo || op->has_hi) {
+            // first / last local grid line to the neighbouring ranks, theirs into the halo buffer (N doubles each)
+            lo = op->has_lo ? op->halo : nullptr;
+            hi = op->has_hi ? op->halo + N : nullptr;
+            LKCHK(halo_exchange(c, op->has_lo ? x : nullptr, op->has_hi ? x + (NJ - 1) * N : nullptr, op->has_lo ? op->halo : nullptr,
+                                op->has_hi ? op->halo + N : nullptr, N));
+        }
+        dim3 grid((unsigned)((N / 2 + 1 + 255) / 256), (unsigned)NJ);
+        hipLaunchKernelGGL(k_lap5, grid, dim3(256), 0, c->stream, x, y, N, NJ, lo, hi, s, c->guard());
         break;
     }
     }

@@ -938,8 +938,11 @@ __global__ __launch_bounds__(256) void k_gemv_h(const double *__restrict__ A, in
 
 // 5-point Laplacian, N x N grid, Dirichlet, scale s = (N+1)^2.  One thread per 2 grid points
 // along the fast index; neighbours come from L1/L2 (each row is re-used by 3 stencil rows).
-__global__ __launch_bounds__(256) void k_lap5(const double *__restrict__ u, double *__restrict__ v, int64_t N,
-                                              double s, Guard guard) {
+// Row-sharded: this rank holds NJ consecutive grid lines; `lo` / `hi` are the neighbouring ranks' boundary lines
+// (N doubles each, delivered by the halo exchange) or NULL where the global Dirichlet boundary is.
+__global__ __launch_bounds__(256) void k_lap5(const double *__restrict__ u, double *__restrict__ v, int64_t N, int64_t NJ,
+                                              const double *__restrict__ lo, const double *__restrict__ hi, double s,
+                                              Guard guard) {
     if (stopped(guard)) return;
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     const int64_t j = blockIdx.y;
@@ -953,7 +956,9 @@ __global__ __launch_bounds__(256) void k_lap5(const double *__restrict__ u, doub
     a1 -= c0;
     if (i + 2 < N) a1 -= u[c + 2];
     if (j > 0) { a0 -= u[c - N]; if (two) a1 -= u[c + 1 - N]; }
-    if (j < N - 1) { a0 -= u[c + N]; if (two) a1 -= u[c + 1 + N]; }
+    else if (lo) { a0 -= lo[i]; if (two) a1 -= lo[i + 1]; }
+    if (j < NJ - 1) { a0 -= u[c + N]; if (two) a1 -= u[c + 1 + N]; }
+    else if (hi) { a0 -= hi[i]; if (two) a1 -= hi[i + 1]; }
     v[c] = s * a0;
     if (two) v[c + 1] = s * a1;
 }
@@ -967,13 +972,20 @@ __global__ __launch_bounds__(256) void k_gl_stage(const double *__restrict__ u, 
                                                   double a, double *__restrict__ kout, double *__restrict__ acc,
                                                   double b, int first, int64_t n, double dx, double halfL,
                                                   double nu_re, double nu_im, double ga_re, double ga_im,
-                                                  double mu_c, double mu2, int adjoint, Guard guard) {
+                                                  double mu_c, double mu2, int adjoint, int64_t row0, int64_t n_global,
+                                                  const double *__restrict__ halo, Guard guard) {
+    // n = LOCAL rows [row0, row0 + n) of n_global; halo = {v(row0 - 1), v(row0 + n)} (2 complex) from the neighbouring
+    // ranks when the block does not touch the global boundary (NULL for a single rank).
     if (stopped(guard)) return;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 0-based; reference index i+1
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // 0-based local; reference index row0 + i + 1
     if (i >= n) return;
+    const int64_t gi = row0 + i;
     const v2d *uv = reinterpret_cast<const v2d *>(u);
     const v2d *kv = reinterpret_cast<const v2d *>(kprev);
+    const v2d *hv = reinterpret_cast<const v2d *>(halo);
     auto val = [&](int64_t j) -> v2d {
+        if (j < 0) return hv[0];
+        if (j >= n) return hv[1];
         v2d r = uv[j];
         if (kprev) r += kv[j] * a;
         return r;
@@ -981,15 +993,15 @@ __global__ __launch_bounds__(256) void k_gl_stage(const double *__restrict__ u, 
     const v2d c = val(i);
     v2d cu, d2u;
     const double inv2dx = 1.0 / (2.0 * dx), invdx2 = 1.0 / (dx * dx);
-    if (n == 1) {
+    if (n_global == 1) {
         cu = v2d{0.0, 0.0};
         d2u = c * (-2.0) * invdx2;
-    } else if (i == 0) {
-        const v2d r = val(1);
+    } else if (gi == 0) {
+        const v2d r = val(i + 1);
         cu = r * inv2dx;
         d2u = (r - c * 2.0) * invdx2;
-    } else if (i == n - 1) {
-        const v2d l = val(n - 2);
+    } else if (gi == n_global - 1) {
+        const v2d l = val(i - 1);
         cu = l * (-inv2dx);
         d2u = (c * (-2.0) + l) * inv2dx;          // sic: the reference divides this row by 2*dx
     } else {
@@ -997,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_gl_stage(const double *__restrict__ u, 
         cu = (r - l) * inv2dx;
         d2u = (r - c * 2.0 + l) * invdx2;
     }
-    const double x = -halfL + (double)(i + 1) * dx;
+    const double x = -halfL + (double)(gi + 1) * dx;
     const double mu = mu_c + 0.5 * mu2 * x * x;
     v2d f;
     if (adjoint) f = cmul(v2d{nu_re, -nu_im}, cu) + cmul(v2d{ga_re, -ga_im}, d2u) + c * mu;
@@ -1005,6 +1017,17 @@ __global__ __launch_bounds__(256) void k_gl_stage(const double *__restrict__ u, 
     reinterpret_cast<v2d *>(kout)[i] = f;
     v2d *av = reinterpret_cast<v2d *>(acc);
     av[i] = (first ? uv[i] : av[i]) + f * b;
+}
+
+// the two edge values v = u + a*kprev of this rank's block, for the halo exchange of the next stage
+__global__ void k_gl_edges(const double *__restrict__ u, const double *__restrict__ kprev, double a, int64_t n,
+                           double *__restrict__ sendbuf, Guard guard) {
+    if (stopped(guard)) return;
+    if (threadIdx.x >= 2) return;
+    const int64_t j = threadIdx.x == 0 ? 0 : n - 1;
+    v2d r = reinterpret_cast<const v2d *>(u)[j];
+    if (kprev) r += reinterpret_cast<const v2d *>(kprev)[j] * a;
+    reinterpret_cast<v2d *>(sendbuf)[threadIdx.x] = r;
 }
 
 }  // namespace lk

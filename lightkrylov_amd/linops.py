@@ -178,15 +178,30 @@ class diag_linop_gpu(_engine_linop):
 
 
 class laplacian2d_linop_gpu(_engine_linop):
-    """5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (config 3, Poisson)."""
+    """5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (config 3, Poisson).
+    Row-sharded runs pass the grid lines this rank owns (`j0`, `nj`, see `grid_partition`): vector rows
+    [j0*N, (j0+nj)*N); one line is exchanged with each neighbouring rank per application (halo exchange)."""
 
-    def __init__(self, N: int, ctx: Context | None = None):
+    def __init__(self, N: int, ctx: Context | None = None, j0: int | None = None, nj: int | None = None):
         super().__init__(ctx)
-        self.dtype, self.n, self.N = np.dtype(np.float64), N * N, N
-        _capi.check(self._lib.lk_linop_lap5_create(self.ctx._h, int(N), C.byref(self._h)))
+        self.N = int(N)
+        if j0 is None:
+            self.dtype, self.n = np.dtype(np.float64), N * N
+            _capi.check(self._lib.lk_linop_lap5_create(self.ctx._h, int(N), C.byref(self._h)))
+        else:
+            self.dtype, self.n = np.dtype(np.float64), int(nj) * N
+            _capi.check(self._lib.lk_linop_lap5_create_sharded(self.ctx._h, int(N), int(j0), int(nj), C.byref(self._h)))
 
     def rmatvec(self, vec_in, vec_out) -> None:  # symmetric
         self._apply(_capi.LK_OP_N, vec_in, vec_out)
+
+
+def grid_partition(N: int, nranks: int, rank: int):
+    """Grid lines [j0, j0 + nj) of an N x N grid owned by `rank` (whole lines, so a rank's vector block is nj*N rows)."""
+    base = N // nranks
+    j0 = base * rank
+    nj = base if rank < nranks - 1 else N - base * (nranks - 1)
+    return j0, nj
 
 
 class ginzburg_landau_linop_gpu(_engine_linop):
@@ -198,13 +213,22 @@ class ginzburg_landau_linop_gpu(_engine_linop):
 
     def __init__(self, n: int, ctx: Context | None = None, tau: float = 0.01, nsub: int = 1,
                  nu: complex = 2.0 + 0.2j, gamma: complex = 1.0 - 1.0j, mu_0: float = 0.38, c_mu: float = 0.2,
-                 mu_2: float | None = None, dx: float = 200.0 / 513.0):
+                 mu_2: float | None = None, dx: float = 200.0 / 513.0, row0: int | None = None, n_local: int | None = None):
+        """`n` is the GLOBAL size; row-sharded runs also pass this rank's block (`row0`, `n_local`) -- every RK4 stage then
+        exchanges one point with each neighbouring rank (halo exchange)."""
         super().__init__(ctx)
-        self.dtype, self.n = np.dtype(np.complex128), int(n)
-        L = dx * (n + 1)
+        n_global = int(n)
+        self.dtype = np.dtype(np.complex128)
+        self.n = n_global if n_local is None else int(n_local)
+        L = dx * (n_global + 1)
         self.mu_2 = -0.01 * (200.0 / L) ** 2 if mu_2 is None else mu_2
-        self.params = dict(n=self.n, dx=dx, tau=tau, nsub=nsub, nu=nu, gamma=gamma, mu_c=mu_0 - c_mu ** 2, mu2=self.mu_2)
+        self.params = dict(n=n_global, dx=dx, tau=tau, nsub=nsub, nu=nu, gamma=gamma, mu_c=mu_0 - c_mu ** 2, mu2=self.mu_2)
         nu_a = (C.c_double * 2)(nu.real, nu.imag)
         ga_a = (C.c_double * 2)(gamma.real, gamma.imag)
-        _capi.check(self._lib.lk_linop_gl_create(self.ctx._h, self.n, float(dx), float(tau), int(nsub), nu_a, ga_a,
-                                                 float(mu_0 - c_mu ** 2), float(self.mu_2), C.byref(self._h)))
+        if row0 is None:
+            _capi.check(self._lib.lk_linop_gl_create(self.ctx._h, n_global, float(dx), float(tau), int(nsub), nu_a, ga_a,
+                                                     float(mu_0 - c_mu ** 2), float(self.mu_2), C.byref(self._h)))
+        else:
+            _capi.check(self._lib.lk_linop_gl_create_sharded(self.ctx._h, n_global, int(row0), int(self.n), float(dx), float(tau),
+                                                             int(nsub), nu_a, ga_a, float(mu_0 - c_mu ** 2), float(self.mu_2),
+                                                             C.byref(self._h)))

@@ -139,3 +139,147 @@ def test_sharded_blas1_and_gmres(ctx):
         assert np.abs(hist - np.array(meta.res)).max() <= 1e-12 * meta.res[0]
     xs = np.concatenate([r[3] for r in res])
     assert np.abs(xs - x.to_array()).max() <= 1e-12 * np.abs(x.to_array()).max()
+
+
+# ----------------------------------------------------------------------------- stencil operators with a halo exchange
+class _EmulatedHalo:
+    """Nearest-neighbour exchange between `nranks` threads (lk_halo_fn): what ncclSend / ncclRecv do on a real node."""
+
+    def __init__(self, nranks):
+        import torch
+        self.torch = torch
+        self.n = nranks
+        self.barrier = threading.Barrier(nranks)
+        self.sends = [None] * nranks
+        self.calls = 0
+
+    def hook(self, rank, ctx):
+        torch = self.torch
+
+        def view(ptr, count):
+            return torch.as_tensor(_DevMem(int(ptr), int(count)), device="cuda:0") if ptr else None
+
+        def _cb(_user, send_lo, send_hi, recv_lo, recv_hi, count, _stream):
+            try:
+                ctx.sync_stream_only()
+                self.sends[rank] = (view(send_lo, count), view(send_hi, count))
+                self.barrier.wait(timeout=120)
+                if recv_lo:
+                    view(recv_lo, count).copy_(self.sends[rank - 1][1])      # rank-1's send_hi
+                if recv_hi:
+                    view(recv_hi, count).copy_(self.sends[rank + 1][0])      # rank+1's send_lo
+                torch.cuda.synchronize()
+                if rank == 0:
+                    self.calls += 1
+                self.barrier.wait(timeout=120)
+                return 0
+            except Exception as exc:  # noqa: BLE001
+                print("emulated halo exchange failed:", repr(exc))
+                self.barrier.abort()
+                return 1
+        return _capi.HALO_FN(_cb)
+
+
+def _sharded_with_halo(nranks, body):
+    lib = _capi.load()
+    grp, halo = _EmulatedGroup(nranks), _EmulatedHalo(nranks)
+    out, errs = [None] * nranks, []
+
+    def worker(rank):
+        try:
+            ctx = lk.Context(device=0, use_torch_stream=False)
+            ctx.sync_stream_only = lambda: _capi.check(lib.lk_sync(ctx._h))
+            cb = grp.hook(rank, ctx)
+            _capi.check(lib.lk_set_allreduce(ctx._h, cb, None, nranks, rank))
+            ctx._cb, ctx.nranks, ctx.rank = cb, nranks, rank
+            ctx.set_halo_exchange(halo.hook(rank, ctx))
+            out[rank] = body(rank, ctx)
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+            grp.barrier.abort(); halo.barrier.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errs, errs
+    return out, halo
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_laplacian_matvec_and_gmres(ctx, nranks):
+    """BASELINE config 3's operator row-sharded by grid lines: matvec and a GMRES cycle reproduce the single-context run."""
+    N = 151
+    n = N * N
+    b_full = np.empty(n); from oracle import oracle as ora; ora.fill_counter(b_full, 11)
+
+    def body(rank, c):
+        j0, nj = lk.grid_partition(N, nranks, rank)
+        c.set_partition(j0 * N, n)
+        A = lk.laplacian2d_linop_gpu(N, c, j0=j0, nj=nj)
+        b = lk.dense_vector_gpu.from_array(b_full[j0 * N:(j0 + nj) * N], c)
+        y = b.zeros_like()
+        A.apply_matvec(b, y)
+        x = b.zeros_like()
+        meta = lk.gmres_dp_metadata()
+        info = lk.gmres(A, b, x, rtol=1e-8, options=lk.gmres_dp_opts(kdim=20, maxiter=1), meta=meta)
+        return y.to_array(), x.to_array(), info, np.array(meta.res)
+
+    res, halo = _sharded_with_halo(nranks, body)
+    A1 = lk.laplacian2d_linop_gpu(N, ctx)
+    b1 = lk.dense_vector_gpu.from_array(b_full, ctx)
+    y1 = b1.zeros_like(); A1.apply_matvec(b1, y1)
+    ys = np.concatenate([r[0] for r in res])
+    assert np.array_equal(ys, y1.to_array())                        # same arithmetic per point: bit-identical
+    assert np.abs(ys - ora_lap5(N, b_full)).max() <= 1e-12 * np.abs(ys).max()
+    x1 = b1.zeros_like(); m1 = lk.gmres_dp_metadata()
+    info1 = lk.gmres(A1, b1, x1, rtol=1e-8, options=lk.gmres_dp_opts(kdim=20, maxiter=1), meta=m1)
+    xs = np.concatenate([r[1] for r in res])
+    assert all(r[2] == info1 for r in res)
+    assert np.abs(res[0][3] - np.array(m1.res)).max() <= 1e-12 * m1.res[0]
+    assert np.abs(xs - x1.to_array()).max() <= 1e-11 * np.abs(x1.to_array()).max()
+    assert halo.calls >= 20
+
+
+def ora_lap5(N, u):
+    from oracle import oracle as ora
+    v = np.empty_like(u)
+    ora.Lap5Op(N).matvec(u, v)
+    return v
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_ginzburg_landau_stepper_and_arnoldi(ctx, nranks):
+    """BASELINE config 4's operator row-sharded: one point per RK4 stage crosses each rank boundary; the propagator, its
+    adjoint and an Arnoldi factorisation reproduce the single-context run."""
+    n, m = 30_001, 12
+    x_full = np.empty(n, dtype=np.complex128); from oracle import oracle as ora; ora.fill_counter(x_full, 13)
+    x_full /= np.linalg.norm(x_full)
+
+    def body(rank, c):
+        row0, nl = lk.row_partition(n, nranks, rank)
+        c.set_partition(row0, n)
+        A = lk.ginzburg_landau_linop_gpu(n, c, tau=0.05, nsub=2, row0=row0, n_local=nl)
+        v = lk.dense_vector_gpu.from_array(x_full[row0:row0 + nl], c)
+        w = v.zeros_like(); wt = v.zeros_like()
+        A.apply_matvec(v, w); A.apply_rmatvec(v, wt)
+        X = lk.krylov_basis_gpu(nl, m + 1, np.complex128, c)
+        X.upload(x_full[row0:row0 + nl].reshape(-1, 1), 0)
+        H = np.zeros((m + 1, m), dtype=np.complex128, order="F")
+        info = lk.arnoldi(A, X, H)
+        return w.to_array(), wt.to_array(), info, H
+
+    res, halo = _sharded_with_halo(nranks, body)
+    A1 = lk.ginzburg_landau_linop_gpu(n, ctx, tau=0.05, nsub=2)
+    v1 = lk.dense_vector_gpu.from_array(x_full, ctx)
+    w1 = v1.zeros_like(); wt1 = v1.zeros_like()
+    A1.apply_matvec(v1, w1); A1.apply_rmatvec(v1, wt1)
+    assert np.array_equal(np.concatenate([r[0] for r in res]), w1.to_array())
+    assert np.array_equal(np.concatenate([r[1] for r in res]), wt1.to_array())
+    X1 = lk.krylov_basis_gpu(n, m + 1, np.complex128, ctx); X1.upload(x_full.reshape(-1, 1), 0)
+    H1 = np.zeros((m + 1, m), dtype=np.complex128, order="F")
+    assert lk.arnoldi(A1, X1, H1) == 0
+    for info, H in ((r[2], r[3]) for r in res):
+        assert info == 0
+        for j in range(m):
+            assert np.abs(H[:, j] - H1[:, j]).max() <= 1e-12 * np.abs(H1[:, j]).max()
+    assert halo.calls >= 8 * 2 * (m + 2)                          # 4 stages x 2 sub-steps per application

@@ -163,6 +163,10 @@ int lk_linop_lap5_create(mock_ctx *c, int64_t N, mock_op **op) { (void)c; (void)
 int lk_linop_gl_create(mock_ctx *c, int64_t n, double dx, double tau, int nsub, const double *nu, const double *ga, double mc, double m2, mock_op **op) {
     (void)c; (void)n; (void)dx; (void)tau; (void)nsub; (void)nu; (void)ga; (void)mc; (void)m2; (void)op; return fail("not in the mock");
 }
+int lk_linop_lap5_create_sharded(mock_ctx *c, int64_t N, int64_t j0, int64_t nj, mock_op **op) { (void)c; (void)N; (void)j0; (void)nj; (void)op; return fail("not in the mock"); }
+int lk_linop_gl_create_sharded(mock_ctx *c, int64_t ng, int64_t r0, int64_t nl, double dx, double tau, int nsub, const double *nu, const double *ga, double mc, double m2, mock_op **op) {
+    (void)c; (void)ng; (void)r0; (void)nl; (void)dx; (void)tau; (void)nsub; (void)nu; (void)ga; (void)mc; (void)m2; (void)op; return fail("not in the mock");
+}
 int lk_linop_destroy(mock_op *o) { if (o) { free(o->a); free(o); } return LK_OK; }
 int lk_linop_apply(mock_op *o, int trans, mock_basis *bx, int jx, mock_basis *by, int jy) {
     const int64_t n = o->n;
