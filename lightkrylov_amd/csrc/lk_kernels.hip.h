@@ -574,7 +574,7 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
     constexpr int RG = CPLX ? 16 : 32;           // rows per row group (one MFMA N extent; x2 rows per lane for real)
     constexpr int NACC = CPLX ? 1 : 2;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
-    constexpr int U = (NG * (CPLX ? 1 : 2) >= 8) ? 1 : 2;   // k-steps per pipeline stage (two stages in flight; fewer when the accumulators fill the file)
+    constexpr int U = 4;                         // k-steps of X in flight per wave: 2 U loads of 16 B per lane
     extern __shared__ double tiles[];            // [NG][nt][64]
     const int nt = (k + 3) >> 2;
     for (int i = threadIdx.x; i < NG * nt * 64; i += blockDim.x) tiles[i] = Cp[i];
@@ -601,8 +601,11 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
 #pragma unroll
                 for (int e = 0; e < NACC; ++e) acc[g][g2][e] = v4d{0.0, 0.0, 0.0, 0.0};
 
-        // X operands of U k-steps starting at t0 (unguarded 16-byte loads on the fast path)
-        auto load_steps = [&](int t0, v2d (&x)[U][2]) {
+        // U k-steps per batch: 2 U loads of 16 B per lane in flight, then their MFMAs.  (A software-pipelined variant with
+        // the next batch's loads issued ahead was measured 2-18 % SLOWER: it needs smaller batches to fit the register
+        // file, and the two waves per SIMD already overlap each other's load latency.)
+        for (int t0 = 0; t0 < nt; t0 += U) {
+            v2d x[U][2];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int t = t0 + u;
@@ -619,8 +622,6 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                     }
                 }
             }
-        };
-        auto mfma_steps = [&](int t0, const v2d (&x)[U][2]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int t = t0 + u;
@@ -646,15 +647,6 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                     }
                 }
             }
-        };
-        // software pipeline: the loads of the next U k-steps are in flight while the MFMAs of the current ones issue
-        v2d xa[U][2], xb[U][2];
-        load_steps(0, xa);
-        for (int t0 = 0; t0 < nt; t0 += 2 * U) {
-            load_steps(t0 + U, xb);
-            mfma_steps(t0, xa);
-            load_steps(t0 + 2 * U, xa);
-            mfma_steps(t0 + U, xb);
         }
         // D[n = kk + 4 reg][row j] of group g
         const bool full = (tile + 1) * tile_rows <= n;
