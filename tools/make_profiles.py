@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Turn one round's rocprofv3 outputs (gpurun_out/<dir>/...) into the tracked evidence under profiles/.
+
+  python tools/make_profiles.py gpurun_out/r02p r02
+
+Expects, under the given directory (written on the GPU box by the commands recorded in the JSON this script emits):
+  stats/        rocprofv3 --kernel-trace --stats --output-format csv  -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline
+  stats.log     stdout of that run (the bench JSON line)
+  pmc_fetch/    rocprofv3 --pmc FETCH_SIZE --output-format csv        -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline
+  pmc_write/    rocprofv3 --pmc WRITE_SIZE --output-format csv        -- (same)
+  lincomb/, cfg4/ (optional)  kernel stats of tools/bench_lincomb.py and of bench.py --dtype c128 --rows 1000000
+  commit.txt    git commit of the binary that ran
+HBM traffic follows MI355X_MICROARCH.md (HBM section): separate --pmc passes; FETCH_SIZE/WRITE_SIZE are in KB; on gfx950
+FETCH_SIZE reports 1/2 of a 16-B-per-lane streaming read -> doubled (calibrated on k_scal's known read); WRITE_SIZE exact."""
+import csv, glob, json, os, shutil, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(ROOT, "profiles")
+commit = open(os.path.join(src, "commit.txt")).read().strip() if os.path.exists(os.path.join(src, "commit.txt")) else "unknown"
+
+
+def find(sub, suffix):
+    hits = glob.glob(os.path.join(src, sub, "**", "*" + suffix), recursive=True)
+    return hits[0] if hits else None
+
+
+def bench_line(log):
+    if not os.path.exists(log):
+        return None
+    lines = [ln for ln in open(log) if ln.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+def counter_sums(path, counter):
+    agg = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = r["Kernel_Name"]
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return agg
+
+
+rec = {"commit": commit, "generated_by": "tools/make_profiles.py " + " ".join(sys.argv[1:])}
+st = find("stats", "kernel_stats.csv")
+if st:
+    shutil.copy(st, os.path.join(out, f"{tag}_bench_n1e8_m128_kernel_stats.csv"))
+b = bench_line(os.path.join(src, "stats.log"))
+if b:
+    b["profiled_with"] = "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+    b["commit"] = commit
+    json.dump(b, open(os.path.join(out, f"{tag}_bench_n1e8_m128.json"), "w"), indent=1)
+for sub, name in (("lincomb", "lincomb"), ("cfg4", "cfg4_c128_n1e6_m128")):
+    f = find(sub, "kernel_stats.csv")
+    if f:
+        shutil.copy(f, os.path.join(out, f"{tag}_{name}_kernel_stats.csv"))
+    lg = os.path.join(src, sub + ".log")
+    if os.path.exists(lg):
+        lines = [ln for ln in open(lg) if ln.startswith("{")]
+        if lines:
+            open(os.path.join(out, f"{tag}_{name}.jsonl"), "w").write(json.dumps({"commit": commit}) + "\n" + "".join(lines))
+
+ff, fw = find("pmc_fetch", "counter_collection.csv"), find("pmc_write", "counter_collection.csv")
+if ff and fw:
+    fetch, write = counter_sums(ff, "FETCH_SIZE"), counter_sums(fw, "WRITE_SIZE")
+    pb = bench_line(os.path.join(src, "pmc_fetch.log")) or {}
+    n_local = pb.get("config", {}).get("n_local", 100_000_000)
+    m = pb.get("config", {}).get("m", 128)
+    sweeps = [k for k in fetch if "panel_sweep" in k]
+    launches = sum(fetch[k][0] for k in sweeps)
+    # calibration of the gfx950 FETCH_SIZE halving on a kernel with a known read: k_scal reads n doubles
+    scal = [k for k in fetch if "k_scal" in k]
+    calib = None
+    if scal:
+        cnt, kb = fetch[scal[0]]
+        calib = (8.0 * n_local) / (kb / cnt * 1024.0)
+    fetch_b = sum(fetch[k][1] for k in sweeps) * 1024.0 * 2.0 / max(launches, 1)
+    write_b = sum(write[k][1] for k in write if "panel_sweep" in k) * 1024.0 / max(launches, 1)
+    alg = 8.0 * n_local * sum(3 * k + 5 for k in range(1, m + 1)) / (3.0 * m)
+    must = 8.0 * n_local * sum(3 * k + 4 for k in range(1, m + 1)) / (3.0 * m)
+    pm = {
+        "commit": commit, "n_local": n_local, "m": m, "dtype": "f64",
+        "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+        "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+        "method": "separate --pmc passes; KB units; FETCH_SIZE doubled (gfx950 reports 1/2 of a 16 B/lane streaming read, MI355X_MICROARCH.md); "
+                  "WRITE_SIZE exact; per launch = sum over the three panel_sweep instantiations / their launch count",
+        "fetch_calibration_on_k_scal(expected 2.0)": calib,
+        "sweep_launches": launches,
+        "fetch_bytes_per_launch_corrected": fetch_b, "write_bytes_per_launch": write_b,
+        "hbm_bytes_per_launch": fetch_b + write_b,
+        "algorithmic_bytes_per_launch": alg, "bytes_per_launch_this_schedule_must_move": must,
+        "traffic_over_algorithmic": (fetch_b + write_b) / alg, "traffic_over_must_move": (fetch_b + write_b) / must,
+        "per_kernel": [{"kernel": k[:80], "counter": c, "launches": v[0], "sum_KB": v[1]}
+                       for c, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)) for k, v in sorted(d.items())],
+    }
+    json.dump(pm, open(os.path.join(out, f"{tag}_pmc_n1e8_m128.json"), "w"), indent=1)
+    json.dump({"n_local": n_local, "m": m, "dtype": "f64", "hbm_bytes_per_launch": fetch_b + write_b,
+               "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_b + write_b) / alg,
+               "commit": commit, "source": f"profiles/{tag}_pmc_n1e8_m128.json", "method": pm["method"]},
+              open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    rec["pmc"] = {"traffic_over_algorithmic": pm["traffic_over_algorithmic"], "calibration": calib}
+print(json.dumps(rec))
