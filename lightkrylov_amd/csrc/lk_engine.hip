@@ -176,8 +176,9 @@ struct lk_linop_s {
 namespace {
 
 constexpr int RED_SECTION = (KMAX_FUSED + 1) * 2;  // doubles per result section
-constexpr int RED_SECTIONS = 3;                     // h1 | h2 | ||y''||^2 (multi-RHS sweeps use them as one flat buffer)
-constexpr int PARTIAL_SECTIONS = 2;                 // per-block partials: 2 y-columns per multi-RHS pass
+constexpr int RED_SECTIONS = 3;                     // h1 | h2 | ||y''||^2 of one vector DGS (also the per-step slot of lk_arnoldi)
+constexpr int RED_TOTAL = 4;                        // sections of c->red: the multi-RHS sweeps use it as one flat [4][k+1] buffer
+constexpr int PARTIAL_SECTIONS = 4;                 // per-block partials: up to 4 y-columns per multi-RHS pass
 
 // ---- profiling helpers ----------------------------------------------------------------
 struct ProfScope {
@@ -353,25 +354,51 @@ int sweep(lk_basis_t Bx, int c0, int k, double *y, const double *hin, double *ou
     return sweepm<MODE>(Bx, c0, k, y, hin, nullptr, 1, out);
 }
 
-// M(:, q) = X(:, c0:c0+k)^H Y(:, jy0+q), q < pn <= 2, in one pass over X; results land in c->red as
-// [q][k+1][ED] (slot k of each q = ||Y_q||^2), all-reduced.
-int dots_p2(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int pn) {
+// M(:, q) = X(:, c0:c0+k)^H Y(:, jy0+q), q < pn <= 4 (k <= KMAX_FUSED), in ONE pass over X; results land in c->red as
+// [q][k+1][ED] (slot k of each q = ||Y_q||^2), all-reduced.  pn <= 2: one launch, every wave keeps 16 / 8 columns x 2
+// right-hand sides in registers; pn = 3, 4: 4 columns x 4 right-hand sides per wave, column panels of 64.
+int dots_p(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int pn) {
     lk_context_t c = Bx->ctx;
     const bool cp = Bx->dtype == LK_C128;
     const int ED = Bx->ed();
-    const int nslots = 2 * (k + 1) * ED;
-    SweepCfg s = cp ? sweep_cfg<true, 8, 16>(c, k, Bx->n) : sweep_cfg<false, 16, 8>(c, k, Bx->n);
+    const int P = pn <= 2 ? 2 : 4;
+    const int nslots = P * (k + 1) * ED;
+    int grid = 1;
     {
         ProfScope ps(c, "dots_p", (double)Bx->n * ED * 8.0 * (k + pn));
-        if (cp)
-            hipLaunchKernelGGL((panel_dot_p<true, 8, 16, 2>), dim3(s.grid), dim3(1024), 0, c->stream, Bx->col(c0), Bx->ld, k,
-                               By->col(jy0), By->ld, pn, Bx->n, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw);
-        else
-            hipLaunchKernelGGL((panel_dot_p<false, 16, 8, 2>), dim3(s.grid), dim3(512), 0, c->stream, Bx->col(c0), Bx->ld, k,
-                               By->col(jy0), By->ld, pn, Bx->n, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw);
+        if (P == 2) {
+            SweepCfg s = cp ? sweep_cfg<true, 8, 16>(c, k, Bx->n) : sweep_cfg<false, 16, 8>(c, k, Bx->n);
+            grid = s.grid;
+            if (cp)
+                hipLaunchKernelGGL((panel_dot_p<true, 8, 16, 2>), dim3(s.grid), dim3(1024), 0, c->stream, Bx->col(c0), Bx->ld, k,
+                                   By->col(jy0), By->ld, pn, Bx->n, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, k + 1, 0, 1);
+            else
+                hipLaunchKernelGGL((panel_dot_p<false, 16, 8, 2>), dim3(s.grid), dim3(512), 0, c->stream, Bx->col(c0), Bx->ld, k,
+                                   By->col(jy0), By->ld, pn, Bx->n, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, k + 1, 0, 1);
+        } else {
+            constexpr int PANEL = 64;                                  // 16 waves x 4 columns
+            auto cfg = [&](int kk) { return cp ? sweep_cfg<true, 4, 16>(c, kk, Bx->n) : sweep_cfg<false, 4, 16>(c, kk, Bx->n); };
+            // every panel launch uses the SAME block count (the smallest any panel wants: the kernels are grid-stride)
+            // so that one finish kernel sums every slot over the same blocks
+            grid = MAX_GRID;
+            for (int j0 = 0; j0 < k; j0 += PANEL) {
+                const int g = cfg((k - j0) < PANEL ? (k - j0) : PANEL).grid;
+                if (g < grid) grid = g;
+            }
+            for (int j0 = 0; j0 < k; j0 += PANEL) {
+                const int kk = (k - j0) < PANEL ? (k - j0) : PANEL;
+                const SweepCfg s = cfg(kk);
+                if (cp)
+                    hipLaunchKernelGGL((panel_dot_p<true, 4, 16, 4>), dim3(grid), dim3(1024), 0, c->stream, Bx->col(c0 + j0), Bx->ld, kk,
+                                       By->col(jy0), By->ld, pn, Bx->n, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, k + 1, j0, j0 == 0);
+                else
+                    hipLaunchKernelGGL((panel_dot_p<false, 4, 16, 4>), dim3(grid), dim3(1024), 0, c->stream, Bx->col(c0 + j0), Bx->ld, kk,
+                                       By->col(jy0), By->ld, pn, Bx->n, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, k + 1, j0, j0 == 0);
+            }
+        }
     }
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(finish_partials, dim3((nslots + 3) / 4), dim3(256), 0, c->stream, c->partial, (int64_t)MAX_GRID, s.grid,
+    hipLaunchKernelGGL(finish_partials, dim3((nslots + 3) / 4), dim3(256), 0, c->stream, c->partial, (int64_t)MAX_GRID, grid,
                        nslots, c->red);
     HIPCHK(hipGetLastError());
     return allreduce(c, c->red, nslots);
@@ -619,9 +646,9 @@ int lk_init(int device, void *stream, lk_context_t *ctx) {
             c->own_stream = true;
         }
         HIPCHK(hipMalloc((void **)&c->partial, (size_t)PARTIAL_SECTIONS * RED_SECTION * MAX_GRID * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&c->red, (size_t)RED_SECTIONS * RED_SECTION * sizeof(double)));
-        HIPCHK(hipMemsetAsync(c->red, 0, (size_t)RED_SECTIONS * RED_SECTION * sizeof(double), c->stream));
-        HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)RED_SECTIONS * RED_SECTION * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&c->red, (size_t)RED_TOTAL * RED_SECTION * sizeof(double)));
+        HIPCHK(hipMemsetAsync(c->red, 0, (size_t)RED_TOTAL * RED_SECTION * sizeof(double), c->stream));
+        HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)RED_TOTAL * RED_SECTION * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **)&c->coef, (size_t)KMAX_FUSED * 2 * sizeof(double)));
         HIPCHK(hipHostMalloc((void **)&c->coef_host, (size_t)KMAX_FUSED * 2 * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **)&c->stop_dev, sizeof(int)));
@@ -1148,18 +1175,18 @@ int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M)
     lk_context_t c = Bx->ctx;
     LKCHK(lazy_enter(c, false));
     const int ED = Bx->ed();
-    for (int j = 0; j < p; j += 2) {
-        const int pn = (p - j) < 2 ? (p - j) : 2;
+    for (int j = 0; j < p; j += 4) {
+        const int pn = (p - j) < 4 ? (p - j) : 4;
         for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
             const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
             if (pn == 1) {
                 LKCHK((sweep<false, true>(Bx, c0, kk, By->col(jy0 + j), nullptr, c->red)));
                 LKCHK(fetch(c, 0, 1));
                 memcpy(M + ((size_t)j * k + c0) * ED, c->red_host, (size_t)kk * ED * sizeof(double));
-            } else {                                   // two columns of Y per pass over X
-                LKCHK(dots_p2(Bx, c0, kk, By, jy0 + j, 2));
-                LKCHK(fetch(c, 0, 3));
-                for (int q = 0; q < 2; ++q)
+            } else {                                   // up to four columns of Y per pass over X
+                LKCHK(dots_p(Bx, c0, kk, By, jy0 + j, pn));
+                LKCHK(fetch(c, 0, RED_TOTAL));
+                for (int q = 0; q < pn; ++q)
                     memcpy(M + ((size_t)(j + q) * k + c0) * ED, c->red_host + (size_t)q * (kk + 1) * ED,
                            (size_t)kk * ED * sizeof(double));
             }
@@ -1297,17 +1324,17 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
     int inf = 0;
     if (k >= 1 && k <= KMAX_FUSED && k <= Bx->ncols && p >= 2 && Bx->ctx == By->ctx && Bx->dtype == By->dtype &&
         Bx->n == By->n && !(Bx->data == By->data && jy0 < k)) {
-        // panel x panel schedule, two columns of Y per pass over X:
+        // panel x panel schedule, up to FOUR columns of Y per pass over X (4 passes per group instead of 4 per column):
         //   H1 = X^H Y | Y -= X H1 | H2 = X^H Y | Y -= X H2      (DGS_basis_against_basis, gram_schmidt.fypp:59-105)
         lk_context_t c = Bx->ctx;
         LKCHK(lazy_enter(c, true));
-        for (int j = 0; j < p; j += 2) {
-            const int pn = (p - j) < 2 ? (p - j) : 2;
-            std::vector<double> h1((size_t)2 * (k + 1) * ED);
+        for (int j = 0; j < p; j += 4) {
+            const int pn = (p - j) < 4 ? (p - j) : 4;
+            std::vector<double> h1((size_t)4 * (k + 1) * ED);
             for (int pass = 0; pass < 2; ++pass) {
-                LKCHK(dots_p2(Bx, 0, k, By, jy0 + j, pn));
+                LKCHK(dots_p(Bx, 0, k, By, jy0 + j, pn));
                 LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, c->red, (int64_t)(k + 1)));
-                LKCHK(fetch(c, 0, 3));
+                LKCHK(fetch(c, 0, RED_TOTAL));
                 const double *r = c->red_host;
                 for (int q = 0; q < pn; ++q) {
                     const double nrm = std::sqrt(std::fabs(r[((size_t)q * (k + 1) + k) * ED]));

@@ -325,7 +325,10 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
 template <bool CPLX, int KC, int NW, int P>
 __global__ __launch_bounds__(NW * 64) void panel_dot_p(const double *__restrict__ X, int64_t ldx, int k,
                                                         const double *__restrict__ Y, int64_t ldy, int pn, int64_t n,
-                                                        double *__restrict__ partial, int64_t pstride, int WC, int kcw) {
+                                                        double *__restrict__ partial, int64_t pstride, int WC, int kcw,
+                                                        int kslots, int j0, int with_norm) {
+    // This launch covers columns [j0, j0 + k) of a basis of kslots - 1 columns: results go to slot
+    // (q * kslots + j0 + j) * ED (+part); the norm of Y(:, q) to slot (q * kslots + kslots - 1) * ED when with_norm.
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;
@@ -391,13 +394,18 @@ __global__ __launch_bounds__(NW * 64) void panel_dot_p(const double *__restrict_
         const int q = idx / ((k + 1) * ED), rem = idx % ((k + 1) * ED);
         const int j = rem / ED, part = rem % ED;
         double sm = 0.0;
+        int64_t slot;
         if (j < k) {
             const int wcj = j / kcw, jj = j - wcj * kcw;
             for (int w = 0; w < WR; ++w) sm += red_lds[(w * WC + wcj) * SLOTS + q * (KC * ED + 1) + jj * ED + part];
-        } else if (part == 0) {
-            for (int w = 0; w < WR; ++w) sm += red_lds[(w * WC) * SLOTS + q * (KC * ED + 1) + KC * ED];
+            slot = ((int64_t)q * kslots + j0 + j) * ED + part;
+        } else {
+            if (!with_norm) continue;
+            if (part == 0)
+                for (int w = 0; w < WR; ++w) sm += red_lds[(w * WC) * SLOTS + q * (KC * ED + 1) + KC * ED];
+            slot = ((int64_t)q * kslots + kslots - 1) * ED + part;
         }
-        partial[(int64_t)idx * pstride + blockIdx.x] = sm;
+        partial[slot * pstride + blockIdx.x] = sm;
     }
 }
 

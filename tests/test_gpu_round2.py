@@ -300,3 +300,30 @@ def test_async_arnoldi_equals_the_step_by_step_schedule(dtype):
         assert np.array_equal(X.download(m, 1)[:, 0], marker) and np.array_equal(X.download(7, 1)[:, 0], marker)
     assert res[0] == res[1]
     c.close()
+
+
+# ----------------------------------------------------------------------------- block DGS / innerprod, 4 right-hand sides per pass
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("n,k,p", [(5003, 3, 3), (5003, 64, 4), (4099, 65, 4), (3001, 100, 7), (2500, 128, 4), (130, 17, 5),
+                                   (70_001, 128, 3)])
+def test_block_dgs_four_columns_per_pass(ctx, dtype, n, k, p):
+    """DGS_basis_against_basis (gram_schmidt.fypp:59-105) and innerprod_matrix with the multi-right-hand-side dot sweep
+    (up to 4 columns of Y per pass, column panels of 64 beyond k = 64): coefficients and vectors against the oracle's
+    per-column double_gram_schmidt_step, innerprod against one dot per entry."""
+    Q, _ = np.linalg.qr(basis(n, k, dtype, 70))
+    Q = np.asfortranarray(Q)
+    Y = basis(n, p, dtype, 300)
+    B = lk.krylov_basis_gpu(n, k + p, dtype, ctx)
+    B.upload(Q, 0); B.upload(Y, k)
+    M = lk.innerprod(B[:k], B[k:k + p])
+    Mo = ora.innerprod(Q, Y)
+    assert np.abs(M - Mo).max() <= 1e-12 * np.linalg.norm(Y, axis=0).max()
+    beta = np.zeros((k, p), dtype=dtype, order="F")
+    assert lk.double_gram_schmidt_step(B[k:k + p], B[:k], False, beta) == 0
+    Yg = B.download(k, p)
+    for j in range(p):
+        yo = Y[:, j].copy()
+        ho, _ = ora.double_gram_schmidt_step(yo, Q)
+        assert np.abs(beta[:, j] - ho).max() <= 1e-12 * np.linalg.norm(Y[:, j])
+        assert np.abs(Yg[:, j] - yo).max() <= 1e-12 * np.linalg.norm(Y[:, j])
+    assert np.abs(Q.conj().T @ Yg).max() <= 1e-12 * np.linalg.norm(Y, axis=0).max()
