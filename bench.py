@@ -137,6 +137,8 @@ def main() -> None:
     ap.add_argument("--cpu-m", type=int, default=20)
     ap.add_argument("--grid-mult", type=int, default=0)
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="lk_set_tuning knob (repeatable)")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="diagnostic: leave the library's per-kernel HIP events off (value only; roofline fields are then zero)")
     args = ap.parse_args()
 
     import torch
@@ -218,7 +220,7 @@ def main() -> None:
         one_factorisation()
     fence()
     ctx.profile_reset()
-    ctx.profile_enable(True)
+    ctx.profile_enable(not args.no_profile)
     fence()
     t0 = time.perf_counter()
     info = 0

@@ -30,10 +30,27 @@ __device__ __forceinline__ v2d cmulconj(v2d a, v2d b) {  // conj(a) * b
     return v2d{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x};
 }
 
+// Sum over the 64 lanes of a wave, result in EVERY lane.  Data-parallel-primitive moves inside the 16-lane rows
+// (quad_perm x2, row_half_mirror, row_mirror: VALU cross-lane operands, no LDS crossbar) and four v_readlane for the rows:
+// ~30 instructions, against ~1200 cycles for the six dependent ds_bpermute pairs of a __shfl_down tree -- which made the
+// epilogue of a dot sweep cost 9 us (17 reductions per wave), a third of the whole kernel at launch-bound sizes.
+// Fixed order: ((q0+q1)+(q2+q3)) within quads ... then (r0 + r1) + (r2 + r3) over the rows.  All lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror: every lane holds its row's sum
+    return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 // Early-exit guard of the ASYNCHRONOUS Arnoldi pipeline (lk_arnoldi enqueues every step without waiting for the
