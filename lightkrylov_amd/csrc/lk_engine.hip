@@ -45,6 +45,7 @@ struct ProfRec {
     hipEvent_t e0, e1;
     std::string tag;
     double bytes;
+    bool borrowed = false;   // e0/e1 belong to other records (a span built from their events): not returned to the pool twice
 };
 struct ProfAcc {
     int64_t count = 0;
@@ -130,6 +131,8 @@ struct lk_context_s {
     int pool_slab_cols = 160;
     int64_t pool_stats[2] = {0, 0};            // columns ever carved, acquisitions served by re-use
     // profiling
+    bool prof_sweeps_only = false;   // inside the asynchronous Arnoldi batch only the sweeps carry events (each costs ~4 us of queue time)
+    hipEvent_t span_first = nullptr, span_last = nullptr;   // first start / last stop event recorded since span_first was cleared
     bool prof = false;
     std::vector<ProfRec> prof_pending;
     std::vector<hipEvent_t> ev_pool;
@@ -186,6 +189,7 @@ struct ProfScope {
     bool on;
     ProfRec rec;
     ProfScope(lk_context_t ctx, const char *tag, double bytes) : c(ctx), on(ctx->prof) {
+        if (on && c->prof_sweeps_only && strncmp(tag, "dgs_sweep", 9) != 0) on = false;
         if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -203,12 +207,15 @@ struct ProfScope {
         if (!on) return;
         on = false;
         (void)hipEventRecord(rec.e1, c->stream);
+        if (!c->span_first) c->span_first = rec.e0;
+        c->span_last = rec.e1;
         c->prof_pending.push_back(rec);
     }
     ~ProfScope() { end(); }
 };
 
 void prof_collect(lk_context_t c) {
+    if (c->prof_sweeps_only) return;      // an asynchronous batch is being enqueued: its span records still reference live events
     for (auto &r : c->prof_pending) {
         (void)hipEventSynchronize(r.e1);
         float ms = 0.f;
@@ -217,8 +224,10 @@ void prof_collect(lk_context_t c) {
         a.count += 1;
         a.ms += ms;
         a.bytes += r.bytes;
-        c->ev_pool.push_back(r.e0);
-        c->ev_pool.push_back(r.e1);
+        if (!r.borrowed) {
+            c->ev_pool.push_back(r.e0);
+            c->ev_pool.push_back(r.e1);
+        }
     }
     c->prof_pending.clear();
 }
@@ -1608,19 +1617,27 @@ static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
     const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
     const int ED = X->ed();
     c->guard_on = true;
+    c->prof_sweeps_only = true;
     int rc = LK_OK;
     for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
         c->guard_step = k;
         double *slot = c->step_red + (size_t)(k - k0) * RED_SECTIONS * RED_SECTION;
         rc = lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, k - 1, X, k);
         if (rc != LK_OK) break;
-        ProfScope ps(c, "dgs", (double)X->n * ED * 8.0 * (3.0 * k + 5.0));
+        c->span_first = nullptr;
         rc = dgs_device(X, k, X->col(k), true, slot);
         if (rc != LK_OK) break;
+        if (c->prof && c->span_first) {          // "dgs" = first sweep's start .. last sweep's stop, no events of its own
+            ProfRec span;
+            span.e0 = c->span_first; span.e1 = c->span_last; span.tag = "dgs"; span.borrowed = true;
+            span.bytes = (double)X->n * ED * 8.0 * (3.0 * k + 5.0);
+            c->prof_pending.push_back(span);
+        }
         rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * RED_SECTION + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
     }
     c->guard_on = false;
     c->guard_step = 0;
+    c->prof_sweeps_only = false;
     LKCHK(rc);
     HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)nsteps * RED_SECTIONS * RED_SECTION * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
