@@ -449,13 +449,15 @@ def test_eigs_ginzburg_landau_reference_size_against_oracle(ctx):
         assert np.linalg.norm(Ao.apply(V[:, i]) - vals[i] * V[:, i]) <= 1e-7 * abs(vals[i])
 
 
-def test_eigs_ginzburg_landau_full_size_properties(ctx):
-    """BASELINE config 4: complex(dp) n = 10^6, kdim = 128, nev = 8.  No oracle run at this size, and on a
-    domain this long the spectrum is too clustered for Krylov-Schur to converge in a test's time.  What is
+@pytest.mark.parametrize("tau,nsub", [(0.01, 1), (1.0, 40)])
+def test_eigs_ginzburg_landau_full_size_properties(ctx, tau, nsub):
+    """BASELINE config 4: complex(dp) n = 10^6, kdim = 128, nev = 8, with SURVEY 8(d)'s operator (ONE classical RK4
+    step of tau = 0.01, main.f90:20) and with a unit-time propagator (40 sub-steps).  No oracle run at this size, and on
+    a domain this long the spectrum is too clustered for Krylov-Schur to converge in a test's time.  What is
     checked is every step eigs takes: the 128-step Arnoldi factorisation A X_m = X_{m+1} H and X^H X = I,
     the same relation after a krylov_schur restart, and that a bounded eigs run returns sorted Ritz values."""
     n, nev, kdim = 1_000_000, 8, 128
-    A = lk.ginzburg_landau_linop_gpu(n, ctx, tau=1.0, nsub=40)
+    A = lk.ginzburg_landau_linop_gpu(n, ctx, tau=tau, nsub=nsub)
     X = lk.krylov_basis_gpu(n, kdim + 1, np.complex128, ctx)
     X[0].rand(True, seed=13)
     H = np.zeros((kdim + 1, kdim), dtype=np.complex128, order="F")
