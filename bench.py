@@ -302,8 +302,12 @@ def main() -> None:
                 out["cpu_baseline"] = {"value": None, "unit": "Arnoldi iterations/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {exc!r}"}
         print(json.dumps(out))
+    # orderly teardown: device objects, then the library's own communicator (lk_finalize), then torch's group
+    del X, A
     if dist is not None:
         dist.barrier()
+    ctx.close()
+    if dist is not None:
         dist.destroy_process_group()
 
 
