@@ -181,6 +181,7 @@ void ora_matvec_lap5_d(void *op, int64_t n, const void *x, void *y)
     const double *u = (const double *)x; double *v = (double *)y;
     const double s = (double)(N + 1) * (double)(N + 1);
     (void)n;
+#pragma omp parallel for schedule(static) num_threads(ora_nthreads) if (ora_nthreads > 1)
     for (int64_t j = 0; j < N; ++j)
         for (int64_t i = 0; i < N; ++i) {
             const int64_t c = i + j * N;

@@ -440,9 +440,10 @@ def apply_givens_rotation(h: np.ndarray, c: np.ndarray, s: np.ndarray) -> None:
 
 
 def gmres(A: _OpBase, b: np.ndarray, x: np.ndarray, rtol: float = RTOL_DP, atol: float = ATOL_DP,
-          kdim: int = 30, maxiter: int = 10):
+          kdim: int = 30, maxiter: int = 10, fast: bool = False):
     """Restarted GMRES, no preconditioner.  src/IterativeSolvers/GMRES/gmres.fypp:105-239.
-    Returns (info, residual history); x updated in place."""
+    Returns (info, residual history); x updated in place.  fast=True: the Gram-Schmidt steps run through the
+    multi-threaded, bit-identical evaluation (set_threads)."""
     n, dt = b.size, b.dtype
     tol = atol + rtol * norm(b)                                          # :106
     V = np.zeros((n, kdim + 1), dtype=dt, order="F")
@@ -467,7 +468,7 @@ def gmres(A: _OpBase, b: np.ndarray, x: np.ndarray, rtol: float = RTOL_DP, atol:
         for k in range(1, kdim + 1):
             wrk = V[:, k - 1].copy()                                     # :155
             A.matvec(wrk, V[:, k])
-            h, _ = double_gram_schmidt_step(V[:, k], V[:, :k])           # :167-168
+            h, _ = double_gram_schmidt_step(V[:, k], V[:, :k], fast=fast)  # :167-168
             H[:k, k - 1] = h
             H[k, k - 1] = norm(V[:, k])                                  # :171
             if abs(H[k, k - 1]) > tol:

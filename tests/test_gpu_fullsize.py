@@ -105,3 +105,27 @@ def test_config2_full_size_against_live_oracle_and_fixture(ctx):
         ora.set_threads(1)
     assert Ho.tobytes() == np.asfortranarray(z["H_seq"]).tobytes(), "live oracle differs from the committed fixture"
     assert colerr(H, Ho) <= TOL
+
+
+def test_config3_full_size_gmres_against_live_oracle(ctx):
+    """configs[2] at FULL size: GMRES(30), maxiter = 2 (3 cycles, 93 Gram-Schmidt steps) on the 4096^2 five-point
+    Laplacian, against the oracle's restatement of gmres.fypp run here on the host cores (Gram-Schmidt steps through the
+    bit-identical multi-threaded evaluation).  Residual history and solution within 1e-10 (the tolerance of the small-size
+    test), same info."""
+    N = 4096
+    n = N * N
+    b = np.empty(n)
+    ora.fill_counter(b, 11)
+    x = lk.dense_vector_gpu(n, np.float64, ctx)
+    meta = lk.gmres_dp_metadata()
+    info = lk.gmres(lk.laplacian2d_linop_gpu(N, ctx), lk.dense_vector_gpu.from_array(b, ctx), x, rtol=1e-8,
+                    options=lk.gmres_dp_opts(kdim=30, maxiter=2), meta=meta)
+    xo = np.zeros(n)
+    ora.set_threads(min(32, ora.max_threads()))      # <= 31 independent dots per step; more threads only thrash the host memory
+    try:
+        info_o, res_o = ora.gmres(ora.Lap5Op(N), b, xo, rtol=1e-8, kdim=30, maxiter=2, fast=True)
+    finally:
+        ora.set_threads(1)
+    assert info == info_o and len(meta.res) == len(res_o)
+    assert np.abs(np.array(meta.res) - res_o).max() <= 1e-10 * res_o[0]
+    assert np.abs(x.to_array() - xo).max() <= 1e-10 * np.abs(xo).max()

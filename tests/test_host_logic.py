@@ -263,3 +263,15 @@ def test_composite_linops(dtype):
     T.apply_matvec(vin, out); np.testing.assert_allclose(out.data, A.conj().T @ x, rtol=1e-13)
     T.apply_rmatvec(vin, out); np.testing.assert_allclose(out.data, A @ x, rtol=1e-13)
     assert opA.matvec_counter == 3 and opA.rmatvec_counter == 3 and T.matvec_counter == 1
+
+
+def test_grid_partition_covers_the_grid_in_whole_lines():
+    """Row-sharded 5-point Laplacian: every rank owns whole grid lines, contiguous, together exactly N of them."""
+    for N in (1, 7, 64, 4096):
+        for nranks in (1, 2, 3, 8):
+            if nranks > N:
+                continue
+            parts = [lk.grid_partition(N, nranks, r) for r in range(nranks)]
+            assert parts[0][0] == 0 and sum(nj for _j0, nj in parts) == N
+            for (j0, nj), (j1, _n1) in zip(parts, parts[1:]):
+                assert nj >= 1 and j0 + nj == j1
