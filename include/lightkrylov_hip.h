@@ -224,7 +224,8 @@ int lk_orthogonalize(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, int
 int lk_dgs(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, double *norms, int flags,
            int *info);
 /* basis-against-basis variant (gram_schmidt.fypp:59-105): Y(jy0:jy0+p) against X(:k),
- * h is k x p column-major. */
+ * h is k x p column-major.  Panel x panel schedule for k <= 128: per group of up to 4 columns of Y, one multi-right-hand-
+ * side dot sweep + one MFMA update, twice (4 passes over X per group). */
 int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h, int *info);
 
 /* ---- operators (stand where a user's abstract_linop matvec/rmatvec stands,
