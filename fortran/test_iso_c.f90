@@ -20,8 +20,7 @@ program test_iso_c
     type(c_ptr) :: Xz, Az, slab, slab2
     complex(c_double_complex), target :: dz(n), x0z(n)
     complex(c_double_complex) :: Hz(m + 1, m)
-    real(c_double) :: hb(2*m), nrm3(3), a2(2), b2(2), dres(2)
-    integer(c_int) :: col, col2, cols(m + 1)
+    integer(c_int) :: col2, cols(m + 1)
     integer(c_intptr_t) :: tag
     integer :: it
 
