@@ -180,7 +180,8 @@ namespace {
 
 constexpr int RED_SECTION = (KMAX_FUSED + 1) * 2;  // doubles per result section
 constexpr int RED_SECTIONS = 3;                     // h1 | h2 | ||y''||^2 of one vector DGS (also the per-step slot of lk_arnoldi)
-constexpr int RED_TOTAL = 4;                        // sections of c->red: the multi-RHS sweeps use it as one flat [4][k+1] buffer
+constexpr int RED_MULTI = 4;                        // sections one multi-RHS dot pass fills: a flat [4][k+1] buffer
+constexpr int RED_TOTAL = 2 * RED_MULTI;            // sections of c->red: two such passes (block DGS keeps both on the device)
 constexpr int PARTIAL_SECTIONS = 4;                 // per-block partials: up to 4 y-columns per multi-RHS pass
 
 // ---- profiling helpers ----------------------------------------------------------------
@@ -366,8 +367,9 @@ int sweep(lk_basis_t Bx, int c0, int k, double *y, const double *hin, double *ou
 // M(:, q) = X(:, c0:c0+k)^H Y(:, jy0+q), q < pn <= 4 (k <= KMAX_FUSED), in ONE pass over X; results land in c->red as
 // [q][k+1][ED] (slot k of each q = ||Y_q||^2), all-reduced.  pn <= 2: one launch, every wave keeps 16 / 8 columns x 2
 // right-hand sides in registers; pn = 3, 4: 4 columns x 4 right-hand sides per wave, column panels of 64.
-int dots_p(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int pn) {
+int dots_p(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int pn, double *out = nullptr) {
     lk_context_t c = Bx->ctx;
+    if (!out) out = c->red;
     const bool cp = Bx->dtype == LK_C128;
     const int ED = Bx->ed();
     const int P = pn <= 2 ? 2 : 4;
@@ -408,9 +410,9 @@ int dots_p(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int pn) {
     }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(finish_partials, dim3((nslots + 3) / 4), dim3(256), 0, c->stream, c->partial, (int64_t)MAX_GRID, grid,
-                       nslots, c->red);
+                       nslots, out);
     HIPCHK(hipGetLastError());
-    return allreduce(c, c->red, nslots);
+    return allreduce(c, out, nslots);
 }
 
 int ensure_scratch(lk_context_t c, int64_t doubles) {
@@ -1194,7 +1196,7 @@ int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M)
                 memcpy(M + ((size_t)j * k + c0) * ED, c->red_host, (size_t)kk * ED * sizeof(double));
             } else {                                   // up to four columns of Y per pass over X
                 LKCHK(dots_p(Bx, c0, kk, By, jy0 + j, pn));
-                LKCHK(fetch(c, 0, RED_TOTAL));
+                LKCHK(fetch(c, 0, RED_MULTI));
                 for (int q = 0; q < pn; ++q)
                     memcpy(M + ((size_t)(j + q) * k + c0) * ED, c->red_host + (size_t)q * (kk + 1) * ED,
                            (size_t)kk * ED * sizeof(double));
@@ -1339,22 +1341,22 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
         LKCHK(lazy_enter(c, true));
         for (int j = 0; j < p; j += 4) {
             const int pn = (p - j) < 4 ? (p - j) : 4;
-            std::vector<double> h1((size_t)4 * (k + 1) * ED);
+            // both passes stay on the device (pass 2 reads the Y that pass 1's update wrote); ONE copy + sync per group
             for (int pass = 0; pass < 2; ++pass) {
-                LKCHK(dots_p(Bx, 0, k, By, jy0 + j, pn));
-                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, c->red, (int64_t)(k + 1)));
-                LKCHK(fetch(c, 0, RED_TOTAL));
-                const double *r = c->red_host;
-                for (int q = 0; q < pn; ++q) {
-                    const double nrm = std::sqrt(std::fabs(r[((size_t)q * (k + 1) + k) * ED]));
-                    if (pass == 1 && nrm < ATOL_DP) inf = j + q + 1;             // gram_schmidt.fypp:171-173 (pass 2 overwrites)
-                    if (nrm != nrm) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
-                    for (int i = 0; i < k * ED; ++i) {
-                        const double v = r[(size_t)q * (k + 1) * ED + i];
-                        if (pass == 0) h1[(size_t)q * (k + 1) * ED + i] = v;
-                        else if (h) h[((size_t)(j + q) * k) * ED + i] = h1[(size_t)q * (k + 1) * ED + i] + v;   // :97
-                    }
-                }
+                double *out = c->red + (size_t)pass * RED_MULTI * RED_SECTION;
+                LKCHK(dots_p(Bx, 0, k, By, jy0 + j, pn, out));
+                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, out, (int64_t)(k + 1)));
+            }
+            LKCHK(fetch(c, 0, RED_TOTAL));
+            const double *r1 = c->red_host, *r2 = c->red_host + (size_t)RED_MULTI * RED_SECTION;
+            for (int q = 0; q < pn; ++q) {
+                const double n1 = std::sqrt(std::fabs(r1[((size_t)q * (k + 1) + k) * ED]));
+                const double n2 = std::sqrt(std::fabs(r2[((size_t)q * (k + 1) + k) * ED]));
+                if (n2 < ATOL_DP) inf = j + q + 1;                              // gram_schmidt.fypp:171-173 (pass 2 overwrites)
+                if (n1 != n1 || n2 != n2) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+                if (h)
+                    for (int i = 0; i < k * ED; ++i)
+                        h[((size_t)(j + q) * k) * ED + i] = r1[(size_t)q * (k + 1) * ED + i] + r2[(size_t)q * (k + 1) * ED + i];   // :97
             }
         }
         if (info) *info = inf;
