@@ -13,7 +13,16 @@
  * (test/TestKrylov.fypp:194-242, test/TestVectors.fypp:50-179).  tests/test_oracle_kat.py
  * checks this oracle against every one of those.  The Fortran reference itself is
  * unbuildable in this image without writing stand-ins for fortran-lang/stdlib (absent),
- * so no oracle/_ref build exists.
+ * so no oracle/_ref build exists.  Those KATs and invariants hold at the reference's own
+ * tolerance (rtol_dp ~ 3e-8): H-entry parity at 1e-12 therefore rests on this file being a
+ * faithful line-by-line transcription of the cited reference lines -- as tight as the
+ * reference allows, not a pin in the strict sense.
+ *
+ * lk_oracle_fast.inc adds a multi-threaded evaluation of the same schedule that is
+ * BIT-IDENTICAL to the one-thread functions here (tests/test_oracle_fast.py), used to run
+ * the oracle at the metric size, a compensated-dot mode that is NOT the reference's
+ * arithmetic (it separates the reference's summation rounding from the engine's error), and a
+ * fused all-core schedule used only as bench.py's best-effort host baseline.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: no FMA contraction, so the
  * accumulation order and rounding are exactly the loops written here).
