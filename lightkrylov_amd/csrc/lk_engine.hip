@@ -357,13 +357,6 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
     return launch_sweep<false, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
 }
 
-// legacy spelling used by the single-purpose callers: <UPDATE, DOT>
-template <bool UPDATE, bool DOT>
-int sweep(lk_basis_t Bx, int c0, int k, double *y, const double *hin, double *out) {
-    constexpr int MODE = !UPDATE ? 1 : (DOT ? 2 : 3);
-    return sweepm<MODE>(Bx, c0, k, y, hin, nullptr, 1, out);
-}
-
 // M(:, q) = X(:, c0:c0+k)^H Y(:, jy0+q), q < pn <= 4 (k <= KMAX_FUSED), in ONE pass over X; results land in c->red as
 // [q][k+1][ED] (slot k of each q = ||Y_q||^2), all-reduced.  pn <= 2: one launch, every wave keeps 16 / 8 columns x 2
 // right-hand sides in registers; pn = 3, 4: 4 columns x 4 right-hand sides per wave, column panels of 64.
@@ -1191,7 +1184,7 @@ int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M)
         for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
             const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
             if (pn == 1) {
-                LKCHK((sweep<false, true>(Bx, c0, kk, By->col(jy0 + j), nullptr, c->red)));
+                LKCHK((sweepm<1>(Bx, c0, kk, By->col(jy0 + j), nullptr, nullptr, 0, c->red)));
                 LKCHK(fetch(c, 0, 1));
                 memcpy(M + ((size_t)j * k + c0) * ED, c->red_host, (size_t)kk * ED * sizeof(double));
             } else {                                   // up to four columns of Y per pass over X
@@ -1282,7 +1275,7 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
         for (int pass = 0; pass < npass; ++pass) {
             for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
                 const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
-                LKCHK((sweep<false, true>(Bx, c0, kk, y, nullptr, c->red)));
+                LKCHK((sweepm<1>(Bx, c0, kk, y, nullptr, nullptr, 0, c->red)));
                 LKCHK(fetch(c, 0, 1));
                 memcpy(hp.data() + (size_t)c0 * ED, c->red_host, (size_t)kk * ED * sizeof(double));
                 if (c0 == 0) (pass == 0 ? n0 : n1) = c->red_host[kk * ED];
@@ -1291,7 +1284,7 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
                 const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
                 HIPCHK(hipMemcpyAsync(c->coef, hp.data() + (size_t)c0 * ED, (size_t)kk * ED * sizeof(double),
                                       hipMemcpyHostToDevice, c->stream));
-                LKCHK((sweep<true, false>(Bx, c0, kk, y, c->coef, c->red + 2 * RED_SECTION)));
+                LKCHK((sweepm<3>(Bx, c0, kk, y, c->coef, nullptr, 1, c->red + 2 * RED_SECTION)));
                 LKCHK(fetch(c, 2, 1));
                 (pass == 0 && two_pass ? n1 : n2) = c->red_host[2 * RED_SECTION + kk * ED];
             }
