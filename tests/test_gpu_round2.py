@@ -327,3 +327,29 @@ def test_block_dgs_four_columns_per_pass(ctx, dtype, n, k, p):
         assert np.abs(beta[:, j] - ho).max() <= 1e-12 * np.linalg.norm(Y[:, j])
         assert np.abs(Yg[:, j] - yo).max() <= 1e-12 * np.linalg.norm(Y[:, j])
     assert np.abs(Q.conj().T @ Yg).max() <= 1e-12 * np.linalg.norm(Y, axis=0).max()
+
+
+def test_arnoldi_beyond_the_fused_width_and_restarted_ranges(ctx):
+    """kdim = 140 > 128: steps 1..128 run as one asynchronous batch, the rest through the wide (unfused) schedule; and a
+    factorisation continued with kstart > 1 (what krylov_schur restarts do) equals the one-shot run.  H against the oracle."""
+    n, m = 20_011, 140
+    d = 1.0 + np.arange(n) / n
+    x0 = seeded(n, np.float64, 7); x0 /= np.linalg.norm(x0)
+    X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx); X.upload(x0.reshape(-1, 1), 0)
+    H = np.zeros((m + 1, m), order="F")
+    A = lk.diag_linop_gpu(d, ctx)
+    assert lk.arnoldi(A, X, H) == 0
+    Xo = np.zeros((n, m + 1), order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), order="F")
+    assert ora.arnoldi(ora.DiagOp(d), Xo, Ho) == 0
+    for j in range(m):
+        assert np.abs(H[:, j] - Ho[:, j]).max() <= 1e-12 * np.abs(Ho[:, j]).max()
+    G = lk.Gram(X[:m + 1])
+    assert np.abs(G - np.eye(m + 1)).max() <= 1e-12
+    # the same factorisation in three pieces
+    X2 = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx); X2.upload(x0.reshape(-1, 1), 0)
+    H2 = np.zeros((m + 1, m), order="F")
+    assert lk.arnoldi(A, X2, H2, kstart=1, kend=50) == 0
+    assert lk.arnoldi(A, X2, H2, kstart=51, kend=51) == 0            # a single step takes the synchronous path
+    assert lk.arnoldi(A, X2, H2, kstart=52, kend=m) == 0
+    assert H2.tobytes() == H.tobytes() and X2.download().tobytes() == X.download().tobytes()
