@@ -129,3 +129,36 @@ def test_config3_full_size_gmres_against_live_oracle(ctx):
     assert info == info_o and len(meta.res) == len(res_o)
     assert np.abs(np.array(meta.res) - res_o).max() <= 1e-10 * res_o[0]
     assert np.abs(x.to_array() - xo).max() <= 1e-10 * np.abs(xo).max()
+
+
+def test_config4_size_complex_arnoldi_against_live_oracle(ctx):
+    """The complex(dp) kind at configs[3]'s size (n = 10^6, m = 128) on a well-conditioned (diagonal, complex) operator,
+    against a live multi-threaded oracle run: H columns and Ritz values within 1e-12.  (With configs[3]'s own operator,
+    one small RK4 step of Ginzburg-Landau, the Krylov vectors are nearly dependent and an entry-wise comparison would
+    measure that conditioning -- see DESIGN.md section 4; its full-size test checks invariants instead.)"""
+    n, m = 1_000_000, 128
+    g = np.arange(n) / n
+    d = ((1.0 + g) * np.exp(1j * g)).astype(np.complex128)
+    x0 = np.empty(n, dtype=np.complex128)
+    ora.fill_counter(x0, 13)
+    x0 /= np.linalg.norm(x0)
+    X = lk.krylov_basis_gpu(n, m + 1, np.complex128, ctx)
+    X.upload(x0.reshape(-1, 1), 0)
+    H = np.zeros((m + 1, m), dtype=np.complex128, order="F")
+    assert lk.arnoldi(lk.diag_linop_gpu(d, ctx), X, H) == 0
+    G = lk.Gram(X[:m + 1])
+    assert np.abs(G - np.eye(m + 1)).max() <= TOL
+    del X
+    ora.set_threads(min(64, ora.max_threads()))
+    try:
+        Xo = np.zeros((n, m + 1), dtype=np.complex128, order="F")
+        Xo[:, 0] = x0
+        Ho = np.zeros((m + 1, m), dtype=np.complex128, order="F")
+        assert ora.arnoldi(ora.DiagOp(d), Xo, Ho, fast=True) == 0
+    finally:
+        ora.set_threads(1)
+    assert colerr(H, Ho) <= TOL
+    w, wo = np.linalg.eigvals(H[:m, :m]), np.linalg.eigvals(Ho[:m, :m])
+    # Ritz values of a normal operator are well conditioned; match each to its nearest oracle value
+    dist = np.abs(w[:, None] - wo[None, :]).min(axis=1)
+    assert dist.max() <= 1e-11 * np.abs(wo).max(), dist.max()
