@@ -48,7 +48,7 @@ module lightkrylov_gpu
     public :: dense_linop_gpu, diag_linop_gpu, diag_linspace_linop_gpu, laplacian2d_linop_gpu, ginzburg_landau_linop_gpu
     public :: lk_gpu_init, lk_gpu_finalize, lk_gpu_release_all, lk_gpu_context, lk_gpu_pool_stats
     public :: lk_gpu_set_partition, lk_gpu_comm_unique_id, lk_gpu_comm_init
-    public :: gpu_arnoldi_rdp
+    public :: gpu_arnoldi_rdp, gpu_arnoldi_cdp
 
     type(c_ptr), save :: ctx = c_null_ptr
     integer(c_int64_t), save :: part_row0 = 0          ! first global row of this rank's block (lk_gpu_set_partition)
@@ -573,6 +573,24 @@ contains
         k1 = size(H, 2); if (present(kend)) k1 = kend
         t = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) t = tol      ! atol_dp, Constants.f90:35
         call chk(lk_arnoldi(op, X, H, int(size(H, 1), c_int64_t), k0, k1, t, 0_c_int, cinfo), 'gpu_arnoldi_rdp')
+        info = cinfo
+    end subroutine
+
+    !> complex(dp) kind of the same call: H is the host Hessenberg array, passed to the engine as interleaved doubles.
+    subroutine gpu_arnoldi_cdp(op, X, H, info, kstart, kend, tol)
+        type(c_ptr), intent(in) :: op, X
+        complex(dp), intent(inout), target, contiguous :: H(:, :)
+        integer, intent(out) :: info
+        integer, optional, intent(in) :: kstart, kend
+        real(dp), optional, intent(in) :: tol
+        integer(c_int) :: k0, k1, cinfo
+        real(c_double) :: t
+        real(c_double), pointer :: Hr(:)
+        k0 = 1; if (present(kstart)) k0 = kstart
+        k1 = size(H, 2); if (present(kend)) k1 = kend
+        t = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) t = tol
+        call c_f_pointer(c_loc(H), Hr, [2*size(H)])
+        call chk(lk_arnoldi(op, X, Hr, int(size(H, 1), c_int64_t), k0, k1, t, 0_c_int, cinfo), 'gpu_arnoldi_cdp')
         info = cinfo
     end subroutine
 end module lightkrylov_gpu
