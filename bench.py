@@ -88,7 +88,7 @@ def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int) -> dict
         "value": m_full / t_full, "unit": "Arnoldi iterations/s", "cores": 1,
         "samples": [{"n": n1, "m": m1, "seconds": dt1}, {"n": n2, "m": m2, "seconds": dt2},
                     {"n": n3, "m": m3, "seconds": dt3, "predicted_seconds_by_fit": pred3,
-                     "model_error": abs(pred3 - dt3) / dt3}],
+                     "model_error": abs(pred3 - dt3) / dt3, "within_10_percent": bool(abs(pred3 - dt3) / dt3 <= 0.10)}],
         "fit_seconds_per_row": {"per_step": a, "per_step_per_column": b, "used": bool(fit_ok)},
         "value_by_byte_model_only": m_full / t_full_bytes,
         "effective_GBps_on_reference_schedule": bw3 / 1e9,
