@@ -1,15 +1,15 @@
-"""Full-size parity run (GPU box): the engine's Arnoldi on the diag-linspace workload of BASELINE configs 2 / 5
-against the multi-threaded oracle in SEQUENTIAL (= the reference's arithmetic, bit-identical to the 1-thread
-restatement) and COMPENSATED (twice-working-precision dots) modes.
+"""Generator of the full-size golden fixtures (run on the GPU box, whose host has the cores and the 104 GB of RAM):
+the multi-threaded oracle in SEQUENTIAL mode (= the reference's arithmetic, bit-identical to the 1-thread
+restatement) and in COMPENSATED mode (twice-working-precision dots) on the diag-linspace Arnoldi workload of
+BASELINE configs[1] / configs[4], with the engine's own run beside them for the report.
 
-  python tools/fullsize_parity.py --rows 100000000 --kdim 128 --out gpurun_out/r02/fullsize_n1e8_m128.npz
+  python tests/golden/make_fullsize_golden.py --rows 100000000 --kdim 128 --out gpurun_out/r02/fullsize_n1e8_m128.npz
 
-Writes H_seq, H_comp (the golden data tests/golden/ keeps), H_gpu (this run's engine output, for the report
-only) and a JSON `meta` string.  Test infrastructure: imports the oracle, so it lives in tools/, not in the
-package."""
+Writes H_seq, H_comp (what tests/golden/arnoldi_diaglin_*.npz keep), H_gpu (this run's engine output, for the
+report only) and a JSON `meta` string.  Test infrastructure: it imports the oracle, so it lives under tests/."""
 import argparse, json, os, subprocess, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 ap = argparse.ArgumentParser()

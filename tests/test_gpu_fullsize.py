@@ -3,7 +3,7 @@
 * BASELINE configs[4] / bench.py's workload -- n = 10^8 real(dp), m = 128, diagonal-linspace operator, counter-RNG
   x0 -- against tests/golden/arnoldi_diaglin_n100000000_m128_rdp.npz: H of the oracle in SEQUENTIAL mode (= the
   reference's arithmetic: per-primitive BLAS-1, left-to-right sums; 424 s on 128 host threads of the GPU box, produced
-  by tools/fullsize_parity.py) and in COMPENSATED mode (twice-working-precision dots), which separates the
+  by tests/golden/make_fullsize_golden.py) and in COMPENSATED mode (twice-working-precision dots), which separates the
   reference's own summation rounding from the engine's error.
 * configs[1] -- n = 10^7, m = 64 -- against its fixture AND against a live multi-threaded oracle run (~20 s).
 Plus size-independent properties: orthonormality of the basis (lk_gram), the Arnoldi relation on row samples.
