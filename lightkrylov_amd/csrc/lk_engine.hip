@@ -76,6 +76,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
+    int cplx_wide = 1;         // complex sweeps with 8 waves x 16 columns per block (k > 32) instead of 16 waves x 8
     // reduction workspace
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
     double *red = nullptr;      // device results: 3 sections of (KMAX_FUSED+1)*2 doubles
@@ -308,11 +309,9 @@ SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n) {
 //   MODE 4: y'' = (y - X hin) - X hin2      (UPDATE, two coefficient sets; pairs with MODE 2, store = 0)
 // out == nullptr (update-only modes): the norm of the result is not wanted -- no finish kernel, and above all NO
 // all-reduce (the lazy flush runs at rank-dependent times; a collective there could mismatch across ranks).
-template <bool CPLX, int MODE>
+template <bool CPLX, int MODE, int KC = (CPLX ? 8 : 16), int NW = (CPLX ? 16 : 8)>
 int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y, int64_t n, const double *hin,
                  const double *hin2, int store, double *out) {
-    constexpr int KC = CPLX ? 8 : 16;
-    constexpr int NW = CPLX ? 16 : 8;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr bool UPDATE = MODE != 1, DOT = MODE <= 2;
     static_assert(KC * NW == KMAX_FUSED, "fused capacity");
@@ -353,7 +352,13 @@ template <int MODE>
 int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const double *hin2, int store, double *out) {
     lk_context_t c = Bx->ctx;
     const double *X = Bx->col(c0);
-    if (Bx->dtype == LK_C128) return launch_sweep<true, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+    if (Bx->dtype == LK_C128) {
+        // complex block shape: 16 waves x 8 columns for narrow bases, 8 waves x 16 columns beyond 32 columns (half the
+        // waves per barrier and per LDS exchange: +1-9 % per sweep at k >= 64, A/B in DESIGN.md; "cplx_wide" = 0 disables).
+        // The choice depends on k only, so the three sweeps of one DGS always share it (sweep 3 re-forms y' in sweep 2's order).
+        if (c->cplx_wide && k > 32) return launch_sweep<true, MODE, 16, 8>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        return launch_sweep<true, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+    }
     return launch_sweep<false, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
 }
 
@@ -765,6 +770,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
+    if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value != 0; return LK_OK; }
     if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }
     if (!strcmp(key, "pool_slab_cols")) {
         if (value < 2 || value > 4096) return fail(LK_ERR_INVALID, "pool_slab_cols must be in [2,4096]");
