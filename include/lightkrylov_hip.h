@@ -111,7 +111,7 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * in registers and sweep 3 re-forms it, so y' is never written to HBM); "store_policy" (cache policy of the sweeps'
  * 16-byte y store: 0 plain, 1 nt, 2 sc1 = write-through [default], 3 sc0 sc1) and "store_split"; "async_arnoldi"
  * (default 1: lk_arnoldi enqueues all steps with a device-side breakdown flag, one host synchronisation per call; 0:
- * one host round trip per step); "cplx_wide" (complex sweeps on 8 waves x 16 columns beyond 32 basis columns, default 1); "pool_slab_cols" (columns per
+ * one host round trip per step); "cplx_wide" (complex sweeps on 8 waves x 16 columns when k exceeds this threshold, default 32, 0 = never); "pool_slab_cols" (columns per
  * pool slab); "lazy" (see lk_lazy_stats).  None of them
  * changes a result bit (tests/test_gpu_round2.py). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);

@@ -76,7 +76,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
-    int cplx_wide = 1;         // complex sweeps with 8 waves x 16 columns per block (k > 32) instead of 16 waves x 8
+    int cplx_wide = 32;        // complex sweeps with 8 waves x 16 columns per block when k exceeds this (0: never) instead of 16 x 8
     // reduction workspace
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
     double *red = nullptr;      // device results: 3 sections of (KMAX_FUSED+1)*2 doubles
@@ -354,9 +354,10 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
     const double *X = Bx->col(c0);
     if (Bx->dtype == LK_C128) {
         // complex block shape: 16 waves x 8 columns for narrow bases, 8 waves x 16 columns beyond 32 columns (half the
-        // waves per barrier and per LDS exchange: +1-9 % per sweep at k >= 64, A/B in DESIGN.md; "cplx_wide" = 0 disables).
+        // waves per barrier and per LDS exchange: +1-9 % per sweep at k >= 64, A/B in DESIGN.md; "cplx_wide" = threshold, 0 disables).
         // The choice depends on k only, so the three sweeps of one DGS always share it (sweep 3 re-forms y' in sweep 2's order).
-        if (c->cplx_wide && k > 32) return launch_sweep<true, MODE, 16, 8>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        // (the dot-only sweep is free to choose on its own and prefers the narrow shape up to ~56 columns)
+        if (c->cplx_wide && k > (MODE == 1 ? c->cplx_wide + 24 : c->cplx_wide)) return launch_sweep<true, MODE, 16, 8>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
         return launch_sweep<true, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
     }
     return launch_sweep<false, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
@@ -770,7 +771,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
-    if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value != 0; return LK_OK; }
+    if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value < 0 ? 0 : value; return LK_OK; }
     if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }
     if (!strcmp(key, "pool_slab_cols")) {
         if (value < 2 || value > 4096) return fail(LK_ERR_INVALID, "pool_slab_cols must be in [2,4096]");
