@@ -4,6 +4,34 @@
 !> (deep-copy assignment, bit copies, intent(out) re-acquisition, column re-use).  Linked twice by the script: against
 !> liblightkrylov_hip.so (link check; cannot run without a GPU) and against the host mock of the C ABI (executed).
 !> `eigs` is referenced so that it must link, but not executed (the stdlib stand-ins have no geev / trsen).
+!> A user operator on the REFERENCE's own dense_vector_rdp (a diagonal matrix), for the Appendix-A reproduction below.
+module plugin_check_ref_ops
+    use LightKrylov_Constants, only: dp
+    use LightKrylov_AbstractVectors
+    use LightKrylov_AbstractLinops
+    implicit none
+    type, extends(abstract_linop_rdp) :: diag_linop_ref
+        real(dp), allocatable :: d(:)
+    contains
+        procedure, pass(self) :: matvec => ref_diag_matvec
+        procedure, pass(self) :: rmatvec => ref_diag_matvec
+    end type
+contains
+    subroutine ref_diag_matvec(self, vec_in, vec_out)
+        class(diag_linop_ref), intent(inout) :: self
+        class(abstract_vector_rdp), intent(in) :: vec_in
+        class(abstract_vector_rdp), intent(out) :: vec_out
+        select type (vec_in)
+        type is (dense_vector_rdp)
+            select type (vec_out)
+            type is (dense_vector_rdp)
+                vec_out%n = vec_in%n
+                vec_out%data = self%d*vec_in%data
+            end select
+        end select
+    end subroutine
+end module plugin_check_ref_ops
+
 program plugin_driver
     use, intrinsic :: iso_c_binding
     use LightKrylov_Constants, only: dp
@@ -11,14 +39,17 @@ program plugin_driver
     use LightKrylov_AbstractVectors
     use LightKrylov_AbstractLinops
     use LightKrylov_BaseKrylov, only: arnoldi, double_gram_schmidt_step
-    use LightKrylov_IterativeSolvers, only: gmres, eigs, gmres_dp_opts
+    use LightKrylov_IterativeSolvers, only: gmres, eigs, gmres_dp_opts, gmres_dp_metadata
     use lightkrylov_gpu
+    use plugin_check_ref_ops
     implicit none
     integer, parameter :: n = 120, m = 12
     integer :: nfail = 0
 
     call logger_setup(log_level=100, log_stdout=.false.)
     call lk_gpu_init(0)
+    call check_survey_values()
+    call dump_reference_runs()
     call check_arnoldi_rdp()
     call check_arnoldi_cdp()
     call check_gmres_rdp()
@@ -45,6 +76,111 @@ contains
             print '(A,A,ES10.2,A,ES10.2)', '  FAIL ', name, err, ' > ', tol
             nfail = nfail + 1
         end if
+    end subroutine
+
+    !> SURVEY.md Appendix A item 4: the reference's own arnoldi on its own dense_vector, n = 1000, m = 8,
+    !> d_i = 1 + (i-1)/n, x0_i = sin(i)/||.||, built against stand-in stdlib modules.  The survey recorded three H
+    !> entries of that run; tests/golden/survey_reference_run_n1000_m8.npz keeps them and the oracle reproduces them to
+    !> 17 digits.  This reproduces the RUN (recipe committed here); it remains a stand-in build, so it pins nothing formally.
+    subroutine check_survey_values()
+        integer, parameter :: ns = 1000, ms = 8
+        type(diag_linop_ref) :: A
+        type(dense_vector_rdp), allocatable :: X(:)
+        real(dp) :: H(ms + 1, ms), x0(ns)
+        integer :: i, info
+        allocate (A%d(ns))
+        do i = 1, ns
+            A%d(i) = 1.0_dp + real(i - 1, dp)/real(ns, dp)
+            x0(i) = sin(real(i, dp))
+        end do
+        x0 = x0/sqrt(sum(x0**2))
+        allocate (X(ms + 1)); do i = 1, ms + 1; X(i)%n = ns; call X(i)%zero(); end do
+        X(1) = dense_vector(x0)
+        H = 0.0_dp; call arnoldi(A, X, H, info)
+        call report('survey run: H(1,1)   vs recorded             ', abs(H(1, 1) - 1.4991929804973552_dp), 4.0e-15_dp)
+        call report('survey run: H(2,1)   vs recorded             ', abs(H(2, 1) - 0.28878608972273856_dp), 4.0e-15_dp)
+        call report('survey run: H(m+1,m) vs recorded             ', abs(H(ms + 1, ms) - 0.2505741778943683_dp), 4.0e-15_dp)
+    end subroutine
+
+    !> Runs of the REFERENCE's own arnoldi / double_gram_schmidt_step / gmres on its own dense_vector, inputs and outputs
+    !> written in full precision to ref_runs.txt: tests/test_plugin_check.py feeds the same inputs to the oracle
+    !> (oracle/) and compares.  An execution check that the oracle's restatement follows the reference's control flow --
+    !> indicative only (stand-in stdlib), never a pin.
+    subroutine dump_reference_runs()
+        integer, parameter :: na = 700, ma = 12, ng = 60
+        integer :: u, i, j, info
+        ! arnoldi, real and complex diagonal operator
+        type(diag_linop_ref) :: Ad
+        type(dense_vector_rdp), allocatable :: X(:)
+        real(dp) :: H(ma + 1, ma), x0(na), yv(na), beta(ma)
+        type(dense_vector_rdp) :: yvec
+        type(dense_linop_cdp) :: Az
+        type(dense_vector_cdp), allocatable :: Xz(:)
+        complex(dp) :: Hz(ma + 1, ma), x0z(ng), Amat(ng, ng)
+        ! gmres
+        type(dense_linop_rdp) :: Ag
+        type(dense_vector_rdp) :: bg, xg
+        real(dp) :: Ar(ng, ng), br(ng)
+        type(gmres_dp_opts) :: opts
+        type(gmres_dp_metadata) :: meta
+        open (newunit=u, file='ref_runs.txt', status='replace', action='write')
+        allocate (Ad%d(na))
+        do i = 1, na
+            Ad%d(i) = 1.0_dp + real(i - 1, dp)/real(na, dp)
+            x0(i) = sin(real(3*i, dp)) + 0.25_dp
+            yv(i) = cos(real(7*i, dp))
+        end do
+        x0 = x0/sqrt(sum(x0**2))
+        allocate (X(ma + 1)); do i = 1, ma + 1; X(i)%n = na; call X(i)%zero(); end do
+        X(1) = dense_vector(x0)
+        H = 0.0_dp; call arnoldi(Ad, X, H, info)
+        write (u, '(A,3I8)') 'case arnoldi_rdp_diag', na, ma, info
+        write (u, '(ES25.17)') Ad%d, x0, H
+        ! double_gram_schmidt_step of an arbitrary vector against the basis just built
+        yvec = dense_vector(yv)
+        call double_gram_schmidt_step(yvec, X(:ma), info, if_chk_orthonormal=.false., beta=beta)
+        write (u, '(A,3I8)') 'case dgs_rdp', na, ma, info
+        write (u, '(ES25.17)') yv
+        do j = 1, ma
+            write (u, '(ES25.17)') X(j)%data
+        end do
+        write (u, '(ES25.17)') beta, yvec%data
+        ! complex Arnoldi with a dense complex operator (gemv restated by the oracle as a column sweep)
+        do j = 1, ng
+            do i = 1, ng
+                Amat(i, j) = cmplx(sin(real(3*i + 7*j, dp)), cos(real(5*i - 2*j, dp)), kind=dp)/real(ng, dp)
+            end do
+            Amat(j, j) = Amat(j, j) + cmplx(1.0_dp + real(j, dp)/real(ng, dp), 0.3_dp, kind=dp)
+            x0z(j) = cmplx(cos(real(j, dp)), sin(real(2*j, dp)), kind=dp)
+        end do
+        x0z = x0z/sqrt(sum(abs(x0z)**2))
+        Az = dense_linop(Amat)
+        allocate (Xz(ma + 1)); do i = 1, ma + 1; Xz(i)%n = ng; call Xz(i)%zero(); end do
+        Xz(1) = dense_vector(x0z)
+        Hz = (0.0_dp, 0.0_dp); call arnoldi(Az, Xz, Hz, info)
+        write (u, '(A,3I8)') 'case arnoldi_cdp_dense', ng, ma, info
+        write (u, '(2ES25.17)') Amat, x0z, Hz
+        ! GMRES(20), maxiter = 2, real dense operator
+        call test_matrix_small(Ar, br)
+        Ag = dense_linop(Ar); bg = dense_vector(br); xg%n = ng; call xg%zero()
+        opts = gmres_dp_opts(kdim=10, maxiter=2)
+        call gmres(Ag, bg, xg, info, rtol=1.0e-10_dp, atol=1.0e-14_dp, options=opts, meta=meta)
+        write (u, '(A,4I8)') 'case gmres_rdp_dense', ng, 10, info, size(meta%res)
+        write (u, '(ES25.17)') Ar, br, xg%data, meta%res
+        close (u)
+    end subroutine
+
+    subroutine test_matrix_small(A, b)
+        real(dp), intent(out) :: A(:, :), b(:)
+        integer :: i, j, nn
+        nn = size(b)
+        do j = 1, nn
+            do i = 1, nn
+                A(i, j) = sin(real(3*i + 7*j, dp))/real(nn, dp)
+            end do
+            A(j, j) = A(j, j) + 1.0_dp + real(j, dp)/real(nn, dp)
+            b(j) = cos(real(j, dp))
+        end do
     end subroutine
 
     subroutine test_matrix_rdp(A, x0)
