@@ -29,9 +29,10 @@
 !>   110-115, IterativeSolvers.fypp:1032-1034, AbstractVectors.fypp:595-598, 628-630, qr.fypp:186); user code that
 !>   needs an independent copy should assign (`y = x`), not source-allocate.
 !> Lazy batching.  Columns are handed out in the order objects are first written -- V(1), V(2), ... for
-!> `allocate(V(kdim+1), source=b); call zero_basis(V)` -- and the engine runs in "lazy" mode (lk_lazy_stats): the
-!> k calls `X(i)%dot(y)` of `innerprod` cost one panel sweep and the k calls `y%axpby(a_i, X(i), 1)` of
-!> `linear_combination` one panel update.  The fully fused three-sweep DGS is reached through `gpu_arnoldi_rdp`.
+!> `allocate(V(kdim+1), source=b); call zero_basis(V)` -- and the engine runs in "lazy" mode (lk_lazy_stats,
+!> lk_lazy_fusion_stats): the k calls `X(i)%dot(y)` of `innerprod` cost one panel sweep; `linear_combination`'s
+!> temporary stays virtual (never written) and `y%sub(proj)` + the next `y%norm()` + the next k dots cost ONE sweep:
+!> one pass over the basis per Gram-Schmidt pass.  The fully fused three-sweep DGS is reached through `gpu_arnoldi_rdp`.
 module lightkrylov_gpu
     use, intrinsic :: iso_c_binding
     use lightkrylov_hip_c

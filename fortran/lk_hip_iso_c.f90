@@ -64,6 +64,12 @@ module lightkrylov_hip_c
             integer(c_int64_t), intent(out) :: out4(4)
             integer(c_int) :: rc
         end function
+        function lk_lazy_fusion_stats(ctx, out4) bind(C, name="lk_lazy_fusion_stats") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), intent(out) :: out4(4)
+            integer(c_int) :: rc
+        end function
         function lk_orthogonalize(Bx, k, By, jy, h, info) bind(C, name="lk_orthogonalize") result(rc)
             import :: c_int, c_ptr, c_double
             type(c_ptr), value :: Bx, By

@@ -15,7 +15,7 @@ program test_iso_c
     ! lazy per-object pass
     type(c_ptr) :: Z
     real(c_double) :: hl(m), hf(m), d2(2), ny_lazy, ny_fused, one(1), ai(1), mone(1)
-    integer(c_int64_t) :: st(4), ps0(4), ps1(4)
+    integer(c_int64_t) :: st(4), fs(4), ps0(4), ps1(4)
     ! complex(dp) pass + column pool
     type(c_ptr) :: Xz, Az, slab, slab2
     complex(c_double_complex), target :: dz(n), x0z(n)
@@ -54,7 +54,7 @@ program test_iso_c
     print '(A,ES24.16)', 'norm_last ', nrm
     ! ---- the reference's per-object schedule (innerprod loop, then linear_combination loop, then sub:
     !      gram_schmidt.fypp:141-145 through AbstractVectors.fypp:672-674, 600-602) driven from Fortran with
-    !      the engine in lazy mode: m dots must cost ONE sweep, m axpbys ONE panel update.
+    !      the engine in lazy mode: m dots must cost ONE sweep; proj stays virtual and y%sub(proj) + the next norm ONE more.
     one = 1.0d0; mone = -1.0d0
     rc = lk_set_tuning(ctx, 'lazy'//c_null_char, 1_c_int); call chk(rc, 'lk_set_tuning')
     rc = lk_basis_create(ctx, LK_F64, int(n, c_int64_t), int(m + 3, c_int), Z); call chk(rc, 'lk_basis_create(Z)')
@@ -75,12 +75,15 @@ program test_iso_c
     rc = lk_vec_axpby(mone, Z, int(m + 1, c_int), one, Z, int(m, c_int)); call chk(rc, 'lk_vec_axpby(sub)')  ! y%sub(proj)
     rc = lk_vec_norm(Z, int(m, c_int), ny_lazy); call chk(rc, 'lk_vec_norm')
     rc = lk_lazy_stats(ctx, st); call chk(rc, 'lk_lazy_stats')
+    rc = lk_lazy_fusion_stats(ctx, fs); call chk(rc, 'lk_lazy_fusion_stats')
     rc = lk_orthogonalize(Z, int(m, c_int), Z, int(m + 2, c_int), hf, info); call chk(rc, 'lk_orthogonalize')
     rc = lk_vec_norm(Z, int(m + 2, c_int), ny_fused); call chk(rc, 'lk_vec_norm')
     print '(A,I0)', 'lazy_hits ', st(1)
     print '(A,I0)', 'lazy_sweeps ', st(2)
     print '(A,I0)', 'lazy_queued ', st(3)
     print '(A,I0)', 'lazy_flushes ', st(4)
+    print '(A,I0)', 'lazy_fused_sweeps ', fs(1)
+    print '(A,I0)', 'lazy_temporaries_written ', fs(4)
     print '(A,ES12.4)', 'lazy_h_err ', maxval(abs(hl - hf))
     print '(A,ES12.4)', 'lazy_y_err ', abs(ny_lazy - ny_fused)
     rc = lk_basis_destroy(Z)

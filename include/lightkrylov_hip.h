@@ -124,6 +124,14 @@ int lk_set_tuning(lk_context_t ctx, const char *key, int value);
  * AbstractVectors.fypp:672-674, 600-602) into fused traffic.  out4 = {dot memo hits, batched dot sweeps,
  * queued axpbys, queue flushes}. */
 int lk_lazy_stats(lk_context_t ctx, int64_t *out4);
+/* The temporary of linear_combination (AbstractVectors.fypp:595-603: `allocate(y, source=X(1)); y%zero(); y%axpby(..)`)
+ * stays VIRTUAL in lazy mode: its zero() and its k axpbys are recorded, the `y%sub(proj)` that consumes it
+ * (gram_schmidt.fypp:145) becomes a pending y -= X h, and the NEXT pass's `y%norm()` (gram_schmidt.fypp:126, qr.fypp:135)
+ * runs one sweep that forms and stores y', and returns ||y'|| and X^H y' for the k dot calls that follow: ONE pass over
+ * X per Gram-Schmidt pass, 3k+6 columns per double_gram_schmidt_step against 3k+4 for lk_dgs.  The temporary is
+ * written only if something reads it.  out4 = {fused update+dot sweeps, pending updates applied as plain panel updates,
+ * virtual temporaries dropped unwritten, virtual temporaries written after all}. */
+int lk_lazy_fusion_stats(lk_context_t ctx, int64_t *out4);
 
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg).
  * tags: "dgs_sweep1|2|3" (the three panel sweeps; "dgs_sweep*" sums them -- a trailing '*' is a

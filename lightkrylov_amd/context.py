@@ -149,6 +149,13 @@ class Context:
         _capi.check(self._lib.lk_lazy_stats(self._h, out))
         return tuple(out)
 
+    def lazy_fusion_stats(self):
+        """(fused update+dot sweeps, pending updates applied as plain panel updates, virtual temporaries dropped
+        unwritten, virtual temporaries written after all) -- see lk_lazy_fusion_stats in the header."""
+        out = (C.c_int64 * 4)()
+        _capi.check(self._lib.lk_lazy_fusion_stats(self._h, out))
+        return tuple(out)
+
     def sync(self) -> None:
         _capi.check(self._lib.lk_sync(self._h))
 

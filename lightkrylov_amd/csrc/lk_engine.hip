@@ -101,12 +101,26 @@ struct lk_context_s {
         int j0 = 0, cnt = 0;
         std::vector<double> vals;
     } memo;
+    // queue: pending  T <- [zeroed ? 0 : T] + sum_i a_i X(:, j0+i)  (linear_combination's loop).  `zeroed`: the queue
+    // began with T%zero() (which was itself deferred), so T is DEFINED by the queue and can stay VIRTUAL -- never
+    // written -- as long as nobody reads it: linear_combination's temporary is consumed by one y%sub(proj) and dies.
+    // By == nullptr: T's storage is already gone (its 1-column panel was destroyed); the coefficients live on for `sub`.
     struct {
-        bool active = false;
+        bool active = false, zeroed = false;
         lk_basis_t Bx = nullptr, By = nullptr;
         int j0 = 0, cnt = 0, jy = 0;
         std::vector<double> coef;        // a_i, ED doubles each
     } queue;
+    // sub: pending  y <- y + s * T  with T the (zeroed) queue's still virtual target, i.e. y += s X a.  Applied as ONE
+    // fused sweep together with the dots and the norm the NEXT Gram-Schmidt pass asks for (y%norm(), X(i)%dot(y)).
+    struct {
+        bool active = false;
+        lk_basis_t By = nullptr;
+        int jy = 0;
+        double s[2] = {0.0, 0.0};
+    } sub;
+    struct { bool valid = false; const double *y = nullptr; double nrm2 = 0.0; } nmemo;   // ||y||^2 from the last fused sweep
+    int64_t fusion_stats[4] = {0, 0, 0, 0};  // fused update+dot sweeps, plain deferred updates, virtual temporaries dropped, materialised
     double *coef_host = nullptr;         // pinned staging for queued coefficients
     hipEvent_t coef_ev = nullptr;        // completion of the last staging copy
     int64_t lazy_stats[4] = {0, 0, 0, 0};  // dot memo hits, batched dot sweeps, queued axpbys, queue flushes
@@ -579,26 +593,121 @@ int scal_launch(lk_basis_t B, int j, double ar, double ai, const double *inv_sqr
 }
 
 // ---- lazy batching of the per-object path --------------------------------------------------------------
-// Pending `y <- y + sum_i a_i X(:, j0+i)` (queued by consecutive lk_vec_axpby calls with beta == 1) is
-// applied as ONE panel update; every other ABI entry flushes it first, so no call ever observes a stale y.
-int lazy_flush(lk_context_t c) {
-    if (!c->queue.active) return LK_OK;
-    auto &q = c->queue;
-    q.active = false;
-    const int ED = q.Bx->ed();
+// What an unchanged LightKrylov issues per Gram-Schmidt pass (gram_schmidt.fypp:113-154, AbstractVectors.fypp:571-603):
+//   y%norm(); X(1..k)%dot(y); allocate(proj, source=X(1)); proj%zero(); proj%axpby(h_i, X(i), 1) x k; y%sub(proj)
+// Deferred here as: virtual zero -> queue (proj = X h, never written) -> sub (y -= X h pending) -> the next pass's
+// y%norm() runs ONE sweep that forms y' = y - X h, stores it, and returns ||y'||^2 and X^H y' (memoised for the k dot
+// calls that follow): one pass over X per Gram-Schmidt pass, as in the fused lk_dgs.  Every other entry point first
+// brings the vectors it touches up to date, so no call ever observes a stale vector.
+
+// h = -(s * a_i) into the device coefficient buffer (the sweeps compute y - X h)
+int stage_coef(lk_context_t c, const std::vector<double> &a, int cnt, int ED, double sr, double si) {
     if (c->coef_ev) HIPCHK(hipEventSynchronize(c->coef_ev));      // previous staging copy has left the pinned buffer
-    for (int i = 0; i < q.cnt * ED; ++i) c->coef_host[i] = -q.coef[i];   // the kernel computes y - X h
-    HIPCHK(hipMemcpyAsync(c->coef, c->coef_host, (size_t)q.cnt * ED * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < cnt; ++i) {
+        if (ED == 2) {
+            const double ar = a[2 * i], ai = a[2 * i + 1];
+            c->coef_host[2 * i] = -(sr * ar - si * ai);
+            c->coef_host[2 * i + 1] = -(sr * ai + si * ar);
+        } else {
+            c->coef_host[i] = -(sr * a[i]);
+        }
+    }
+    HIPCHK(hipMemcpyAsync(c->coef, c->coef_host, (size_t)cnt * ED * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipEventRecord(c->coef_ev, c->stream));
-    c->lazy_stats[3] += 1;
-    return sweepm<3>(q.Bx, q.j0, q.cnt, q.By->col(q.jy), c->coef, nullptr, 1, nullptr);   // norm unused: no collective
+    return LK_OK;
 }
 
-// Called at the top of every ABI entry that reads or writes vector data.
+// pending y += s X a as one plain panel update (no norm wanted: no finish kernel, no collective)
+int apply_sub(lk_context_t c) {
+    if (!c->sub.active) return LK_OK;
+    auto &q = c->queue;
+    c->sub.active = false;
+    c->memo.valid = false; c->nmemo.valid = false;
+    LKCHK(stage_coef(c, q.coef, q.cnt, q.Bx->ed(), c->sub.s[0], c->sub.s[1]));
+    c->fusion_stats[1] += 1;
+    return sweepm<3>(q.Bx, q.j0, q.cnt, c->sub.By->col(c->sub.jy), c->coef, nullptr, 1, nullptr);
+}
+
+void drop_queue(lk_context_t c) {
+    if (c->queue.active && c->queue.zeroed && c->queue.cnt > 0) c->fusion_stats[2] += 1;
+    c->queue.active = false;
+}
+
+// write the queue's target: T = [zeroed ? 0 : T] + X a
+int materialise_queue(lk_context_t c) {
+    auto &q = c->queue;
+    if (!q.active) return LK_OK;
+    q.active = false;
+    if (!q.By) {                                                    // storage already gone: nothing to write
+        if (q.zeroed && q.cnt > 0) c->fusion_stats[2] += 1;
+        return LK_OK;
+    }
+    c->memo.valid = false; c->nmemo.valid = false;                  // a column changes: batched dots may have covered it
+    double *T = q.By->col(q.jy);
+    if (q.zeroed) {
+        HIPCHK(hipMemsetAsync(T, 0, (size_t)q.By->n * q.By->ed() * sizeof(double), c->stream));
+        if (q.cnt > 0) c->fusion_stats[3] += 1;
+    }
+    if (q.cnt == 0) return LK_OK;
+    LKCHK(stage_coef(c, q.coef, q.cnt, q.Bx->ed(), 1.0, 0.0));
+    c->lazy_stats[3] += 1;
+    return sweepm<3>(q.Bx, q.j0, q.cnt, T, c->coef, nullptr, 1, nullptr);   // norm unused: no collective
+}
+
+// Everything pending becomes real (panel-level entry points, sync, tuning changes).
+int lazy_flush(lk_context_t c) {
+    LKCHK(apply_sub(c));
+    return materialise_queue(c);
+}
+
+// Called at the top of every ABI entry that works on whole panels (or whose operands are not tracked).
 inline int lazy_enter(lk_context_t c, bool mutates) {
     if (!c->lazy) return LK_OK;
-    if (mutates) c->memo.valid = false;
+    if (mutates) { c->memo.valid = false; c->nmemo.valid = false; }
     return lazy_flush(c);
+}
+
+// Per-vector entries name their operands: w = the column written (overwrite: its old contents are not read),
+// r1 / r2 = columns read.  A virtual T survives the call unless the call reads it, partially updates it, or writes
+// into one of the columns it is defined from.
+struct VecRef { lk_basis_t B; int j; };
+int lazy_enter_vec(lk_context_t c, const VecRef *w, bool overwrite, const VecRef *r1, const VecRef *r2) {
+    if (!c->lazy) return LK_OK;
+    if (w) { c->memo.valid = false; c->nmemo.valid = false; }
+    LKCHK(apply_sub(c));                                            // y is live: bring it up to date first
+    auto &q = c->queue;
+    if (!q.active) return LK_OK;
+    if (!q.zeroed) return materialise_queue(c);                     // the target's own contents are pending
+    const double *T = q.By ? q.By->col(q.jy) : nullptr;
+    auto is_T = [&](const VecRef *v) { return v && T && v->B->col(v->j) == T; };
+    if (is_T(r1) || is_T(r2)) return materialise_queue(c);
+    if (is_T(w)) {
+        if (overwrite) { drop_queue(c); return LK_OK; }
+        return materialise_queue(c);
+    }
+    if (w && q.cnt > 0) {                                           // a write into the columns T is defined from
+        const double *p = w->B->col(w->j);
+        const double *lo = q.Bx->col(q.j0), *hi = lo + (int64_t)q.cnt * q.Bx->ld * q.Bx->ed();
+        if (p >= lo && p < hi) return materialise_queue(c);
+    }
+    return LK_OK;
+}
+
+// sub pending on y: ONE sweep forms y' = y + s X a, stores it, and leaves X^H y' and ||y'||^2 in the memos.
+int fused_sub_with_dots(lk_context_t c) {
+    auto &q = c->queue;
+    const int ED = q.Bx->ed();
+    double *y = c->sub.By->col(c->sub.jy);
+    c->sub.active = false;
+    LKCHK(stage_coef(c, q.coef, q.cnt, ED, c->sub.s[0], c->sub.s[1]));
+    LKCHK((sweepm<2>(q.Bx, q.j0, q.cnt, y, c->coef, nullptr, 1, c->red)));
+    LKCHK(fetch(c, 0, 1));
+    auto &mm = c->memo;
+    mm.vals.assign(c->red_host, c->red_host + (size_t)q.cnt * ED);
+    mm.valid = true; mm.xbase = q.Bx->data; mm.y = y; mm.j0 = q.j0; mm.cnt = q.cnt;
+    c->nmemo.valid = true; c->nmemo.y = y; c->nmemo.nrm2 = c->red_host[(size_t)q.cnt * ED];
+    c->fusion_stats[0] += 1;
+    return LK_OK;
 }
 
 // Core of double_gram_schmidt_step for one vector; results stay in c->red (device):
@@ -759,7 +868,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "stream_update")) { c->stream_update = value != 0; return LK_OK; }
     if (!strcmp(key, "lazy")) {
         LKCHK(lazy_flush(c));
-        c->memo.valid = false;
+        c->memo.valid = false; c->nmemo.valid = false;
         c->lazy = value != 0;
         return LK_OK;
     }
@@ -828,6 +937,12 @@ int lk_profile_get(lk_context_t c, const char *tag, int64_t *count, double *tota
     return LK_OK;
 }
 
+int lk_lazy_fusion_stats(lk_context_t c, int64_t *out4) {
+    if (!c || !out4) return fail(LK_ERR_INVALID, "lk_lazy_fusion_stats: null argument");
+    for (int i = 0; i < 4; ++i) out4[i] = c->fusion_stats[i];
+    return LK_OK;
+}
+
 int lk_lazy_stats(lk_context_t c, int64_t *out4) {
     if (!c || !out4) return fail(LK_ERR_INVALID, "lk_lazy_stats: null argument");
     for (int i = 0; i < 4; ++i) out4[i] = c->lazy_stats[i];
@@ -874,8 +989,12 @@ int lk_basis_destroy(lk_basis_t B) {
     {
         std::lock_guard<std::mutex> lock(g_ctx_mu);
         if (g_live_ctx.count(B->ctx)) {          // a queued update may still target / read this panel
-            (void)lazy_flush(B->ctx);
-            B->ctx->memo.valid = false;
+            lk_context_t c = B->ctx;
+            auto &q = c->queue;
+            const bool only_target = q.active && q.zeroed && q.By == B && q.Bx != B && !(c->sub.active && c->sub.By == B);
+            if (only_target) q.By = nullptr;     // a virtual temporary dies unwritten; its coefficients may still serve `sub`
+            else (void)lazy_flush(c);
+            c->memo.valid = false; c->nmemo.valid = false;
         }
     }
     // hipFree waits for outstanding device work itself; the context may already be finalized.
@@ -997,6 +1116,10 @@ int lk_pool_release(lk_context_t c, lk_basis_t slab, int col) {
     if (si < 0 || col < 0 || col >= c->pool[si].used) return fail(LK_ERR_INVALID, "lk_pool_release: not a pool column");
     const uint64_t tag = c->pool[si].owner[col];
     if (tag == 0) return LK_OK;
+    if (c->lazy && c->queue.active && c->queue.By == slab && c->queue.jy == col) {   // the column's contents die with its owner
+        if (c->queue.zeroed) c->queue.By = nullptr;
+        else c->queue.active = false;
+    }
     c->pool_by_tag.erase(tag);
     c->pool[si].owner[col] = 0;
     c->pool_free.insert({si, col});
@@ -1026,9 +1149,18 @@ int lk_pool_stats(lk_context_t c, int64_t *out4) {
 int lk_vec_zero(lk_basis_t B, int j) {
     LKCHK(check_vec(B, j, "lk_vec_zero"));
     DevGuard dev_guard(B->ctx);
-    LKCHK(lazy_enter(B->ctx, true));
+    lk_context_t c = B->ctx;
+    const VecRef w{B, j};
+    LKCHK(lazy_enter_vec(c, &w, true, nullptr, nullptr));
     B->touch(j);
-    HIPCHK(hipMemsetAsync(B->col(j), 0, (size_t)B->n * B->ed() * sizeof(double), B->ctx->stream));
+    if (c->lazy) {
+        // proj%zero() opens linear_combination (AbstractVectors.fypp:598): the memset is deferred with the queue
+        LKCHK(materialise_queue(c));                             // one slot: an older virtual vector becomes real
+        auto &q = c->queue;
+        q.active = true; q.zeroed = true; q.By = B; q.jy = j; q.Bx = nullptr; q.j0 = 0; q.cnt = 0; q.coef.clear();
+        return LK_OK;
+    }
+    HIPCHK(hipMemsetAsync(B->col(j), 0, (size_t)B->n * B->ed() * sizeof(double), c->stream));
     return LK_OK;
 }
 
@@ -1036,7 +1168,8 @@ int lk_vec_scal(lk_basis_t B, int j, const double *alpha) {
     LKCHK(check_vec(B, j, "lk_vec_scal"));
     DevGuard dev_guard(B->ctx);
     if (!alpha) return fail(LK_ERR_INVALID, "lk_vec_scal: null alpha");
-    LKCHK(lazy_enter(B->ctx, true));
+    const VecRef w{B, j};
+    LKCHK(lazy_enter_vec(B->ctx, &w, false, &w, nullptr));
     B->touch(j);
     return scal_launch(B, j, alpha[0], B->dtype == LK_C128 ? alpha[1] : 0.0, nullptr, 0.0);
 }
@@ -1051,26 +1184,49 @@ int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta,
     const bool cp = Bx->dtype == LK_C128;
     By->touch(jy);
     if (c->lazy) {
-        // y <- a X(:, jx) + 1 y with X a column of a multi-column panel: queue it (linear_combination's loop,
-        // AbstractVectors.fypp:600-602 / 637-642); consecutive columns onto the same y extend the queue.
         const int ED = Bx->ed();
         const bool unit_beta = beta[0] == 1.0 && (!cp || beta[1] == 0.0);
-        const bool y_in_range = (By->data == Bx->data) && jy == jx;
-        c->memo.valid = false;                                   // y is (about to be) modified
-        if (unit_beta && Bx->ncols > 1 && !y_in_range && Bx->col(jx) != By->col(jy)) {
-            auto &q = c->queue;
-            const bool extends = q.active && q.Bx == Bx && q.By == By && q.jy == jy && jx == q.j0 + q.cnt &&
-                                 q.cnt < KMAX_FUSED && !(By->data == Bx->data && jy == jx);
+        const bool zero_beta = beta[0] == 0.0 && (!cp || beta[1] == 0.0);
+        const double *xp = Bx->col(jx);
+        double *yp = By->col(jy);
+        auto &q = c->queue;
+        const double *T = (q.active && q.By) ? q.By->col(q.jy) : nullptr;
+        auto in_xrange = [&](const double *p) {
+            if (!q.active || q.cnt == 0) return false;
+            const double *lo = q.Bx->col(q.j0), *hi = lo + (int64_t)q.cnt * q.Bx->ld * q.Bx->ed();
+            return p >= lo && p < hi;
+        };
+        // y%sub(proj) / x%add(dx) with the operand still virtual (gram_schmidt.fypp:145, gmres.fypp:202): y += s X a pending
+        if (unit_beta && q.active && q.zeroed && q.cnt >= 1 && !c->sub.active && T && xp == T && yp != T && !in_xrange(yp) &&
+            q.Bx->ctx == By->ctx && q.Bx->n == By->n) {
+            c->memo.valid = false; c->nmemo.valid = false;
+            c->sub.active = true; c->sub.By = By; c->sub.jy = jy;
+            c->sub.s[0] = alpha[0]; c->sub.s[1] = cp ? alpha[1] : 0.0;
+            return LK_OK;
+        }
+        // y <- a X(:, jx) + 1 y with X a column of a multi-column panel: queue it (linear_combination's loop,
+        // AbstractVectors.fypp:600-602 / 637-642); consecutive columns onto the same y extend the queue.
+        if (unit_beta && Bx->ncols > 1 && xp != yp && xp != T) {
+            LKCHK(apply_sub(c));                                 // an earlier y update used the queue as it was
+            const bool same_target = q.active && q.By && q.By->col(q.jy) == yp;
+            const bool extends = same_target && q.cnt < KMAX_FUSED &&
+                                 (q.cnt == 0 || (q.Bx == Bx && jx == q.j0 + q.cnt));
             if (!extends) {
-                LKCHK(lazy_flush(c));
-                q.active = true; q.Bx = Bx; q.By = By; q.jy = jy; q.j0 = jx; q.cnt = 0; q.coef.clear();
+                const VecRef w{By, jy}, r{Bx, jx};
+                LKCHK(lazy_enter_vec(c, &w, false, &r, &w));
+                LKCHK(materialise_queue(c));
+                q.active = true; q.zeroed = false; q.Bx = Bx; q.By = By; q.jy = jy; q.j0 = jx; q.cnt = 0; q.coef.clear();
+            } else if (q.cnt == 0) {
+                q.Bx = Bx; q.j0 = jx;
             }
+            c->memo.valid = false; c->nmemo.valid = false;       // y is (about to be) modified
             for (int e = 0; e < ED; ++e) q.coef.push_back(alpha[e]);
             q.cnt += 1;
             c->lazy_stats[2] += 1;
             return LK_OK;
         }
-        LKCHK(lazy_flush(c));
+        const VecRef w{By, jy}, r{Bx, jx};
+        LKCHK(lazy_enter_vec(c, &w, zero_beta, &r, zero_beta ? nullptr : &w));
     }
     const int64_t nv = Bx->n * Bx->ed() / 2 + 1;
     ProfScope ps(c, "blas1", (double)Bx->n * Bx->ed() * 24.0);
@@ -1091,7 +1247,13 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
     LKCHK(check_pair(Bx, By, "lk_vec_dot"));
     if (!out) return fail(LK_ERR_INVALID, "lk_vec_dot: null out");
     lk_context_t c = Bx->ctx;
-    LKCHK(lazy_enter(c, false));
+    if (c->lazy && c->sub.active && c->sub.By->col(c->sub.jy) == By->col(jy) && Bx->data == c->queue.Bx->data &&
+        jx >= c->queue.j0 && jx < c->queue.j0 + c->queue.cnt) {
+        LKCHK(fused_sub_with_dots(c));                           // pass 2 asked for the dots without asking for the norm first
+    } else {
+        const VecRef r1{Bx, jx}, r2{By, jy};
+        LKCHK(lazy_enter_vec(c, nullptr, false, &r1, &r2));
+    }
     if (c->lazy && Bx->ncols > 1) {
         // innerprod's loop (AbstractVectors.fypp:672-674, 690-694) asks X(1)%dot(y), X(2)%dot(y), ...:
         // the first miss computes the dots of the whole run of columns in ONE sweep, the rest are memo hits.
@@ -1108,6 +1270,8 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
         int jend = (By->data == Bx->data && jy > jx) ? jy : (Bx->hwm < Bx->ncols ? Bx->hwm : Bx->ncols);
         int cnt = jend - jx;
         if (cnt > KMAX_FUSED) cnt = KMAX_FUSED;
+        if (c->queue.active && c->queue.By && c->queue.By->data == Bx->data && c->queue.jy > jx && c->queue.jy < jx + cnt)
+            cnt = c->queue.jy - jx;                              // never sweep a column whose contents are still virtual
         const bool y_inside = (By->data == Bx->data) && jy >= jx && jy < jx + cnt;
         if (cnt >= 2 && !y_inside) {
             LKCHK((sweepm<1>(Bx, jx, cnt, By->col(jy), nullptr, nullptr, 0, c->red)));
@@ -1131,7 +1295,19 @@ int lk_vec_norm(lk_basis_t B, int j, double *out) {
     DevGuard dev_guard(B->ctx);
     if (!out) return fail(LK_ERR_INVALID, "lk_vec_norm: null out");
     lk_context_t c = B->ctx;
-    LKCHK(lazy_enter(c, false));
+    if (c->lazy && c->sub.active && c->sub.By->col(c->sub.jy) == B->col(j)) {
+        // the zero-vector check that opens the next Gram-Schmidt pass (gram_schmidt.fypp:126), or qr's norm after the
+        // last one (qr.fypp:135): y' = y - X h is formed here, together with X^H y' for the dot calls that follow
+        LKCHK(fused_sub_with_dots(c));
+    } else {
+        const VecRef r{B, j};
+        LKCHK(lazy_enter_vec(c, nullptr, false, &r, nullptr));
+    }
+    if (c->lazy && c->nmemo.valid && c->nmemo.y == B->col(j)) {
+        *out = std::sqrt(std::fabs(c->nmemo.nrm2));
+        c->lazy_stats[0] += 1;
+        return LK_OK;
+    }
     LKCHK(dot_device(B, j, B, j, c->red));
     LKCHK(fetch(c, 0, 1));
     // alpha = abs(self%dot(self)); alpha = sqrt(alpha)   AbstractVectors.fypp:431
@@ -1151,7 +1327,10 @@ int lk_vec_copy(lk_basis_t Bd, int jd, lk_basis_t Bs, int js) {
     DevGuard dev_guard(Bd->ctx);
     LKCHK(check_pair(Bd, Bs, "lk_vec_copy"));
     if (Bd->col(jd) == Bs->col(js)) return LK_OK;
-    LKCHK(lazy_enter(Bd->ctx, true));
+    {
+        const VecRef w{Bd, jd}, r{Bs, js};
+        LKCHK(lazy_enter_vec(Bd->ctx, &w, true, &r, nullptr));
+    }
     Bd->touch(jd);
     ProfScope ps(Bd->ctx, "blas1", (double)Bd->n * Bd->ed() * 16.0);
     HIPCHK(hipMemcpyAsync(Bd->col(jd), Bs->col(js), (size_t)Bd->n * Bd->ed() * sizeof(double), hipMemcpyDeviceToDevice,
@@ -1163,7 +1342,10 @@ int lk_vec_rand(lk_basis_t B, int j, uint64_t seed, int64_t row0, int ifnorm) {
     LKCHK(check_vec(B, j, "lk_vec_rand"));
     DevGuard dev_guard(B->ctx);
     lk_context_t c = B->ctx;
-    LKCHK(lazy_enter(c, true));
+    {
+        const VecRef w{B, j};
+        LKCHK(lazy_enter_vec(c, &w, true, nullptr, nullptr));
+    }
     B->touch(j);
     if (B->dtype == LK_C128)
         hipLaunchKernelGGL(k_rand<true>, dim3(blas1_grid(c, B->n)), dim3(256), 0, c->stream, B->col(j), B->n, seed, row0);
@@ -1488,10 +1670,13 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
     LKCHK(check_pair(Bx, By, "lk_linop_apply"));
     if (Bx->dtype != op->dtype || Bx->n != op->n) return fail(LK_ERR_INVALID, "lk_linop_apply: operator/vector mismatch");
     lk_context_t c = op->ctx;
-    LKCHK(lazy_enter(c, true));
     const double *x = Bx->col(jx);
     double *y = By->col(jy);
     if (x == y) return fail(LK_ERR_INVALID, "lk_linop_apply: vec_in and vec_out alias");
+    {
+        const VecRef w{By, jy}, r{Bx, jx};
+        LKCHK(lazy_enter_vec(c, &w, true, &r, nullptr));       // vec_out is intent(out): AbstractLinops.fypp:74-87
+    }
     By->touch(jy);
     const bool cp = op->dtype == LK_C128;
     const int64_t n = op->n;

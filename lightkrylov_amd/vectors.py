@@ -15,6 +15,7 @@ package ships no CPU vector type).
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 from typing import Sequence
 
 import numpy as np
@@ -160,6 +161,31 @@ class _prefix_view(krylov_basis_gpu):
         pass
 
 
+_pool_tags = itertools.count(1)
+
+
+class _pool_column(krylov_basis_gpu):
+    """One column of a pool slab (lk_pool_*, the header's section on object ownership).  The temporaries of the
+    per-object path -- `allocate(y, source=X(1))` in linear_combination (AbstractVectors.fypp:595-598), `wrk` in
+    gmres -- live here exactly as the Fortran plugin's do: no allocation per call, and they sit in panels."""
+
+    def __init__(self, n_local: int, dtype, ctx: Context | None):  # noqa: D401 - no super().__init__ on purpose
+        self.ctx = ctx or default_context()
+        self.dtype = np.dtype(dtype)
+        self.n_local = int(n_local)
+        self._lib, self._owner = _capi.load(), None
+        slab, col = C.c_void_p(), C.c_int()
+        _capi.check(self._lib.lk_pool_acquire(self.ctx._h, _DT[self.dtype], self.n_local, C.c_uint64(next(_pool_tags)),
+                                              C.byref(slab), C.byref(col)))
+        self._h, self.col = slab, col.value
+        self.ncols = self.info()[2]
+
+    def close(self) -> None:  # the column goes back to the pool; the slab belongs to the context
+        if getattr(self, "_h", None) and self._h.value and self.ctx._h:
+            self._lib.lk_pool_release(self.ctx._h, self._h, self.col)
+        self._h = C.c_void_p()
+
+
 class dense_vector_gpu(abstract_vector):
     """extends(abstract_vector_{rdp,cdp}): the GPU counterpart of dense_vector
     (AbstractVectors.fypp:390-407, 476-562)."""
@@ -185,7 +211,10 @@ class dense_vector_gpu(abstract_vector):
         return self.basis.download(self.col, 1)[:, 0]
 
     def zeros_like(self) -> "dense_vector_gpu":
-        return dense_vector_gpu(self.basis.n_local, self.dtype, self.basis.ctx)
+        pc = _pool_column(self.basis.n_local, self.dtype, self.basis.ctx)
+        v = dense_vector_gpu(_basis=pc, _col=pc.col)
+        v.zero()
+        return v
 
     # -- six deferred procedures
     def zero(self) -> None:

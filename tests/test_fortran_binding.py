@@ -38,10 +38,11 @@ def test_fortran_host_program_runs_arnoldi_on_the_gpu():
         assert abs(vals[key] - ref) <= 1e-12 * abs(ref), (key, vals[key], ref)
     assert vals["orth"] < 1e-13
     assert abs(vals["norm_last"] - 1.0) < 1e-14
-    # the per-object (type-bound-procedure) schedule driven from Fortran in lazy mode: 8 dots -> 1 sweep + 7 hits;
-    # 8 axpbys into proj -> 1 panel update; y%sub(proj) is queued too (proj is a panel column) and applied when
-    # norm reads y: 9 queued, 2 flushes; same coefficients and same vector as the fused single-pass call
-    assert (vals["lazy_sweeps"], vals["lazy_hits"], vals["lazy_queued"], vals["lazy_flushes"]) == (1, 7, 9, 2)
+    # the per-object (type-bound-procedure) schedule driven from Fortran in lazy mode, compared with the fused single-pass call.
+    # m = 8 dots: one batched sweep + 7 memo hits; the 8 axpbys are queued onto a virtual proj; y%sub(proj) + y%norm()
+    # = one fused sweep (the norm is the 8th memo hit); nothing was flushed as a plain panel update, proj never written
+    assert (vals["lazy_sweeps"], vals["lazy_hits"], vals["lazy_queued"], vals["lazy_flushes"]) == (1, 8, 8, 0)
+    assert (vals["lazy_fused_sweeps"], vals["lazy_temporaries_written"]) == (1, 0)
     assert vals["lazy_h_err"] < 1e-13 and vals["lazy_y_err"] < 1e-13
     # complex(dp) pass: the same case through the oracle
     from oracle import oracle as ora

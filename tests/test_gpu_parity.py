@@ -557,14 +557,20 @@ def test_lazy_per_object_path_batches_the_reference_schedule(dtype):
         X = [B[j] for j in range(k)]                       # python LIST of vectors => generic per-object path
         beta = np.zeros(k, dtype=dtype)
         info = lk.double_gram_schmidt_step(B[k], X, if_chk_orthonormal=False, beta=beta)
-        results[lazy] = (info, beta.copy(), B.download(k, 1)[:, 0], c.lazy_stats())
+        yk = B.download(k, 1)[:, 0]
+        results[lazy] = (info, beta.copy(), yk, c.lazy_stats(), c.lazy_fusion_stats())
         del X, B
         c.close()
-    (i0, b0, y_eager, s0), (i1, b1, y_lazy, s1) = results[0], results[1]
-    assert s0 == (0, 0, 0, 0)
+    (i0, b0, y_eager, s0, f0), (i1, b1, y_lazy, s1, f1) = results[0], results[1]
+    assert s0 == (0, 0, 0, 0) and f0 == (0, 0, 0, 0)
     hits, sweeps, queued, flushes = s1
-    assert sweeps == 2 and hits == 2 * (k - 1)             # one batched sweep per pass, the other k-1 dots are memo hits
-    assert queued == 2 * k and flushes == 2                # k queued axpbys per pass, applied as one panel update each
+    fused, plain, dropped, written = f1
+    # pass 1: one batched dot sweep (k-1 memo hits); its projection stays virtual and is applied by pass 2's y%norm()
+    # in ONE sweep that also yields the norm (1 hit) and all k dots of pass 2 (k hits); pass 2's projection is applied
+    # as a plain panel update when the result is downloaded.  Neither temporary is ever written.
+    assert sweeps == 1 and hits == (k - 1) + 1 + k
+    assert queued == 2 * k and flushes == 0
+    assert (fused, plain, dropped, written) == (1, 1, 2, 0)
     yo = y0.copy()
     ho, info_o = ora.double_gram_schmidt_step(yo, Q)
     ynorm = np.linalg.norm(y0)
@@ -594,7 +600,7 @@ def test_lazy_mode_arnoldi_gmres_and_interleaved_calls_stay_correct():
     assert ora.arnoldi(ora.DiagOp(d), Xo, Ho) == 0
     for j in range(m):
         assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL_RED * np.abs(Ho[:, j]).max()
-    assert c.lazy_stats()[1] >= 2 * (m - 1)               # batched sweeps actually happened
+    assert c.lazy_stats()[1] >= m - 1 and c.lazy_fusion_stats()[0] >= 2 * (m - 1)   # batched dots (pass 1) and fused sweeps (pass 2, qr) happened
 
     # interleavings
     P = lk.krylov_basis_gpu(n, 4, np.float64, c)
@@ -615,6 +621,94 @@ def test_lazy_mode_arnoldi_gmres_and_interleaved_calls_stay_correct():
     y.axpby(1.0, P[3], 0.25)
     ref = 0.25 * (0.5 * (yh + 2 * Ph[:, 0] - 3 * Ph[:, 1]) + Ph[:, 2]) + Ph[:, 3]
     assert np.abs(y.to_array() - ref).max() <= 1e-13 * np.abs(ref).max()
+    c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_lazy_virtual_temporary_is_written_exactly_when_something_reads_it(dtype):
+    """linear_combination's temporary stays virtual in lazy mode (lk_lazy_fusion_stats).  Every way of observing it
+    must see X h: reading it after it was consumed, changing a column it is defined from and then reading it, scaling
+    it in place; overwriting it (zero / copy) drops it unwritten."""
+    n, k = 30_007, 9
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", 1)
+    B = lk.krylov_basis_gpu(n, k + 3, dtype, c)
+    for j in range(k + 3):
+        B[j].rand(False, seed=50 + j)
+    Xh = B.download()
+    X = [B[j] for j in range(k)]
+    y, T = B[k], B[k + 1]
+    h = seeded(k, dtype, 5)
+    tol = 1e-13 * np.abs(Xh).max() * k
+
+    def lincomb_into_T():
+        T.zero()
+        for i in range(k):
+            T.axpby(h[i], X[i], 1.0)
+
+    # 1. consumed by y%sub, then read: y is updated by the fused sweep (norm), T is written when it is read
+    lincomb_into_T(); y.sub(T)
+    yref = Xh[:, k] - Xh[:, :k] @ h
+    assert abs(y.norm() - np.linalg.norm(yref)) <= 1e-12 * np.linalg.norm(yref)
+    assert c.lazy_fusion_stats()[0] == 1 and c.lazy_fusion_stats()[3] == 0
+    d = np.array([X[i].dot(y) for i in range(k)])                      # memo hits of that same sweep
+    assert np.abs(d - Xh[:, :k].conj().T @ yref).max() <= 1e-12 * np.linalg.norm(yref) * np.sqrt(n)
+    assert np.abs(T.to_array() - Xh[:, :k] @ h).max() <= tol           # now it had to be written
+    assert c.lazy_fusion_stats()[3] == 1
+    assert np.abs(y.to_array() - yref).max() <= tol
+    # 2. a column T is defined from changes while T is virtual: T keeps the value it had
+    lincomb_into_T()
+    X[2].scal(3.0)
+    assert np.abs(T.to_array() - Xh[:, :k] @ h).max() <= tol
+    X[2].scal(1.0 / 3.0)
+    Xh2 = B.download()
+    # 3. partial update of the virtual vector itself
+    lincomb_into_T(); T.scal(2.0)
+    assert np.abs(T.to_array() - 2.0 * (Xh2[:, :k] @ h)).max() <= 4 * tol
+    # 4. overwriting drops it: no write of X h, and the new contents win
+    before = c.lazy_fusion_stats()
+    lincomb_into_T(); lk.copy(T, B[k + 2])
+    assert np.array_equal(T.to_array(), Xh2[:, k + 2])
+    lincomb_into_T(); T.zero()
+    assert np.all(T.to_array() == 0)
+    after = c.lazy_fusion_stats()
+    assert after[2] == before[2] + 2 and after[3] == before[3]
+    # 5. x%add(dx) (gmres.fypp:202) with a non-unit scale, applied by an unrelated read of x
+    lincomb_into_T(); ybefore = y.to_array()
+    y.axpby(-0.5, T, 1.0)
+    assert np.abs(y.to_array() - (ybefore - 0.5 * (Xh2[:, :k] @ h))).max() <= 4 * tol
+    # 6. the consumer is one of the columns the temporary is defined from: eager order
+    lincomb_into_T(); X[1].sub(T)
+    assert np.abs(X[1].to_array() - (Xh2[:, 1] - Xh2[:, :k] @ h)).max() <= 4 * tol
+    c.close()
+
+
+def test_lazy_per_object_arnoldi_runs_one_sweep_per_gram_schmidt_pass():
+    """The reference's arnoldi through per-object vectors (python LIST => the type-bound-procedure schedule): every
+    Gram-Schmidt pass after the first costs ONE fused sweep (update + dots + norm); no temporary is ever written."""
+    n, m = 40_009, 12
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", 1)
+    d = 1.0 + np.arange(n) / n
+    A = lk.diag_linop_gpu(d, c)
+
+    class pyop(lk.abstract_linop):
+        def matvec(self, vi, vo): A.matvec(vi, vo)
+    x0 = seeded(n, np.float64, 7); x0 /= np.linalg.norm(x0)
+    B = lk.krylov_basis_gpu(n, m + 1, np.float64, c); B.upload(x0.reshape(-1, 1), 0)
+    X = [B[j] for j in range(m + 1)]
+    H = np.zeros((m + 1, m), order="F")
+    assert lk.arnoldi(pyop(), X, H) == 0
+    fused, plain, dropped, written = c.lazy_fusion_stats()
+    assert fused == 2 * m and plain == 0 and written == 0 and dropped == 2 * m - 1   # the last temporary is still virtual
+    assert c.lazy_stats()[3] == 0                                      # no panel update outside the fused sweeps
+    Xo = np.zeros((n, m + 1), order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), order="F")
+    assert ora.arnoldi(ora.DiagOp(d), Xo, Ho) == 0
+    for j in range(m):
+        assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL_RED * np.abs(Ho[:, j]).max()
+    G = B.download()
+    assert np.abs(G.T @ G - np.eye(m + 1)).max() <= 1e-12
     c.close()
 
 
