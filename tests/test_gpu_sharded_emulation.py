@@ -283,3 +283,34 @@ def test_sharded_ginzburg_landau_stepper_and_arnoldi(ctx, nranks):
         for j in range(m):
             assert np.abs(H[:, j] - H1[:, j]).max() <= 1e-12 * np.abs(H1[:, j]).max()
     assert halo.calls == 8 * (m + 2)                              # 4 stages x 2 sub-steps per application, m + 2 applications
+
+
+def test_sharded_per_object_arnoldi_in_lazy_mode_matches_single_context(ctx):
+    """The per-object (type-bound-procedure) schedule with the lazy path on two emulated ranks: the fused
+    update + dot + norm sweep all-reduces inside y%norm() -- the same point of the call sequence on every rank --,
+    the catch-all flush never does.  Same H on every rank, equal to the single-context fused factorisation."""
+    n, m, nranks = 120_007, 10, 2
+
+    def body(rank, c, row0, nl):
+        c.set_tuning("lazy", 1)
+        A = lk.diag_linop_gpu(1.0 + (row0 + np.arange(nl)) / n, c)
+
+        class pyop(lk.abstract_linop):                            # python operator => the python (reference) step loop
+            def matvec(self, vi, vo): A.matvec(vi, vo)
+        B = lk.krylov_basis_gpu(nl, m + 1, np.float64, c)
+        B[0].rand(True, seed=7)
+        X = [B[j] for j in range(m + 1)]
+        H = np.zeros((m + 1, m), order="F")
+        info = lk.arnoldi(pyop(), X, H)
+        return info, H, c.lazy_fusion_stats()
+
+    res, grp = _sharded(n, nranks, body)
+    X1 = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
+    X1[0].rand(True, seed=7)
+    H1 = np.zeros((m + 1, m), order="F")
+    assert lk.arnoldi(lk.diag_linop_gpu(1.0 + np.arange(n) / n, ctx), X1, H1) == 0
+    for info, H, fs in res:
+        assert info == 0 and fs[0] == 2 * m and fs[1] == 0 and fs[3] == 0
+        assert np.array_equal(H, res[0][1])
+        for j in range(m):
+            assert np.abs(H[:, j] - H1[:, j]).max() <= 1e-12 * np.abs(H1[:, j]).max()
