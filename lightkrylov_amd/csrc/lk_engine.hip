@@ -93,6 +93,7 @@ struct lk_context_s {
     int64_t row0 = 0, n_global = -1;  // this rank's row block [row0, row0 + n_local) of n_global rows
     // lazy batching of the PER-OBJECT path (opt-in, tuning key "lazy"): what an unchanged LightKrylov drives
     // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
+    int blas1_grid_mult = 2;   // blocks of 256 threads per CU for the one-to-three-stream kernels
     int lazy = 0;
     struct {
         bool valid = false;
@@ -262,9 +263,11 @@ struct DevGuard {
     }
 };
 
+// non-temporal accesses for vectors that cannot stay in the 32 MB of L2 anyway (the next kernel re-reads them from HBM)
+inline int blas1_nt(lk_basis_t B) { return (int64_t)B->n * B->ed() * 8 >= (int64_t)32 << 20; }
 inline int blas1_grid(lk_context_t c, int64_t nvec) {
     int64_t g = (nvec + 255) / 256;
-    int64_t cap = (int64_t)c->num_cu * 8;
+    int64_t cap = (int64_t)c->num_cu * c->blas1_grid_mult;   // 2 blocks per CU: lk_kernels.hip.h, BLAS-1 header
     if (g > cap) g = cap;
     if (g < 1) g = 1;
     return (int)g;
@@ -557,10 +560,10 @@ int dot_device(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out_dev) {
         ProfScope ps(c, "blas1", (double)Bx->n * Bx->ed() * 16.0);
         if (Bx->dtype == LK_C128)
             hipLaunchKernelGGL(k_dot<true>, dim3(g), dim3(256), 0, c->stream, Bx->col(jx), By->col(jy), Bx->n, c->partial,
-                               (int64_t)MAX_GRID);
+                               (int64_t)MAX_GRID, blas1_nt(Bx));
         else
             hipLaunchKernelGGL(k_dot<false>, dim3(g), dim3(256), 0, c->stream, Bx->col(jx), By->col(jy), Bx->n, c->partial,
-                               (int64_t)MAX_GRID);
+                               (int64_t)MAX_GRID, blas1_nt(Bx));
     }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(finish_partials, dim3(1), dim3(256), 0, c->stream, c->partial, (int64_t)MAX_GRID, g, 2, out_dev);
@@ -584,10 +587,10 @@ int scal_launch(lk_basis_t B, int j, double ar, double ai, const double *inv_sqr
     ProfScope ps(c, "blas1", (double)B->n * B->ed() * 16.0);
     if (B->dtype == LK_C128)
         hipLaunchKernelGGL(k_scal<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, B->col(j), B->n, ar, ai,
-                           inv_sqrt_of, tol, c->guard(), stop_out, tol_break);
+                           inv_sqrt_of, tol, c->guard(), stop_out, tol_break, blas1_nt(B));
     else
         hipLaunchKernelGGL(k_scal<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, B->col(j), B->n, ar, ai,
-                           inv_sqrt_of, tol, c->guard(), stop_out, tol_break);
+                           inv_sqrt_of, tol, c->guard(), stop_out, tol_break, blas1_nt(B));
     HIPCHK(hipGetLastError());
     return LK_OK;
 }
@@ -863,6 +866,11 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "grid_mult must be in [1,16]");
         c->grid_mult = value;
+        return LK_OK;
+    }
+    if (!strcmp(key, "blas1_grid_mult")) {
+        if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: blas1_grid_mult must be in [1, 64]");
+        c->blas1_grid_mult = value;
         return LK_OK;
     }
     if (!strcmp(key, "stream_update")) { c->stream_update = value != 0; return LK_OK; }
@@ -1232,10 +1240,10 @@ int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta,
     ProfScope ps(c, "blas1", (double)Bx->n * Bx->ed() * 24.0);
     if (cp)
         hipLaunchKernelGGL(k_axpby<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, alpha[0], alpha[1], Bx->col(jx),
-                           beta[0], beta[1], By->col(jy), Bx->n);
+                           beta[0], beta[1], By->col(jy), Bx->n, blas1_nt(Bx));
     else
         hipLaunchKernelGGL(k_axpby<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, alpha[0], 0.0, Bx->col(jx),
-                           beta[0], 0.0, By->col(jy), Bx->n);
+                           beta[0], 0.0, By->col(jy), Bx->n, blas1_nt(Bx));
     HIPCHK(hipGetLastError());
     return LK_OK;
 }
@@ -1333,8 +1341,10 @@ int lk_vec_copy(lk_basis_t Bd, int jd, lk_basis_t Bs, int js) {
     }
     Bd->touch(jd);
     ProfScope ps(Bd->ctx, "blas1", (double)Bd->n * Bd->ed() * 16.0);
-    HIPCHK(hipMemcpyAsync(Bd->col(jd), Bs->col(js), (size_t)Bd->n * Bd->ed() * sizeof(double), hipMemcpyDeviceToDevice,
-                          Bd->ctx->stream));
+    const int64_t nd = Bd->n * Bd->ed();
+    hipLaunchKernelGGL(k_copy, dim3(blas1_grid(Bd->ctx, nd / 2 + 1)), dim3(256), 0, Bd->ctx->stream, Bs->col(js), Bd->col(jd), nd,
+                       blas1_nt(Bd));
+    HIPCHK(hipGetLastError());
     return LK_OK;
 }
 

@@ -761,11 +761,16 @@ __global__ __launch_bounds__(256) void finish_partials(const double *__restrict_
 
 // =====================================================================================
 // BLAS-1 (abstract_vector TBPs).  Grid-stride, 16 B per lane.
+// Shape from tools/blas1_probe.hip (n = 1e8, profiles/r02_blas1_probe.txt): these two- and three-stream kernels run
+// fastest with FEW loads in flight -- 2 blocks of 256 threads per CU, two independent 16-byte accesses per lane for the
+// 1- and 2-stream reads (scal, dot), one per stream for axpby -- and with non-temporal accesses: 6.2 / 6.5 / 7.2 TB/s
+// for scal / axpby / dot against 4.7 / 4.9 / 5.6 at 8 blocks per CU with plain accesses; more blocks or deeper
+// unrolling LOSE bandwidth.  `nt` (block-uniform) is set by the launcher for vectors that do not fit the caches anyway.
 // =====================================================================================
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_scal(double *__restrict__ x, int64_t n, double ar, double ai,
                                               const double *__restrict__ inv_sqrt_of, double tol, Guard guard,
-                                              int *__restrict__ stop_out, double tol_break) {
+                                              int *__restrict__ stop_out, double tol_break, int nt) {
     // inv_sqrt_of != NULL: alpha = 1/sqrt(|*inv_sqrt_of|) read on the device (fused normalise);
     // skipped (alpha = 1) when the norm is below tol so the host can take the breakdown path.
     // stop_out != NULL (asynchronous Arnoldi): a norm below tol_break, or a NaN, stops every LATER step.
@@ -781,35 +786,68 @@ __global__ __launch_bounds__(256) void k_scal(double *__restrict__ x, int64_t n,
     const int64_t nd = n * ED, nv = nd / 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     v2d *xv = reinterpret_cast<v2d *>(x);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
-        v2d v = xv[i];
-        if constexpr (CPLX) v = cmul(v2d{ar, ai}, v);
-        else v = v * ar;
-        xv[i] = v;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto f = [&](v2d v) { if constexpr (CPLX) return cmul(v2d{ar, ai}, v); else return v * ar; };
+    if (nt) {
+        for (; i + stride < nv; i += 2 * stride) {
+            const v2d v0 = __builtin_nontemporal_load(xv + i), v1 = __builtin_nontemporal_load(xv + i + stride);
+            __builtin_nontemporal_store(f(v0), xv + i);
+            __builtin_nontemporal_store(f(v1), xv + i + stride);
+        }
+    } else {
+        for (; i + stride < nv; i += 2 * stride) {
+            const v2d v0 = xv[i], v1 = xv[i + stride];
+            xv[i] = f(v0);
+            xv[i + stride] = f(v1);
+        }
     }
+    for (; i < nv; i += stride) xv[i] = f(xv[i]);
     if (!CPLX && (nd & 1) && blockIdx.x == 0 && threadIdx.x == 0) x[nd - 1] *= ar;
 }
 
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_axpby(double ar, double ai, const double *__restrict__ x, double br,
-                                               double bi, double *__restrict__ y, int64_t n) {
+                                               double bi, double *__restrict__ y, int64_t n, int nt) {
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     const int64_t nd = n * ED, nv = nd / 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const v2d *xv = reinterpret_cast<const v2d *>(x);
     v2d *yv = reinterpret_cast<v2d *>(y);
     const bool bzero = (br == 0.0 && bi == 0.0);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
-        v2d a = xv[i];
-        v2d r;
-        if constexpr (CPLX) {
-            r = cmul(v2d{ar, ai}, a);
-            if (!bzero) r += cmul(v2d{br, bi}, yv[i]);
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto ax = [&](v2d a) { if constexpr (CPLX) return cmul(v2d{ar, ai}, a); else return a * ar; };
+    auto by = [&](v2d b) { if constexpr (CPLX) return cmul(v2d{br, bi}, b); else return b * br; };
+    // four loops so that both loads of an element are issued back to back, with no data-dependent branch between them
+    if (bzero) {                  // one read stream + one write stream: two elements per lane in flight, like k_scal
+        int64_t i = i0;
+        if (nt) {
+            for (; i + stride < nv; i += 2 * stride) {
+                const v2d a0 = __builtin_nontemporal_load(xv + i), a1 = __builtin_nontemporal_load(xv + i + stride);
+                __builtin_nontemporal_store(ax(a0), yv + i);
+                __builtin_nontemporal_store(ax(a1), yv + i + stride);
+            }
         } else {
-            r = a * ar;
-            if (!bzero) r += yv[i] * br;
+            for (; i + stride < nv; i += 2 * stride) {
+                const v2d a0 = xv[i], a1 = xv[i + stride];
+                yv[i] = ax(a0);
+                yv[i + stride] = ax(a1);
+            }
         }
-        yv[i] = r;
+        for (; i < nv; i += stride) yv[i] = ax(xv[i]);
+    } else if (nt) {
+        for (int64_t i = i0; i < nv; i += stride) {
+            const v2d a = __builtin_nontemporal_load(xv + i), b = __builtin_nontemporal_load(yv + i);
+            v2d r = ax(a);
+            r += by(b);
+            __builtin_nontemporal_store(r, yv + i);
+        }
+    } else {
+        for (int64_t i = i0; i < nv; i += stride) {
+            const v2d a = xv[i], b = yv[i];
+            v2d r = ax(a);
+            r += by(b);
+            yv[i] = r;
+        }
     }
     if (!CPLX && (nd & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         double r = ar * x[nd - 1];
@@ -818,21 +856,60 @@ __global__ __launch_bounds__(256) void k_axpby(double ar, double ai, const doubl
     }
 }
 
+// copy(out, from): nd doubles, same shape as the beta == 0 branch above without the multiply (bit copy)
+__global__ __launch_bounds__(256) void k_copy(const double *__restrict__ x, double *__restrict__ y, int64_t nd, int nt) {
+    const int64_t nv = nd / 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const v2d *xv = reinterpret_cast<const v2d *>(x);
+    v2d *yv = reinterpret_cast<v2d *>(y);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (nt) {
+        for (; i + stride < nv; i += 2 * stride) {
+            const v2d a0 = __builtin_nontemporal_load(xv + i), a1 = __builtin_nontemporal_load(xv + i + stride);
+            __builtin_nontemporal_store(a0, yv + i);
+            __builtin_nontemporal_store(a1, yv + i + stride);
+        }
+    }
+    for (; i < nv; i += stride) yv[i] = xv[i];
+    if ((nd & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[nd - 1] = x[nd - 1];
+}
+
 // partial[0*pstride + b] (+ [1*pstride + b] imag) = sum conj(x) y over this block's rows
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_dot(const double *__restrict__ x, const double *__restrict__ y, int64_t n,
-                                             double *__restrict__ partial, int64_t pstride) {
+                                             double *__restrict__ partial, int64_t pstride, int nt) {
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     const int64_t nd = n * ED, nv = nd / 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const v2d *xv = reinterpret_cast<const v2d *>(x);
     const v2d *yv = reinterpret_cast<const v2d *>(y);
     v2d acc = v2d{0.0, 0.0};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
-        v2d a = xv[i], b = yv[i];
-        if constexpr (CPLX) acc += cmulconj(a, b);
-        else acc += a * b;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto add = [&](v2d a, v2d b) { if constexpr (CPLX) acc += cmulconj(a, b); else acc += a * b; };
+    if (x == y) {                 // norm: ONE stream, so four loads per lane in flight
+        for (; i + 3 * stride < nv; i += 4 * stride) {
+            v2d a0, a1, a2, a3;
+            if (nt) {
+                a0 = __builtin_nontemporal_load(xv + i); a1 = __builtin_nontemporal_load(xv + i + stride);
+                a2 = __builtin_nontemporal_load(xv + i + 2 * stride); a3 = __builtin_nontemporal_load(xv + i + 3 * stride);
+            } else {
+                a0 = xv[i]; a1 = xv[i + stride]; a2 = xv[i + 2 * stride]; a3 = xv[i + 3 * stride];
+            }
+            add(a0, a0); add(a1, a1); add(a2, a2); add(a3, a3);
+        }
+    } else if (nt) {
+        for (; i + stride < nv; i += 2 * stride) {
+            const v2d a0 = __builtin_nontemporal_load(xv + i), b0 = __builtin_nontemporal_load(yv + i);
+            const v2d a1 = __builtin_nontemporal_load(xv + i + stride), b1 = __builtin_nontemporal_load(yv + i + stride);
+            add(a0, b0); add(a1, b1);
+        }
+    } else {
+        for (; i + stride < nv; i += 2 * stride) {
+            const v2d a0 = xv[i], b0 = yv[i], a1 = xv[i + stride], b1 = yv[i + stride];
+            add(a0, b0); add(a1, b1);
+        }
     }
+    for (; i < nv; i += stride) add(xv[i], yv[i]);
     if (!CPLX && (nd & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc.x += x[nd - 1] * y[nd - 1];
     __shared__ double red[2 * 4];
     double re, im = 0.0;
@@ -890,11 +967,17 @@ __global__ __launch_bounds__(256) void k_diag_linspace(double d0, double dstep, 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const v2d *xv = reinterpret_cast<const v2d *>(x);
     v2d *yv = reinterpret_cast<v2d *>(y);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    auto dd = [&](int64_t i) {
         const double g = (double)(row0 + 2 * i);
-        v2d dd = v2d{fma(dstep, g, d0), fma(dstep, g + 1.0, d0)};   // ONE rounding per d_i
-        yv[i] = dd * xv[i];
+        return v2d{fma(dstep, g, d0), fma(dstep, g + 1.0, d0)};     // ONE rounding per d_i
+    };
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + stride < nv; i += 2 * stride) {                      // two elements per lane in flight (one read + one write stream)
+        const v2d a0 = __builtin_nontemporal_load(xv + i), a1 = __builtin_nontemporal_load(xv + i + stride);
+        yv[i] = dd(i) * a0;
+        yv[i + stride] = dd(i + stride) * a1;
     }
+    for (; i < nv; i += stride) yv[i] = dd(i) * xv[i];
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(dstep, (double)(row0 + n - 1), d0) * x[n - 1];
 }
 
