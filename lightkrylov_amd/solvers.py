@@ -12,8 +12,12 @@ from dataclasses import dataclass, field
 import numpy as np
 from scipy.linalg import lapack as _lapack
 
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+from . import _hostlapack
 from .constants import atol_dp, rtol_dp
-from .krylov import arnoldi, double_gram_schmidt_step, krylov_schur
+from .krylov import _engine_linop, arnoldi, double_gram_schmidt_step, krylov_schur
 from .linops import abstract_linop
 from .outputs import eigs_output, write_results
 from .vectors import abstract_vector, copy, dense_vector_gpu, krylov_basis_gpu, linear_combination, zero_basis
@@ -182,14 +186,15 @@ def gmres(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float
 # ------------------------------------------------------------------------------------------
 def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | None = None,
          tolerance: float = rtol_dp, transpose: bool = False, write_intermediate: bool = False,
-         max_restarts: int | None = None):
+         max_restarts: int | None = None, pipelined: bool | None = None):
     """Krylov-Schur eigensolver for the leading len(X) eigenpairs.
     src/IterativeSolvers/IterativeSolvers.fypp:972-1143.
     X (sequence / basis of nev vectors) receives the eigenvectors.
     Returns (eigvals[nev] complex, residuals[nev], info = number of Arnoldi steps).
     (`write_intermediate` defaults to False here -- the reference's default is .true. -- because the per-step
     text dump is file I/O outside the path; when True it writes `eigs_output.txt` exactly like :1091.
-    `max_restarts` is an engine extra: the reference loops until `nev` pairs converge, however long.)"""
+    `max_restarts` is an engine extra: the reference loops until `nev` pairs converge, however long.
+    `pipelined` (engine extra; None = whenever possible): see the comment at the cycle loop -- same results.)"""
     nev = len(X)
     kdim_ = 4 * nev if kdim is None else kdim                                      # :1023
     proto = X[0]
@@ -207,32 +212,71 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
     def median_selector(lam):                                                      # :1137-1142
         return np.abs(lam) > np.median(np.abs(lam))
 
+    def ritz_test(k):
+        """Ritz values of H(1:k, 1:k) and their residuals |H(k+1,k) * last eigenvector component|   :1065-1082"""
+        vecs, vals = _hostlapack.geev(H[:k, :k])                                   # :1065 (same LAPACK routine as `eig`)
+        beta = H[k, k - 1]
+        r = np.empty(k)
+        if dt == np.complex128:
+            r[:] = np.abs(beta * vecs[k - 1, :k])                                  # :1071
+        else:
+            for i in range(k):                                                     # :1073-1082
+                if vals[i].imag > 0:
+                    alpha = abs(complex(vecs[k - 1, i], vecs[k - 1, i + 1]))
+                elif vals[i].imag < 0:
+                    alpha = abs(complex(vecs[k - 1, i - 1], vecs[k - 1, i]))
+                else:
+                    alpha = abs(vecs[k - 1, i])
+                r[i] = abs(beta * alpha)
+        return vals, r
+
+    # Whole-cycle pipeline (engine extra, result-identical).  The reference alternates ONE Arnoldi step with ONE geev of
+    # H(1:k, 1:k) and stops at the first k with `nev` converged Ritz pairs (:1059-1093).  The Hessenberg columns do not
+    # depend on when they are looked at, so here the cycle's steps are enqueued in one asynchronous lk_arnoldi call, and the
+    # per-step tests -- independent once H is known -- run afterwards on several host threads, in step order, stopping at
+    # the first k the reference would have stopped at.  Steps computed beyond it only touched eigs' private work basis.
+    can_pipeline = isinstance(Xwrk, krylov_basis_gpu) and isinstance(A, _engine_linop) and not write_intermediate
+    pipelined = can_pipeline and (_hostlapack.threaded() if pipelined is None else bool(pipelined))
+    nthreads = max(1, min(32, os.cpu_count() or 1))
+
     restarts = 0
     while conv < nev:
         if max_restarts is not None and restarts > max_restarts:
             break
         restarts += 1
-        for k in range(kstart, kdim_ + 1):
-            arnoldi(A, Xwrk, H, kstart=k, kend=k, transpose=transpose)            # :1059
-            vecs, vals = eig(H[:k, :k])                                           # :1065
-            beta = H[k, k - 1]
-            if dt == np.complex128:
-                res[:k] = np.abs(beta * vecs[k - 1, :k])                           # :1071
-            else:
-                for i in range(k):                                                 # :1073-1082
-                    if vals[i].imag > 0:
-                        alpha = abs(complex(vecs[k - 1, i], vecs[k - 1, i + 1]))
-                    elif vals[i].imag < 0:
-                        alpha = abs(complex(vecs[k - 1, i - 1], vecs[k - 1, i]))
-                    else:
-                        alpha = abs(vecs[k - 1, i])
-                    res[i] = abs(beta * alpha)
-            niter += 1
-            conv = int(np.count_nonzero(res[:k] < tolerance))                      # :1087
-            if write_intermediate:
-                write_results(eigs_output, vals[:k], res[:k], tolerance)           # :1091 (sorts res(:k) in place)
-            if conv >= nev:
-                break
+        k_from, stopped = kstart, False
+        if pipelined and kstart <= kdim_:
+            ainfo = arnoldi(A, Xwrk, H, kstart=kstart, kend=kdim_, transpose=transpose)
+            klast = ainfo if ainfo > 0 else kdim_                                  # an exhausted Krylov space ends the batch early
+            with _hostlapack.blas_threads(1), ThreadPoolExecutor(nthreads) as pool:
+                for c0 in range(kstart, klast + 1, nthreads):
+                    ks = range(c0, min(c0 + nthreads, klast + 1))
+                    for k, (_vals, r) in zip(ks, pool.map(ritz_test, ks)):
+                        res[:k] = r
+                        niter += 1
+                        conv = int(np.count_nonzero(res[:k] < tolerance))          # :1087
+                        if conv >= nev:
+                            stopped = True
+                            break
+                    if stopped:
+                        break
+            if stopped and k < klast:
+                # put the work arrays into the state the reference is in when it leaves the loop at step k (:1093):
+                # krylov_schur below acts on ALL of H and Xwrk
+                H[:, k:] = 0
+                zero_basis(Xwrk[k + 1:])
+            k_from = klast + 1                                                     # (breakdown without convergence: go on step by step)
+        if not stopped:
+            for k in range(k_from, kdim_ + 1):
+                arnoldi(A, Xwrk, H, kstart=k, kend=k, transpose=transpose)        # :1059
+                vals, r = ritz_test(k)
+                res[:k] = r
+                niter += 1
+                conv = int(np.count_nonzero(res[:k] < tolerance))                  # :1087
+                if write_intermediate:
+                    write_results(eigs_output, vals[:k], res[:k], tolerance)       # :1091 (sorts res(:k) in place)
+                if conv >= nev:
+                    break
         kstart = krylov_schur(Xwrk, H, median_selector) + 1                        # :1100
     k = min(k, kdim_)
     vecs, vals = eig(H[:k, :k])                                                    # :1115

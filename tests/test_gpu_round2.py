@@ -353,3 +353,30 @@ def test_arnoldi_beyond_the_fused_width_and_restarted_ranges(ctx):
     assert lk.arnoldi(A, X2, H2, kstart=51, kend=51) == 0            # a single step takes the synchronous path
     assert lk.arnoldi(A, X2, H2, kstart=52, kend=m) == 0
     assert H2.tobytes() == H.tobytes() and X2.download().tobytes() == X.download().tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_pipelined_eigs_cycle_equals_the_step_by_step_one(ctx, dtype):
+    """eigs' whole-cycle pipeline (one asynchronous lk_arnoldi per Krylov-Schur cycle, the per-step geev tests afterwards
+    on several host threads) returns exactly what the reference's step / geev / step / geev loop returns: same number of
+    Arnoldi steps, same eigenvalues and residuals bit for bit, same eigenvectors -- converging mid-cycle (early stop:
+    the work arrays are put back into the reference's state before the restart) and after restarts."""
+    n, nev = 4_000, 4
+    rng = np.random.default_rng(11)
+    d = np.r_[np.array([3.0, 2.6, 2.2, 1.9, 1.7]), 1.0 + 0.4 * rng.random(n - 5)]
+    if np.dtype(dtype).kind == "c":
+        d = d * np.exp(0.2j * rng.random(n))
+    A = lk.diag_linop_gpu(d.astype(dtype), ctx)
+    out = {}
+    for kdim, tag in ((40, "early stop inside the first cycle"), (12, "several restarts")):
+        for pipe in (False, True):
+            V = lk.krylov_basis_gpu(n, nev, dtype, ctx)
+            x0 = lk.dense_vector_gpu(n, dtype, ctx); x0.rand(False, seed=3)
+            vals, res, info = lk.eigs(A, V, x0=x0, kdim=kdim, tolerance=1e-10, max_restarts=60, pipelined=pipe)
+            out[(kdim, pipe)] = (vals, res, info, V.download())
+        (v0, r0, i0, X0), (v1, r1, i1, X1) = out[(kdim, False)], out[(kdim, True)]
+        assert i0 == i1, tag
+        assert np.array_equal(v0, v1) and np.array_equal(r0, r1), tag
+        assert np.array_equal(X0, X1), tag
+        assert np.abs(np.sort(np.abs(v1))[::-1] - np.sort(np.abs(d))[::-1][:nev]).max() <= 1e-8, tag
+    assert out[(40, True)][2] < 40 and out[(12, True)][2] > 12

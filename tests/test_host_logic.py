@@ -275,3 +275,26 @@ def test_grid_partition_covers_the_grid_in_whole_lines():
             assert parts[0][0] == 0 and sum(nj for _j0, nj in parts) == N
             for (j0, nj), (j1, _n1) in zip(parts, parts[1:]):
                 assert nj >= 1 and j0 + nj == j1
+
+
+def test_threadable_geev_is_bit_identical_to_scipys_wrapper():
+    """lightkrylov_amd._hostlapack.geev calls the same OpenBLAS routine scipy.linalg.lapack.{d,z}geev calls, with the
+    same workspace size, outside the interpreter lock: same bits, from one thread or from eight at once."""
+    from concurrent.futures import ThreadPoolExecutor
+    from scipy.linalg import lapack
+    from lightkrylov_amd import _hostlapack as hl
+    rng = np.random.default_rng(5)
+    Hr = np.asfortranarray(np.triu(rng.standard_normal((41, 40)), -1))
+    Hz = np.asfortranarray(np.triu(rng.standard_normal((41, 40)) + 1j * rng.standard_normal((41, 40)), -1))
+
+    def check(k):
+        vr, vals = hl.geev(Hz[:k, :k])
+        w, _vl, v2, info = lapack.zgeev(np.asfortranarray(Hz[:k, :k]), compute_vl=0, compute_vr=1)
+        ok = info == 0 and np.array_equal(vals, w) and np.array_equal(vr, v2)
+        vr, vals = hl.geev(Hr[:k, :k])
+        wr, wi, _vl, v2, info = lapack.dgeev(np.asfortranarray(Hr[:k, :k]), compute_vl=0, compute_vr=1)
+        return ok and info == 0 and np.array_equal(vals, wr + 1j * wi) and np.array_equal(vr, v2)
+
+    assert all(check(k) for k in range(1, 41))
+    with hl.blas_threads(1), ThreadPoolExecutor(8) as pool:
+        assert all(pool.map(check, list(range(1, 41)) * 3))
