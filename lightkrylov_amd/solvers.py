@@ -128,10 +128,13 @@ def gmres(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float
             m.res = [abs(beta)]
         k = 0
         for k in range(1, kdim + 1):
-            copy(wrk, V[k - 1])                                                    # :155  wrk = V(k)
-            if preconditioner is not None:
-                preconditioner.apply(wrk, k, beta, tol)
-            mv(wrk, V[k])                                                          # :161-165
+            if preconditioner is None and isinstance(V, krylov_basis_gpu):
+                mv(V[k - 1], V[k])             # wrk is only a copy of V(k) for the preconditioner to overwrite (:155-165)
+            else:
+                copy(wrk, V[k - 1])                                                # :155  wrk = V(k)
+                if preconditioner is not None:
+                    preconditioner.apply(wrk, k, beta, tol)
+                mv(wrk, V[k])                                                      # :161-165
             hcol = np.zeros(k, dtype=dt)
             norms: list = []
             if isinstance(V, krylov_basis_gpu):

@@ -107,6 +107,31 @@ def test_config2_full_size_against_live_oracle_and_fixture(ctx):
     assert colerr(H, Ho) <= TOL
 
 
+def test_config2_full_size_through_the_per_object_lazy_path():
+    """configs[1] again, but driven the way an UNCHANGED LightKrylov drives the plugin: per-object vectors (python list =>
+    the type-bound-procedure schedule of arnoldi / double_gram_schmidt_step / linear_combination), engine in lazy mode
+    (virtual temporaries, one fused sweep per Gram-Schmidt pass).  Same 1e-12 against the committed oracle fixture."""
+    z = np.load(os.path.join(GOLD, "arnoldi_diaglin_n10000000_m64_rdp.npz"))
+    n, m = 10_000_000, 64
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", 1)
+    A = lk.diag_linop_gpu(n_local=n, row0=0, d0=1.0, dstep=1.0 / n, ctx=c)
+
+    class pyop(lk.abstract_linop):                            # python operator => the reference's step loop
+        def matvec(self, vi, vo): A.matvec(vi, vo)
+    B = lk.krylov_basis_gpu(n, m + 1, np.float64, c)
+    B[0].rand(True, seed=7)
+    H = np.zeros((m + 1, m), order="F")
+    assert lk.arnoldi(pyop(), [B[j] for j in range(m + 1)], H) == 0
+    fused, plain, _dropped, written = c.lazy_fusion_stats()
+    assert fused == 2 * m and plain == 0 and written == 0
+    assert colerr(H, z["H_seq"]) <= TOL and colerr(H, z["H_comp"]) <= 1e-13
+    assert np.max(np.abs(ritz(H) - ritz(z["H_seq"])) / np.abs(ritz(z["H_seq"]))) <= TOL
+    check_properties(B, H, n, m)
+    del B, A
+    c.close()
+
+
 def test_config3_full_size_gmres_against_live_oracle(ctx):
     """configs[2] at FULL size: GMRES(30), maxiter = 2 (3 cycles, 93 Gram-Schmidt steps) on the 4096^2 five-point
     Laplacian, against the oracle's restatement of gmres.fypp run here on the host cores (Gram-Schmidt steps through the
