@@ -677,6 +677,9 @@ struct VecRef { lk_basis_t B; int j; };
 int lazy_enter_vec(lk_context_t c, const VecRef *w, bool overwrite, const VecRef *r1, const VecRef *r2) {
     if (!c->lazy) return LK_OK;
     if (w) { c->memo.valid = false; c->nmemo.valid = false; }
+    if (c->sub.active && w && overwrite && w->B->col(w->j) == c->sub.By->col(c->sub.jy) &&
+        !(r1 && r1->B->col(r1->j) == w->B->col(w->j)) && !(r2 && r2->B->col(r2->j) == w->B->col(w->j)))
+        c->sub.active = false;                                      // the vector with the pending update is overwritten: nothing to apply
     LKCHK(apply_sub(c));                                            // y is live: bring it up to date first
     auto &q = c->queue;
     if (!q.active) return LK_OK;
@@ -1026,7 +1029,12 @@ int lk_basis_upload(lk_basis_t B, int col0, int ncols, const void *host, int64_t
     DevGuard dev_guard(B->ctx);
     if (col0 < 0 || ncols < 0 || col0 + ncols > B->ncols || ldh < B->n) return fail(LK_ERR_INVALID, "lk_basis_upload: bad range");
     if (ncols == 0 || B->n == 0) return LK_OK;
-    LKCHK(lazy_enter(B->ctx, true));
+    if (ncols == 1) {                                               // one vector (y%upload(x)): like any other overwrite of it
+        const VecRef w{B, col0};
+        LKCHK(lazy_enter_vec(B->ctx, &w, true, nullptr, nullptr));
+    } else {
+        LKCHK(lazy_enter(B->ctx, true));
+    }
     B->touch(col0, ncols);
     const size_t es = (size_t)B->ed() * sizeof(double);
     HIPCHK(hipMemcpy2DAsync(B->col(col0), (size_t)B->ld * es, host, (size_t)ldh * es, (size_t)B->n * es, ncols,
@@ -1040,7 +1048,12 @@ int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh
     DevGuard dev_guard(B->ctx);
     if (col0 < 0 || ncols < 0 || col0 + ncols > B->ncols || ldh < B->n) return fail(LK_ERR_INVALID, "lk_basis_download: bad range");
     if (ncols == 0 || B->n == 0) return LK_OK;
-    LKCHK(lazy_enter(B->ctx, false));
+    if (ncols == 1) {
+        const VecRef r{B, col0};
+        LKCHK(lazy_enter_vec(B->ctx, nullptr, false, &r, nullptr));
+    } else {
+        LKCHK(lazy_enter(B->ctx, false));
+    }
     const size_t es = (size_t)B->ed() * sizeof(double);
     HIPCHK(hipMemcpy2DAsync(host, (size_t)ldh * es, B->col(col0), (size_t)B->ld * es, (size_t)B->n * es, ncols,
                             hipMemcpyDeviceToHost, B->ctx->stream));
@@ -1255,12 +1268,20 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
     LKCHK(check_pair(Bx, By, "lk_vec_dot"));
     if (!out) return fail(LK_ERR_INVALID, "lk_vec_dot: null out");
     lk_context_t c = Bx->ctx;
-    if (c->lazy && c->sub.active && c->sub.By->col(c->sub.jy) == By->col(jy) && Bx->data == c->queue.Bx->data &&
-        jx >= c->queue.j0 && jx < c->queue.j0 + c->queue.cnt) {
-        LKCHK(fused_sub_with_dots(c));                           // pass 2 asked for the dots without asking for the norm first
+    // y%norm() reaches the plugin as y%dot(y): LightKrylov's norm is sqrt(abs(self%dot(self))) (AbstractVectors.fypp:424-432)
+    const bool self_dot = Bx->col(jx) == By->col(jy);
+    if (c->lazy && c->sub.active && c->sub.By->col(c->sub.jy) == By->col(jy) &&
+        (self_dot || (Bx->data == c->queue.Bx->data && jx >= c->queue.j0 && jx < c->queue.j0 + c->queue.cnt))) {
+        LKCHK(fused_sub_with_dots(c));                           // the norm / the first dot of the next pass: one fused sweep
     } else {
         const VecRef r1{Bx, jx}, r2{By, jy};
         LKCHK(lazy_enter_vec(c, nullptr, false, &r1, &r2));
+    }
+    if (c->lazy && self_dot && c->nmemo.valid && c->nmemo.y == By->col(jy)) {
+        out[0] = c->nmemo.nrm2;
+        if (Bx->dtype == LK_C128) out[1] = 0.0;
+        c->lazy_stats[0] += 1;
+        return LK_OK;
     }
     if (c->lazy && Bx->ncols > 1) {
         // innerprod's loop (AbstractVectors.fypp:672-674, 690-694) asks X(1)%dot(y), X(2)%dot(y), ...:
