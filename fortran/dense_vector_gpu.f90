@@ -47,6 +47,7 @@ module lightkrylov_gpu
     public :: dense_vector_gpu_rdp, dense_vector_gpu_cdp, dense_vector_gpu
     public :: linop_gpu_rdp, linop_gpu_cdp, dense_linop_gpu_rdp, dense_linop_gpu_cdp
     public :: dense_linop_gpu, diag_linop_gpu, diag_linspace_linop_gpu, laplacian2d_linop_gpu, ginzburg_landau_linop_gpu
+    public :: csr_linop_gpu
     public :: lk_gpu_init, lk_gpu_finalize, lk_gpu_release_all, lk_gpu_context, lk_gpu_pool_stats
     public :: lk_gpu_set_partition, lk_gpu_comm_unique_id, lk_gpu_comm_init
     public :: gpu_arnoldi_rdp, gpu_arnoldi_cdp
@@ -124,6 +125,10 @@ module lightkrylov_gpu
     end interface
     interface diag_linop_gpu
         module procedure diag_linop_gpu_from_rdp, diag_linop_gpu_from_cdp
+    end interface
+    !> a sparse operator in CSR with Fortran's 1-based `rowptr(n+1)` / `colind(nnz)`; matvec and rmatvec on the device
+    interface csr_linop_gpu
+        module procedure csr_linop_gpu_from_rdp, csr_linop_gpu_from_cdp
     end interface
 
 contains
@@ -509,6 +514,28 @@ contains
         type(dense_linop_gpu_cdp) :: L
         call chk(lk_linop_dense_create(ctx, LK_C128, int(size(A, 1), c_int64_t), c_loc(A), int(size(A, 1), c_int64_t), L%op), &
                  'dense_linop_gpu')
+    end function
+    function csr_linop_gpu_from_rdp(rowptr, colind, vals) result(L)
+        integer, intent(in) :: rowptr(:), colind(:)
+        real(dp), intent(in), target :: vals(:)
+        type(linop_gpu_rdp) :: L
+        integer(c_int64_t), allocatable, target :: rp(:)
+        integer(c_int32_t), allocatable, target :: ci(:)
+        rp = int(rowptr, c_int64_t) - 1_c_int64_t
+        ci = int(colind, c_int32_t) - 1_c_int32_t
+        call chk(lk_linop_csr_create(ctx, LK_F64, int(size(rowptr) - 1, c_int64_t), c_loc(rp), c_loc(ci), c_loc(vals), L%op), &
+                 'csr_linop_gpu')
+    end function
+    function csr_linop_gpu_from_cdp(rowptr, colind, vals) result(L)
+        integer, intent(in) :: rowptr(:), colind(:)
+        complex(dp), intent(in), target :: vals(:)
+        type(linop_gpu_cdp) :: L
+        integer(c_int64_t), allocatable, target :: rp(:)
+        integer(c_int32_t), allocatable, target :: ci(:)
+        rp = int(rowptr, c_int64_t) - 1_c_int64_t
+        ci = int(colind, c_int32_t) - 1_c_int32_t
+        call chk(lk_linop_csr_create(ctx, LK_C128, int(size(rowptr) - 1, c_int64_t), c_loc(rp), c_loc(ci), c_loc(vals), L%op), &
+                 'csr_linop_gpu')
     end function
     function diag_linop_gpu_from_rdp(d) result(L)
         real(dp), intent(in), target :: d(:)

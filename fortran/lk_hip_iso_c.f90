@@ -190,6 +190,14 @@ module lightkrylov_hip_c
             type(c_ptr), intent(out) :: op
             integer(c_int) :: rc
         end function
+        function lk_linop_csr_create(ctx, dtype, n, rowptr, colind, vals, op) bind(C, name="lk_linop_csr_create") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx, rowptr, colind, vals
+            integer(c_int), value :: dtype
+            integer(c_int64_t), value :: n
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
         function lk_context_info(ctx, device, stream) bind(C, name="lk_context_info") result(rc)
             import :: c_int, c_ptr
             type(c_ptr), value :: ctx

@@ -250,6 +250,12 @@ int lk_linop_diag_linspace_create(lk_context_t ctx, int64_t n_local, int64_t row
  * AbstractLinops.fypp:265-271, 608-660.  Single-rank only. */
 int lk_linop_dense_create(lk_context_t ctx, int dtype, int64_t n, const void *A_host, int64_t lda,
                           lk_linop_t *op);
+/* sparse operator in CSR: y = A x ('N') or A^H x ('H'), A n x n, 0-based `rowptr[n+1]` / `colind[nnz]`, values of
+ * `dtype` -- a user's sparse `abstract_linop` (AbstractLinops.fypp:58-87; the reference has no sparse type of its own:
+ * its Poisson / Ginzburg-Landau examples write the stencil by hand).  The arrays are copied; A^H is built once on the
+ * host so that rmatvec is a row-parallel product too.  Single-rank. */
+int lk_linop_csr_create(lk_context_t ctx, int dtype, int64_t n, const int64_t *rowptr, const int32_t *colind,
+                        const void *vals, lk_linop_t *op);
 /* 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (BASELINE config 3).
  * F64; whole grid on one rank (row-sharded: the _sharded variant below). */
 int lk_linop_lap5_create(lk_context_t ctx, int64_t N, lk_linop_t *op);

@@ -14,7 +14,7 @@ from .constants import atol_dp, rtol_dp  # noqa: F401
 from .context import Context, default_context, row_partition  # noqa: F401
 from .vectors import (Gram, abstract_vector, axpby_basis, copy, dense_vector_gpu, innerprod,  # noqa: F401
                       krylov_basis_gpu, linear_combination, rand_basis, verify_vector_axioms, zero_basis)
-from .linops import (Id, abstract_linop, adjoint_linop, axpby_linop, scaled_linop, dense_linop_gpu, diag_linop_gpu, ginzburg_landau_linop_gpu,
+from .linops import (Id, abstract_linop, adjoint_linop, axpby_linop, scaled_linop, csr_linop_gpu, dense_linop_gpu, diag_linop_gpu, ginzburg_landau_linop_gpu,
                      grid_partition, laplacian2d_linop_gpu)  # noqa: F401
 from .krylov import (arnoldi, bidiagonalization, double_gram_schmidt_step, is_orthonormal, krylov_schur, lanczos,  # noqa: F401
                      orthogonalize_against_basis, qr)

@@ -75,6 +75,7 @@ SIGNATURES = {
     "lk_linop_diag_create": (_int, [_p, _int, _i64, _p, _pp]),
     "lk_linop_diag_linspace_create": (_int, [_p, _i64, _i64, C.c_double, C.c_double, _pp]),
     "lk_linop_dense_create": (_int, [_p, _int, _i64, _p, _i64, _pp]),
+    "lk_linop_csr_create": (_int, [_p, _int, _i64, _p, _p, _p, _pp]),
     "lk_linop_lap5_create": (_int, [_p, _i64, _pp]),
     "lk_linop_lap5_create_sharded": (_int, [_p, _i64, _i64, _i64, _pp]),
     "lk_linop_gl_create_sharded": (_int, [_p, _i64, _i64, _i64, C.c_double, C.c_double, _int, _dp, _dp, C.c_double, C.c_double, _pp]),

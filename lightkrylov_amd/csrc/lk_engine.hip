@@ -93,6 +93,8 @@ struct lk_context_s {
     int64_t row0 = 0, n_global = -1;  // this rank's row block [row0, row0 + n_local) of n_global rows
     // lazy batching of the PER-OBJECT path (opt-in, tuning key "lazy"): what an unchanged LightKrylov drives
     // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
+    int lap5_grid_mult = 8;    // persistent blocks per CU of the stencil operator
+    int csr_lanes = 0;         // 0: lanes per row of the CSR product chosen from the mean row length; 2..64 forces it
     int blas1_grid_mult = 2;   // blocks of 256 threads per CU for the one-to-three-stream kernels
     int lazy = 0;
     struct {
@@ -168,7 +170,7 @@ struct lk_basis_s {
     double *col(int j) const { return data + (int64_t)j * ld * ed(); }
 };
 
-enum OpKind { OP_DIAG, OP_DIAG_LIN, OP_DENSE, OP_LAP5, OP_GL };
+enum OpKind { OP_DIAG, OP_DIAG_LIN, OP_DENSE, OP_LAP5, OP_GL, OP_CSR };
 struct lk_linop_s {
     lk_context_t ctx;
     OpKind kind;
@@ -190,6 +192,8 @@ struct lk_linop_s {
     bool has_lo = false, has_hi = false;   // a neighbouring rank below / above this block
     double *halo = nullptr;    // lap5: 2 N doubles (line from rank-1 | line from rank+1); GL: 4 doubles
     double *edges = nullptr;   // GL: this rank's two edge values (send buffer), 4 doubles
+    // CSR: A (for 'N') and its conjugate transpose (for 'H'), both row-compressed; W = lanes per row
+    struct Csr { int64_t *rowptr = nullptr; int32_t *colind = nullptr; double *vals = nullptr; int W = 8; } csr[2];
 };
 
 namespace {
@@ -869,6 +873,12 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "grid_mult must be in [1,16]");
         c->grid_mult = value;
+        return LK_OK;
+    }
+    if (!strcmp(key, "lap5_grid_mult")) { if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: lap5_grid_mult in [1, 64]"); c->lap5_grid_mult = value; return LK_OK; }
+    if (!strcmp(key, "csr_lanes")) {
+        if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(LK_ERR_INVALID, "lk_set_tuning: csr_lanes must be 0 or a power of two in [1, 64]");
+        c->csr_lanes = value;
         return LK_OK;
     }
     if (!strcmp(key, "blas1_grid_mult")) {
@@ -1684,8 +1694,74 @@ int lk_linop_gl_create(lk_context_t c, int64_t n, double dx, double tau, int nsu
     return lk_linop_gl_create_sharded(c, n, 0, n, dx, tau, nsub, nu, gamma, mu_c, mu2, op);
 }
 
+// A = (rowptr, colind, vals) in CSR, 0-based; `which` = 0 stores A itself, 1 its conjugate transpose (built on the host by a
+// counting sort: column indices within a row of A^H come out ascending, so both products sum in index order).
+static int csr_upload(lk_linop_t o, int which, int64_t n, const int64_t *rowptr, const int32_t *colind, const double *vals, int ED) {
+    const int64_t nnz = rowptr[n];
+    auto &m = o->csr[which];
+    HIPCHK(hipMalloc((void **)&m.rowptr, (size_t)(n + 1) * sizeof(int64_t)));
+    HIPCHK(hipMalloc((void **)&m.colind, (size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void **)&m.vals, (size_t)(nnz > 0 ? nnz : 1) * ED * sizeof(double)));
+    HIPCHK(hipMemcpy(m.rowptr, rowptr, (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        HIPCHK(hipMemcpy(m.colind, colind, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(m.vals, vals, (size_t)nnz * ED * sizeof(double), hipMemcpyHostToDevice));
+    }
+    const double mean = n > 0 ? (double)nnz / (double)n : 0.0;
+    int W = 1;                                   // lanes per row: the power of two at or below half the mean row length
+    while (W < 64 && 2 * W <= mean / 2.0) W <<= 1;   // (5-point Laplacian, n = 1.7e7: W = 1 / 2 / 4 / 8 / 16 -> see DESIGN.md)
+    m.W = W;
+    return LK_OK;
+}
+
+int lk_linop_csr_create(lk_context_t c, int dtype, int64_t n, const int64_t *rowptr, const int32_t *colind, const void *vals,
+                        lk_linop_t *op) {
+    if (!c || !rowptr || !op) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null argument");
+    DevGuard dev_guard(c);
+    if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "lk_linop_csr_create: bad dtype %d", dtype);
+    if (c->nranks > 1) return fail(LK_ERR_INVALID, "lk_linop_csr_create: single-rank operator");
+    if (n < 0 || n > 2147483647LL) return fail(LK_ERR_INVALID, "lk_linop_csr_create: bad size %lld", (long long)n);
+    if (rowptr[0] != 0) return fail(LK_ERR_INVALID, "lk_linop_csr_create: rowptr must be 0-based");
+    const int64_t nnz = rowptr[n];
+    if (nnz > 0 && (!colind || !vals)) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null colind / vals");
+    for (int64_t i = 0; i < n; ++i)
+        if (rowptr[i + 1] < rowptr[i]) return fail(LK_ERR_INVALID, "lk_linop_csr_create: rowptr decreases at row %lld", (long long)i);
+    for (int64_t p = 0; p < nnz; ++p)
+        if (colind[p] < 0 || colind[p] >= n) return fail(LK_ERR_INVALID, "lk_linop_csr_create: column index %d out of range at entry %lld", colind[p], (long long)p);
+    const int ED = dtype == LK_C128 ? 2 : 1;
+    const double *v = (const double *)vals;
+    // conjugate transpose by counting sort over the column indices
+    std::vector<int64_t> tp((size_t)n + 1, 0);
+    for (int64_t p = 0; p < nnz; ++p) tp[(size_t)colind[p] + 1] += 1;
+    for (int64_t j = 0; j < n; ++j) tp[(size_t)j + 1] += tp[(size_t)j];
+    std::vector<int32_t> tc((size_t)(nnz > 0 ? nnz : 1));
+    std::vector<double> tv((size_t)(nnz > 0 ? nnz : 1) * ED);
+    {
+        std::vector<int64_t> next(tp.begin(), tp.end() - 1);
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
+                const int64_t q = next[(size_t)colind[p]]++;
+                tc[(size_t)q] = (int32_t)i;
+                tv[(size_t)q * ED] = v[p * ED];
+                if (ED == 2) tv[(size_t)q * 2 + 1] = -v[p * 2 + 1];
+            }
+    }
+    lk_linop_t o = new lk_linop_s();
+    o->ctx = c; o->kind = OP_CSR; o->dtype = dtype; o->n = n;
+    int rc = csr_upload(o, 0, n, rowptr, colind, v, ED);
+    if (rc == LK_OK) rc = csr_upload(o, 1, n, tp.data(), tc.data(), tv.data(), ED);
+    if (rc != LK_OK) { (void)lk_linop_destroy(o); return rc; }
+    *op = o;
+    return LK_OK;
+}
+
 int lk_linop_destroy(lk_linop_t op) {
     if (!op) return LK_OK;
+    for (auto &m : op->csr) {
+        if (m.rowptr) (void)hipFree(m.rowptr);
+        if (m.colind) (void)hipFree(m.colind);
+        if (m.vals) (void)hipFree(m.vals);
+    }
     if (op->kind == OP_LAP5 && op->halo) (void)hipFree(op->halo);
     if (op->wk) (void)hipFree(op->wk);
     if (op->dev) (void)hipFree(op->dev);  // synchronises; the context may already be finalized
@@ -1730,6 +1806,26 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
             else hipLaunchKernelGGL(k_gemv_h<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y, c->guard());
         }
         break;
+    case OP_CSR: {
+        auto m = op->csr[trans == LK_OP_N ? 0 : 1];
+        if (c->csr_lanes) m.W = c->csr_lanes;
+        const int64_t rows_per_block = 256 / m.W;
+        int64_t g = (n + rows_per_block - 1) / rows_per_block;
+        const int64_t cap = (int64_t)c->num_cu * 16;
+        if (g > cap) g = cap;
+        if (g < 1) g = 1;
+#define LK_CSR_LAUNCH(WW)                                                                                                  \
+    case WW:                                                                                                               \
+        if (cp) hipLaunchKernelGGL((k_csr<true, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, x, y, n, c->guard()); \
+        else hipLaunchKernelGGL((k_csr<false, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, x, y, n, c->guard());   \
+        break;
+        switch (m.W) {
+            LK_CSR_LAUNCH(1) LK_CSR_LAUNCH(2) LK_CSR_LAUNCH(4) LK_CSR_LAUNCH(8) LK_CSR_LAUNCH(16) LK_CSR_LAUNCH(32) LK_CSR_LAUNCH(64)
+        default: return fail(LK_ERR_INVALID, "internal: CSR lanes per row %d", m.W);
+        }
+#undef LK_CSR_LAUNCH
+        break;
+    }
     case OP_GL: {
         // nsub classical RK4 steps of dt = tau/nsub; 4 stage launches per step.
         const double dt = op->tau / op->nsub;
@@ -1774,6 +1870,10 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
                                 op->has_hi ? op->halo + N : nullptr, N));
         }
         dim3 grid((unsigned)((N / 2 + 1 + 255) / 256), (unsigned)NJ);
+        if ((N & 1) == 0) {                               // persistent blocks over (line, segment) tiles
+            int64_t tiles = NJ * ((N / 2 + 255) / 256), g = (int64_t)c->num_cu * c->lap5_grid_mult;
+            grid = dim3((unsigned)(tiles < g ? (tiles > 0 ? tiles : 1) : g), 1);
+        }
         hipLaunchKernelGGL(k_lap5, grid, dim3(256), 0, c->stream, x, y, N, NJ, lo, hi, s, c->guard());
         break;
     }

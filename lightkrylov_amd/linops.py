@@ -159,6 +159,33 @@ class dense_linop_gpu(_engine_linop):
                                                     A.ctypes.data_as(C.c_void_p), A.shape[0], C.byref(self._h)))
 
 
+class csr_linop_gpu(_engine_linop):
+    """A user's sparse `abstract_linop` (AbstractLinops.fypp:58-87) in CSR: y = A x / A^H x on the device.
+    `A`: anything with `.indptr`, `.indices`, `.data`, `.shape` in CSR layout (a scipy.sparse.csr_matrix / csr_array), or
+    a tuple (rowptr, colind, vals) with 0-based indices."""
+
+    def __init__(self, A, ctx: Context | None = None):
+        super().__init__(ctx)
+        if isinstance(A, tuple):
+            rowptr, colind, vals = A
+            n = len(rowptr) - 1
+        else:
+            if getattr(A, "format", "csr") != "csr":
+                A = A.tocsr()
+            if A.shape[0] != A.shape[1]:
+                raise TypeError("csr_linop_gpu needs a square matrix")
+            rowptr, colind, vals, n = A.indptr, A.indices, A.data, A.shape[0]
+        vals = np.ascontiguousarray(vals)
+        if vals.dtype not in _DT:
+            raise TypeError("csr_linop_gpu needs float64 / complex128 values")
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        colind = np.ascontiguousarray(colind, dtype=np.int32)
+        self.dtype, self.n, self.nnz = vals.dtype, int(n), int(rowptr[-1])
+        _capi.check(self._lib.lk_linop_csr_create(self.ctx._h, _DT[vals.dtype], self.n, rowptr.ctypes.data_as(C.c_void_p),
+                                                  colind.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
+                                                  C.byref(self._h)))
+
+
 class diag_linop_gpu(_engine_linop):
     """y = d .* x (config "arnoldi with synthetic diagonal linop")."""
 

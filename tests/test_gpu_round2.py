@@ -380,3 +380,89 @@ def test_pipelined_eigs_cycle_equals_the_step_by_step_one(ctx, dtype):
         assert np.array_equal(X0, X1), tag
         assert np.abs(np.sort(np.abs(v1))[::-1] - np.sort(np.abs(d))[::-1][:nev]).max() <= 1e-8, tag
     assert out[(40, True)][2] < 40 and out[(12, True)][2] > 12
+
+
+# ----------------------------------------------------------------------------- CSR operator (a user's sparse abstract_linop)
+def _lap5_csr(N):
+    import scipy.sparse as sp
+    T = sp.diags([-np.ones(N - 1), 4.0 * np.ones(N), -np.ones(N - 1)], [-1, 0, 1])
+    S = sp.diags([-np.ones(N - 1), -np.ones(N - 1)], [-1, 1])
+    return ((sp.kron(sp.identity(N), T) + sp.kron(S, sp.identity(N))) * float((N + 1) ** 2)).tocsr()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_csr_linop_matvec_and_rmatvec_against_scipy(ctx, dtype):
+    """y = A x and y = A^H x for random sparse matrices with empty rows, short rows and a few very long ones
+    (every lanes-per-row setting from 2 to 64), against scipy's CSR product."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    n = 6_007
+    for density, longrows in ((0.0004, 0), (0.002, 3), (0.01, 0), (0.03, 5)):
+        A = sp.random(n, n, density=density, random_state=rng, format="lil", dtype=np.float64)
+        for r in rng.integers(0, n, longrows):
+            A[r, rng.integers(0, n, 900)] = 1.0
+        A[7, :] = 0.0                                                   # an empty row
+        A = A.tocsr()
+        vals = rng.standard_normal(A.nnz)
+        if np.dtype(dtype).kind == "c":
+            vals = vals + 1j * rng.standard_normal(A.nnz)
+        A = sp.csr_matrix((vals.astype(dtype), A.indices, A.indptr), shape=(n, n))
+        A.sort_indices()
+        op = lk.csr_linop_gpu(A, ctx)
+        xh = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if np.dtype(dtype).kind == "c" else 0)).astype(dtype)
+        x = lk.dense_vector_gpu.from_array(xh, ctx)
+        y = lk.dense_vector_gpu(n, dtype, ctx)
+        scale = abs(A).dot(np.abs(xh)).max() + 1e-300
+        op.apply_matvec(x, y)
+        assert np.abs(y.to_array() - A @ xh).max() <= 1e-13 * scale
+        op.apply_rmatvec(x, y)
+        scale_h = abs(A).T.dot(np.abs(xh)).max() + 1e-300
+        assert np.abs(y.to_array() - A.conj().T @ xh).max() <= 1e-13 * scale_h
+        assert (op.matvec_counter, op.rmatvec_counter) == (1, 1)
+
+
+def test_csr_laplacian_reproduces_the_stencil_operator_in_gmres_and_arnoldi(ctx):
+    """BASELINE's "5-point Laplacian SpMV linop" literally as a sparse matrix: same products as the matrix-free
+    lk_linop_lap5 and the same GMRES(30) residual history and Arnoldi factorisation (whole step loop in the engine)."""
+    N = 96
+    n = N * N
+    A = _lap5_csr(N)
+    Ac, As = lk.csr_linop_gpu(A, ctx), lk.laplacian2d_linop_gpu(N, ctx)
+    bh = np.empty(n); ora.fill_counter(bh, 11)
+    x = lk.dense_vector_gpu.from_array(bh, ctx)
+    y1, y2 = lk.dense_vector_gpu(n, np.float64, ctx), lk.dense_vector_gpu(n, np.float64, ctx)
+    Ac.apply_matvec(x, y1); As.apply_matvec(x, y2)
+    assert np.abs(y1.to_array() - y2.to_array()).max() <= 1e-13 * np.abs(y2.to_array()).max()
+    out = []
+    for op in (Ac, As):
+        xs = lk.dense_vector_gpu(n, np.float64, ctx)
+        meta = lk.gmres_dp_metadata()
+        info = lk.gmres(op, lk.dense_vector_gpu.from_array(bh, ctx), xs, rtol=1e-8, options=lk.gmres_dp_opts(kdim=30, maxiter=2),
+                        meta=meta)
+        out.append((info, np.array(meta.res), xs.to_array()))
+    assert out[0][0] == out[1][0] and len(out[0][1]) == len(out[1][1])
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-10 * out[1][1][0]
+    assert np.abs(out[0][2] - out[1][2]).max() <= 1e-10 * np.abs(out[1][2]).max()
+    m = 20
+    X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
+    X[0].rand(True, seed=5)
+    H = np.zeros((m + 1, m), order="F")
+    assert lk.arnoldi(Ac, X, H) == 0
+    Xo = np.zeros((n, m + 1), order="F"); Xo[:, 0] = X.download(0, 1)[:, 0]
+    Ho = np.zeros((m + 1, m), order="F")
+    assert ora.arnoldi(ora.PyOp(lambda v: A @ v, np.float64), Xo, Ho) == 0
+    for j in range(m):
+        assert np.abs(H[:, j] - Ho[:, j]).max() <= 1e-12 * np.abs(Ho[:, j]).max()
+
+
+def test_csr_linop_rejects_malformed_input(ctx):
+    rowptr = np.array([0, 2, 3], dtype=np.int64)
+    vals = np.array([1.0, 2.0, 3.0])
+    with pytest.raises(_capi.LightKrylovHipError, match="out of range"):
+        lk.csr_linop_gpu((rowptr, np.array([0, 5, 1], dtype=np.int32), vals), ctx)
+    with pytest.raises(_capi.LightKrylovHipError, match="0-based"):
+        lk.csr_linop_gpu((rowptr + 1, np.array([0, 1, 1], dtype=np.int32), vals), ctx)
+    with pytest.raises(_capi.LightKrylovHipError, match="decreases"):
+        lk.csr_linop_gpu((np.array([0, 3, 2], dtype=np.int64), np.array([0, 1, 1], dtype=np.int32), vals), ctx)
+    with pytest.raises(TypeError):
+        lk.csr_linop_gpu((rowptr, np.array([0, 1, 1], dtype=np.int32), vals.astype(np.float32)), ctx)
