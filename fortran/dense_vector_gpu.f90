@@ -80,6 +80,8 @@ module lightkrylov_gpu
         procedure, pass(self) :: get_size => gpu_get_size
         procedure, pass(self) :: upload => gpu_upload
         procedure, pass(self) :: download => gpu_download
+        procedure, pass(self) :: device_ptr_in => gpu_ptr_in          !! for a user's own kernels: see gpu_ptr_in / gpu_ptr_out
+        procedure, pass(self) :: device_ptr_out => gpu_ptr_out
     end type
 
     !> complex(dp) kind: same layout, interleaved (re, im) on the device (LK_C128)
@@ -95,6 +97,8 @@ module lightkrylov_gpu
         procedure, pass(self) :: get_size => gpuz_get_size
         procedure, pass(self) :: upload => gpuz_upload
         procedure, pass(self) :: download => gpuz_download
+        procedure, pass(self) :: device_ptr_in => gpuz_ptr_in
+        procedure, pass(self) :: device_ptr_out => gpuz_ptr_out
     end type
 
     !> Any engine operator (lk_linop_*) behind LightKrylov's abstract_linop: matvec / rmatvec = lk_linop_apply N / H.
@@ -343,6 +347,36 @@ contains
         call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), .false.)
         call chk(lk_basis_upload(self%h%buf, self%h%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'upload')
     end subroutine
+
+    !> A user's own `matvec(self, vec_in, vec_out)` written with device kernels (hipfort, OpenMP target `is_device_ptr`, a C
+    !> wrapper ...): `vec_in%device_ptr_in()` is the device address of the n real(dp) values to READ, `vec_out%device_ptr_out()`
+    !> the address to WRITE all n values to (vec_out is intent(out): it gets a column of its own here, previous contents are
+    !> not kept).  Pending engine work on the vector is applied first (lk_vec_device_ptr); the kernel must run on the engine's
+    !> stream (lk_context_info) or after lk_sync.
+    function gpu_ptr_in(self) result(p)
+        class(dense_vector_gpu_rdp), intent(in) :: self
+        type(c_ptr) :: p
+        if (.not. handle_is_readable(self%h)) call stop_error("vector holds no data", this_module, 'device_ptr_in')
+        call chk(lk_vec_device_ptr(self%h%buf, self%h%col, LK_ACCESS_READ, p), 'device_ptr_in')
+    end function
+    function gpu_ptr_out(self) result(p)
+        class(dense_vector_gpu_rdp), intent(inout) :: self
+        type(c_ptr) :: p
+        call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), .false.)
+        call chk(lk_vec_device_ptr(self%h%buf, self%h%col, LK_ACCESS_OVERWRITE, p), 'device_ptr_out')
+    end function
+    function gpuz_ptr_in(self) result(p)
+        class(dense_vector_gpu_cdp), intent(in) :: self
+        type(c_ptr) :: p
+        if (.not. handle_is_readable(self%h)) call stop_error("vector holds no data", this_module, 'device_ptr_in')
+        call chk(lk_vec_device_ptr(self%h%buf, self%h%col, LK_ACCESS_READ, p), 'device_ptr_in')
+    end function
+    function gpuz_ptr_out(self) result(p)
+        class(dense_vector_gpu_cdp), intent(inout) :: self
+        type(c_ptr) :: p
+        call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), .false.)
+        call chk(lk_vec_device_ptr(self%h%buf, self%h%col, LK_ACCESS_OVERWRITE, p), 'device_ptr_out')
+    end function
 
     subroutine gpu_download(self, x)
         class(dense_vector_gpu_rdp), intent(in) :: self

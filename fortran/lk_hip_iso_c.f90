@@ -11,6 +11,7 @@ module lightkrylov_hip_c
     integer(c_int), parameter :: LK_OK = 0
     integer(c_int), parameter :: LK_DGS_NORMALIZE = 1
     integer(c_int), parameter :: LK_OP_N = 0, LK_OP_H = 1
+    integer(c_int), parameter :: LK_ACCESS_READ = 0, LK_ACCESS_OVERWRITE = 1, LK_ACCESS_READWRITE = 2
 
     interface
         function lk_version() bind(C, name="lk_version") result(v)
@@ -188,6 +189,13 @@ module lightkrylov_hip_c
             integer(c_int), value :: dtype
             integer(c_int64_t), value :: n, lda
             type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
+        function lk_vec_device_ptr(B, j, access, dev_ptr) bind(C, name="lk_vec_device_ptr") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: B
+            integer(c_int), value :: j, access
+            type(c_ptr), intent(out) :: dev_ptr
             integer(c_int) :: rc
         end function
         function lk_linop_csr_create(ctx, dtype, n, rowptr, colind, vals, op) bind(C, name="lk_linop_csr_create") result(rc)

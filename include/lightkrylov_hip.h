@@ -153,6 +153,15 @@ int lk_basis_wrap(lk_context_t ctx, int dtype, int64_t n_local, int ncols, int64
 int lk_basis_destroy(lk_basis_t B);
 int lk_basis_info(lk_basis_t B, int *dtype, int64_t *n_local, int *ncols, int64_t *ld,
                   void **dev_ptr);
+/* A USER'S OWN KERNEL on a vector (a hand-written `matvec`, AbstractLinops.fypp:74-87): the device address of column j,
+ * valid until the vector is released, with everything the engine still owes that vector applied first (lazy mode defers
+ * updates).  `access` says what the caller will do: LK_ACCESS_READ, LK_ACCESS_OVERWRITE (previous contents not read:
+ * `vec_out` is intent(out)) or LK_ACCESS_READWRITE.  The caller's work must be ordered after the engine's: enqueue it on
+ * the context's stream (lk_context_info) or call lk_sync first; n_local elements of the basis' dtype, contiguous. */
+#define LK_ACCESS_READ 0
+#define LK_ACCESS_OVERWRITE 1
+#define LK_ACCESS_READWRITE 2
+int lk_vec_device_ptr(lk_basis_t B, int j, int access, void **dev_ptr);
 /* host <-> device, `ncols` columns starting at col0; host is column-major with leading
  * dimension ldh (elements).  Synchronous. */
 int lk_basis_upload(lk_basis_t B, int col0, int ncols, const void *host, int64_t ldh);

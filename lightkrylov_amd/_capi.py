@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "liblightkrylov_hip.so")
 LK_F64, LK_C128 = 0, 1
 LK_DGS_NORMALIZE = 1
 LK_OP_N, LK_OP_H = 0, 1
+LK_ACCESS_READ, LK_ACCESS_OVERWRITE, LK_ACCESS_READWRITE = 0, 1, 2
 LK_COMM_ID_BYTES = 128
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
@@ -51,6 +52,7 @@ SIGNATURES = {
     "lk_basis_wrap": (_int, [_p, _int, _i64, _int, _i64, _p, _pp]),
     "lk_basis_destroy": (_int, [_p]),
     "lk_basis_info": (_int, [_p, _ip, C.POINTER(_i64), _ip, C.POINTER(_i64), _pp]),
+    "lk_vec_device_ptr": (_int, [_p, _int, _int, _pp]),
     "lk_basis_upload": (_int, [_p, _int, _int, _p, _i64]),
     "lk_basis_download": (_int, [_p, _int, _int, _p, _i64]),
     "lk_pool_acquire": (_int, [_p, _int, _i64, C.c_uint64, _pp, _ip]),

@@ -1034,6 +1034,20 @@ int lk_basis_info(lk_basis_t B, int *dtype, int64_t *n_local, int *ncols, int64_
     return LK_OK;
 }
 
+int lk_vec_device_ptr(lk_basis_t B, int j, int access, void **dev_ptr) {
+    LKCHK(check_vec(B, j, "lk_vec_device_ptr"));
+    if (!dev_ptr) return fail(LK_ERR_INVALID, "lk_vec_device_ptr: null dev_ptr");
+    if (access < LK_ACCESS_READ || access > LK_ACCESS_READWRITE) return fail(LK_ERR_INVALID, "lk_vec_device_ptr: bad access %d", access);
+    DevGuard dev_guard(B->ctx);
+    const VecRef v{B, j};
+    // the caller's kernel sees (and, when writing, defines) the vector's contents: pending work on it is applied first
+    LKCHK(lazy_enter_vec(B->ctx, access == LK_ACCESS_READ ? nullptr : &v, access == LK_ACCESS_OVERWRITE,
+                         access == LK_ACCESS_OVERWRITE ? nullptr : &v, nullptr));
+    if (access != LK_ACCESS_READ) B->touch(j);
+    *dev_ptr = B->col(j);
+    return LK_OK;
+}
+
 int lk_basis_upload(lk_basis_t B, int col0, int ncols, const void *host, int64_t ldh) {
     if (!B || !host) return fail(LK_ERR_INVALID, "lk_basis_upload: null argument");
     DevGuard dev_guard(B->ctx);

@@ -210,6 +210,23 @@ class dense_vector_gpu(abstract_vector):
     def to_array(self) -> np.ndarray:
         return self.basis.download(self.col, 1)[:, 0]
 
+    def as_torch(self, access: str = "rw"):
+        """The vector as a torch tensor that ALIASES its device memory (float64 of n rows, or complex128), for operators
+        written with torch ops or custom kernels: `class my_op(lk.abstract_linop): def matvec(self, vi, vo):
+        torch.mul(d, vi.as_torch("r"), out=vo.as_torch("w"))`.  `access`: "r" read, "w" overwrite (previous contents
+        not read), "rw".  Pending engine work on the vector is applied first (lk_vec_device_ptr); the tensor must be used on
+        the context's stream -- torch's current stream when the context was created with use_torch_stream (the default) --
+        and not kept across later engine calls that write the vector."""
+        import torch
+        from .context import _DevMem
+        acc = {"r": _capi.LK_ACCESS_READ, "w": _capi.LK_ACCESS_OVERWRITE, "rw": _capi.LK_ACCESS_READWRITE}[access]
+        ptr = C.c_void_p()
+        _capi.check(self._lib.lk_vec_device_ptr(self.basis._h, self.col, acc, C.byref(ptr)))
+        n = self.basis.n_local
+        cplx = self.dtype == np.complex128
+        t = torch.as_tensor(_DevMem(int(ptr.value or 0), n * (2 if cplx else 1)), device=f"cuda:{self.basis.ctx.device}")
+        return torch.view_as_complex(t.view(n, 2)) if cplx else t
+
     def zeros_like(self) -> "dense_vector_gpu":
         pc = _pool_column(self.basis.n_local, self.dtype, self.basis.ctx)
         v = dense_vector_gpu(_basis=pc, _col=pc.col)

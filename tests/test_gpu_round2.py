@@ -466,3 +466,48 @@ def test_csr_linop_rejects_malformed_input(ctx):
         lk.csr_linop_gpu((np.array([0, 3, 2], dtype=np.int64), np.array([0, 1, 1], dtype=np.int32), vals), ctx)
     with pytest.raises(TypeError):
         lk.csr_linop_gpu((rowptr, np.array([0, 1, 1], dtype=np.int32), vals.astype(np.float32)), ctx)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_user_operator_written_with_torch_on_device_pointers(dtype):
+    """A user's own abstract_linop whose matvec runs on the vectors' device memory (lk_vec_device_ptr through
+    dense_vector_gpu.as_torch): per-object Arnoldi in lazy mode -- where the engine defers updates, so the accessor must
+    first apply what it still owes the vector -- equals the engine's diagonal operator and the oracle."""
+    import torch
+    n, m = 60_013, 14
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", 1)
+    g = np.arange(n) / n
+    d = (1.0 + g) * (np.exp(0.4j * g) if np.dtype(dtype).kind == "c" else 1.0)
+    d = d.astype(dtype)
+    dt = torch.as_tensor(d, device="cuda:0")
+
+    class torch_diag(lk.abstract_linop):
+        def matvec(self, vi, vo):
+            torch.mul(dt, vi.as_torch("r"), out=vo.as_torch("w"))
+
+    x0 = seeded(n, dtype, 7); x0 /= np.linalg.norm(x0)
+    B = lk.krylov_basis_gpu(n, m + 1, dtype, c); B.upload(x0.reshape(-1, 1), 0)
+    H = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.arnoldi(torch_diag(), [B[j] for j in range(m + 1)], H) == 0
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.arnoldi(ora.DiagOp(d), Xo, Ho) == 0
+    for j in range(m):
+        assert np.abs(H[:, j] - Ho[:, j]).max() <= 1e-12 * np.abs(Ho[:, j]).max()
+    assert c.lazy_fusion_stats()[0] == 2 * m                      # the fast path survived the foreign kernels
+    # a pending update is applied before the pointer is handed out: y%sub(proj) then a torch read of y
+    y, T = B[m], lk.dense_vector_gpu(n, dtype, c)
+    before = y.to_array()
+    T.zero(); T.axpby(0.5, B[0], 1.0); T.axpby(-2.0, B[1], 1.0)
+    y.sub(T)
+    got = y.as_torch("r").cpu().numpy()
+    X = B.download()
+    assert np.abs(got - (before - 0.5 * X[:, 0] + 2.0 * X[:, 1])).max() <= 1e-14
+    # and a write through the pointer invalidates what the engine remembered about the vector
+    nrm = y.norm()
+    y.as_torch("rw").mul_(3.0)
+    torch.cuda.synchronize()
+    assert abs(y.norm() - 3.0 * nrm) <= 1e-13 * nrm
+    del B, T, y
+    c.close()
