@@ -149,6 +149,21 @@ class Context:
         _capi.check(self._lib.lk_lazy_stats(self._h, out))
         return tuple(out)
 
+    def engine_stream(self) -> int:
+        """The HIP stream every engine call of this context runs on (lk_context_info)."""
+        dev, st = C.c_int(), C.c_void_p()
+        _capi.check(self._lib.lk_context_info(self._h, C.byref(dev), C.byref(st)))
+        return int(st.value or 0)
+
+    def torch_stream(self):
+        """`with ctx.torch_stream(): ...` makes torch ops inside run ON the engine's stream, i.e. ordered with every engine
+        call before and after -- what code touching `dense_vector_gpu.as_torch()` views needs.  (A context created from
+        torch's DEFAULT stream gets a stream of its own, so torch ops outside this block are NOT ordered with the engine.)"""
+        import torch
+        if getattr(self, "_ext_stream", None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(self.engine_stream(), device=self.device)
+        return torch.cuda.stream(self._ext_stream)
+
     def lazy_fusion_stats(self):
         """(fused update+dot sweeps, pending updates applied as plain panel updates, virtual temporaries dropped
         unwritten, virtual temporaries written after all) -- see lk_lazy_fusion_stats in the header."""

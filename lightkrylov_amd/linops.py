@@ -33,12 +33,14 @@ class abstract_linop:
     def apply_matvec(self, vec_in, vec_out) -> None:
         """AbstractLinops.fypp:391-407"""
         self.matvec_counter += 1
-        self.matvec(vec_in, vec_out)
+        with _user_kernel_stream(self, vec_in):
+            self.matvec(vec_in, vec_out)
 
     def apply_rmatvec(self, vec_in, vec_out) -> None:
         """AbstractLinops.fypp:409-424"""
         self.rmatvec_counter += 1
-        self.rmatvec(vec_in, vec_out)
+        with _user_kernel_stream(self, vec_in):
+            self.rmatvec(vec_in, vec_out)
 
     def get_counter(self, trans: bool = False) -> int:
         return self.rmatvec_counter if trans else self.matvec_counter
@@ -48,6 +50,18 @@ class abstract_linop:
             self.rmatvec_counter = 0
         else:
             self.matvec_counter = 0
+
+
+def _user_kernel_stream(op, vec_in):
+    """A user's operator may run torch ops / its own kernels on the vectors' device memory (dense_vector_gpu.as_torch):
+    those must be ordered with the engine, so a python-level operator on GPU vectors runs with torch's current stream set
+    to the engine's.  Engine operators (and processes that never imported torch) need nothing."""
+    import contextlib
+    import sys
+    basis = getattr(vec_in, "basis", None)
+    if isinstance(op, _engine_linop) or basis is None or "torch" not in sys.modules:
+        return contextlib.nullcontext()
+    return basis.ctx.torch_stream()
 
 
 # ---- composite operators built on the vector contract only (AbstractLinops.fypp; generated .f90 lines cited) ----

@@ -214,11 +214,16 @@ class dense_vector_gpu(abstract_vector):
         """The vector as a torch tensor that ALIASES its device memory (float64 of n rows, or complex128), for operators
         written with torch ops or custom kernels: `class my_op(lk.abstract_linop): def matvec(self, vi, vo):
         torch.mul(d, vi.as_torch("r"), out=vo.as_torch("w"))`.  `access`: "r" read, "w" overwrite (previous contents
-        not read), "rw".  Pending engine work on the vector is applied first (lk_vec_device_ptr); the tensor must be used on
-        the context's stream -- torch's current stream when the context was created with use_torch_stream (the default) --
-        and not kept across later engine calls that write the vector."""
+        not read), "rw".  Pending engine work on the vector is applied first (lk_vec_device_ptr).  The tensor must be used
+        on the ENGINE's stream: inside an operator's matvec / rmatvec called through apply_matvec / apply_rmatvec that is
+        already the case; elsewhere wrap the torch code in `with ctx.torch_stream():` (checked here -- a torch op on
+        another stream would race with the engine silently).  Do not keep it across later engine calls that write the vector."""
         import torch
         from .context import _DevMem
+        ctx = self.basis.ctx
+        if torch.cuda.current_stream(ctx.device).cuda_stream != ctx.engine_stream():
+            raise RuntimeError("as_torch: torch's current stream is not the engine's stream; use `with ctx.torch_stream():` "
+                               "(operators applied through apply_matvec / apply_rmatvec already run inside one)")
         acc = {"r": _capi.LK_ACCESS_READ, "w": _capi.LK_ACCESS_OVERWRITE, "rw": _capi.LK_ACCESS_READWRITE}[access]
         ptr = C.c_void_p()
         _capi.check(self._lib.lk_vec_device_ptr(self.basis._h, self.col, acc, C.byref(ptr)))

@@ -501,13 +501,16 @@ def test_user_operator_written_with_torch_on_device_pointers(dtype):
     before = y.to_array()
     T.zero(); T.axpby(0.5, B[0], 1.0); T.axpby(-2.0, B[1], 1.0)
     y.sub(T)
-    got = y.as_torch("r").cpu().numpy()
+    with pytest.raises(RuntimeError, match="torch_stream"):          # outside an operator the stream must be named
+        y.as_torch("r")
+    with c.torch_stream():
+        got = y.as_torch("r").cpu().numpy()
     X = B.download()
     assert np.abs(got - (before - 0.5 * X[:, 0] + 2.0 * X[:, 1])).max() <= 1e-14
     # and a write through the pointer invalidates what the engine remembered about the vector
     nrm = y.norm()
-    y.as_torch("rw").mul_(3.0)
-    torch.cuda.synchronize()
+    with c.torch_stream():
+        y.as_torch("rw").mul_(3.0)
     assert abs(y.norm() - 3.0 * nrm) <= 1e-13 * nrm
     del B, T, y
     c.close()
