@@ -1012,7 +1012,8 @@ int lk_basis_destroy(lk_basis_t B) {
         if (g_live_ctx.count(B->ctx)) {          // a queued update may still target / read this panel
             lk_context_t c = B->ctx;
             auto &q = c->queue;
-            const bool only_target = q.active && q.zeroed && q.By == B && q.Bx != B && !(c->sub.active && c->sub.By == B);
+            // (a non-owning handle is a VIEW of memory that lives on: what is pending there must be written)
+            const bool only_target = B->own && q.active && q.zeroed && q.By == B && q.Bx != B && !(c->sub.active && c->sub.By == B);
             if (only_target) q.By = nullptr;     // a virtual temporary dies unwritten; its coefficients may still serve `sub`
             else (void)lazy_flush(c);
             c->memo.valid = false; c->nmemo.valid = false;

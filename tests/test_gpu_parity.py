@@ -834,3 +834,25 @@ def test_arnoldi_and_gmres_with_transpose(ctx, dtype):
                     options=lk.gmres_dp_opts(kdim=40, maxiter=5))
     assert info > 0
     assert np.linalg.norm(AH @ x.to_array() - b) <= 1e-9 * np.linalg.norm(b)
+
+
+def test_lazy_pending_work_survives_the_destruction_of_a_view_handle():
+    """A basis VIEW (lk_basis_wrap) is a handle on memory that lives on: destroying the handle while a virtual
+    linear combination targets one of its columns must write it out, not drop it."""
+    n, k = 20_011, 5
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", 1)
+    B = lk.krylov_basis_gpu(n, k + 3, np.float64, c)
+    for j in range(k + 3):
+        B[j].rand(False, seed=70 + j)
+    Xh = B.download()
+    V = B[k + 1:]                                  # columns k+1, k+2 through a wrapped handle
+    T = V[0]
+    T.zero()
+    for i in range(k):
+        T.axpby(0.5 + i, B[i], 1.0)
+    del T, V                                       # the view handle goes away; column k+1 of B does not
+    import gc; gc.collect()
+    want = Xh[:, :k] @ (0.5 + np.arange(k))
+    assert np.abs(B.download(k + 1, 1)[:, 0] - want).max() <= 1e-13 * np.abs(want).max()
+    c.close()
