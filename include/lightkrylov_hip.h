@@ -151,6 +151,9 @@ int lk_basis_create(lk_context_t ctx, int dtype, int64_t n_local, int ncols, lk_
 int lk_basis_wrap(lk_context_t ctx, int dtype, int64_t n_local, int ncols, int64_t ld,
                   void *dev_ptr, lk_basis_t *B);
 int lk_basis_destroy(lk_basis_t B);
+/* shape and base address of the panel.  The address is for building views (lk_basis_wrap) and for memory the caller owns;
+ * to READ OR WRITE a vector's contents from a kernel of your own use lk_vec_device_ptr, which first applies what the engine
+ * may still owe that vector in lazy mode. */
 int lk_basis_info(lk_basis_t B, int *dtype, int64_t *n_local, int *ncols, int64_t *ld,
                   void **dev_ptr);
 /* A USER'S OWN KERNEL on a vector (a hand-written `matvec`, AbstractLinops.fypp:74-87): the device address of column j,
