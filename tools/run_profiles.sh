@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+# Runs ON THE GPU BOX (gpurun): the rocprofv3 passes tools/make_profiles.py turns into profiles/<tag>_*.
+#   gpurun -- 'bash tools/run_profiles.sh r02x <commit>'      then here:  python tools/make_profiles.py gpurun_out/r02x r02
+# Counters are collected in passes of their own (--pmc alone), never together with a trace.
+set -u
+TAG=${1:?tag}; COMMIT=${2:-unknown}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+D=$R/gpurun_out/$TAG
+mkdir -p "$D"; echo "$COMMIT" > "$D/commit.txt"
+cd /tmp; export TMPDIR=/tmp
+python3 "$R/bench.py" > "$D/bench_default.log" 2> "$D/bench_default.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -o bench -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$D/stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_fetch" -o bench -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$D/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/pmc_write" -o bench -- python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$D/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$D/lincomb" -o lincomb -- python3 "$R/tools/bench_lincomb.py" > "$D/lincomb.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$D/cfg4" -o cfg4 -- python3 "$R/bench.py" --dtype c128 --rows 1000000 --steps 5 --warmup 2 --no-cpu-baseline > "$D/cfg4.log" 2>&1
+python3 "$R/bench.py" --rows 10000000 --kdim 64 --steps 5 --warmup 2 --no-cpu-baseline > "$D/cfg2.log" 2>&1
+python3 "$R/tools/bench_configs.py" > "$D/configs.log" 2>&1
+python3 "$R/tools/bench_blas1.py" 1e8 2 > "$D/blas1.log" 2>&1
+python3 "$R/tools/bench_per_object_arnoldi.py" 1e7 64 > "$D/per_object_arnoldi.log" 2>&1
+tail -c 600 "$D/bench_default.log"
