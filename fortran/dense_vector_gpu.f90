@@ -39,7 +39,8 @@ module lightkrylov_gpu
     use LightKrylov_Constants, only: dp
     use LightKrylov_Logger, only: stop_error, type_error
     use LightKrylov_AbstractVectors, only: abstract_vector_rdp, abstract_vector_cdp
-    use LightKrylov_AbstractLinops, only: abstract_linop_rdp, abstract_linop_cdp
+    use LightKrylov_AbstractLinops, only: abstract_linop_rdp, abstract_linop_cdp, abstract_sym_linop_rdp, &
+                                          abstract_hermitian_linop_cdp
     implicit none
     private
     character(len=*), parameter :: this_module = 'LK_GPU'
@@ -48,12 +49,14 @@ module lightkrylov_gpu
     public :: linop_gpu_rdp, linop_gpu_cdp, dense_linop_gpu_rdp, dense_linop_gpu_cdp
     public :: dense_linop_gpu, diag_linop_gpu, diag_linspace_linop_gpu, laplacian2d_linop_gpu, ginzburg_landau_linop_gpu
     public :: csr_linop_gpu
+    public :: sym_linop_gpu_rdp, hermitian_linop_gpu_cdp, sym_linop_gpu, hermitian_linop_gpu
     public :: lk_gpu_init, lk_gpu_finalize, lk_gpu_release_all, lk_gpu_context, lk_gpu_pool_stats
     public :: lk_gpu_set_partition, lk_gpu_comm_unique_id, lk_gpu_comm_init
     public :: gpu_arnoldi_rdp, gpu_arnoldi_cdp
 
     type(c_ptr), save :: ctx = c_null_ptr
     integer(c_int64_t), save :: part_row0 = 0          ! first global row of this rank's block (lk_gpu_set_partition)
+    integer, save :: last_n = -1                       ! size of the vector bound most recently (resolve_size)
 
     !> Device storage of one vector: a column of a pool slab.  Defined assignment = deep copy.
     type :: gpu_handle
@@ -68,8 +71,8 @@ module lightkrylov_gpu
     end type
 
     type, extends(abstract_vector_rdp) :: dense_vector_gpu_rdp
-        integer :: n                        !! number of (local) rows; set by the user like dense_vector%n (no default
-                                            !! initialisation, like dense_vector: an intent(out) dummy keeps its size)
+        integer :: n = -1                   !! number of (local) rows; set by the user like dense_vector%n.  Unset (a
+                                            !! `mold=` allocation, an intent(out) dummy) it is inferred: see resolve_size
         type(gpu_handle) :: h
     contains
         procedure, pass(self) :: zero => gpu_zero
@@ -86,7 +89,7 @@ module lightkrylov_gpu
 
     !> complex(dp) kind: same layout, interleaved (re, im) on the device (LK_C128)
     type, extends(abstract_vector_cdp) :: dense_vector_gpu_cdp
-        integer :: n
+        integer :: n = -1
         type(gpu_handle) :: h
     contains
         procedure, pass(self) :: zero => gpuz_zero
@@ -113,6 +116,18 @@ module lightkrylov_gpu
     contains
         procedure, pass(self) :: matvec => gpu_matvec_cdp
         procedure, pass(self) :: rmatvec => gpu_rmatvec_cdp
+    end type
+    !> the same engine operator behind LightKrylov's SYMMETRIC / HERMITIAN operator types (AbstractLinops.fypp:204-256: only
+    !> `matvec` is deferred), which `cg` and `eighs` require: S = sym_linop_gpu(L), H = hermitian_linop_gpu(L) share L's handle
+    type, extends(abstract_sym_linop_rdp) :: sym_linop_gpu_rdp
+        type(c_ptr) :: op = c_null_ptr
+    contains
+        procedure, pass(self) :: matvec => gpu_sym_matvec_rdp
+    end type
+    type, extends(abstract_hermitian_linop_cdp) :: hermitian_linop_gpu_cdp
+        type(c_ptr) :: op = c_null_ptr
+    contains
+        procedure, pass(self) :: matvec => gpu_herm_matvec_cdp
     end type
     !> dense_linop on the device (AbstractLinops.fypp:265-271, 608-660), both double-precision kinds
     type, extends(linop_gpu_rdp) :: dense_linop_gpu_rdp
@@ -193,6 +208,16 @@ contains
         if (rc /= LK_OK) call stop_error(lk_error_message(), this_module, procedure)
     end subroutine
 
+    !> Size of a vector that does not know it yet.  `allocate(r, mold=b)` (CG.fypp:113-121, eighs.fypp:60, svd_solvers: the
+    !> work vectors of cg / eighs / svds) gives an object of the right TYPE but no size, and the first call on it is
+    !> `zero()`: the plugin then assumes the size of the vector bound most recently (one problem size per program is the
+    !> rule; with several sizes in play allocate with `source=` or set `%n`).  Operators and `axpby` / `copy` take the size
+    !> from their input instead (apply_rdp, gpu_axpby), as dense_axpby does (AbstractVectors.fypp:521-524).
+    subroutine resolve_size(n)
+        integer, intent(inout) :: n
+        if (n < 0) n = last_n
+    end subroutine
+
     ! ---- handle ----------------------------------------------------------------------------------------------
     !> .true. when `h` is registered to the object it sits in (not a bit copy, not stale) with this shape
     logical function handle_is_own(h, dtype, n) result(own)
@@ -229,7 +254,10 @@ contains
         integer(c_intptr_t) :: tag
         logical :: copy_old
         if (n <= 0) call stop_error('vector size not set (set %n or upload first)', this_module, 'bind')
-        if (handle_is_own(h, dtype, n)) return
+        if (handle_is_own(h, dtype, n)) then
+            last_n = int(n)
+            return
+        end if
         copy_old = .false.
         if (keep .and. h%dtype == dtype .and. h%n == n) copy_old = handle_is_readable(h)
         old_buf = h%buf; old_col = h%col
@@ -240,6 +268,7 @@ contains
                 call chk(lk_vec_copy(fresh, fresh_col, old_buf, old_col), 'bind')
         end if
         h%buf = fresh; h%col = fresh_col; h%dtype = dtype; h%n = n; h%owner = tag
+        last_n = int(n)
     end subroutine
 
     !> defined assignment of the handle component = DEEP COPY (intrinsic assignment `wrk = V(k)`, `p = r`)
@@ -276,6 +305,7 @@ contains
     ! ---- real(dp) kind ---------------------------------------------------------------------------------------
     subroutine gpu_zero(self)
         class(dense_vector_gpu_rdp), intent(inout) :: self
+        call resolve_size(self%n)
         call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), .false.)
         call chk(lk_vec_zero(self%h%buf, self%h%col), 'zero')
     end subroutine
@@ -286,6 +316,7 @@ contains
         integer(c_int) :: nrm
         integer(c_int64_t), save :: seed = 1
         nrm = 0; if (present(ifnorm)) nrm = merge(1_c_int, 0_c_int, ifnorm)
+        call resolve_size(self%n)
         call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), .false.)
         seed = seed + 1
         call chk(lk_vec_rand(self%h%buf, self%h%col, seed, part_row0, nrm), 'rand')
@@ -362,6 +393,7 @@ contains
     function gpu_ptr_out(self) result(p)
         class(dense_vector_gpu_rdp), intent(inout) :: self
         type(c_ptr) :: p
+        call resolve_size(self%n)
         call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), .false.)
         call chk(lk_vec_device_ptr(self%h%buf, self%h%col, LK_ACCESS_OVERWRITE, p), 'device_ptr_out')
     end function
@@ -374,6 +406,7 @@ contains
     function gpuz_ptr_out(self) result(p)
         class(dense_vector_gpu_cdp), intent(inout) :: self
         type(c_ptr) :: p
+        call resolve_size(self%n)
         call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), .false.)
         call chk(lk_vec_device_ptr(self%h%buf, self%h%col, LK_ACCESS_OVERWRITE, p), 'device_ptr_out')
     end function
@@ -388,6 +421,7 @@ contains
     ! ---- complex(dp) kind ------------------------------------------------------------------------------------
     subroutine gpuz_zero(self)
         class(dense_vector_gpu_cdp), intent(inout) :: self
+        call resolve_size(self%n)
         call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), .false.)
         call chk(lk_vec_zero(self%h%buf, self%h%col), 'zero')
     end subroutine
@@ -398,6 +432,7 @@ contains
         integer(c_int) :: nrm
         integer(c_int64_t), save :: seed = 1000001
         nrm = 0; if (present(ifnorm)) nrm = merge(1_c_int, 0_c_int, ifnorm)
+        call resolve_size(self%n)
         call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), .false.)
         seed = seed + 1
         call chk(lk_vec_rand(self%h%buf, self%h%col, seed, part_row0, nrm), 'rand')
@@ -523,6 +558,28 @@ contains
         class(abstract_vector_rdp), intent(out) :: vec_out
         call apply_rdp(self%op, LK_OP_H, vec_in, vec_out, 'rmatvec')
     end subroutine
+    subroutine gpu_sym_matvec_rdp(self, vec_in, vec_out)
+        class(sym_linop_gpu_rdp), intent(inout) :: self
+        class(abstract_vector_rdp), intent(in) :: vec_in
+        class(abstract_vector_rdp), intent(out) :: vec_out
+        call apply_rdp(self%op, LK_OP_N, vec_in, vec_out, 'matvec')
+    end subroutine
+    subroutine gpu_herm_matvec_cdp(self, vec_in, vec_out)
+        class(hermitian_linop_gpu_cdp), intent(inout) :: self
+        class(abstract_vector_cdp), intent(in) :: vec_in
+        class(abstract_vector_cdp), intent(out) :: vec_out
+        call apply_cdp(self%op, LK_OP_N, vec_in, vec_out, 'matvec')
+    end subroutine
+    function sym_linop_gpu(L) result(S)
+        class(linop_gpu_rdp), intent(in) :: L
+        type(sym_linop_gpu_rdp) :: S
+        S%op = L%op
+    end function
+    function hermitian_linop_gpu(L) result(H)
+        class(linop_gpu_cdp), intent(in) :: L
+        type(hermitian_linop_gpu_cdp) :: H
+        H%op = L%op
+    end function
     subroutine gpu_matvec_cdp(self, vec_in, vec_out)
         class(linop_gpu_cdp), intent(inout) :: self
         class(abstract_vector_cdp), intent(in) :: vec_in

@@ -651,6 +651,24 @@ int materialise_queue(lk_context_t c) {
     }
     c->memo.valid = false; c->nmemo.valid = false;                  // a column changes: batched dots may have covered it
     double *T = q.By->col(q.jy);
+    if (q.cnt == 1) {
+        // a single queued term is a plain axpby (cg's x%axpby(alpha, p, 1), r%axpby(-alpha, Ap, 1): CG.fypp:125-131): the
+        // BLAS-1 kernel streams it faster than a one-column panel update; T = a x + (zeroed ? 0 : 1) T
+        const bool cp = q.Bx->dtype == LK_C128;
+        const int64_t nv = q.Bx->n * q.Bx->ed() / 2 + 1;
+        const double b = q.zeroed ? 0.0 : 1.0;
+        if (q.zeroed) c->fusion_stats[3] += 1;
+        c->lazy_stats[3] += 1;
+        ProfScope ps(c, "blas1", (double)q.Bx->n * q.Bx->ed() * 24.0);
+        if (cp)
+            hipLaunchKernelGGL(k_axpby<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, q.coef[0], q.coef[1], q.Bx->col(q.j0), b, 0.0,
+                               T, q.Bx->n, blas1_nt(q.Bx));
+        else
+            hipLaunchKernelGGL(k_axpby<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, q.coef[0], 0.0, q.Bx->col(q.j0), b, 0.0, T,
+                               q.Bx->n, blas1_nt(q.Bx));
+        HIPCHK(hipGetLastError());
+        return LK_OK;
+    }
     if (q.zeroed) {
         HIPCHK(hipMemsetAsync(T, 0, (size_t)q.By->n * q.By->ed() * sizeof(double), c->stream));
         if (q.cnt > 0) c->fusion_stats[3] += 1;

@@ -39,7 +39,7 @@ program plugin_driver
     use LightKrylov_AbstractVectors
     use LightKrylov_AbstractLinops
     use LightKrylov_BaseKrylov, only: arnoldi, double_gram_schmidt_step
-    use LightKrylov_IterativeSolvers, only: gmres, eigs, gmres_dp_opts, gmres_dp_metadata
+    use LightKrylov_IterativeSolvers, only: gmres, eigs, cg, gmres_dp_opts, gmres_dp_metadata, cg_dp_opts, cg_dp_metadata
     use lightkrylov_gpu
     use plugin_check_ref_ops
     implicit none
@@ -54,6 +54,8 @@ program plugin_driver
     call check_arnoldi_cdp()
     call check_gmres_rdp()
     call check_gmres_cdp()
+    call check_cg_rdp()
+    call check_cg_cdp()
     call check_assignment_is_deep()
     call check_pool_is_bounded()
     if (command_argument_count() > 99) call never_executed_eigs()
@@ -262,6 +264,68 @@ contains
         call xgpu%download(xg)
         call report('gmres rdp: max |x_gpu - x_ref|               ', maxval(abs(xg - xr)), 1.0e-11_dp)
         call report('gmres rdp: residual |A x - b|                ', maxval(abs(matmul(A, xg) - rhs)), 1.0e-10_dp)
+    end subroutine
+
+    !> The reference's conjugate gradient through the plugin.  cg allocates its work vectors with `mold=b` (no size: the
+    !> plugin infers it), copies with `p = r` (CG.fypp:116: deep copy through the handle's defined assignment) and then
+    !> updates r and p separately (CG.fypp:131, 163) -- the pattern a shallow handle copy would corrupt.  The reference cannot
+    !> run cg on its own dense_vector (mold= leaves dense_vector%n undefined), so the check is the textbook recurrence on
+    !> plain arrays in cg's own operation order: same iterates to rounding, same iteration count.
+    subroutine check_cg_rdp()
+        real(dp) :: M(n, n), A(n, n), rhs(n), xg(n), xr(n), r(n), p(n), Ap(n)
+        real(dp) :: alpha, beta, rr_old, rr_new, tol
+        type(dense_linop_gpu_rdp) :: Lgpu
+        type(sym_linop_gpu_rdp) :: S
+        type(dense_vector_gpu_rdp) :: bgpu, xgpu
+        type(cg_dp_opts) :: opts
+        type(cg_dp_metadata) :: meta
+        integer :: info, it, i
+        call test_matrix_rdp(M, rhs)
+        A = matmul(transpose(M), M)
+        do i = 1, n; A(i, i) = A(i, i) + 1.0_dp; end do
+        Lgpu = dense_linop_gpu(A); S = sym_linop_gpu(Lgpu)
+        opts = cg_dp_opts(maxiter=200)
+        call bgpu%upload(rhs); xgpu%n = n; call xgpu%zero()
+        call cg(S, bgpu, xgpu, info, rtol=1.0e-10_dp, atol=1.0e-14_dp, options=opts, meta=meta)
+        call xgpu%download(xg)
+        ! plain-array restatement (CG.fypp:105-170, no preconditioner)
+        tol = 1.0e-14_dp + 1.0e-10_dp*sqrt(sum(rhs**2))
+        xr = 0.0_dp; r = rhs; p = r; rr_old = sum(r*r); it = 0
+        do i = 1, 200
+            Ap = matmul(A, p)
+            alpha = rr_old/sum(p*Ap)
+            xr = xr + alpha*p
+            r = r - alpha*Ap
+            rr_new = sum(r*r)
+            it = i
+            if (sqrt(rr_new) < tol) exit
+            beta = rr_new/rr_old
+            p = r + beta*p
+            rr_old = rr_new
+        end do
+        call report('cg rdp: max |x_gpu - x_plain_arrays|         ', maxval(abs(xg - xr)), 1.0e-10_dp)
+        call report('cg rdp: residual |A x - b|                   ', maxval(abs(matmul(A, xg) - rhs)), 1.0e-8_dp)
+        call report('cg rdp: iterations differ from the restatement', real(abs(meta%n_iter - it), dp), 0.5_dp)
+    end subroutine
+
+    subroutine check_cg_cdp()
+        real(dp) :: Mr(n, n), rr(n)
+        complex(dp) :: M(n, n), A(n, n), rhs(n), xg(n)
+        type(dense_linop_gpu_cdp) :: Lgpu
+        type(hermitian_linop_gpu_cdp) :: H
+        type(dense_vector_gpu_cdp) :: bgpu, xgpu
+        type(cg_dp_opts) :: opts
+        integer :: info, i
+        call test_matrix_rdp(Mr, rr)
+        M = cmplx(Mr, 0.3_dp*transpose(Mr), kind=dp); rhs = cmplx(rr, rr(n:1:-1), kind=dp)
+        A = matmul(conjg(transpose(M)), M)
+        do i = 1, n; A(i, i) = A(i, i) + (1.0_dp, 0.0_dp); end do
+        Lgpu = dense_linop_gpu(A); H = hermitian_linop_gpu(Lgpu)
+        opts = cg_dp_opts(maxiter=200)
+        call bgpu%upload(rhs); xgpu%n = n; call xgpu%zero()
+        call cg(H, bgpu, xgpu, info, rtol=1.0e-10_dp, atol=1.0e-14_dp, options=opts)
+        call xgpu%download(xg)
+        call report('cg cdp: residual |A x - b|                   ', maxval(abs(matmul(A, xg) - rhs)), 1.0e-8_dp)
     end subroutine
 
     subroutine check_gmres_cdp()
