@@ -94,6 +94,7 @@ struct lk_context_s {
     // lazy batching of the PER-OBJECT path (opt-in, tuning key "lazy"): what an unchanged LightKrylov drives
     // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
     int lap5_grid_mult = 8;    // persistent blocks per CU of the stencil operator
+    int block_fused = 1;       // block DGS: fused update+dot / two-coefficient sweeps (3 passes per group) instead of 4
     int csr_lanes = 0;         // 0: lanes per row of the CSR product chosen from the mean row length; 2..64 forces it
     int blas1_grid_mult = 2;   // blocks of 256 threads per CU for the one-to-three-stream kernels
     int lazy = 0;
@@ -433,6 +434,34 @@ int dots_p(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int pn, double 
                        nslots, out);
     HIPCHK(hipGetLastError());
     return allreduce(c, out, nslots);
+}
+
+// Passes B and C of the fused block DGS (panel_sweep_p) for columns [jy0, jy0 + pn) of Y against X(:, :k):
+//   B: Y' = Y - X H1 in registers, H2 = X^H Y' and ||Y'_q||^2 -> out2 (panel_dot_p's layout, all-reduced)
+//   C: Y'' = (Y - X H1) - X H2 stored                      (no reduction: lk_dgs_block returns no norm of Y'')
+template <bool CPLX, int KC, int NW, int P>
+int block_sweeps(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int pn, const double *out1, double *out2) {
+    lk_context_t c = Bx->ctx;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    const SweepCfg s = sweep_cfg<CPLX, KC, NW>(c, k, Bx->n);
+    const int nslots = P * (k + 1) * ED;
+    {
+        ProfScope ps(c, "dgs_block_sweep2", (double)Bx->n * ED * 8.0 * (k + pn));
+        hipLaunchKernelGGL((panel_sweep_p<CPLX, KC, NW, P, true, false>), dim3(s.grid), dim3(NW * 64), 0, c->stream, Bx->col(0), Bx->ld, k,
+                           By->col(jy0), By->ld, pn, Bx->n, out1, nullptr, k + 1, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, 0);
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(finish_partials, dim3((nslots + 3) / 4), dim3(256), 0, c->stream, c->partial, (int64_t)MAX_GRID, s.grid, nslots, out2);
+    HIPCHK(hipGetLastError());
+    LKCHK(allreduce(c, out2, nslots));
+    {
+        ProfScope ps(c, "dgs_block_sweep3", (double)Bx->n * ED * 8.0 * (k + 2 * pn));
+        hipLaunchKernelGGL((panel_sweep_p<CPLX, KC, NW, P, false, true>), dim3(s.grid), dim3(NW * 64), 0, c->stream, Bx->col(0), Bx->ld, k,
+                           By->col(jy0), By->ld, pn, Bx->n, out1, out2, k + 1, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw,
+                           1 | (c->store_policy << 1));
+    }
+    HIPCHK(hipGetLastError());
+    return LK_OK;
 }
 
 int ensure_scratch(lk_context_t c, int64_t doubles) {
@@ -894,6 +923,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "lap5_grid_mult")) { if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: lap5_grid_mult in [1, 64]"); c->lap5_grid_mult = value; return LK_OK; }
+    if (!strcmp(key, "block_fused")) { c->block_fused = value != 0; return LK_OK; }
     if (!strcmp(key, "csr_lanes")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(LK_ERR_INVALID, "lk_set_tuning: csr_lanes must be 0 or a power of two in [1, 64]");
         c->csr_lanes = value;
@@ -1598,10 +1628,21 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
         for (int j = 0; j < p; j += 4) {
             const int pn = (p - j) < 4 ? (p - j) : 4;
             // both passes stay on the device (pass 2 reads the Y that pass 1's update wrote); ONE copy + sync per group
-            for (int pass = 0; pass < 2; ++pass) {
-                double *out = c->red + (size_t)pass * RED_MULTI * RED_SECTION;
-                LKCHK(dots_p(Bx, 0, k, By, jy0 + j, pn, out));
-                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, out, (int64_t)(k + 1)));
+            double *out1 = c->red, *out2 = c->red + (size_t)RED_MULTI * RED_SECTION;
+            const bool cpx = Bx->dtype == LK_C128;
+            if (c->block_fused && (pn <= 2 || (!cpx && k <= 64))) {
+                // THREE passes over X for the group: multi-right-hand-side dots, then the fused update + dot sweep
+                // (Y' stays in registers), then the two-coefficient update that writes Y''
+                LKCHK(dots_p(Bx, 0, k, By, jy0 + j, pn, out1));
+                if (cpx) LKCHK((block_sweeps<true, 8, 16, 2>(Bx, k, By, jy0 + j, pn, out1, out2)));
+                else if (pn <= 2) LKCHK((block_sweeps<false, 16, 8, 2>(Bx, k, By, jy0 + j, pn, out1, out2)));
+                else LKCHK((block_sweeps<false, 8, 8, 4>(Bx, k, By, jy0 + j, pn, out1, out2)));   // 4 right-hand sides x 8 columns per wave: k <= 64
+            } else {
+                for (int pass = 0; pass < 2; ++pass) {           // dots / MFMA update / dots / MFMA update: four passes
+                    double *out = pass == 0 ? out1 : out2;
+                    LKCHK(dots_p(Bx, 0, k, By, jy0 + j, pn, out));
+                    LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, out, (int64_t)(k + 1)));
+                }
             }
             LKCHK(fetch(c, 0, RED_TOTAL));
             const double *r1 = c->red_host, *r2 = c->red_host + (size_t)RED_MULTI * RED_SECTION;

@@ -426,6 +426,151 @@ __global__ __launch_bounds__(NW * 64) void panel_dot_p(const double *__restrict_
     }
 }
 
+// The fused sweeps of the DGS for up to P columns of Y at once (DGS_basis_against_basis, gram_schmidt.fypp:59-105):
+//   UPDATE + DOT       : Y' = Y - X H1 (kept in registers unless `store`), H2 = X^H Y', ||Y'_q||^2      (pass B)
+//   UPDATE + TWO       : Y'' = (Y - X H1) - X H2, stored                                                 (pass C)
+// Same wave split and summation order in both, so pass C re-forms exactly the Y' that pass B projected (see panel_sweep).
+// One pass over X serves all P columns: with the multi-right-hand-side dot pass in front (panel_dot_p) a block DGS
+// costs THREE passes over X per group of P columns, against four for dots / update / dots / update.
+// Coefficients and results use panel_dot_p's layout: slot (q * kslots + j) * ED (+part), j = kslots - 1 = the norm slot.
+// One accumulator per (column, right-hand side) -- real: a two-FMA chain over the lane's two rows -- and a single LDS
+// exchange buffer with two barriers per tile keep P = 4 x 16 columns inside the register file and 64 KB of LDS.
+template <bool CPLX, int KC, int NW, int P, bool DOT, bool TWO>
+__global__ __launch_bounds__(NW * 64) void panel_sweep_p(const double *__restrict__ X, int64_t ldx, int k,
+                                                          double *__restrict__ Y, int64_t ldy, int pn, int64_t n,
+                                                          const double *__restrict__ hin, const double *__restrict__ hin2,
+                                                          int kslots, double *__restrict__ partial, int64_t pstride, int WC,
+                                                          int kcw, int store) {
+    static_assert(!(DOT && TWO), "pass B carries the dots, pass C the second coefficient set");
+    constexpr int ROWS = K<CPLX>::ROWS;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int WROWS = 64 * ROWS;
+    constexpr int NU = TWO ? 2 : 1;
+    constexpr int AD = CPLX ? 2 : 1;                    // doubles per accumulator
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wc = wave % WC, wr = wave / WC, WR = NW / WC;
+    const int c0 = wc * kcw;
+    int nc = k - c0;
+    nc = nc > kcw ? kcw : nc;
+    nc = nc < 0 ? 0 : nc;
+    __shared__ v2d u_lds[NU * P * NW * 64];
+    constexpr int SLOTS = (KC * ED + 1) * P;
+    __shared__ double red_lds[DOT ? NW * SLOTS : 1];
+
+    double acc[P][KC][AD];
+    double nrm[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        nrm[q] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj)
+#pragma unroll
+            for (int a = 0; a < AD; ++a) acc[q][jj][a] = 0.0;
+    }
+    const int64_t tile_rows = (int64_t)WR * WROWS;
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const double *Xw = X + (int64_t)c0 * ldx * ED;
+    const int64_t colstride = ldx * ED, ystride = ldy * ED;
+    const int64_t roff = (int64_t)wr * WROWS + (int64_t)lane * ROWS;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t r = t * tile_rows + roff;
+        const bool full = (t + 1) * tile_rows <= n;
+        v2d xv[KC], yv[P];
+        load_cols<CPLX, KC>(Xw, colstride, r, n, full, nc, xv);
+#pragma unroll
+        for (int q = 0; q < P; ++q) yv[q] = (q < pn) ? load_y<CPLX>(Y + q * ystride, r, n, full) : v2d{0.0, 0.0};
+        // this wave's share of X H for every right-hand side (coefficients are wave-uniform: scalar loads)
+        v2d u[NU][P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            u[0][q] = v2d{0.0, 0.0};
+            if constexpr (TWO) u[1][q] = v2d{0.0, 0.0};
+            const double *h1 = hin + ((int64_t)q * kslots + c0) * ED;
+            const double *h2 = TWO ? hin2 + ((int64_t)q * kslots + c0) * ED : nullptr;
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) {
+                if (jj < nc && q < pn) {
+                    if constexpr (CPLX) {
+                        u[0][q] += cmul(xv[jj], v2d{h1[2 * jj], h1[2 * jj + 1]});
+                        if constexpr (TWO) u[1][q] += cmul(xv[jj], v2d{h2[2 * jj], h2[2 * jj + 1]});
+                    } else {
+                        u[0][q] += xv[jj] * h1[jj];
+                        if constexpr (TWO) u[1][q] += xv[jj] * h2[jj];
+                    }
+                }
+            }
+        }
+        if (WC > 1) {
+#pragma unroll
+            for (int s = 0; s < NU; ++s)
+#pragma unroll
+                for (int q = 0; q < P; ++q) u_lds[((s * P + q) * NW + wave) * 64 + lane] = u[s][q];
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < NU; ++s)
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    v2d sum = v2d{0.0, 0.0};
+                    for (int w = 0; w < WC; ++w) sum += u_lds[((s * P + q) * NW + wr * WC + w) * 64 + lane];
+                    u[s][q] = sum;
+                }
+            __syncthreads();                                    // single buffer: everyone has read before the next tile writes
+        }
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            yv[q] -= u[0][q];
+            if constexpr (TWO) yv[q] -= u[1][q];
+            if (store && wc == 0 && q < pn) store_rows<CPLX>(Y + q * ystride, r, n, full, yv[q], (store >> 1) & 3);
+            if constexpr (DOT) {
+#pragma unroll
+                for (int jj = 0; jj < KC; ++jj) {
+                    if constexpr (CPLX) {
+                        const v2d z = cmulconj(xv[jj], yv[q]);
+                        acc[q][jj][0] += z.x;
+                        acc[q][jj][1] += z.y;
+                    } else {
+                        acc[q][jj][0] = fma(xv[jj].y, yv[q].y, fma(xv[jj].x, yv[q].x, acc[q][jj][0]));
+                    }
+                }
+                if (wc == 0) nrm[q] += yv[q].x * yv[q].x + yv[q].y * yv[q].y;
+            }
+        }
+    }
+    if constexpr (DOT) {
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            double *rl = red_lds + wave * SLOTS + q * (KC * ED + 1);
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj)
+#pragma unroll
+                for (int a = 0; a < AD; ++a) {
+                    const double sm = wave_sum(acc[q][jj][a]);
+                    if (lane == 0) rl[jj * ED + a] = sm;
+                }
+            const double sn = wave_sum(nrm[q]);
+            if (lane == 0) rl[KC * ED] = sn;
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < P * (k + 1) * ED; idx += blockDim.x) {
+            const int q = idx / ((k + 1) * ED), rem = idx % ((k + 1) * ED);
+            const int j = rem / ED, part = rem % ED;
+            double sm = 0.0;
+            int64_t slot;
+            if (j < k) {
+                const int wcj = j / kcw, jj = j - wcj * kcw;
+                for (int w = 0; w < WR; ++w) sm += red_lds[(w * WC + wcj) * SLOTS + q * (KC * ED + 1) + jj * ED + part];
+                slot = ((int64_t)q * kslots + j) * ED + part;
+            } else {
+                if (part == 0)
+                    for (int w = 0; w < WR; ++w) sm += red_lds[(w * WC) * SLOTS + q * (KC * ED + 1) + KC * ED];
+                slot = ((int64_t)q * kslots + kslots - 1) * ED + part;
+            }
+            partial[slot * pstride + blockIdx.x] = sm;
+        }
+    }
+}
+
 // Streaming update y <- y - X(:, :k) * hin with ||y_out||^2: no dots, so nothing has to stay in
 // registers and every wave can walk ALL k columns of its own rows in chunks of KC -- no LDS
 // exchange, no barrier in the loop.  Used for DGS sweep 3 and for linear_combination.

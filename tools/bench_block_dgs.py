@@ -5,7 +5,10 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lightkrylov_amd as lk
 ctx = lk.Context(device=0)
-n, p = 10_000_000, 4
+n = 10_000_000
+p = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+if len(sys.argv) > 2:
+    ctx.set_tuning("block_fused", int(sys.argv[2]))       # 1: dots + fused update/dot + two-coefficient update (3 passes); 0: 4 passes
 for k in (64, 128):
     B = lk.krylov_basis_gpu(n, k + p, np.float64, ctx)
     for j in range(k + p):
@@ -18,6 +21,6 @@ for k in (64, 128):
         lk.double_gram_schmidt_step(B[k:k + p], B[:k], False, beta)
     ctx.sync(); dt = (time.perf_counter() - t0) / reps
     xbytes = 8.0 * n * k
-    print(json.dumps({"n": n, "k": k, "p": p, "ms_per_block_dgs": dt * 1e3, "X_GB": xbytes / 1e9,
+    print(json.dumps({"n": n, "k": k, "p": p, "block_fused": int(sys.argv[2]) if len(sys.argv) > 2 else 1, "ms_per_block_dgs": dt * 1e3, "X_GB": xbytes / 1e9,
                       "passes_over_X_if_at_6.4TBps": dt * 6.4e12 / xbytes}), flush=True)
     del B
