@@ -514,3 +514,33 @@ def test_user_operator_written_with_torch_on_device_pointers(dtype):
     assert abs(y.norm() - 3.0 * nrm) <= 1e-13 * nrm
     del B, T, y
     c.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("k,p", [(7, 2), (40, 2), (64, 4), (128, 2), (100, 3), (33, 5)])
+def test_block_dgs_fused_schedule_equals_the_four_pass_one(dtype, k, p):
+    """DGS_basis_against_basis (gram_schmidt.fypp:59-105) through lk_dgs_block: the fused three-pass schedule
+    (panel_sweep_p) and the four-pass one (dots / update / dots / update) return the same coefficients and leave the same
+    vectors to 1e-12, and both match the oracle's per-column double Gram-Schmidt; ragged rows, odd group sizes."""
+    n = 7001
+    Q = np.asfortranarray(np.linalg.qr(np.column_stack([seeded(n, dtype, 5 + j) for j in range(k)]))[0])
+    Y = np.asfortranarray(np.column_stack([seeded(n, dtype, 200 + j) for j in range(p)]))
+    out = []
+    for fused in (0, 1):
+        c = lk.Context(device=0)
+        c.set_tuning("block_fused", fused)
+        B = lk.krylov_basis_gpu(n, k + p, dtype, c)
+        B.upload(Q, 0); B.upload(Y, k)
+        beta = np.zeros((k, p), dtype=dtype, order="F")
+        info = lk.double_gram_schmidt_step(B[k:k + p], B[:k], False, beta)
+        out.append((info, beta.copy(), B.download(k, p)))
+        del B
+        c.close()
+    (i0, b0, y0), (i1, b1, y1) = out
+    assert i0 == i1 == 0
+    scale = max(np.linalg.norm(Y[:, j]) for j in range(p))
+    assert np.abs(b0 - b1).max() <= 1e-12 * scale and np.abs(y0 - y1).max() <= 1e-12 * scale
+    for j in range(p):
+        yo = Y[:, j].copy()
+        ho, _ = ora.double_gram_schmidt_step(yo, Q)
+        assert np.abs(b1[:, j] - ho).max() <= 1e-12 * scale and np.abs(y1[:, j] - yo).max() <= 1e-12 * scale
