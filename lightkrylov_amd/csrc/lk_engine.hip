@@ -2,6 +2,7 @@
 // HIP only: there is no CPU code path in this library.
 #include "lk_internal.h"
 #include "lk_kernels.hip.h"
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -94,6 +95,7 @@ struct lk_context_s {
     // lazy batching of the PER-OBJECT path (opt-in, tuning key "lazy"): what an unchanged LightKrylov drives
     // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
     int lap5_grid_mult = 8;    // persistent blocks per CU of the stencil operator
+    int prof_ext = 1;          // profiling events of the sweeps attached to the kernel dispatch instead of recorded on the stream
     int block_fused = 1;       // block DGS: fused update+dot / two-coefficient sweeps (3 passes per group) instead of 4
     int csr_lanes = 0;         // 0: lanes per row of the CSR product chosen from the mean row length; 2..64 forces it
     int blas1_grid_mult = 2;   // blocks of 256 threads per CU for the one-to-three-stream kernels
@@ -210,7 +212,8 @@ struct ProfScope {
     lk_context_t c;
     bool on;
     ProfRec rec;
-    ProfScope(lk_context_t ctx, const char *tag, double bytes) : c(ctx), on(ctx->prof) {
+    bool ext = false;   // the launch itself carries the two events (hipExtLaunchKernelGGL): nothing is recorded on the stream
+    ProfScope(lk_context_t ctx, const char *tag, double bytes, bool ext_launch = false) : c(ctx), on(ctx->prof), ext(ext_launch) {
         if (on && c->prof_sweeps_only && strncmp(tag, "dgs_sweep", 9) != 0) on = false;
         if (!on) return;
         auto get = [&]() {
@@ -223,12 +226,12 @@ struct ProfScope {
         rec.e1 = get();
         rec.tag = tag;
         rec.bytes = bytes;
-        (void)hipEventRecord(rec.e0, c->stream);
+        if (!ext) (void)hipEventRecord(rec.e0, c->stream);
     }
     void end() {
         if (!on) return;
         on = false;
-        (void)hipEventRecord(rec.e1, c->stream);
+        if (!ext) (void)hipEventRecord(rec.e1, c->stream);
         if (!c->span_first) c->span_first = rec.e0;
         c->span_last = rec.e1;
         c->prof_pending.push_back(rec);
@@ -342,8 +345,12 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
     const double bytes = (double)n * ED * 8.0 * (k + 1 + (UPDATE ? 1 : 0));
     int nblocks = s.grid;
     {
-        ProfScope ps(c, MODE == 1 ? "dgs_sweep1" : (MODE == 2 ? "dgs_sweep2" : "dgs_sweep3"), bytes);
+        // the sweep's two HIP events ride on the kernel's own dispatch (start / stop timestamps of the launch itself), not on
+        // separate stream markers: six markers per Arnoldi step cost 3-4 % of a launch-bound factorisation (n = 10^6 complex)
+        ProfScope ps(c, MODE == 1 ? "dgs_sweep1" : (MODE == 2 ? "dgs_sweep2" : "dgs_sweep3"), bytes, c->prof_ext);
         if ((MODE == 3 && c->stream_update) || (MODE == 4 && c->stream_two)) {
+            ps.ext = false;
+            if (ps.on) (void)hipEventRecord(ps.rec.e0, c->stream);
             const int64_t tile_rows = (int64_t)NW * 64 * K<CPLX>::ROWS;
             int64_t g = (n + tile_rows - 1) / tile_rows;
             const int64_t cap = (int64_t)c->num_cu * c->update_grid_mult;
@@ -355,8 +362,13 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
                                n, hin, hin2, c->partial, (int64_t)MAX_GRID, c->store_policy, c->guard());
         } else {
             const int st = store ? (1 | (c->store_policy << 1) | (c->store_split ? 8 : 0)) : 0;
-            hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
-                               ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st, c->guard());
+            if (ps.on && ps.ext)
+                hipExtLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream,
+                                      ps.rec.e0, ps.rec.e1, 0, X, ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st,
+                                      c->guard());
+            else
+                hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
+                                   ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st, c->guard());
         }
     }
     HIPCHK(hipGetLastError());
@@ -923,6 +935,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "lap5_grid_mult")) { if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: lap5_grid_mult in [1, 64]"); c->lap5_grid_mult = value; return LK_OK; }
+    if (!strcmp(key, "prof_ext")) { c->prof_ext = value != 0; return LK_OK; }
     if (!strcmp(key, "block_fused")) { c->block_fused = value != 0; return LK_OK; }
     if (!strcmp(key, "csr_lanes")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(LK_ERR_INVALID, "lk_set_tuning: csr_lanes must be 0 or a power of two in [1, 64]");
