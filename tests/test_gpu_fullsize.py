@@ -187,3 +187,52 @@ def test_config4_size_complex_arnoldi_against_live_oracle(ctx):
     # Ritz values of a normal operator are well conditioned; match each to its nearest oracle value
     dist = np.abs(w[:, None] - wo[None, :]).min(axis=1)
     assert dist.max() <= 1e-11 * np.abs(wo).max(), dist.max()
+
+
+@pytest.mark.parametrize("dtype,ncol", [(np.float64, 5), (np.complex128, 3)])
+def test_maximum_vector_size(ctx, dtype, ncol):
+    """The largest vector the contract allows: get_size() returns a default integer (AbstractVectors.fypp:375-381), so
+    n = 2^31 - 1 rows (17 GB per real vector, 34 GB per complex one; odd, so every kernel also takes its ragged tail).
+    Every byte offset beyond 2^32 and every row index near 2^31 is exercised: rand against the oracle's counter generator at
+    both ends of the vector, the BLAS-1 identities, qr + double Gram-Schmidt (all three sweeps) and orthonormality."""
+    n = 2_147_483_647
+    with pytest.raises(_capi.LightKrylovHipError):
+        lk.krylov_basis_gpu(n + 1, 1, dtype, ctx)                                  # one more row is refused
+    B = lk.krylov_basis_gpu(n, ncol, dtype, ctx)
+    for j in range(ncol):
+        B[j].rand(False, seed=40 + j)
+    # the generator is indexed by the global row: compare both ends of column 1 with the oracle
+    _dt, _n, nc, ld, ptr = B.info()
+    es = np.dtype(dtype).itemsize
+    for r0 in (0, (n - 4096) & ~1):
+        rows = min(4096, n - r0)
+        h = C.c_void_p()
+        _capi.check(B._lib.lk_basis_wrap(ctx._h, _capi.LK_C128 if es == 16 else _capi.LK_F64, rows, 1, ld,
+                                         C.c_void_p(ptr + es * (ld * 1 + r0)), C.byref(h)))
+        got = np.empty(rows, dtype=dtype)
+        _capi.check(B._lib.lk_basis_download(h, 0, 1, got.ctypes.data_as(C.c_void_p), rows))
+        B._lib.lk_basis_destroy(h)
+        want = np.empty(rows, dtype=dtype)
+        ora.fill_counter(want, 41, i0=r0)
+        assert np.array_equal(got, want), r0
+    # BLAS-1 identities at this size
+    nx = B[0].norm()
+    expect = np.sqrt(n / 3.0 * (2 if es == 16 else 1))                              # entries uniform on [-1, 1): E x^2 = 1/3
+    assert abs(nx - expect) <= 1e-3 * expect
+    assert abs(B[0].dot(B[0]) - nx * nx) <= 1e-12 * nx * nx
+    d01 = B[0].dot(B[1])
+    B[0].scal(2.0)
+    assert abs(B[0].norm() - 2.0 * nx) <= 1e-12 * nx and abs(B[0].dot(B[1]) - 2.0 * d01) <= 1e-11 * nx * nx
+    B[0].axpby(0.5, B[1], -1.0)                                                    # x <- 0.5 y - x
+    assert abs(B[1].dot(B[0]) - (0.5 * B[1].dot(B[1]) - 2.0 * np.conj(d01))) <= 1e-10 * nx * nx     # y^H (0.5 y - 2 x)
+    # qr of the first ncol-1 columns (DGS inside), then the last column through the fused DGS
+    k = ncol - 1
+    R = np.zeros((k, k), dtype=dtype, order="F")
+    assert lk.qr(B[:k], R) == 0
+    beta = np.zeros(k, dtype=dtype)
+    ny = B[k].norm()
+    assert lk.double_gram_schmidt_step(B[k], B[:k], if_chk_orthonormal=False, beta=beta) == 0
+    assert np.abs(lk.innerprod(B[:k], B[k])).max() <= 1e-12 * ny
+    B[k].scal(1.0 / B[k].norm())
+    G = lk.Gram(B)
+    assert np.abs(G - np.eye(ncol)).max() <= 1e-12
