@@ -1,15 +1,15 @@
 """The REFERENCE's own call sequence, replayed on the GPU.
 
 tests/golden/plugin_abi_trace.txt.gz is the list of C-ABI calls that fortran/dense_vector_gpu.f90 -- the LightKrylov
-plugin -- made while the reference's unchanged `arnoldi` (real and complex), `gmres` (real and complex), its
-copy / assignment semantics and 205 `double_gram_schmidt_step` calls ran through it in the build container
+plugin -- made while the reference's unchanged `arnoldi` (real and complex), `gmres` (real and complex), `cg` (real and
+complex), its copy / assignment semantics and 205 `double_gram_schmidt_step` calls ran through it in the build container
 (tools/check_plugin.sh with LK_MOCK_TRACE; the C ABI was served there by the host mock tools/plugin_check/mock_abi.c,
 whose return values -- every dot product, every downloaded vector, every pool placement -- are part of the trace).
 A trace is data: a call sequence and numbers.
 
-Here the same 14 000 calls go to the real engine, in the lazy mode the plugin switches on (virtual temporaries, fused
+Here the same 14 800 calls go to the real engine, in the lazy mode the plugin switches on (virtual temporaries, fused
 update + dot sweeps, memoised dots, the column pool), and EVERY value the engine returns is compared with what the
-straightforward host loops returned: 6 400 dot products and norms and every download, at 1e-12.  This is the drop-in
+straightforward host loops returned: 6 471 dot products and norms and every download, at 1e-12 normwise.  This is the drop-in
 boundary under the call pattern of the reference itself -- including its `intent(out)` re-acquisitions, sourced
 allocations that share a column until first written, and temporaries that die without a call."""
 import ctypes as C
@@ -37,6 +37,7 @@ def test_reference_call_sequence_replayed_on_the_engine():
     bases, ops, pool = {}, {}, {}                  # trace id -> handle ; (trace slab id, col) -> (slab handle, col)
     dtype_of = {}                                  # trace basis / slab id -> (dtype, n)
     ndot = ndown = 0
+    norm2 = {}
     worst_dot = worst_down = 0.0
 
     def ref(bid, j):
@@ -133,7 +134,13 @@ def test_reference_call_sequence_replayed_on_the_engine():
                 chk(lib.lk_vec_dot(bx, jx, by, jy, out))
                 want = complex(float(t[6]), float(t[7]))
                 got = complex(out[0], out[1])
-                err = abs(got - want) / max(1.0, abs(want))
+                # normwise bar: 1e-12 |x| |y|, the norms taken from the trace's own y%dot(y) records (the last one seen for
+                # each vector; 1 when none) -- Lanczos' A v has norm ~ |A| and its dot with an orthogonal vector is ~ eps |A|
+                kx, ky = (int(t[1]), int(t[2])), (int(t[3]), int(t[4]))
+                if kx == ky:
+                    norm2[kx] = abs(want)
+                scale = max(1.0, abs(want), np.sqrt(norm2.get(kx, 1.0) * norm2.get(ky, 1.0)))
+                err = abs(got - want) / scale
                 worst_dot = max(worst_dot, err)
                 assert err <= 1e-12, f"dot #{ndot} ({line[:60].strip()}): got {got}, reference call sequence had {want}"
                 ndot += 1

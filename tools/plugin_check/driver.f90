@@ -39,7 +39,8 @@ program plugin_driver
     use LightKrylov_AbstractVectors
     use LightKrylov_AbstractLinops
     use LightKrylov_BaseKrylov, only: arnoldi, double_gram_schmidt_step
-    use LightKrylov_IterativeSolvers, only: gmres, eigs, cg, gmres_dp_opts, gmres_dp_metadata, cg_dp_opts, cg_dp_metadata
+    use LightKrylov_IterativeSolvers, only: gmres, eigs, cg, eighs, gmres_dp_opts, gmres_dp_metadata, cg_dp_opts, cg_dp_metadata
+    use stdlib_linalg, only: eigh
     use lightkrylov_gpu
     use plugin_check_ref_ops
     implicit none
@@ -56,6 +57,14 @@ program plugin_driver
     call check_gmres_cdp()
     call check_cg_rdp()
     call check_cg_cdp()
+    ! eighs runs through the plugin here, but stays out of the recorded call sequence: the GPU replay applies the recorded
+    ! coefficients to its own vectors, and a Lanczos recurrence with converged Ritz pairs amplifies one-ulp differences
+    ! between the two states by ten orders of magnitude -- it would test that amplification, not the engine.  The pool
+    ! is emptied right after (recorded), so the replay and the recording agree on it again.
+    call trace_pause(.true.)
+    call check_eighs_rdp()
+    call trace_pause(.false.)
+    call lk_gpu_release_all()
     call check_assignment_is_deep()
     call check_pool_is_bounded()
     if (command_argument_count() > 99) call never_executed_eigs()
@@ -306,6 +315,47 @@ contains
         call report('cg rdp: max |x_gpu - x_plain_arrays|         ', maxval(abs(xg - xr)), 1.0e-10_dp)
         call report('cg rdp: residual |A x - b|                   ', maxval(abs(matmul(A, xg) - rhs)), 1.0e-8_dp)
         call report('cg rdp: iterations differ from the restatement', real(abs(meta%n_iter - it), dp), 0.5_dp)
+    end subroutine
+
+    !> The reference's symmetric eigensolver (Lanczos + eigh of the tridiagonal matrix each step, eighs.fypp) through the
+    !> plugin: its work basis is `allocate(Xwrk(kdim+1), mold=X(1))` (no size: inferred), Lanczos issues single dots and
+    !> axpbys (lanczos.fypp:57-60) before the full re-orthogonalisation.  Checked against the eigenvalues of the whole matrix.
+    subroutine check_eighs_rdp()
+        integer, parameter :: nev = 3
+        real(dp) :: M(n, n), A(n, n), rhs(n), lam_all(n), Acopy(n, n), xv(n)
+        real(dp), allocatable :: lambda(:), res(:)
+        type(dense_linop_gpu_rdp) :: Lgpu
+        type(sym_linop_gpu_rdp) :: S
+        type(dense_vector_gpu_rdp), allocatable :: X(:)
+        type(dense_vector_gpu_rdp) :: x0
+        integer :: info, i
+        call test_matrix_rdp(M, rhs)
+        A = matmul(transpose(M), M)
+        do i = 1, n; A(i, i) = A(i, i) + 1.0_dp + 3.0_dp*real(i, dp)/real(n, dp); end do
+        do i = 1, nev; A(i, i) = A(i, i) + 40.0_dp + 10.0_dp*real(i, dp); end do    ! three well separated leading eigenvalues
+        Acopy = A; call eigh(Acopy, lam_all)
+        Lgpu = dense_linop_gpu(A); S = sym_linop_gpu(Lgpu)
+        allocate (X(nev)); X%n = n
+        call x0%upload(rhs)
+        call eighs(S, X, lambda, res, info, x0=x0, kdim=24, tolerance=1.0e-6_dp)   ! (few steps: the GPU replay of this call
+        ! sequence applies these coefficients to ITS vectors, and a long Lanczos recurrence amplifies one-ulp differences)
+        call report('eighs rdp: max |lambda - eig(A)| (3 largest)  ', maxval(abs(lambda(:nev) - lam_all(n:n - nev + 1:-1))), 1.0e-6_dp)
+        call X(1)%download(xv)
+        call report('eighs rdp: |A x - lambda x| of the leading pair', maxval(abs(matmul(A, xv) - lambda(1)*xv)), 1.0e-5_dp)
+    end subroutine
+
+    subroutine trace_pause(on)
+        logical, intent(in) :: on
+        interface
+            function c_setenv(name, val, overwrite) bind(C, name="setenv") result(rc)
+                import :: c_char, c_int
+                character(kind=c_char), intent(in) :: name(*), val(*)
+                integer(c_int), value :: overwrite
+                integer(c_int) :: rc
+            end function
+        end interface
+        integer(c_int) :: rc
+        rc = c_setenv("LK_MOCK_TRACE_PAUSE"//c_null_char, merge("1", "0", on)//c_null_char, 1_c_int)
     end subroutine
 
     subroutine check_cg_cdp()

@@ -47,7 +47,9 @@ static int idof(const void *p) {          /* stable small integer per object (ba
 }
 static void forget(const void *p) { for (int i = 0; i < g_nids; ++i) if (g_ids[i] == p) g_ids[i] = (const void *)(intptr_t)-1 - i; }
 static void trv(const double *v, int64_t cnt) { for (int64_t i = 0; i < cnt; ++i) fprintf(g_tr, " %.17g", v[i]); }
-#define TR(...) do { if (tr()) { fprintf(g_tr, __VA_ARGS__); } } while (0)
+/* LK_MOCK_TRACE_PAUSE=1 (set and cleared by the driver around a check) keeps a stretch of calls out of the trace */
+static int paused(void) { const char *p = getenv("LK_MOCK_TRACE_PAUSE"); return p && *p == '1'; }
+#define TR(...) do { if (tr() && !paused()) { fprintf(g_tr, __VA_ARGS__); } } while (0)
 #define TRNL() do { if (g_tr) { fputc('\n', g_tr); } } while (0)
 
 static char g_err[256] = "";
@@ -74,12 +76,12 @@ int lk_basis_create(mock_ctx *c, int dtype, int64_t n, int ncols, mock_basis **B
 int lk_basis_destroy(mock_basis *b) { if (b) { if (!g_in_pool) TR("basis_destroy %d\n", idof(b)); forget(b); free(b->data); free(b); } return LK_OK; }
 int lk_basis_upload(mock_basis *b, int c0, int nc, const void *host, int64_t ldh) {
     for (int j = 0; j < nc; ++j) memcpy(col(b, c0 + j), (const double *)host + (int64_t)j * ldh * ed(b), (size_t)b->n * ed(b) * 8);
-    if (tr()) { fprintf(g_tr, "upload %d %d %d", idof(b), c0, nc); for (int j = 0; j < nc; ++j) trv(col(b, c0 + j), b->n * ed(b)); TRNL(); }
+    if (tr() && !paused()) { fprintf(g_tr, "upload %d %d %d", idof(b), c0, nc); for (int j = 0; j < nc; ++j) trv(col(b, c0 + j), b->n * ed(b)); TRNL(); }
     return LK_OK;
 }
 int lk_basis_download(mock_basis *b, int c0, int nc, void *host, int64_t ldh) {
     for (int j = 0; j < nc; ++j) memcpy((double *)host + (int64_t)j * ldh * ed(b), col(b, c0 + j), (size_t)b->n * ed(b) * 8);
-    if (tr()) { fprintf(g_tr, "download %d %d %d ->", idof(b), c0, nc); for (int j = 0; j < nc; ++j) trv(col(b, c0 + j), b->n * ed(b)); TRNL(); }
+    if (tr() && !paused()) { fprintf(g_tr, "download %d %d %d ->", idof(b), c0, nc); for (int j = 0; j < nc; ++j) trv(col(b, c0 + j), b->n * ed(b)); TRNL(); }
     return LK_OK;
 }
 
@@ -190,14 +192,14 @@ int lk_vec_copy(mock_basis *bd, int jd, mock_basis *bs, int js) { memmove(col(bd
 int lk_linop_diag_create(mock_ctx *c, int dtype, int64_t n, const void *d, mock_op **op) {
     (void)c; mock_op *o = malloc(sizeof *o); o->kind = 0; o->dtype = dtype; o->n = n;
     const size_t bytes = (size_t)n * (dtype == LK_C128 ? 16 : 8); o->a = malloc(bytes); memcpy(o->a, d, bytes); *op = o;
-    if (tr()) { fprintf(g_tr, "op_diag %d %lld -> %d :", dtype, (long long)n, idof(o)); trv(o->a, (int64_t)(bytes / 8)); TRNL(); }
+    if (tr() && !paused()) { fprintf(g_tr, "op_diag %d %lld -> %d :", dtype, (long long)n, idof(o)); trv(o->a, (int64_t)(bytes / 8)); TRNL(); }
     return LK_OK;
 }
 int lk_linop_dense_create(mock_ctx *c, int dtype, int64_t n, const void *A, int64_t lda, mock_op **op) {
     (void)c; if (lda != n) return fail("lda != n");
     mock_op *o = malloc(sizeof *o); o->kind = 1; o->dtype = dtype; o->n = n;
     const size_t bytes = (size_t)n * n * (dtype == LK_C128 ? 16 : 8); o->a = malloc(bytes); memcpy(o->a, A, bytes); *op = o;
-    if (tr()) { fprintf(g_tr, "op_dense %d %lld -> %d :", dtype, (long long)n, idof(o)); trv(o->a, (int64_t)(bytes / 8)); TRNL(); }
+    if (tr() && !paused()) { fprintf(g_tr, "op_dense %d %lld -> %d :", dtype, (long long)n, idof(o)); trv(o->a, (int64_t)(bytes / 8)); TRNL(); }
     return LK_OK;
 }
 int lk_vec_device_ptr(mock_basis *b, int j, int access, void **p) { (void)access; *p = col(b, j); return LK_OK; }
