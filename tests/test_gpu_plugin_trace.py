@@ -7,9 +7,9 @@ complex), its copy / assignment semantics and 205 `double_gram_schmidt_step` cal
 whose return values -- every dot product, every downloaded vector, every pool placement -- are part of the trace).
 A trace is data: a call sequence and numbers.
 
-Here the same 14 800 calls go to the real engine, in the lazy mode the plugin switches on (virtual temporaries, fused
+Here the same 15 200 calls go to the real engine, in the lazy mode the plugin switches on (virtual temporaries, fused
 update + dot sweeps, memoised dots, the column pool), and EVERY value the engine returns is compared with what the
-straightforward host loops returned: 6 471 dot products and norms and every download, at 1e-12 normwise.  This is the drop-in
+straightforward host loops returned: 6 663 dot products and norms and every download, at 1e-12 normwise.  This is the drop-in
 boundary under the call pattern of the reference itself -- including its `intent(out)` re-acquisitions, sourced
 allocations that share a column until first written, and temporaries that die without a call."""
 import ctypes as C

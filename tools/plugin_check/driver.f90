@@ -227,6 +227,13 @@ contains
         call Xgpu(1)%upload(x0)
         Hgpu = 0.0_dp; call arnoldi(Lgpu, Xgpu, Hgpu, info)
         call report('arnoldi rdp: max |H_gpu - H_ref|            ', maxval(abs(Hgpu - Href)), 1.0e-12_dp)
+        ! the adjoint operator (apply_rmatvec -> the plugin's rmatvec): arnoldi(..., transpose=.true.)   arnoldi.fypp:39-47
+        do i = 2, m + 1; call Xref(i)%zero(); end do
+        Xref(1) = dense_vector(x0)
+        Href = 0.0_dp; call arnoldi(Lref, Xref, Href, info, transpose=.true.)
+        call zero_basis(Xgpu); call Xgpu(1)%upload(x0)
+        Hgpu = 0.0_dp; call arnoldi(Lgpu, Xgpu, Hgpu, info, transpose=.true.)
+        call report('arnoldi rdp, transpose: max |H_gpu - H_ref| ', maxval(abs(Hgpu - Href)), 1.0e-12_dp)
         call lk_gpu_pool_stats(st)
         call report('arnoldi rdp: pool slabs (expect 1)           ', real(st(1), dp), 1.0_dp)
     end subroutine
