@@ -97,6 +97,7 @@ struct lk_context_s {
     int lap5_grid_mult = 8;    // persistent blocks per CU of the stencil operator
     int prof_ext = 1;          // profiling events of the sweeps attached to the kernel dispatch instead of recorded on the stream
     int block_fused = 1;       // block DGS: fused update+dot / two-coefficient sweeps (3 passes per group) instead of 4
+    int csr_stream = 1;        // CSR product through LDS for matrices with short rows (mean <= 32 entries); 0: lanes-per-row kernel
     int csr_lanes = 0;         // 0: lanes per row of the CSR product chosen from the mean row length; 2..64 forces it
     int blas1_grid_mult = 2;   // blocks of 256 threads per CU for the one-to-three-stream kernels
     int lazy = 0;
@@ -196,7 +197,10 @@ struct lk_linop_s {
     double *halo = nullptr;    // lap5: 2 N doubles (line from rank-1 | line from rank+1); GL: 4 doubles
     double *edges = nullptr;   // GL: this rank's two edge values (send buffer), 4 doubles
     // CSR: A (for 'N') and its conjugate transpose (for 'H'), both row-compressed; W = lanes per row
-    struct Csr { int64_t *rowptr = nullptr; int32_t *colind = nullptr; double *vals = nullptr; int W = 8; } csr[2];
+    struct Csr {
+        int64_t *rowptr = nullptr; int32_t *colind = nullptr; double *vals = nullptr; int W = 8;
+        int64_t *rowblocks = nullptr; int64_t nblocks = 0, nnz_hint = 0;   // CSR-stream partition (short rows), see k_csr_stream
+    } csr[2];
 };
 
 namespace {
@@ -937,6 +941,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "lap5_grid_mult")) { if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: lap5_grid_mult in [1, 64]"); c->lap5_grid_mult = value; return LK_OK; }
     if (!strcmp(key, "prof_ext")) { c->prof_ext = value != 0; return LK_OK; }
     if (!strcmp(key, "block_fused")) { c->block_fused = value != 0; return LK_OK; }
+    if (!strcmp(key, "csr_stream")) { c->csr_stream = value != 0; return LK_OK; }
     if (!strcmp(key, "csr_lanes")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(LK_ERR_INVALID, "lk_set_tuning: csr_lanes must be 0 or a power of two in [1, 64]");
         c->csr_lanes = value;
@@ -1794,6 +1799,21 @@ static int csr_upload(lk_linop_t o, int which, int64_t n, const int64_t *rowptr,
         HIPCHK(hipMemcpy(m.colind, colind, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(m.vals, vals, (size_t)nnz * ED * sizeof(double), hipMemcpyHostToDevice));
     }
+    {   // CSR-stream partition: consecutive rows, at most CSR_NNZ entries and 256 rows per block; a longer row stands alone
+        std::vector<int64_t> rb;
+        rb.push_back(0);
+        int64_t r = 0;
+        while (r < n) {
+            int64_t e = r + 1;                                              // at least one row, however long
+            while (e < n && e - r < 256 && rowptr[e + 1] - rowptr[r] <= CSR_NNZ) ++e;
+            rb.push_back(e);
+            r = e;
+        }
+        m.nblocks = (int64_t)rb.size() - 1;
+        HIPCHK(hipMalloc((void **)&m.rowblocks, rb.size() * sizeof(int64_t)));
+        HIPCHK(hipMemcpy(m.rowblocks, rb.data(), rb.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    m.nnz_hint = nnz;
     const double mean = n > 0 ? (double)nnz / (double)n : 0.0;
     int W = 1;                                   // lanes per row: the power of two at or below half the mean row length
     while (W < 64 && 2 * W <= mean / 2.0) W <<= 1;   // (5-point Laplacian, n = 1.7e7: W = 1 / 2 / 4 / 8 / 16 -> see DESIGN.md)
@@ -1848,6 +1868,7 @@ int lk_linop_destroy(lk_linop_t op) {
         if (m.rowptr) (void)hipFree(m.rowptr);
         if (m.colind) (void)hipFree(m.colind);
         if (m.vals) (void)hipFree(m.vals);
+        if (m.rowblocks) (void)hipFree(m.rowblocks);
     }
     if (op->kind == OP_LAP5 && op->halo) (void)hipFree(op->halo);
     if (op->wk) (void)hipFree(op->wk);
@@ -1895,6 +1916,16 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
         break;
     case OP_CSR: {
         auto m = op->csr[trans == LK_OP_N ? 0 : 1];
+        if (c->csr_stream && n > 0 && (double)m.nnz_hint / (double)n <= 32.0 && !c->csr_lanes) {
+            // short rows: stream the entries through LDS (k_csr_stream)
+            int64_t g = m.nblocks;
+            const int64_t cap = (int64_t)c->num_cu * 16;
+            if (g > cap) g = cap;
+            if (g < 1) g = 1;
+            if (cp) hipLaunchKernelGGL(k_csr_stream<true>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, x, y, m.nblocks, c->guard());
+            else hipLaunchKernelGGL(k_csr_stream<false>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, x, y, m.nblocks, c->guard());
+            break;
+        }
         if (c->csr_lanes) m.W = c->csr_lanes;
         const int64_t rows_per_block = 256 / m.W;
         int64_t g = (n + rows_per_block - 1) / rows_per_block;

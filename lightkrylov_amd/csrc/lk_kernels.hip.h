@@ -1162,6 +1162,72 @@ __global__ __launch_bounds__(256) void k_csr(const int64_t *__restrict__ rowptr,
     }
 }
 
+// CSR product for SHORT rows ("CSR-stream"): a block owns a run of consecutive rows holding at most CSR_NNZ entries
+// (rowblocks[], built on the host); its 256 threads stream those entries -- values and column indices fully coalesced,
+// x gathered -- into LDS as products, then one thread per row adds its segment in index order (the order a sequential
+// host loop uses).  A row longer than CSR_NNZ is a block of its own: strided partial sums, then a fixed tree.
+constexpr int CSR_NNZ = 2048;
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_csr_stream(const int64_t *__restrict__ rowblocks, const int64_t *__restrict__ rowptr,
+                                                    const int32_t *__restrict__ colind, const double *__restrict__ vals,
+                                                    const double *__restrict__ x, double *__restrict__ y, int64_t nblocks, Guard guard) {
+    if (stopped(guard)) return;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    __shared__ double prod[CSR_NNZ * ED];
+    __shared__ double red[2 * 4];
+    for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const int64_t r0 = rowblocks[b], r1 = rowblocks[b + 1];
+        const int64_t p0 = rowptr[r0], p1 = rowptr[r1];
+        const int64_t nnzb = p1 - p0;
+        if (nnzb > CSR_NNZ) {                                   // one long row
+            double sr = 0.0, si = 0.0;
+            for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+                const int64_t j = colind[p];
+                if constexpr (CPLX) {
+                    const v2d a = *reinterpret_cast<const v2d *>(vals + 2 * p), c = *reinterpret_cast<const v2d *>(x + 2 * j);
+                    sr += a.x * c.x - a.y * c.y;
+                    si += a.x * c.y + a.y * c.x;
+                } else {
+                    sr += vals[p] * x[j];
+                }
+            }
+            sr = wave_sum(sr);
+            if constexpr (CPLX) si = wave_sum(si);
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            __syncthreads();
+            if (lane == 0) { red[wave] = sr; red[4 + wave] = si; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                y[r0 * ED] = (red[0] + red[1]) + (red[2] + red[3]);
+                if constexpr (CPLX) y[r0 * ED + 1] = (red[4] + red[5]) + (red[6] + red[7]);
+            }
+            continue;
+        }
+        __syncthreads();                                        // the previous block's segments have been read
+        for (int64_t i = threadIdx.x; i < nnzb; i += 256) {
+            const int64_t p = p0 + i, j = colind[p];
+            if constexpr (CPLX) {
+                const v2d a = *reinterpret_cast<const v2d *>(vals + 2 * p), c = *reinterpret_cast<const v2d *>(x + 2 * j);
+                prod[2 * i] = a.x * c.x - a.y * c.y;
+                prod[2 * i + 1] = a.x * c.y + a.y * c.x;
+            } else {
+                prod[i] = vals[p] * x[j];
+            }
+        }
+        __syncthreads();
+        for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+            const int64_t q0 = rowptr[r] - p0, q1 = rowptr[r + 1] - p0;
+            double sr = 0.0, si = 0.0;
+            for (int64_t q = q0; q < q1; ++q) {
+                if constexpr (CPLX) { sr += prod[2 * q]; si += prod[2 * q + 1]; }
+                else sr += prod[q];
+            }
+            if constexpr (CPLX) *reinterpret_cast<v2d *>(y + 2 * r) = v2d{sr, si};
+            else y[r] = sr;
+        }
+    }
+}
+
 // y = A x, A n x n column-major.  Block = 4 waves x 64 rows; wave w sums columns j == w (mod 4).
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_gemv_n(const double *__restrict__ A, int64_t lda, int64_t n,

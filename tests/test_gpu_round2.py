@@ -401,6 +401,8 @@ def test_csr_linop_matvec_and_rmatvec_against_scipy(ctx, dtype):
         A = sp.random(n, n, density=density, random_state=rng, format="lil", dtype=np.float64)
         for r in rng.integers(0, n, longrows):
             A[r, rng.integers(0, n, 900)] = 1.0
+        if longrows:
+            A[11, rng.integers(0, n, 4000)] = 1.0                      # longer than one CSR-stream block holds: a block of its own
         A[7, :] = 0.0                                                   # an empty row
         A = A.tocsr()
         vals = rng.standard_normal(A.nnz)
@@ -409,6 +411,7 @@ def test_csr_linop_matvec_and_rmatvec_against_scipy(ctx, dtype):
         A = sp.csr_matrix((vals.astype(dtype), A.indices, A.indptr), shape=(n, n))
         A.sort_indices()
         op = lk.csr_linop_gpu(A, ctx)
+        ctx.set_tuning("csr_stream", int(density < 0.02))               # both kernels: through LDS (short rows) / lanes per row
         xh = (rng.standard_normal(n) + (1j * rng.standard_normal(n) if np.dtype(dtype).kind == "c" else 0)).astype(dtype)
         x = lk.dense_vector_gpu.from_array(xh, ctx)
         y = lk.dense_vector_gpu(n, dtype, ctx)
@@ -419,6 +422,7 @@ def test_csr_linop_matvec_and_rmatvec_against_scipy(ctx, dtype):
         scale_h = abs(A).T.dot(np.abs(xh)).max() + 1e-300
         assert np.abs(y.to_array() - A.conj().T @ xh).max() <= 1e-13 * scale_h
         assert (op.matvec_counter, op.rmatvec_counter) == (1, 1)
+    ctx.set_tuning("csr_stream", 1)
 
 
 def test_csr_laplacian_reproduces_the_stencil_operator_in_gmres_and_arnoldi(ctx):
