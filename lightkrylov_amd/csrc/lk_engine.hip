@@ -208,7 +208,8 @@ namespace {
 constexpr int RED_SECTION = (KMAX_FUSED + 1) * 2;  // doubles per result section
 constexpr int RED_SECTIONS = 3;                     // h1 | h2 | ||y''||^2 of one vector DGS (also the per-step slot of lk_arnoldi)
 constexpr int RED_MULTI = 4;                        // sections one multi-RHS dot pass fills: a flat [4][k+1] buffer
-constexpr int RED_TOTAL = 2 * RED_MULTI;            // sections of c->red: two such passes (block DGS keeps both on the device)
+constexpr int RED_TOTAL = 2 * RED_MULTI + 1;        // sections of c->red: two such passes (block DGS keeps both on the device); the
+                                                    // wide single-vector DGS uses up to 4 + 4 panels of coefficients + one norm section
 constexpr int PARTIAL_SECTIONS = 4;                 // per-block partials: up to 4 y-columns per multi-RHS pass
 
 // ---- profiling helpers ----------------------------------------------------------------
@@ -1579,8 +1580,43 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
         n0 = r0[k * ED];
         n1 = r1[k * ED];
         n2 = two_pass ? r2[k * ED] : n1;
+    } else if (k <= 4 * KMAX_FUSED) {
+        // wide basis, up to four column panels of KMAX_FUSED: everything stays on the device, ONE copy + synchronisation.
+        //   sweep 1 : h1_p = X_p^H y for every panel                                   (k columns)
+        //   pass B  : y' = y - X h1 -- update-only sweeps for all panels but the last, whose sweep is the fused update + dot
+        //             (h2 of that panel, ||y'||^2); then dot sweeps of the OTHER panels against the finished y'   (2k - |last| columns)
+        //   pass C  : y'' = y' - X h2, panel by panel, ||y''||^2 from the last                      (k columns)
+        // = 4k - |last panel| columns against 4k (+ a host round trip per panel) for the schedule below.
+        const int npan = (k + KMAX_FUSED - 1) / KMAX_FUSED, last = npan - 1;
+        auto c0 = [&](int p) { return p * KMAX_FUSED; };
+        auto kk = [&](int p) { return (k - c0(p)) < KMAX_FUSED ? (k - c0(p)) : KMAX_FUSED; };
+        auto r1 = [&](int p) { return c->red + (size_t)p * RED_SECTION; };
+        auto r2 = [&](int p) { return c->red + (size_t)(npan + p) * RED_SECTION; };
+        double *r3 = c->red + (size_t)(2 * npan) * RED_SECTION;
+        for (int p = 0; p < npan; ++p) LKCHK((sweepm<1>(Bx, c0(p), kk(p), y, nullptr, nullptr, 0, r1(p))));
+        if (two_pass) {
+            for (int p = 0; p < last; ++p) LKCHK((sweepm<3>(Bx, c0(p), kk(p), y, r1(p), nullptr, 1, nullptr)));
+            LKCHK((sweepm<2>(Bx, c0(last), kk(last), y, r1(last), nullptr, 1, r2(last))));
+            for (int p = 0; p < last; ++p) LKCHK((sweepm<1>(Bx, c0(p), kk(p), y, nullptr, nullptr, 0, r2(p))));
+            for (int p = 0; p < last; ++p) LKCHK((sweepm<3>(Bx, c0(p), kk(p), y, r2(p), nullptr, 1, nullptr)));
+            LKCHK((sweepm<3>(Bx, c0(last), kk(last), y, r2(last), nullptr, 1, r3)));
+        } else {
+            for (int p = 0; p < last; ++p) LKCHK((sweepm<3>(Bx, c0(p), kk(p), y, r1(p), nullptr, 1, nullptr)));
+            LKCHK((sweepm<3>(Bx, c0(last), kk(last), y, r1(last), nullptr, 1, r3)));
+        }
+        if (flags & LK_DGS_NORMALIZE) LKCHK(scal_launch(By, jy, 1.0, 0.0, r3 + (size_t)kk(last) * ED, ATOL_DP));
+        ps.end();
+        LKCHK(fetch(c, 0, 2 * npan + 1));
+        auto host = [&](double *dev) { return c->red_host + (dev - c->red); };
+        if (h)
+            for (int p = 0; p < npan; ++p)
+                for (int i = 0; i < kk(p) * ED; ++i)
+                    h[(size_t)c0(p) * ED + i] = two_pass ? host(r1(p))[i] + host(r2(p))[i] : host(r1(p))[i];   // gram_schmidt.fypp:49
+        n0 = host(r1(0))[kk(0) * ED];
+        n2 = host(r3)[kk(last) * ED];
+        n1 = two_pass ? host(r2(last))[kk(last) * ED] : n2;
     } else {
-        // wide basis: column panels of KMAX_FUSED, unfused schedule (dots of all panels, then updates)
+        // wider still: column panels of KMAX_FUSED, unfused schedule with a host round trip per panel
         std::vector<double> hacc((size_t)k * ED, 0.0), hp((size_t)k * ED);
         const int npass = two_pass ? 2 : 1;
         for (int pass = 0; pass < npass; ++pass) {

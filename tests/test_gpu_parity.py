@@ -143,7 +143,8 @@ def test_innerprod_lincomb_gram(ctx, dtype, n, k, p):
 
 # ----------------------------------------------------------------------------- the sweep
 DGS_CASES = [(1000, 1), (1001, 2), (999, 3), (4096, 15), (4097, 16), (4099, 17), (10_000, 31), (10_001, 33),
-             (30_000, 64), (30_011, 100), (30_011, 127), (30_011, 128), (5003, 129), (5003, 200), (129, 64), (65, 8),
+             (30_000, 64), (30_011, 100), (30_011, 127), (30_011, 128), (5003, 129), (5003, 200), (4001, 256), (4001, 300),
+             (3001, 512), (3001, 513), (129, 64), (65, 8),
              (1, 1), (300_007, 32)]
 
 
