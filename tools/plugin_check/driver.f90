@@ -39,8 +39,8 @@ program plugin_driver
     use LightKrylov_AbstractVectors
     use LightKrylov_AbstractLinops
     use LightKrylov_BaseKrylov, only: arnoldi, double_gram_schmidt_step
-    use LightKrylov_IterativeSolvers, only: gmres, eigs, cg, eighs, gmres_dp_opts, gmres_dp_metadata, cg_dp_opts, cg_dp_metadata
-    use stdlib_linalg, only: eigh
+    use LightKrylov_IterativeSolvers, only: gmres, eigs, cg, eighs, svds, gmres_dp_opts, gmres_dp_metadata, cg_dp_opts, cg_dp_metadata
+    use stdlib_linalg, only: eigh, svd
     use lightkrylov_gpu
     use plugin_check_ref_ops
     implicit none
@@ -63,6 +63,7 @@ program plugin_driver
     ! is emptied right after (recorded), so the replay and the recording agree on it again.
     call trace_pause(.true.)
     call check_eighs_rdp()
+    call check_svds_rdp()
     call trace_pause(.false.)
     call lk_gpu_release_all()
     call check_assignment_is_deep()
@@ -363,6 +364,29 @@ contains
         end interface
         integer(c_int) :: rc
         rc = c_setenv("LK_MOCK_TRACE_PAUSE"//c_null_char, merge("1", "0", on)//c_null_char, 1_c_int)
+    end subroutine
+
+    !> The reference's svds (Golub-Kahan bidiagonalisation: matvec AND rmatvec through the plugin, two work bases allocated with
+    !> `mold=`, svd of the bidiagonal matrix each step) against the singular values of the whole matrix.
+    subroutine check_svds_rdp()
+        integer, parameter :: nsv = 3
+        real(dp) :: A(n, n), rhs(n), sall(n), Acopy(n, n), uv(n), vv(n)
+        real(dp), allocatable :: sig(:), res(:)
+        type(dense_linop_gpu_rdp) :: Lgpu
+        type(dense_vector_gpu_rdp), allocatable :: U(:), V(:)
+        type(dense_vector_gpu_rdp) :: u0
+        integer :: info, i
+        call test_matrix_rdp(A, rhs)
+        do i = 1, nsv; A(i, i) = A(i, i) + 20.0_dp + 10.0_dp*real(i, dp); end do     ! three well separated leading singular values
+        Acopy = A; call svd(Acopy, sall)
+        Lgpu = dense_linop_gpu(A)
+        allocate (U(nsv)); U%n = n
+        allocate (V(nsv)); V%n = n
+        call u0%upload(rhs)
+        call svds(Lgpu, U, sig, V, res, info, u0=u0, kdim=30, tolerance=1.0e-8_dp)
+        call report('svds rdp: max |sigma - svd(A)| (3 largest)    ', maxval(abs(sig(:nsv) - sall(:nsv))), 1.0e-8_dp)
+        call U(1)%download(uv); call V(1)%download(vv)
+        call report('svds rdp: |A v - sigma u| of the leading triplet', maxval(abs(matmul(A, vv) - sig(1)*uv)), 1.0e-6_dp)
     end subroutine
 
     subroutine check_cg_cdp()
