@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.environ.get("LK_PLUGIN_CHECK_DIR", "/tmp/lk_plugin_check")
 SOURCES = ["fortran/dense_vector_gpu.f90", "fortran/lk_hip_iso_c.f90", "tools/check_plugin.sh",
-           "tools/plugin_check/driver.f90", "tools/plugin_check/mock_abi.c", "tools/plugin_check/gen_stdlib_stubs.py",
+           "tools/plugin_check/driver.f90", "examples/fortran/gmres_dense.f90", "tools/plugin_check/mock_abi.c", "tools/plugin_check/gen_stdlib_stubs.py",
            "include/lightkrylov_hip.h"]
 
 
