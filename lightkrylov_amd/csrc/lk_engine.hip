@@ -95,6 +95,7 @@ struct lk_context_s {
     // lazy batching of the PER-OBJECT path (opt-in, tuning key "lazy"): what an unchanged LightKrylov drives
     // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
     int lap5_grid_mult = 8;    // persistent blocks per CU of the stencil operator
+    int xcd_map = 0;           // A/B: contiguous eighth of the rows per XCD instead of grid-cyclic tiles (null: DESIGN tuning log)
     int prof_ext = 1;          // profiling events of the sweeps attached to the kernel dispatch instead of recorded on the stream
     int block_fused = 1;       // block DGS: fused update+dot / two-coefficient sweeps (3 passes per group) instead of 4
     int csr_stream = 1;        // CSR product through LDS for matrices with short rows (mean <= 32 entries); 0: lanes-per-row kernel
@@ -366,7 +367,7 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
             hipLaunchKernelGGL((panel_update<CPLX, KC, NW, MODE == 4>), dim3(nblocks), dim3(NW * 64), 0, c->stream, X, ldx, k, y,
                                n, hin, hin2, c->partial, (int64_t)MAX_GRID, c->store_policy, c->guard());
         } else {
-            const int st = store ? (1 | (c->store_policy << 1) | (c->store_split ? 8 : 0)) : 0;
+            const int st = (store ? (1 | (c->store_policy << 1) | (c->store_split ? 8 : 0)) : 0) | (c->xcd_map ? 16 : 0);
             if (ps.on && ps.ext)
                 hipExtLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream,
                                       ps.rec.e0, ps.rec.e1, 0, X, ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st,
@@ -940,6 +941,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "lap5_grid_mult")) { if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: lap5_grid_mult in [1, 64]"); c->lap5_grid_mult = value; return LK_OK; }
+    if (!strcmp(key, "xcd_map")) { c->xcd_map = value != 0; return LK_OK; }
     if (!strcmp(key, "prof_ext")) { c->prof_ext = value != 0; return LK_OK; }
     if (!strcmp(key, "block_fused")) { c->block_fused = value != 0; return LK_OK; }
     if (!strcmp(key, "csr_stream")) { c->csr_stream = value != 0; return LK_OK; }

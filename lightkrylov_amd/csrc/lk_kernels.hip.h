@@ -238,7 +238,15 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     const int64_t roff = (int64_t)wr * WROWS + (int64_t)lane * ROWS;
     int buf = 0;
 
-    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // tile order.  Default: cyclic over the whole grid (block b takes tiles b, b + G, ...).  Bit 4 of `store` (A/B knob
+    // "xcd_map"): workgroups are dealt round-robin to the 8 XCDs, so give XCD x (= blockIdx % 8) a CONTIGUOUS eighth of the
+    // rows and let its blocks walk it cyclically -- each XCD's L2 then streams one address range per column.
+    const bool xmap = (store & 16) && gridDim.x >= 8 && (gridDim.x & 7) == 0;
+    const int64_t chunk = xmap ? (ntiles + 7) / 8 : ntiles;
+    const int64_t tbase = xmap ? (int64_t)(blockIdx.x & 7) * chunk : 0;
+    const int64_t tend = xmap ? (tbase + chunk < ntiles ? tbase + chunk : ntiles) : ntiles;
+    const int64_t tstep = xmap ? gridDim.x >> 3 : gridDim.x;
+    for (int64_t t = tbase + (xmap ? blockIdx.x >> 3 : blockIdx.x); t < tend; t += tstep) {
         const int64_t r = t * tile_rows + roff;        // first row of this lane
         const bool full = (t + 1) * tile_rows <= n;   // block-uniform
         v2d xv[KC];
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
             // `store`: 0 = keep y' in registers; otherwise bit 0 set, bits 1-2 = cache policy of the 16-B
             // store, bit 3 = every wave of the column split stores its own 64/WC-lane slice of the rows
             // (instead of the wc == 0 wave storing all 64 lanes).
-            if (store) {
+            if (store & 1) {
                 const int pol = (store >> 1) & 3;
                 if (store & 8) {
                     const int per = 64 / WC;
