@@ -18,7 +18,8 @@ from .linops import (Id, abstract_linop, adjoint_linop, axpby_linop, scaled_lino
                      grid_partition, laplacian2d_linop_gpu)  # noqa: F401
 from .krylov import (arnoldi, bidiagonalization, double_gram_schmidt_step, is_orthonormal, krylov_schur, lanczos,  # noqa: F401
                      orthogonalize_against_basis, qr)
-from .solvers import (apply_givens_rotation, eig, eigs, gmres, gmres_dp_metadata, gmres_dp_opts)  # noqa: F401
+from .solvers import (apply_givens_rotation, cg, cg_dp_metadata, cg_dp_opts, eig, eighs, eigs, gmres, gmres_dp_metadata,  # noqa: F401
+                      gmres_dp_opts, svds)
 
 from .outputs import save_eigenspectrum, write_results  # noqa: F401
 

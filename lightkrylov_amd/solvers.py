@@ -17,7 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 from . import _hostlapack
 from .constants import atol_dp, rtol_dp
-from .krylov import _engine_linop, arnoldi, double_gram_schmidt_step, krylov_schur
+from .krylov import _engine_linop, arnoldi, bidiagonalization, double_gram_schmidt_step, krylov_schur, lanczos
 from .linops import abstract_linop
 from .outputs import eigs_output, write_results
 from .vectors import abstract_vector, copy, dense_vector_gpu, krylov_basis_gpu, linear_combination, zero_basis
@@ -39,6 +39,22 @@ class gmres_dp_metadata:
     n_iter: int = 0
     n_inner: int = 0
     n_outer: int = 0
+    res: list = field(default_factory=list)
+    converged: bool = False
+    info: int = 0
+
+
+@dataclass
+class cg_dp_opts:
+    """IterativeSolvers.fypp (cg_dp_opts)"""
+    maxiter: int = 100
+    if_print_metadata: bool = False
+
+
+@dataclass
+class cg_dp_metadata:
+    """IterativeSolvers.fypp (cg_dp_metadata)"""
+    n_iter: int = 0
     res: list = field(default_factory=list)
     converged: bool = False
     info: int = 0
@@ -294,3 +310,134 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
     Y = linear_combination(Xwrk[:k], coef)
     copy(X, Y)
     return vals_f[:nev].copy(), res_f[:nev].copy(), niter
+
+
+# ------------------------------------------------------------------------------------------
+# The other solver families of the reference: callers of the same primitives, restated for completeness of the
+# host-side mirror (through the Fortran plugin the reference's own drivers run unchanged).
+def cg(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float = rtol_dp, atol: float = atol_dp,
+       preconditioner=None, options: cg_dp_opts | None = None, meta: cg_dp_metadata | None = None) -> int:
+    """Conjugate gradient for symmetric / Hermitian positive definite operators.
+    src/IterativeSolvers/CG/CG.fypp:98-200.  x is the initial guess and is overwritten by the solution.
+    Returns info = +n_iter if converged, -n_iter otherwise."""
+    opts = options or cg_dp_opts()
+    tol = atol + rtol * b.norm()                                                   # :110
+    r, p, Ap = b.zeros_like(), b.zeros_like(), b.zeros_like()                      # allocate(..., mold=b); zero()   :113-121
+    m = cg_dp_metadata()
+    A.reset_counter(False, "cg%init")
+    if x.norm() > 0:
+        A.apply_matvec(x, r)                                                       # :130
+    r.sub(b)
+    r.chsgn()                                                                      # r = b - A x   :131
+    z = None
+    if preconditioner is not None:
+        z = r.zeros_like(); copy(z, r); preconditioner.apply(z); copy(p, z)        # z = r ; apply ; p = z   :134
+        rr_old = r.dot(z)
+    else:
+        copy(p, r)                                                                 # p = r   :137
+        rr_old = r.dot(r)
+    m.res = [float(np.sqrt(abs(rr_old)))]
+    for _ in range(opts.maxiter):
+        A.apply_matvec(p, Ap)                                                      # :146
+        alpha = rr_old / p.dot(Ap)                                                 # :148
+        x.axpby(alpha, p, 1.0)                                                     # :150
+        r.axpby(-alpha, Ap, 1.0)                                                   # :152
+        if preconditioner is not None:
+            copy(z, r); preconditioner.apply(z)
+            rr_new = r.dot(z)
+        else:
+            rr_new = r.dot(r)
+        residual = float(np.sqrt(abs(rr_new)))
+        m.n_iter += 1
+        m.res.append(residual)
+        if residual < tol:
+            m.converged = True
+            break
+        beta = rr_new / rr_old                                                     # :174
+        p.axpby(1.0, z if preconditioner is not None else r, beta)                 # :178-180
+        rr_old = rr_new
+    info = m.n_iter if m.converged else -m.n_iter
+    m.info = info
+    if meta is not None:
+        meta.__dict__.update(m.__dict__)
+    A.reset_counter(False, "cg%post")
+    return info
+
+
+def eighs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | None = None,
+          tolerance: float = rtol_dp, write_intermediate: bool = False):
+    """Lanczos eigensolver for the leading len(X) eigenpairs of a symmetric / Hermitian operator.
+    src/IterativeSolvers/EIGHS/eighs.fypp:46-140.  Returns (eigvals[nev], residuals[nev], info = Lanczos steps)."""
+    from scipy.linalg import eigh
+    nev = len(X)
+    kdim_ = 4 * nev if kdim is None else kdim
+    proto = X[0]
+    dt = _dtype_of(proto)
+    Xwrk = _new_basis(proto, kdim_ + 1)                                            # allocate(Xwrk, mold=X(1)); zero_basis   :60
+    if x0 is not None:
+        copy(Xwrk[0], x0)
+        Xwrk[0].scal(1.0 / x0.norm())
+    else:
+        Xwrk[0].rand(True)
+    T = np.zeros((kdim_ + 1, kdim_), dtype=dt, order="F")
+    vals = np.zeros(kdim_)
+    vecs = np.zeros((kdim_, kdim_), dtype=dt)
+    res = np.zeros(kdim_)
+    k = 0
+    for k in range(1, kdim_ + 1):
+        lanczos(A, Xwrk, T, kstart=k, kend=k)                                      # :84
+        vals[:] = 0
+        vecs[:] = 0
+        w, v = eigh(T[:k, :k])                                                     # :87  (syev / heev: ascending)
+        vals[:k], vecs[:k, :k] = w, v
+        res[:k] = np.abs(T[k, k - 1] * vecs[k - 1, :k])                            # :93
+        if write_intermediate:
+            write_results("eighs_output.txt", vals[:k].astype(complex), res[:k], tolerance)
+        if np.count_nonzero(res[:k] < tolerance) >= nev:                           # :96, :101
+            break
+    idx = np.argsort(-vals, kind="stable")                                         # sort_index(..., reverse=.true.) over all kdim   :106
+    vals, vecs, res = vals[idx], vecs[:, idx], res[idx]
+    k = min(k, kdim_)
+    Y = linear_combination(Xwrk[:k], np.asfortranarray(vecs[:k, :nev].astype(dt)))  # X(i) = sum_j eigvecs(j, i) Xwrk(j)   :113-118
+    copy(X, Y)
+    return vals[:nev].copy(), res[:nev].copy(), k
+
+
+def svds(A: abstract_linop, U, V, u0: abstract_vector | None = None, kdim: int | None = None,
+         tolerance: float = rtol_dp, write_intermediate: bool = False):
+    """Golub-Kahan solver for the leading len(U) singular triplets.  src/IterativeSolvers/SVDS/svd_solvers.fypp:44-150.
+    Returns (S[nsv], residuals[nsv], info)."""
+    from scipy.linalg import svd
+    nsv = len(U)
+    kdim_ = 4 * nsv if kdim is None else kdim
+    dt = _dtype_of(U[0])
+    Uwrk = _new_basis(U[0], kdim_ + 1)
+    if u0 is not None:
+        copy(Uwrk[0], u0)
+        Uwrk[0].scal(1.0 / u0.norm())
+    else:
+        Uwrk[0].rand(True)
+    Vwrk = _new_basis(V[0], kdim_ + 1)
+    B = np.zeros((kdim_ + 1, kdim_), dtype=dt, order="F")
+    sv = np.zeros(kdim_)
+    um = np.zeros((kdim_, kdim_), dtype=dt)
+    vm = np.zeros((kdim_, kdim_), dtype=dt)
+    res = np.zeros(kdim_)
+    k = 0
+    for k in range(1, kdim_ + 1):
+        bidiagonalization(A, Uwrk, Vwrk, B, kstart=k, kend=k, tol=tolerance)      # :96
+        sv[:] = 0
+        um[:] = 0
+        vm[:] = 0
+        u, s_, vh = svd(B[:k, :k])                                                 # :102
+        sv[:k], um[:k, :k] = s_, u
+        vm[:k, :k] = vh.conj().T                                                   # vmat = hermitian(vmat)   :104
+        res[:k] = np.abs(B[k, k - 1] * vm[k - 1, :k])                              # :106
+        if write_intermediate:
+            write_results("svds_output.txt", sv[:k].astype(complex), res[:k], tolerance)
+        if np.count_nonzero(res[:k] < tolerance) >= nsv:
+            break
+    k = min(k, kdim_)
+    copy(U, linear_combination(Uwrk[:k], np.asfortranarray(um[:k, :nsv].astype(dt))))   # :121-127
+    copy(V, linear_combination(Vwrk[:k], np.asfortranarray(vm[:k, :nsv].astype(dt))))
+    return sv[:nsv].copy(), res[:nsv].copy(), k

@@ -375,11 +375,12 @@ def lanczos(A: _OpBase, X: np.ndarray, T: np.ndarray, kstart: int = 1, kend: int
 
 
 def bidiagonalization(A: _OpBase, Ah: _OpBase, U: np.ndarray, V: np.ndarray, B: np.ndarray,
-                      tol: float = ATOL_DP) -> int:
+                      tol: float = ATOL_DP, kstart: int = 1, kend: int | None = None) -> int:
     """lanczos_bidiagonalization.  src/Krylov/golub_kahan.fypp:7-64.  `Ah` applies A^H (rmatvec)."""
     kdim = U.shape[1] - 1
+    kend = kdim if kend is None else kend
     info = 0
-    for k in range(1, kdim + 1):
+    for k in range(kstart, kend + 1):
         Ah.matvec(U[:, k - 1], V[:, k - 1])                                # :27
         if k > 1:
             double_gram_schmidt_step(V[:, k - 1], V[:, :k - 1])            # :30-33
@@ -590,3 +591,108 @@ def eigs(A: _OpBase, x0: np.ndarray, nev: int, kdim: int | None = None, toleranc
     for i in range(nev):                                                 # :1127-1132
         vecs[:, i] = linear_combination(X[:, :k], np.ascontiguousarray(vsorted[:k, i].astype(dt)))
     return wsorted[:nev], rsorted[:nev], vecs, niter
+
+
+# ----------------------------------------------------------------------------------------
+# the remaining solver families (callers of the same primitives; restated for the host-side mirror's tests)
+# ----------------------------------------------------------------------------------------
+def cg(A: _OpBase, b: np.ndarray, x: np.ndarray, rtol: float = RTOL_DP, atol: float = ATOL_DP, maxiter: int = 100):
+    """Conjugate gradient without preconditioner.  src/IterativeSolvers/CG/CG.fypp:98-200.
+    Returns (info, residual history); x updated in place."""
+    tol = atol + rtol * norm(b)                                          # :110
+    r = np.zeros_like(b)
+    Ap = np.zeros_like(b)
+    if norm(x) > 0:
+        A.matvec(x, r)                                                   # :130
+    axpby(-1.0, b, 1.0, r)
+    scal(r, -1.0)                                                        # r = b - A x   :131
+    p = r.copy()                                                         # p = r        :137
+    rr_old = dot(r, r)
+    res = [float(np.sqrt(abs(rr_old)))]
+    n_iter, converged = 0, False
+    for _ in range(maxiter):
+        A.matvec(p, Ap)                                                  # :146
+        alpha = rr_old / dot(p, Ap)                                      # :148
+        axpby(alpha, p, 1.0, x)                                          # :150
+        axpby(-alpha, Ap, 1.0, r)                                        # :152
+        rr_new = dot(r, r)
+        residual = float(np.sqrt(abs(rr_new)))
+        n_iter += 1
+        res.append(residual)
+        if residual < tol:
+            converged = True
+            break
+        beta = rr_new / rr_old                                           # :174
+        axpby(1.0, r, beta, p)                                           # p = r + beta p   :180
+        rr_old = rr_new
+    return (n_iter if converged else -n_iter), np.array(res)
+
+
+def eighs(A: _OpBase, x0: np.ndarray, nev: int, kdim: int | None = None, tolerance: float = RTOL_DP):
+    """Lanczos eigensolver for symmetric / Hermitian operators.  src/IterativeSolvers/EIGHS/eighs.fypp:46-140.
+    Returns (eigvals[nev], residuals[nev], X[n, nev], info = Lanczos steps)."""
+    from scipy.linalg import eigh
+    n, dt = x0.size, x0.dtype
+    kdim = 4 * nev if kdim is None else kdim
+    Xw = np.zeros((n, kdim + 1), dtype=dt, order="F")
+    Xw[:, 0] = x0
+    scal(Xw[:, 0], 1.0 / norm(x0))
+    T = np.zeros((kdim + 1, kdim), dtype=dt, order="F")
+    vals = np.zeros(kdim)
+    vecs = np.zeros((kdim, kdim), dtype=dt)
+    res = np.zeros(kdim)
+    k = 0
+    for k in range(1, kdim + 1):
+        lanczos(A, Xw, T, kstart=k, kend=k)
+        vals[:] = 0
+        vecs[:] = 0
+        w, v = eigh(T[:k, :k])                                           # stdlib eigh = syev / heev, ascending
+        vals[:k], vecs[:k, :k] = w, v
+        res[:k] = np.abs(T[k, k - 1] * vecs[k - 1, :k])
+        if np.count_nonzero(res[:k] < tolerance) >= nev:
+            break
+    idx = np.argsort(-vals, kind="stable")                               # sort_index(eigvals_wrk, reverse=.true.) over ALL kdim entries
+    vals, vecs, res = vals[idx], vecs[:, idx], res[idx]
+    k = min(k, kdim)
+    X = np.zeros((n, nev), dtype=dt, order="F")
+    for i in range(nev):
+        for j in range(k):
+            axpby(vecs[j, i], Xw[:, j], 1.0, X[:, i])
+    return vals[:nev].copy(), res[:nev].copy(), X, k
+
+
+def svds(A: _OpBase, Ah: _OpBase, u0: np.ndarray, nsv: int, kdim: int | None = None, tolerance: float = RTOL_DP):
+    """Golub-Kahan singular value solver.  src/IterativeSolvers/SVDS/svd_solvers.fypp:44-150.
+    Returns (S[nsv], residuals[nsv], U[n, nsv], V[n, nsv], info)."""
+    from scipy.linalg import svd
+    n, dt = u0.size, u0.dtype
+    kdim = 4 * nsv if kdim is None else kdim
+    Uw = np.zeros((n, kdim + 1), dtype=dt, order="F")
+    Vw = np.zeros((n, kdim + 1), dtype=dt, order="F")
+    Uw[:, 0] = u0
+    scal(Uw[:, 0], 1.0 / norm(u0))
+    B = np.zeros((kdim + 1, kdim), dtype=dt, order="F")
+    sv = np.zeros(kdim)
+    um = np.zeros((kdim, kdim), dtype=dt)
+    vm = np.zeros((kdim, kdim), dtype=dt)
+    res = np.zeros(kdim)
+    k = 0
+    for k in range(1, kdim + 1):
+        bidiagonalization(A, Ah, Uw, Vw, B, tol=tolerance, kstart=k, kend=k)
+        sv[:] = 0
+        um[:] = 0
+        vm[:] = 0
+        u, s, vh = svd(B[:k, :k])
+        sv[:k], um[:k, :k] = s, u
+        vm[:k, :k] = vh.conj().T                                         # vmat = hermitian(vmat)
+        res[:k] = np.abs(B[k, k - 1] * vm[k - 1, :k])
+        if np.count_nonzero(res[:k] < tolerance) >= nsv:
+            break
+    k = min(k, kdim)
+    U = np.zeros((n, nsv), dtype=dt, order="F")
+    V = np.zeros((n, nsv), dtype=dt, order="F")
+    for i in range(nsv):
+        for j in range(k):
+            axpby(um[j, i], Uw[:, j], 1.0, U[:, i])
+            axpby(vm[j, i], Vw[:, j], 1.0, V[:, i])
+    return sv[:nsv].copy(), res[:nsv].copy(), U, V, k

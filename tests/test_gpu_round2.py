@@ -548,3 +548,70 @@ def test_block_dgs_fused_schedule_equals_the_four_pass_one(dtype, k, p):
         yo = Y[:, j].copy()
         ho, _ = ora.double_gram_schmidt_step(yo, Q)
         assert np.abs(b1[:, j] - ho).max() <= 1e-12 * scale and np.abs(y1[:, j] - yo).max() <= 1e-12 * scale
+
+
+# ----------------------------------------------------------------------------- the other solver families (callers of the same primitives)
+def _spd(n, seed, lead=(8.0, 6.0, 4.0)):
+    rng = np.random.default_rng(seed)
+    M = rng.standard_normal((n, n)) / np.sqrt(n)
+    A = M.T @ M + np.eye(n)
+    A[:len(lead), :len(lead)] += np.diag(lead)
+    return np.asfortranarray(A)
+
+
+@pytest.mark.parametrize("lazy", [0, 1])
+def test_cg_against_oracle(lazy):
+    """cg (CG.fypp:98-200: mold= work vectors, p = r, single axpbys and dots) on an SPD dense operator: iteration count,
+    residual history and solution against the oracle's restatement; eager and lazy engine."""
+    n = 600
+    A = _spd(n, 1)
+    bh = seeded(n, np.float64, 3)
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", lazy)
+    x = lk.dense_vector_gpu(n, np.float64, c)
+    meta = lk.cg_dp_metadata()
+    info = lk.cg(lk.dense_linop_gpu(A, c), lk.dense_vector_gpu.from_array(bh, c), x, rtol=1e-10, atol=1e-14,
+                 options=lk.cg_dp_opts(maxiter=200), meta=meta)
+    xo = np.zeros(n)
+    info_o, res_o = ora.cg(ora.DenseOp(A), bh, xo, rtol=1e-10, atol=1e-14, maxiter=200)
+    assert info == info_o > 0 and len(meta.res) == len(res_o)
+    assert np.abs(np.array(meta.res) - res_o).max() <= 1e-9 * res_o[0]
+    assert np.abs(x.to_array() - xo).max() <= 1e-9 * np.abs(xo).max()
+    assert np.abs(A @ x.to_array() - bh).max() <= 1e-8 * np.abs(bh).max()
+    c.close()
+
+
+def test_eighs_against_oracle_and_known_spectrum(ctx):
+    """eighs (EIGHS/eighs.fypp: Lanczos one step at a time + eigh of T) against the oracle and numpy's spectrum."""
+    n, nev = 500, 3
+    A = _spd(n, 2)
+    x0 = seeded(n, np.float64, 5)
+    X = lk.krylov_basis_gpu(n, nev, np.float64, ctx)
+    vals, res, info = lk.eighs(lk.dense_linop_gpu(A, ctx), X, x0=lk.dense_vector_gpu.from_array(x0, ctx), kdim=40, tolerance=1e-10)
+    vo, ro, Xo, info_o = ora.eighs(ora.DenseOp(A), x0.copy(), nev, kdim=40, tolerance=1e-10)
+    assert info == info_o
+    assert np.abs(vals - vo).max() <= 1e-11 * np.abs(vo).max()
+    assert np.abs(vals - np.sort(np.linalg.eigvalsh(A))[::-1][:nev]).max() <= 1e-9
+    V = X.download()
+    for i in range(nev):
+        assert np.linalg.norm(A @ V[:, i] - vals[i] * V[:, i]) <= 1e-8 * abs(vals[i])
+
+
+def test_svds_against_oracle_and_known_singular_values(ctx):
+    """svds (SVDS/svd_solvers.fypp: Golub-Kahan bidiagonalisation, matvec + rmatvec, svd of B each step)."""
+    n, nsv = 400, 3
+    rng = np.random.default_rng(6)
+    G = rng.standard_normal((n, n)) / np.sqrt(n)
+    G[:3, :3] += np.diag([9.0, 7.0, 5.0])
+    G = np.asfortranarray(G)
+    u0 = seeded(n, np.float64, 8)
+    U = lk.krylov_basis_gpu(n, nsv, np.float64, ctx)
+    V = lk.krylov_basis_gpu(n, nsv, np.float64, ctx)
+    S, res, info = lk.svds(lk.dense_linop_gpu(G, ctx), U, V, u0=lk.dense_vector_gpu.from_array(u0, ctx), kdim=40, tolerance=1e-10)
+    So, ro, Uo, Vo, info_o = ora.svds(ora.DenseOp(G), ora.DenseOp(np.asfortranarray(G.T)), u0.copy(), nsv, kdim=40, tolerance=1e-10)
+    assert info == info_o
+    assert np.abs(S - So).max() <= 1e-11 * So[0]
+    assert np.abs(S - np.linalg.svd(G, compute_uv=False)[:nsv]).max() <= 1e-9
+    Uh, Vh = U.download(), V.download()
+    for i in range(nsv):
+        assert np.linalg.norm(G @ Vh[:, i] - S[i] * Uh[:, i]) <= 1e-8 * S[i]
