@@ -298,3 +298,28 @@ def test_threadable_geev_is_bit_identical_to_scipys_wrapper():
     assert all(check(k) for k in range(1, 41))
     with hl.blas_threads(1), ThreadPoolExecutor(8) as pool:
         assert all(pool.map(check, list(range(1, 41)) * 3))
+
+
+def test_oracle_cg_eighs_svds_known_answers():
+    """The oracle's restatements of the three thin solver loops against numpy: cg solves an SPD system, eighs finds the
+    leading eigenvalues, svds the leading singular values (the reference's own tests check the same invariants:
+    test/TestIterativeSolvers.fypp, cg / eighs / svds sections)."""
+    from oracle import oracle as ora
+    rng = np.random.default_rng(0)
+    n = 300
+    M = rng.standard_normal((n, n)) / np.sqrt(n)
+    A = np.asfortranarray(M.T @ M + np.eye(n))
+    A[:3, :3] += np.diag([8.0, 6.0, 4.0])
+    b = rng.standard_normal(n)
+    x = np.zeros(n)
+    info, res = ora.cg(ora.DenseOp(A), b, x, rtol=1e-10)
+    assert info > 0 and np.abs(A @ x - b).max() <= 1e-8 and (np.diff(np.log(res[::5])) < 0).all()
+    vals, r, X, k = ora.eighs(ora.DenseOp(A), b.copy(), 3, kdim=40, tolerance=1e-10)
+    assert np.abs(vals - np.sort(np.linalg.eigvalsh(A))[::-1][:3]).max() <= 1e-9 and (r < 1e-10).all()
+    assert np.abs(X.T @ X - np.eye(3)).max() <= 1e-10
+    G = rng.standard_normal((n, n)) / np.sqrt(n)
+    G[:3, :3] += np.diag([9.0, 7.0, 5.0])
+    G = np.asfortranarray(G)
+    S, r, U, V, k = ora.svds(ora.DenseOp(G), ora.DenseOp(np.asfortranarray(G.T)), b.copy(), 3, kdim=40, tolerance=1e-10)
+    assert np.abs(S - np.linalg.svd(G, compute_uv=False)[:3]).max() <= 1e-9
+    assert np.abs(G @ V - U * S).max() <= 1e-8
