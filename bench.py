@@ -12,7 +12,7 @@ scaling: total work fixed), the only cross-rank traffic being the RCCL all-reduc
 reduction scalars after each sweep.  Inputs are generated in HBM before the timed region.
 
 Prints ONE JSON line on rank 0; `value` = Arnoldi iterations per second, whole job.
-  roofline   : the panel sweep kernel (lk::panel_sweep, three instantiations) -- algorithmic bytes s*n_local*(k+1|k+2)
+  roofline   : the DGS sweep kernels (lk::panel_dot_cw for sweep 1, lk::panel_sweep for sweeps 2 and 3) -- algorithmic bytes s*n_local*(k+1|k+2)
                per launch (s*n*(3k+5) per DGS) / HIP-event duration on the kernel's
                stream, averaged over every sweep launch of the timed region; peak = 8 TB/s HBM3E.
   cpu_baseline: the reference-schedule CPU oracle (oracle/, 1 thread, kind "port") timed on this
@@ -279,7 +279,7 @@ def main() -> None:
                 "all_reduce": reduce_path,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "lk::panel_sweep, the three DGS sweeps (DOT | UPDATE+DOT, y' kept in registers | UPDATE with two coefficient sets)",
+                "bound": "hbm", "kernel": "the three DGS sweeps: lk::panel_dot_cw (DOT, one column at a time) | lk::panel_sweep (UPDATE+DOT, y' kept in registers) | lk::panel_sweep (UPDATE with two coefficient sets)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src if traffic is not None else

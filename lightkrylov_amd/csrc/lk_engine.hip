@@ -95,6 +95,8 @@ struct lk_context_s {
     // lazy batching of the PER-OBJECT path (opt-in, tuning key "lazy"): what an unchanged LightKrylov drives
     // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
     int lap5_grid_mult = 8;    // persistent blocks per CU of the stencil operator
+    int dot_colwise = 1;       // sweep 1 by panel_dot_cw (one column at a time, y in registers) instead of panel_sweep<DOT>
+    int cw_grid_mult = 3;      // its blocks per CU (A/B at n = 10^8: 3 > 4 > 6)
     int xcd_map = 0;           // A/B: contiguous eighth of the rows per XCD instead of grid-cyclic tiles (null: DESIGN tuning log)
     int prof_ext = 1;          // profiling events of the sweeps attached to the kernel dispatch instead of recorded on the stream
     int block_fused = 1;       // block DGS: fused update+dot / two-coefficient sweeps (3 passes per group) instead of 4
@@ -350,7 +352,30 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
     // ALGORITHMIC bytes of the three-sweep schedule: k+1 | k+2 | k+2 columns
     const double bytes = (double)n * ED * 8.0 * (k + 1 + (UPDATE ? 1 : 0));
     int nblocks = s.grid;
-    {
+    if (MODE == 1 && c->dot_colwise) {
+        // sweep 1 one column at a time (panel_dot_cw): y in registers, U KiB of contiguous rows per wave and column
+        constexpr int UU = 4;
+        const int64_t tile_rows = (int64_t)256 * K<CPLX>::ROWS * UU;
+        int64_t g = (n + tile_rows - 1) / tile_rows;
+        int64_t cap = (int64_t)c->num_cu * c->cw_grid_mult;
+        if (cap > MAX_GRID) cap = MAX_GRID;
+        if (g > cap) {
+            // every block the same number of tiles: 977 tiles on 768 blocks would leave a second round for 209 of them
+            // (n = 10^6 complex: 5.9 TB/s; on 489 blocks of 2 tiles each 6.9)
+            const int64_t rounds = (g + cap - 1) / cap;
+            g = (g + rounds - 1) / rounds;
+        }
+        if (g < 1) g = 1;
+        nblocks = (int)g;
+        const size_t lds = (size_t)4 * (k + 1) * ED * sizeof(double);
+        ProfScope ps(c, "dgs_sweep1", bytes, c->prof_ext);
+        if (ps.on && ps.ext)
+            hipExtLaunchKernelGGL((panel_dot_cw<CPLX, UU>), dim3(nblocks), dim3(256), lds, c->stream, ps.rec.e0, ps.rec.e1, 0, X, ldx, k, y, n,
+                                  c->partial, (int64_t)MAX_GRID, c->guard());
+        else
+            hipLaunchKernelGGL((panel_dot_cw<CPLX, UU>), dim3(nblocks), dim3(256), lds, c->stream, X, ldx, k, y, n, c->partial,
+                               (int64_t)MAX_GRID, c->guard());
+    } else {
         // the sweep's two HIP events ride on the kernel's own dispatch (start / stop timestamps of the launch itself), not on
         // separate stream markers: six markers per Arnoldi step cost 3-4 % of a launch-bound factorisation (n = 10^6 complex)
         ProfScope ps(c, MODE == 1 ? "dgs_sweep1" : (MODE == 2 ? "dgs_sweep2" : "dgs_sweep3"), bytes, c->prof_ext);
@@ -941,6 +966,8 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "lap5_grid_mult")) { if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: lap5_grid_mult in [1, 64]"); c->lap5_grid_mult = value; return LK_OK; }
+    if (!strcmp(key, "dot_colwise")) { c->dot_colwise = value != 0; return LK_OK; }
+    if (!strcmp(key, "cw_grid_mult")) { if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "lk_set_tuning: cw_grid_mult must be in [1, 16]"); c->cw_grid_mult = value; return LK_OK; }
     if (!strcmp(key, "xcd_map")) { c->xcd_map = value != 0; return LK_OK; }
     if (!strcmp(key, "prof_ext")) { c->prof_ext = value != 0; return LK_OK; }
     if (!strcmp(key, "block_fused")) { c->block_fused = value != 0; return LK_OK; }

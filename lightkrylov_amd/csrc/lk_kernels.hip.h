@@ -343,6 +343,81 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     }
 }
 
+// Dot sweep, ONE COLUMN AT A TIME (DGS sweep 1, innerprod): h[j] = conj(X(:, j)) . y and ||y||^2.
+// X is used once and nothing has to meet across columns, so a block can keep its rows of y in registers and walk the k
+// columns one after the other, reading U wave-instructions = U KiB of contiguous rows per wave from each: long contiguous
+// runs per column instead of 1 KiB per column per wave.  tools/colwise_probe.hip: 7.0 TB/s against 6.8 for every shape of
+// the all-columns-per-tile sweep (tools/sweep_probe.hip).  Per column and tile a wave reduces its partial sum with the DPP
+// wave_sum and its lane 0 adds it to the wave's own LDS slot: fixed order, no atomics; the 4 waves' slots meet at the end.
+// partial layout as panel_sweep: slot j (ED doubles) = h[j], slot k = the norm.
+template <bool CPLX, int U>
+__global__ __launch_bounds__(256) void panel_dot_cw(const double *__restrict__ X, int64_t ldx, int k,
+                                                    const double *__restrict__ y, int64_t n, double *__restrict__ partial,
+                                                    int64_t pstride, Guard guard) {
+    if (stopped(guard)) return;
+    constexpr int ROWS = K<CPLX>::ROWS;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int SEG = 256 * ROWS;                 // rows one block-wide 16-byte access covers
+    extern __shared__ double acc_lds[];             // [4 waves][(k + 1) * ED]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nslot = (k + 1) * ED;
+    double *mine = acc_lds + wave * nslot;
+    for (int i = lane; i < nslot; i += 64) mine[i] = 0.0;
+    const int64_t tile_rows = (int64_t)SEG * U;
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const int64_t colstride = ldx * ED;
+    double nrm = 0.0;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t r0 = t * tile_rows + (int64_t)threadIdx.x * ROWS;
+        const bool full = (t + 1) * tile_rows <= n;
+        v2d yv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            yv[u] = load_y<CPLX>(y, r0 + (int64_t)u * SEG, n, full);
+            nrm += yv[u].x * yv[u].x + yv[u].y * yv[u].y;
+        }
+#pragma unroll 2
+        for (int j = 0; j < k; ++j) {
+            const double *xc = X + (int64_t)j * colstride;
+            v2d xv[U];
+            if (full) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    xv[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xc + (r0 + (int64_t)u * SEG) * ED));
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) xv[u] = load_y<CPLX>(xc, r0 + (int64_t)u * SEG, n, false);
+            }
+            if constexpr (CPLX) {
+                double re = 0.0, im = 0.0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const v2d z = cmulconj(xv[u], yv[u]);
+                    re += z.x;
+                    im += z.y;
+                }
+                re = wave_sum(re);
+                im = wave_sum(im);
+                if (lane == 0) { mine[2 * j] += re; mine[2 * j + 1] += im; }
+            } else {
+                double sm = 0.0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) sm = fma(xv[u].y, yv[u].y, fma(xv[u].x, yv[u].x, sm));
+                sm = wave_sum(sm);
+                if (lane == 0) mine[j] += sm;
+            }
+        }
+    }
+    {
+        const double sn = wave_sum(nrm);
+        if (lane == 0) { mine[k * ED] = sn; if constexpr (CPLX) mine[k * ED + 1] = 0.0; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nslot; i += 256)
+        partial[(int64_t)i * pstride + blockIdx.x] = (acc_lds[i] + acc_lds[nslot + i]) + (acc_lds[2 * nslot + i] + acc_lds[3 * nslot + i]);
+}
+
 // Multi-right-hand-side dots: M(:, q) = X(:, :k)^H Y(:, q) and ||Y(:, q)||^2 for P columns of Y in ONE pass
 // over X (innerprod_matrix, AbstractVectors.fypp:677-695; Gram; the dot sweeps of DGS_basis_against_basis,
 // gram_schmidt.fypp:59-105).  Same wave split as panel_sweep<DOT>; P accumulator sets per column.

@@ -69,7 +69,8 @@ if ff and fw:
     pb = bench_line(os.path.join(src, "pmc_fetch.log")) or {}
     n_local = pb.get("config", {}).get("n_local", 100_000_000)
     m = pb.get("config", {}).get("m", 128)
-    sweeps = [k for k in fetch if "panel_sweep" in k]
+    is_sweep = lambda k: "panel_sweep" in k or "panel_dot_cw" in k          # sweep 1 is panel_dot_cw, sweeps 2 and 3 panel_sweep
+    sweeps = [k for k in fetch if is_sweep(k)]
     launches = sum(fetch[k][0] for k in sweeps)
     # calibration of the gfx950 FETCH_SIZE halving on a kernel with a known read: k_scal reads n doubles
     scal = [k for k in fetch if "k_scal" in k]
@@ -78,7 +79,7 @@ if ff and fw:
         cnt, kb = fetch[scal[0]]
         calib = (8.0 * n_local) / (kb / cnt * 1024.0)
     fetch_b = sum(fetch[k][1] for k in sweeps) * 1024.0 * 2.0 / max(launches, 1)
-    write_b = sum(write[k][1] for k in write if "panel_sweep" in k) * 1024.0 / max(launches, 1)
+    write_b = sum(write[k][1] for k in write if is_sweep(k)) * 1024.0 / max(launches, 1)
     alg = 8.0 * n_local * sum(3 * k + 5 for k in range(1, m + 1)) / (3.0 * m)
     must = 8.0 * n_local * sum(3 * k + 4 for k in range(1, m + 1)) / (3.0 * m)
     pm = {
@@ -86,7 +87,7 @@ if ff and fw:
         "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
         "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
         "method": "separate --pmc passes; KB units; FETCH_SIZE doubled (gfx950 reports 1/2 of a 16 B/lane streaming read, MI355X_MICROARCH.md); "
-                  "WRITE_SIZE exact; per launch = sum over the three panel_sweep instantiations / their launch count",
+                  "WRITE_SIZE exact; per launch = sum over the three DGS sweep kernels (panel_dot_cw, panel_sweep x2) / their launch count",
         "fetch_calibration_on_k_scal(expected 2.0)": calib,
         "sweep_launches": launches,
         "fetch_bytes_per_launch_corrected": fetch_b, "write_bytes_per_launch": write_b,
