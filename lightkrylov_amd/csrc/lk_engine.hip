@@ -3,6 +3,7 @@
 #include "lk_internal.h"
 #include "lk_kernels.hip.h"
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 #include <cmath>
 #include <cstdarg>
@@ -96,6 +97,7 @@ struct lk_context_s {
     // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
     int lap5_grid_mult = 8;    // persistent blocks per CU of the stencil operator
     int dot_colwise = 1;       // sweep 1 by panel_dot_cw (one column at a time, y in registers) instead of panel_sweep<DOT>
+    int cw_u = 0;              // its 16-byte loads per lane and column: 4, 8, or 0 = by size (8 on 2 blocks per CU for long panels)
     int cw_grid_mult = 3;      // its blocks per CU (A/B at n = 10^8: 3 > 4 > 6)
     int xcd_map = 0;           // A/B: contiguous eighth of the rows per XCD instead of grid-cyclic tiles (null: DESIGN tuning log)
     int prof_ext = 1;          // profiling events of the sweeps attached to the kernel dispatch instead of recorded on the stream
@@ -354,27 +356,34 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
     int nblocks = s.grid;
     if (MODE == 1 && c->dot_colwise) {
         // sweep 1 one column at a time (panel_dot_cw): y in registers, U KiB of contiguous rows per wave and column
-        constexpr int UU = 4;
-        const int64_t tile_rows = (int64_t)256 * K<CPLX>::ROWS * UU;
-        int64_t g = (n + tile_rows - 1) / tile_rows;
-        int64_t cap = (int64_t)c->num_cu * c->cw_grid_mult;
-        if (cap > MAX_GRID) cap = MAX_GRID;
-        if (g > cap) {
-            // every block the same number of tiles: 977 tiles on 768 blocks would leave a second round for 209 of them
-            // (n = 10^6 complex: 5.9 TB/s; on 489 blocks of 2 tiles each 6.9)
-            const int64_t rounds = (g + cap - 1) / cap;
-            g = (g + rounds - 1) / rounds;
-        }
-        if (g < 1) g = 1;
-        nblocks = (int)g;
-        const size_t lds = (size_t)4 * (k + 1) * ED * sizeof(double);
-        ProfScope ps(c, "dgs_sweep1", bytes, c->prof_ext);
-        if (ps.on && ps.ext)
-            hipExtLaunchKernelGGL((panel_dot_cw<CPLX, UU>), dim3(nblocks), dim3(256), lds, c->stream, ps.rec.e0, ps.rec.e1, 0, X, ldx, k, y, n,
-                                  c->partial, (int64_t)MAX_GRID, c->guard());
-        else
-            hipLaunchKernelGGL((panel_dot_cw<CPLX, UU>), dim3(nblocks), dim3(256), lds, c->stream, X, ldx, k, y, n, c->partial,
-                               (int64_t)MAX_GRID, c->guard());
+        auto go = [&](auto uu, int mult) {
+            constexpr int UU = decltype(uu)::value;
+            const int64_t tile_rows = (int64_t)256 * K<CPLX>::ROWS * UU;
+            int64_t g = (n + tile_rows - 1) / tile_rows;
+            int64_t cap = (int64_t)c->num_cu * mult;
+            if (cap > MAX_GRID) cap = MAX_GRID;
+            if (g > cap) {
+                // every block the same number of tiles: 977 tiles on 768 blocks would leave a second round for 209 of them
+                // (n = 10^6 complex: 5.9 TB/s; on 489 blocks of 2 tiles each 6.9)
+                const int64_t rounds = (g + cap - 1) / cap;
+                g = (g + rounds - 1) / rounds;
+            }
+            if (g < 1) g = 1;
+            nblocks = (int)g;
+            const size_t lds = (size_t)4 * (k + 1) * ED * sizeof(double);
+            ProfScope ps(c, "dgs_sweep1", bytes, c->prof_ext);
+            if (ps.on && ps.ext)
+                hipExtLaunchKernelGGL((panel_dot_cw<CPLX, UU>), dim3(nblocks), dim3(256), lds, c->stream, ps.rec.e0, ps.rec.e1, 0, X, ldx, k,
+                                      y, n, c->partial, (int64_t)MAX_GRID, c->guard());
+            else
+                hipLaunchKernelGGL((panel_dot_cw<CPLX, UU>), dim3(nblocks), dim3(256), lds, c->stream, X, ldx, k, y, n, c->partial,
+                                   (int64_t)MAX_GRID, c->guard());
+        };
+        // long panels: 8 loads per lane and column on 2 blocks per CU (+1-2 % over 4 on 3 at n = 10^8); short ones keep the
+        // smaller tile so every CU still gets several tiles
+        const bool big = c->cw_u ? c->cw_u == 8 : n >= (int64_t)256 * K<CPLX>::ROWS * 8 * c->num_cu * 2 * 4;
+        if (big) go(std::integral_constant<int, 8>{}, c->cw_u ? c->cw_grid_mult : 2);
+        else go(std::integral_constant<int, 4>{}, c->cw_grid_mult);
     } else {
         // the sweep's two HIP events ride on the kernel's own dispatch (start / stop timestamps of the launch itself), not on
         // separate stream markers: six markers per Arnoldi step cost 3-4 % of a launch-bound factorisation (n = 10^6 complex)
@@ -967,6 +976,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     }
     if (!strcmp(key, "lap5_grid_mult")) { if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: lap5_grid_mult in [1, 64]"); c->lap5_grid_mult = value; return LK_OK; }
     if (!strcmp(key, "dot_colwise")) { c->dot_colwise = value != 0; return LK_OK; }
+    if (!strcmp(key, "cw_u")) { c->cw_u = value == 8 ? 8 : (value == 4 ? 4 : 0); return LK_OK; }
     if (!strcmp(key, "cw_grid_mult")) { if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "lk_set_tuning: cw_grid_mult must be in [1, 16]"); c->cw_grid_mult = value; return LK_OK; }
     if (!strcmp(key, "xcd_map")) { c->xcd_map = value != 0; return LK_OK; }
     if (!strcmp(key, "prof_ext")) { c->prof_ext = value != 0; return LK_OK; }

@@ -3,6 +3,7 @@
 // reading R*8 contiguous bytes of each -- long contiguous runs per column instead of 1 KiB per column per wave.
 //   hipcc --offload-arch=gfx950 -O3 -o colwise_probe colwise_probe.hip && ./colwise_probe [rows] [k]
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -70,7 +71,51 @@ template <typename F> float timeit(F f, hipStream_t s) {
     for (int r = 0; r < 5; ++r) { (void)hipEventRecord(a, s); f(); (void)hipEventRecord(b, s); (void)hipEventSynchronize(b); float ms; (void)hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms; }
     return best;
 }
+__global__ void fill_hash(double *p, size_t cnt) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = i * 0x9E3779B97F4A7C15ull; z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+        p[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+// mode "scan": dots_colwise<4>, 3 blocks/CU, over a list of n (same allocation), zeros then pseudo-random data;
+// mode "sustain": the same launch back to back for ~4 s, GB/s per group of launches (does a long run throttle?)
+static int scan_main(int argc, char **argv) {
+    const int k = argc > 3 ? atoi(argv[3]) : 128;
+    const long nmax = argc > 4 ? atol(argv[4]) : 100000000;
+    const bool sustain = !strcmp(argv[1], "sustain");
+    double *X, *out; CK(hipMalloc(&X, (size_t)(nmax + 32) * (k + 1) * 8)); CK(hipMalloc(&out, 4096 * 256 * 8));
+    hipStream_t s; CK(hipStreamCreate(&s));
+    for (int data = 0; data < 2; ++data) {
+        if (data == 0) CK(hipMemset(X, 0, (size_t)(nmax + 32) * (k + 1) * 8));
+        else { hipLaunchKernelGGL(fill_hash, dim3(4096), dim3(256), 0, s, X, (size_t)(nmax + 32) * (k + 1)); CK(hipStreamSynchronize(s)); }
+        if (sustain) {
+            const long n = nmax, ld = n + 32;
+            const double bd = 8.0 * n * (k + 1);
+            hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            const int per = (int)(2.0e12 / bd) + 1;              // ~0.3 s of launches per group
+            printf("sustain data=%s n=%ld k=%d, %d launches per group:", data ? "random" : "zeros", n, k, per);
+            for (int g = 0; g < 14; ++g) {
+                (void)hipEventRecord(a, s);
+                for (int r = 0; r < per; ++r) hipLaunchKernelGGL((dots_colwise<4>), dim3(768), dim3(256), 0, s, X, ld, k, X + (long)k * ld, n, out);
+                (void)hipEventRecord(b, s); (void)hipEventSynchronize(b);
+                float ms; (void)hipEventElapsedTime(&ms, a, b);
+                printf(" %.0f", bd * per / ms / 1e6);
+            }
+            printf("\n");
+            continue;
+        }
+        for (long n : {1000000L, 2000000L, 4000000L, 8000000L, 16000000L, 32000000L, 64000000L, 100000000L}) {
+            if (n > nmax) break;
+            const long ld = n + 32;
+            const double bd = 8.0 * n * (k + 1);
+            float ms = timeit([&] { hipLaunchKernelGGL((dots_colwise<4>), dim3(768), dim3(256), 0, s, X, ld, k, X + (long)k * ld, n, out); }, s);
+            printf("scan data=%s n=%ld k=%d  %.0f GB/s (best of 5, %.3f ms)\n", data ? "random" : "zeros", n, k, bd / ms / 1e6, ms);
+        }
+    }
+    return 0;
+}
 int main(int argc, char **argv) {
+    if (argc > 1 && (!strcmp(argv[1], "scan") || !strcmp(argv[1], "sustain"))) return scan_main(argc, argv);
     const long n = argc > 1 ? atol(argv[1]) : 20000000;
     const int k = argc > 2 ? atoi(argv[2]) : 128;
     const long ld = n + 32;
