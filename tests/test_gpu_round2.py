@@ -241,6 +241,32 @@ def test_store_policy_knobs_are_result_invariant(dtype):
     c.close()
 
 
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("cfg", [dict(dot_colwise=0), dict(dot_colwise=1, cw_u=4), dict(dot_colwise=1, cw_u=8),
+                                 dict(dot_colwise=1, cw_u=8, cw_grid_mult=1)])
+def test_both_sweep1_kernels_match_the_oracle(dtype, cfg):
+    """DGS sweep 1 / innerprod by either kernel -- all columns per tile (panel_sweep<DOT>) or one column at a time
+    (panel_dot_cw, 4 or 8 loads per lane and column, more tiles than blocks) -- against the oracle's innerprod
+    (AbstractVectors.fypp:659-695), normwise 1e-12; ragged sizes around the tile sizes (512 / 1024 / 2048 / 4096 rows)."""
+    c = lk.Context(device=0)
+    for key, val in cfg.items():
+        c.set_tuning(key, val)
+    rng = np.random.default_rng(3)
+    try:
+        for n, k in [(1, 1), (2, 1), (511, 3), (1025, 17), (2047, 128), (4097, 33), (1_000_003, 8), (300_001, 128)]:
+            A = rng.standard_normal((n, k + 1)) + (1j * rng.standard_normal((n, k + 1)) if np.dtype(dtype).kind == "c" else 0)
+            A = np.asfortranarray(A.astype(dtype))
+            B = lk.krylov_basis_gpu(n, k + 1, dtype, c)
+            B.upload(A)
+            got = np.asarray(lk.innerprod(B[:k], B[k]))
+            want = ora.innerprod(A[:, :k], A[:, k])
+            scale = np.linalg.norm(A[:, k]) * np.linalg.norm(A[:, :k], axis=0).max()
+            assert np.abs(got - want).max() <= 1e-12 * scale, (n, k, cfg)
+            del B
+    finally:
+        c.close()
+
+
 def test_lazy_dot_batch_stops_at_the_columns_ever_written(ctx):
     """A slab-like panel with 160 columns of which 5 hold vectors: X(i)%dot(y) with y in ANOTHER panel must sweep 5
     columns, not 128 (the batch is capped by the panel's high-water mark)."""
