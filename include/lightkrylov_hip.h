@@ -112,8 +112,12 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * 16-byte y store: 0 plain, 1 nt, 2 sc1 = write-through [default], 3 sc0 sc1) and "store_split"; "async_arnoldi"
  * (default 1: lk_arnoldi enqueues all steps with a device-side breakdown flag, one host synchronisation per call; 0:
  * one host round trip per step); "cplx_wide" (complex sweeps on 8 waves x 16 columns when k exceeds this threshold, default 32, 0 = never); "pool_slab_cols" (columns per
- * pool slab); "lazy" (see lk_lazy_stats).  None of them
- * changes a result bit (tests/test_gpu_round2.py). */
+ * pool slab); "lazy" (see lk_lazy_stats).  None of those changes a result bit (tests/test_gpu_round2.py).
+ * Kernel selectors -- same results to rounding (different summation order), each checked against the oracle:
+ * "dot_colwise" (default 1: DGS sweep 1 / innerprod one column at a time, panel_dot_cw; 0: all columns per tile) with
+ * "cw_u" (16-byte loads per lane and column: 4, 8, 0 = by size) and "cw_grid_mult"; "xhy_mfma" (default 1: X^H Y with five or
+ * more right-hand sides -- Gram, innerprod_matrix, block DGS -- in one pass over X on the FP64 matrix cores; 0: four
+ * right-hand sides per pass on the vector units) and "xhy_small"; "gemm_mfma" likewise for the tall-skinny product. */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
 
 /* Lazy batching of the per-object path (tuning key "lazy", off by default).  When on, k consecutive

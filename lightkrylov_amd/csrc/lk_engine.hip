@@ -86,6 +86,8 @@ struct lk_context_s {
     double *coef = nullptr;     // device coefficients for lincomb (KMAX_FUSED*2 doubles)
     double *scratch = nullptr;  // scratch vector (grown on demand), scratch_n doubles
     int64_t scratch_n = 0;
+    double *xhy = nullptr;      // panel_xhy_mfma: [2 result sections][norm partials][partials], grown on demand
+    int64_t xhy_n = 0;
     // communication
     lk_allreduce_fn allreduce = nullptr;
     void *allreduce_user = nullptr;
@@ -101,6 +103,8 @@ struct lk_context_s {
     int cw_grid_mult = 3;      // its blocks per CU (A/B at n = 10^8: 3 > 4 > 6)
     int xcd_map = 0;           // A/B: contiguous eighth of the rows per XCD instead of grid-cyclic tiles (null: DESIGN tuning log)
     int prof_ext = 1;          // profiling events of the sweeps attached to the kernel dispatch instead of recorded on the stream
+    int xhy_small = 1;         // its 32-row-tile variant for <= 32 complex right-hand sides
+    int xhy_mfma = 1;          // X^H Y with >= XHY_MIN_P right-hand sides (Gram, innerprod_matrix, block DGS) on the FP64 matrix cores
     int block_fused = 1;       // block DGS: fused update+dot / two-coefficient sweeps (3 passes per group) instead of 4
     int csr_stream = 1;        // CSR product through LDS for matrices with short rows (mean <= 32 entries); 0: lanes-per-row kernel
     int csr_lanes = 0;         // 0: lanes per row of the CSR product chosen from the mean row length; 2..64 forces it
@@ -526,6 +530,62 @@ int ensure_scratch(lk_context_t c, int64_t doubles) {
     return LK_OK;
 }
 
+// ---- X^H Y on the matrix cores (panel_xhy_mfma) ---------------------------------------------------------------
+constexpr int XHY_MIN_P = 5;        // fewer right-hand sides: panel_dot_p (<= 4 per pass) reads X once as well
+constexpr int XHY_MAX = 128;        // columns of X and of Y per launch
+constexpr int XHY_GROUP = 32;       // right-hand sides per pass of the block DGS (beyond ~32 the pass turns MFMA-bound)
+
+// M = X(:, c0 : c0+k)^H Y(:, jy0 : jy0+p), k, p <= XHY_MAX, into result section `sec` (0 / 1) of c->xhy in panel_dot_p's
+// layout [q][k+1][ED] (slot k = ||Y_q||^2), all-reduced.  flags: see the kernel (1 = Y is X, 2 = upper tiles only).
+int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int flags, int sec, double **out_dev) {
+    lk_context_t c = Bx->ctx;
+    const bool cp = Bx->dtype == LK_C128;
+    const int ED = Bx->ed();
+    const int KP = (k + 15) / 16, PJ = (p + 15) / 16;
+    const int NI = KP <= 1 ? 1 : (KP == 2 ? 2 : (KP <= 4 ? 4 : 8));
+    const int WR = 8 / NI;
+    const int64_t nslots = (int64_t)p * (k + 1) * ED;
+    const int64_t sect = (int64_t)XHY_MAX * (XHY_MAX + 1) * 2;                  // doubles per result section
+    const int64_t npart_n = (int64_t)c->num_cu * 2 * XHY_MAX;
+    // complex kind, <= 32 right-hand sides: 32-row tiles and a quarter of the accumulators -- 40 KB of LDS and 88 VGPRs, so
+    // several blocks share a CU and cover each other's barriers (3.9 -> 2.5 ms at n = 5 10^6, k = 128, p = 16; the real kind
+    // has half the MFMAs per byte and gains nothing from it: tools/bench_block.py)
+    const bool small = cp && c->xhy_small && PJ <= 2;
+    const int TR = small ? 32 : 64;
+    const int64_t ntiles = (Bx->n * ED + TR - 1) / TR;
+    int64_t g = (int64_t)c->num_cu * (small ? 2 : 1);
+    if (g > ntiles) g = ntiles;
+    if (g < 1) g = 1;
+    const int grid = (int)g, nvb = grid * WR;
+    const int64_t need = 2 * sect + npart_n + (int64_t)nvb * nslots;
+    if (c->xhy_n < need) {
+        if (c->xhy) HIPCHK(hipFree(c->xhy));
+        c->xhy = nullptr;
+        c->xhy_n = 0;
+        HIPCHK(hipMalloc((void **)&c->xhy, (size_t)need * sizeof(double)));
+        c->xhy_n = need;
+    }
+    double *out = c->xhy + (int64_t)sec * sect, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
+    const size_t lds = (size_t)(KP + ((flags & 1) ? 0 : PJ)) * 16 * (TR + 2) * sizeof(double);
+    {
+        ProfScope ps(c, "xhy_mfma", (double)Bx->n * ED * 8.0 * (k + ((flags & 1) ? 0 : p)));
+        auto go = [&](auto kern) -> int {
+            if (lds > 48 * 1024)
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, (const double *)Bx->col(c0), Bx->ld, k, (const double *)By->col(jy0), By->ld,
+                               p, Bx->n, flags, NI, part, npart);
+            return LK_OK;
+        };
+        if (cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32>) : go(&panel_xhy_mfma<true, 8, 64>));
+        else LKCHK(go(&panel_xhy_mfma<false, 8, 64>));
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, c->stream, part, nvb, npart, grid, k, p, ED, flags, out);
+    HIPCHK(hipGetLastError());
+    if (out_dev) *out_dev = out;
+    return allreduce(c, out, nslots);
+}
+
 // ---- tall-skinny product launcher (panel_gemm) -------------------------------------------------------------
 constexpr int GEMM_QB = 16;       // accumulators (output columns) per lane
 constexpr int GEMM_NQG = 4;       // output-column groups per block (= waves per block)
@@ -927,6 +987,7 @@ int lk_finalize(lk_context_t c) {
     if (c->red) (void)hipFree(c->red);
     if (c->coef) (void)hipFree(c->coef);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->xhy) (void)hipFree(c->xhy);
     if (c->red_host) (void)hipHostFree(c->red_host);
     if (c->coef_host) (void)hipHostFree(c->coef_host);
     if (c->coef_ev) (void)hipEventDestroy(c->coef_ev);
@@ -980,6 +1041,8 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "cw_grid_mult")) { if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "lk_set_tuning: cw_grid_mult must be in [1, 16]"); c->cw_grid_mult = value; return LK_OK; }
     if (!strcmp(key, "xcd_map")) { c->xcd_map = value != 0; return LK_OK; }
     if (!strcmp(key, "prof_ext")) { c->prof_ext = value != 0; return LK_OK; }
+    if (!strcmp(key, "xhy_small")) { c->xhy_small = value != 0; return LK_OK; }
+    if (!strcmp(key, "xhy_mfma")) { c->xhy_mfma = value != 0; return LK_OK; }
     if (!strcmp(key, "block_fused")) { c->block_fused = value != 0; return LK_OK; }
     if (!strcmp(key, "csr_stream")) { c->csr_stream = value != 0; return LK_OK; }
     if (!strcmp(key, "csr_lanes")) {
@@ -1522,7 +1585,8 @@ int lk_vec_rand(lk_basis_t B, int j, uint64_t seed, int64_t row0, int ifnorm) {
 }
 
 // ---- basis helpers ---------------------------------------------------------------------------
-int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M) {
+// upper_only (lk_gram): only entries M(i, j) with i <= j of a diagonal block are wanted
+static int innerprod_impl(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M, bool upper_only) {
     if (!Bx || !By || !M) return fail(LK_ERR_INVALID, "lk_innerprod: null argument");
     DevGuard dev_guard(Bx->ctx);
     LKCHK(check_pair(Bx, By, "lk_innerprod"));
@@ -1530,6 +1594,25 @@ int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M)
     lk_context_t c = Bx->ctx;
     LKCHK(lazy_enter(c, false));
     const int ED = Bx->ed();
+    if (c->xhy_mfma && p >= XHY_MIN_P) {
+        // many right-hand sides: one pass over X per 128 x 128 block of M on the matrix cores
+        std::vector<double> host((size_t)XHY_MAX * (XHY_MAX + 1) * 2);
+        for (int j = 0; j < p; j += XHY_MAX) {
+            const int pn = (p - j) < XHY_MAX ? (p - j) : XHY_MAX;
+            for (int c0 = 0; c0 < k; c0 += XHY_MAX) {
+                const int kk = (k - c0) < XHY_MAX ? (k - c0) : XHY_MAX;
+                const bool same = Bx->data == By->data && jy0 + j == c0 && pn == kk;          // a diagonal block of X^H X
+                double *out = nullptr;
+                LKCHK(dots_mfma(Bx, c0, kk, By, jy0 + j, pn, same ? (1 | (upper_only ? 2 : 0)) : 0, 0, &out));
+                HIPCHK(hipMemcpyAsync(host.data(), out, (size_t)pn * (kk + 1) * ED * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (c->prof) prof_collect(c);
+                for (int q = 0; q < pn; ++q)
+                    memcpy(M + ((size_t)(j + q) * k + c0) * ED, host.data() + (size_t)q * (kk + 1) * ED, (size_t)kk * ED * sizeof(double));
+            }
+        }
+        return LK_OK;
+    }
     for (int j = 0; j < p; j += 4) {
         const int pn = (p - j) < 4 ? (p - j) : 4;
         for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
@@ -1550,12 +1633,14 @@ int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M)
     return LK_OK;
 }
 
+int lk_innerprod(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *M) { return innerprod_impl(Bx, k, By, jy0, p, M, false); }
+
 int lk_gram(lk_basis_t Bx, int k, double *G) {
     if (!Bx || !G) return fail(LK_ERR_INVALID, "lk_gram: null argument");
     if (k < 1 || k > Bx->ncols) return fail(LK_ERR_INVALID, "lk_gram: bad k");
     const int ED = Bx->ed();
     std::vector<double> M((size_t)k * k * ED);
-    LKCHK(lk_innerprod(Bx, k, Bx, 0, k, M.data()));
+    LKCHK(innerprod_impl(Bx, k, Bx, 0, k, M.data(), true));
     // G(i,j) = X(i)%dot(X(j)) for j >= i; G(j,i) = G(i,j) (no conjugation)   AbstractVectors.fypp:650-655
     for (int i = 0; i < k; ++i)
         for (int j = i; j < k; ++j)
@@ -1718,6 +1803,36 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
         //   H1 = X^H Y | Y -= X H1 | H2 = X^H Y | Y -= X H2      (DGS_basis_against_basis, gram_schmidt.fypp:59-105)
         lk_context_t c = Bx->ctx;
         LKCHK(lazy_enter(c, true));
+        if (c->xhy_mfma && p >= XHY_MIN_P) {
+            // many right-hand sides: coefficients AND updates on the matrix cores, FOUR passes over X per group of up to 32
+            // columns of Y (H1 = X^H Y | Y -= X H1 | H2 = X^H Y | Y -= X H2), one copy + synchronisation per group
+            std::vector<double> host((size_t)2 * XHY_GROUP * (k + 1) * ED);
+            for (int j = 0; j < p; j += XHY_GROUP) {
+                const int pn = (p - j) < XHY_GROUP ? (p - j) : XHY_GROUP;
+                const size_t cnt = (size_t)pn * (k + 1) * ED;
+                double *o1 = nullptr, *o2 = nullptr;
+                LKCHK(dots_mfma(Bx, 0, k, By, jy0 + j, pn, 0, 0, &o1));
+                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, o1, (int64_t)(k + 1)));
+                LKCHK(dots_mfma(Bx, 0, k, By, jy0 + j, pn, 0, 1, &o2));
+                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, o2, (int64_t)(k + 1)));
+                HIPCHK(hipMemcpyAsync(host.data(), o1, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipMemcpyAsync(host.data() + cnt, o2, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (c->prof) prof_collect(c);
+                const double *r1 = host.data(), *r2 = host.data() + cnt;
+                for (int q = 0; q < pn; ++q) {
+                    const double n1 = std::sqrt(std::fabs(r1[((size_t)q * (k + 1) + k) * ED]));
+                    const double n2 = std::sqrt(std::fabs(r2[((size_t)q * (k + 1) + k) * ED]));
+                    if (n2 < ATOL_DP) inf = j + q + 1;                              // gram_schmidt.fypp:171-173 (pass 2 overwrites)
+                    if (n1 != n1 || n2 != n2) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+                    if (h)
+                        for (int i = 0; i < k * ED; ++i)
+                            h[((size_t)(j + q) * k) * ED + i] = r1[(size_t)q * (k + 1) * ED + i] + r2[(size_t)q * (k + 1) * ED + i];   // :97
+                }
+            }
+            if (info) *info = inf;
+            return LK_OK;
+        }
         for (int j = 0; j < p; j += 4) {
             const int pn = (p - j) < 4 ? (p - j) : 4;
             // both passes stay on the device (pass 2 reads the Y that pass 1's update wrote); ONE copy + sync per group

@@ -936,6 +936,187 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
     }
 }
 
+// M = X(:, :k)^H Y(:, :p) on the FP64 matrix cores: ONE pass over X (and Y) for up to 128 x 128 results -- Gram matrices,
+// innerprod_matrix and the coefficient passes of the block Gram-Schmidt with many right-hand sides, where panel_dot_p
+// (VALU, <= 4 right-hand sides per pass) would read X p/4 times.
+//   D(16x16) += A(16x4) B(4x16) with the contraction index on the ROWS of the panel: A[i][kk] = X(r + kk, 16 I + i),
+//   B[kk][j] = Y(r + kk, 16 J + j).  Lanes of an MFMA operand run along COLUMNS of the panel, the opposite of how the panel
+//   lies in memory, so a block stages a tile of 64 real rows x all columns in LDS -- 16-byte coalesced loads along the rows,
+//   row stride 66 doubles per column, which makes the lane-indexed ds_read_b64 of an operand (16 columns x 4 rows) bank-
+//   conflict free -- and prefetches the next tile into registers while the MFMAs of the current one run.
+//   Wave w owns tile row I = w (16 columns of X) and keeps the accumulators of all J tiles (<= 8) of that row in registers;
+//   for k <= 64 the 8 waves split NI ways over tile rows and 8/NI ways over the k-steps of a tile.
+//   complex kind: the panel is read as a REAL one of 2n rows (re, im interleaved): Re M = Xr^T Yr, and
+//   Im M = Xr^T Y~ with Y~(2r) = Yi(r), Y~(2r+1) = -Yr(r), i.e. the B operand read one row over with a sign: two MFMAs per
+//   tile and k-step, conj on X as in dotc.
+//   flags: 1 = Y is X (Gram: one tile serves both operands, no norm slots), 2 = upper tiles only (J >= I; tile rows are
+//   dealt so that every SIMD gets 9 of the 36 tiles).
+//   Results: partial[vb][slot], vb = block * (8/NI) + row group, slot = (q (k+1) + i) * ED + part -- panel_dot_p's layout
+//   with the norms ||Y_q||^2 (npartial[block][q]) in slot i = k -- summed over vb in fixed order by finish_xhy.
+// PJM = J tiles a wave can hold (8: up to 128 right-hand sides; 2: up to 32, half the registers), TR = real rows per tile
+// (64, or 32 for the small variant: 40 KB of LDS at k = 128, so that two or three blocks share a CU and cover each other's
+// barriers when there are only a few MFMAs per tile).
+template <bool CPLX, int PJM, int TR>
+__global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__ X, int64_t ldx, int k,
+                                                      const double *__restrict__ Y, int64_t ldy, int p, int64_t n, int flags,
+                                                      int NI, double *__restrict__ partial, double *__restrict__ npartial) {
+    constexpr int ER = CPLX ? 2 : 1;
+    constexpr int S = TR + 2;                    // LDS row stride of a column (S mod 32 == 2: conflict-free operand reads)
+    constexpr int CH = TR / 2, CHS = TR == 64 ? 5 : 4;   // 16-byte chunks per column of a tile (and its log2)
+    constexpr int CPP = 512 / CH;                // columns one block-wide pass stages
+    constexpr int NXP = 128 / CPP, NYP = (16 * PJM + CPP - 1) / CPP;
+    static_assert(TR == 64 || TR == 32, "tile rows");
+    extern __shared__ double xhy_lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int KP = (k + 15) >> 4, PJ = (p + 15) >> 4;
+    const int KS = (k + CPP - 1) / CPP, PS = (p + CPP - 1) / CPP;     // staging passes
+    const bool alias = flags & 1, upper = flags & 2;
+    double *Xt = xhy_lds, *Yt = alias ? xhy_lds : xhy_lds + KP * 16 * S;
+    const int64_t nr = n * ER;
+    const int64_t ntiles = (nr + TR - 1) / TR;
+    const int64_t xcs = ldx * ER, ycs = ldy * ER;
+    const int WR = 8 / NI;
+    int wi = wave % NI;
+    const int wr = wave / NI;
+    if (upper && NI == 8 && wave >= 4) wi = 11 - wave;
+    const bool active = wi < KP;
+    const int arow = lane >> 4, acol = lane & 15;
+
+    v4d acc_re[PJM], acc_im[PJM];
+#pragma unroll
+    for (int J = 0; J < PJM; ++J) { acc_re[J] = v4d{0.0, 0.0, 0.0, 0.0}; acc_im[J] = v4d{0.0, 0.0, 0.0, 0.0}; }
+    double nacc[NYP];
+#pragma unroll
+    for (int s = 0; s < NYP; ++s) nacc[s] = 0.0;
+    v2d xs[NXP], ys[NYP];
+
+    auto gload = [&](int64_t T) {
+        const int64_t rbase = T * TR;
+#pragma unroll
+        for (int s = 0; s < NXP; ++s) {
+            xs[s] = v2d{0.0, 0.0};
+            if (s < KS) {
+                const int c = t + 512 * s, col = c >> CHS;
+                const int64_t rr = rbase + 2 * (c & (CH - 1));
+                if (col < k) {
+                    const double *pc = X + (int64_t)col * xcs;
+                    if (rr + 1 < nr) xs[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(pc + rr));
+                    else if (rr < nr) xs[s].x = pc[rr];
+                }
+            }
+        }
+        if (!alias) {
+#pragma unroll
+            for (int s = 0; s < NYP; ++s) {
+                ys[s] = v2d{0.0, 0.0};
+                if (s < PS) {
+                    const int c = t + 512 * s, col = c >> CHS;
+                    const int64_t rr = rbase + 2 * (c & (CH - 1));
+                    if (col < p) {
+                        const double *pc = Y + (int64_t)col * ycs;
+                        if (rr + 1 < nr) ys[s] = *reinterpret_cast<const v2d *>(pc + rr);
+                        else if (rr < nr) ys[s].x = pc[rr];
+                    }
+                }
+            }
+        }
+    };
+
+    int64_t T = blockIdx.x;
+    if (T < ntiles) gload(T);
+    for (; T < ntiles; T += gridDim.x) {
+        __syncthreads();                                            // the previous tile's operands have been read
+#pragma unroll
+        for (int s = 0; s < NXP; ++s)
+            if (s < KS) {
+                const int c = t + 512 * s;
+                if ((c >> CHS) < KP * 16) *reinterpret_cast<v2d *>(Xt + (c >> CHS) * S + 2 * (c & (CH - 1))) = xs[s];
+            }
+        if (!alias) {
+#pragma unroll
+            for (int s = 0; s < NYP; ++s)
+                if (s < PS) {
+                    const int c = t + 512 * s;
+                    if ((c >> CHS) < PJ * 16) *reinterpret_cast<v2d *>(Yt + (c >> CHS) * S + 2 * (c & (CH - 1))) = ys[s];
+                    nacc[s] += ys[s].x * ys[s].x + ys[s].y * ys[s].y;
+                }
+        }
+        __syncthreads();
+        if (T + gridDim.x < ntiles) gload(T + gridDim.x);           // in flight while this tile's MFMAs run
+        if (active) {
+            for (int step = wr; step < TR / 4; step += WR) {
+                const int ro = 4 * step + arow;
+                const double a = Xt[(16 * wi + acol) * S + ro];
+#pragma unroll
+                for (int J = 0; J < PJM; ++J) {
+                    if (J < PJ && (!upper || J >= wi)) {
+                        const double b = Yt[(16 * J + acol) * S + ro];
+                        acc_re[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc_re[J], 0, 0, 0);
+                        if constexpr (CPLX) {
+                            double b2 = Yt[(16 * J + acol) * S + (ro ^ 1)];
+                            b2 = (ro & 1) ? -b2 : b2;
+                            acc_im[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc_im[J], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const int64_t nslots = (int64_t)p * (k + 1) * ER;
+    double *pb = partial + ((int64_t)blockIdx.x * WR + wr) * nslots;
+    if (active) {
+#pragma unroll
+        for (int J = 0; J < PJM; ++J) {
+            if (J < PJ && (!upper || J >= wi)) {
+                const int q = 16 * J + acol;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * wi + arow + 4 * r;
+                    if (i < k && q < p) {
+                        pb[((int64_t)q * (k + 1) + i) * ER] = acc_re[J][r];
+                        if constexpr (CPLX) pb[((int64_t)q * (k + 1) + i) * ER + 1] = acc_im[J][r];
+                    }
+                }
+            }
+        }
+    }
+    if (!alias) {
+#pragma unroll
+        for (int s = 0; s < NYP; ++s) {
+            if (s < PS) {
+                double v = nacc[s];
+                if constexpr (CH == 32) v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 8);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 1);
+                const int col = (t >> CHS) + CPP * s;
+                if ((t & (CH - 1)) == 0 && col < p) npartial[(int64_t)blockIdx.x * p + col] = v;
+            }
+        }
+    }
+}
+
+// out[slot] = sum over vb of partial[vb][slot] in fixed order; norm slots (i = k) from npartial; tiles panel_xhy_mfma skipped
+// (flag 2: I > J) read as zero.
+__global__ __launch_bounds__(256) void finish_xhy(const double *__restrict__ partial, int nvb, const double *__restrict__ npartial,
+                                                  int nblocks, int k, int p, int ER, int flags, double *__restrict__ out) {
+    const int64_t nslots = (int64_t)p * (k + 1) * ER;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nslots) return;
+    const int part = (int)(idx % ER), i = (int)((idx / ER) % (k + 1)), q = (int)(idx / ((int64_t)ER * (k + 1)));
+    double s = 0.0;
+    if (i == k) {
+        if (part == 0 && !(flags & 1))
+            for (int b = 0; b < nblocks; ++b) s += npartial[(int64_t)b * p + q];
+    } else if (!((flags & 2) && (i >> 4) > (q >> 4))) {
+        for (int vb = 0; vb < nvb; ++vb) s += partial[(int64_t)vb * nslots + idx];
+    }
+    out[idx] = s;
+}
+
 // per-lane coefficient tiles of panel_gemm_mfma from device coefficients laid out [q][ldc][ED] (column-major k x q):
 // Cp[(g * nt + t) * 64 + lane] = A-operand value of lane (kk = lane>>4, n = lane&15) of group g for k-step t.
 __global__ __launch_bounds__(256) void pack_coef_mfma(const double *__restrict__ C, int64_t ldc, int k, int q, int cplx,

@@ -355,6 +355,43 @@ def test_block_dgs_four_columns_per_pass(ctx, dtype, n, k, p):
     assert np.abs(Q.conj().T @ Yg).max() <= 1e-12 * np.linalg.norm(Y, axis=0).max()
 
 
+# ----------------------------------------------------------------------------- many right-hand sides on the matrix cores
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("n,k,p", [(1, 1, 5), (33, 5, 5), (4099, 17, 6), (5003, 128, 16), (3001, 100, 33), (2051, 64, 21),
+                                   (777, 130, 9), (70_001, 128, 32), (1500, 31, 129)])
+def test_many_right_hand_sides_on_the_matrix_cores(dtype, mfma, n, k, p):
+    """innerprod_matrix, Gram (AbstractVectors.fypp:645-695) and DGS_basis_against_basis (gram_schmidt.fypp:59-105) with
+    5+ right-hand sides: X^H Y by panel_xhy_mfma (one pass over X per 128 x 128 block; `xhy_mfma` = 1) and by the VALU
+    schedule (4 right-hand sides per pass; = 0), both against the oracle's one-dot-per-entry / per-column restatement at 1e-12
+    normwise.  Ragged shapes: k, p not multiples of 16, beyond 128, odd and tiny n (k > n makes X rank deficient: innerprod
+    and Gram only)."""
+    c = lk.Context(device=0)
+    c.set_tuning("xhy_mfma", mfma)
+    try:
+        X = np.asfortranarray(np.linalg.qr(basis(n, k, dtype, 70))[0]) if n >= k else basis(n, k, dtype, 70)
+        Y = basis(n, p, dtype, 300)
+        B = lk.krylov_basis_gpu(n, k, dtype, c); B.upload(X)
+        Z = lk.krylov_basis_gpu(n, p, dtype, c); Z.upload(Y)
+        ny = np.linalg.norm(Y, axis=0).max() * max(1.0, np.linalg.norm(X, axis=0).max())
+        M = lk.innerprod(B, Z)
+        assert np.abs(M - ora.innerprod(X, Y)).max() <= 1e-12 * ny
+        G = lk.Gram(B)
+        assert np.abs(G - ora.gram(X)).max() <= 1e-12 * max(1.0, np.linalg.norm(X, axis=0).max() ** 2)
+        if n > k and k <= 128:                                   # (n <= k: nothing is left of Y after the projection)
+            beta = np.zeros((k, p), dtype=dtype, order="F")
+            assert lk.double_gram_schmidt_step(Z, B, False, beta) == 0
+            Yg = Z.download()
+            for j in range(p):
+                yo = Y[:, j].copy()
+                ho, _ = ora.double_gram_schmidt_step(yo, X)
+                assert np.abs(beta[:, j] - ho).max() <= 1e-12 * np.linalg.norm(Y[:, j])
+                assert np.abs(Yg[:, j] - yo).max() <= 1e-12 * np.linalg.norm(Y[:, j])
+        del B, Z
+    finally:
+        c.close()
+
+
 def test_arnoldi_beyond_the_fused_width_and_restarted_ranges(ctx):
     """kdim = 140 > 128: steps 1..128 run as one asynchronous batch, the rest through the wide (unfused) schedule; and a
     factorisation continued with kstart > 1 (what krylov_schur restarts do) equals the one-shot run.  H against the oracle."""

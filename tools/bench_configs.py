@@ -34,10 +34,13 @@ def cfg1():
     V = lk.krylov_basis_gpu(n, 4, np.float64, ctx)
     x0 = lk.dense_vector_gpu.from_array(x0h, ctx)
     vals, res, info = lk.eigs(A, V, x0=x0, kdim=30, tolerance=1e-10, max_restarts=50)
-    return vals, res, info
+    v = V[0].to_array()
+    # the TRUE residual of the leading pair (the `residuals` eigs returns are the reference's: permuted by the restart that
+    # follows convergence, IterativeSolvers.fypp:1100, 1118-1120 -- faithful, but not a convergence measure)
+    return vals, float(np.linalg.norm(A0 @ v - vals[0].real * v) / np.linalg.norm(v)), info
 dt, (vals, res, info) = timed(cfg1)
 print(json.dumps({"config": "configs[0]: eigs, 1000x1000 dense real(dp), kdim 30, nev 4", "seconds": dt, "arnoldi_steps": int(info),
-                  "steps_per_s": info / dt, "leading_eigenvalue": [float(vals[0].real), float(vals[0].imag)], "max_residual": float(res.max())}), flush=True)
+                  "steps_per_s": info / dt, "leading_eigenvalue": [float(vals[0].real), float(vals[0].imag)], "true_residual_of_leading_pair": res}), flush=True)
 del A
 
 # configs[1]: arnoldi, diagonal operator, n = 1e7 real(dp), m = 64
