@@ -18,4 +18,5 @@ python3 "$R/bench.py" --rows 10000000 --kdim 64 --steps 5 --warmup 2 --no-cpu-ba
 python3 "$R/tools/bench_configs.py" > "$D/configs.log" 2>&1
 python3 "$R/tools/bench_blas1.py" 1e8 2 > "$D/blas1.log" 2>&1
 python3 "$R/tools/bench_per_object_arnoldi.py" 1e7 64 > "$D/per_object_arnoldi.log" 2>&1
+python3 "$R/tools/bench_block.py" 1e7 > "$D/block.log" 2>&1
 tail -c 600 "$D/bench_default.log"
