@@ -103,7 +103,8 @@ struct lk_context_s {
     int cw_grid_mult = 3;      // its blocks per CU (A/B at n = 10^8: 3 > 4 > 6)
     int xcd_map = 0;           // A/B: contiguous eighth of the rows per XCD instead of grid-cyclic tiles (null: DESIGN tuning log)
     int prof_ext = 1;          // profiling events of the sweeps attached to the kernel dispatch instead of recorded on the stream
-    int xhy_small = 1;         // its 32-row-tile variant for <= 32 complex right-hand sides
+    int xhy_grid_mult = 0;     // blocks per CU of the 32-row-tile variant (0: 3 real / 2 complex)
+    int xhy_small = 1;         // its 32-row-tile variant for <= 32 right-hand sides
     int xhy_mfma = 1;          // X^H Y with >= XHY_MIN_P right-hand sides (Gram, innerprod_matrix, block DGS) on the FP64 matrix cores
     int block_fused = 1;       // block DGS: fused update+dot / two-coefficient sweeps (3 passes per group) instead of 4
     int csr_stream = 1;        // CSR product through LDS for matrices with short rows (mean <= 32 entries); 0: lanes-per-row kernel
@@ -546,14 +547,14 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     const int WR = 8 / NI;
     const int64_t nslots = (int64_t)p * (k + 1) * ED;
     const int64_t sect = (int64_t)XHY_MAX * (XHY_MAX + 1) * 2;                  // doubles per result section
-    const int64_t npart_n = (int64_t)c->num_cu * 2 * XHY_MAX;
-    // complex kind, <= 32 right-hand sides: 32-row tiles and a quarter of the accumulators -- 40 KB of LDS and 88 VGPRs, so
-    // several blocks share a CU and cover each other's barriers (3.9 -> 2.5 ms at n = 5 10^6, k = 128, p = 16; the real kind
-    // has half the MFMAs per byte and gains nothing from it: tools/bench_block.py)
-    const bool small = cp && c->xhy_small && PJ <= 2;
+    const int64_t npart_n = (int64_t)c->num_cu * 4 * XHY_MAX;
+    // <= 32 right-hand sides: 32-row tiles and a quarter of the accumulators -- 40 KB of LDS and 66-88 VGPRs, so several blocks
+    // share a CU and cover each other's barriers and load latency (n = 10^7 real, k = 128, p = 16: 2.54 -> 1.92 ms on 3 blocks
+    // per CU, one pass over X at 6.5 TB/s being 1.77; complex 3.73 -> 2.29 ms on 2)
+    const bool small = c->xhy_small && PJ <= 2;
     const int TR = small ? 32 : 64;
     const int64_t ntiles = (Bx->n * ED + TR - 1) / TR;
-    int64_t g = (int64_t)c->num_cu * (small ? 2 : 1);
+    int64_t g = (int64_t)c->num_cu * (small ? (c->xhy_grid_mult ? c->xhy_grid_mult : (cp ? 2 : 3)) : 1);
     if (g > ntiles) g = ntiles;
     if (g < 1) g = 1;
     const int grid = (int)g, nvb = grid * WR;
@@ -577,10 +578,10 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
             return LK_OK;
         };
         if (cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32>) : go(&panel_xhy_mfma<true, 8, 64>));
-        else LKCHK(go(&panel_xhy_mfma<false, 8, 64>));
+        else LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32>) : go(&panel_xhy_mfma<false, 8, 64>));
     }
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, c->stream, part, nvb, npart, grid, k, p, ED, flags, out);
+    hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, part, nvb, npart, grid, k, p, ED, flags, out);
     HIPCHK(hipGetLastError());
     if (out_dev) *out_dev = out;
     return allreduce(c, out, nslots);
@@ -1042,6 +1043,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "xcd_map")) { c->xcd_map = value != 0; return LK_OK; }
     if (!strcmp(key, "prof_ext")) { c->prof_ext = value != 0; return LK_OK; }
     if (!strcmp(key, "xhy_small")) { c->xhy_small = value != 0; return LK_OK; }
+    if (!strcmp(key, "xhy_grid_mult")) { c->xhy_grid_mult = value < 0 ? 0 : (value > 4 ? 4 : value); return LK_OK; }
     if (!strcmp(key, "xhy_mfma")) { c->xhy_mfma = value != 0; return LK_OK; }
     if (!strcmp(key, "block_fused")) { c->block_fused = value != 0; return LK_OK; }
     if (!strcmp(key, "csr_stream")) { c->csr_stream = value != 0; return LK_OK; }

@@ -1099,22 +1099,34 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     }
 }
 
-// out[slot] = sum over vb of partial[vb][slot] in fixed order; norm slots (i = k) from npartial; tiles panel_xhy_mfma skipped
-// (flag 2: I > J) read as zero.
+// out[slot] = sum over vb of partial[vb][slot]; norm slots (i = k) from npartial; tiles panel_xhy_mfma skipped (flag 2:
+// I > J) read as zero.  16 slots x 16 lanes per block: lane v adds the entries vb = v, v + 16, ... in order, then the 16 lane
+// sums are added in lane order -- a fixed summation order whatever the grid (there can be thousands of partial blocks for a
+// handful of slots: one thread per slot would walk them as one serial chain).
 __global__ __launch_bounds__(256) void finish_xhy(const double *__restrict__ partial, int nvb, const double *__restrict__ npartial,
                                                   int nblocks, int k, int p, int ER, int flags, double *__restrict__ out) {
+    __shared__ double sums[16][17];
     const int64_t nslots = (int64_t)p * (k + 1) * ER;
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nslots) return;
-    const int part = (int)(idx % ER), i = (int)((idx / ER) % (k + 1)), q = (int)(idx / ((int64_t)ER * (k + 1)));
+    const int sl = threadIdx.x & 15, v = threadIdx.x >> 4;
+    const int64_t idx = (int64_t)blockIdx.x * 16 + sl;
     double s = 0.0;
-    if (i == k) {
-        if (part == 0 && !(flags & 1))
-            for (int b = 0; b < nblocks; ++b) s += npartial[(int64_t)b * p + q];
-    } else if (!((flags & 2) && (i >> 4) > (q >> 4))) {
-        for (int vb = 0; vb < nvb; ++vb) s += partial[(int64_t)vb * nslots + idx];
+    if (idx < nslots) {
+        const int part = (int)(idx % ER), i = (int)((idx / ER) % (k + 1)), q = (int)(idx / ((int64_t)ER * (k + 1)));
+        if (i == k) {
+            if (part == 0 && !(flags & 1))
+                for (int b = v; b < nblocks; b += 16) s += npartial[(int64_t)b * p + q];
+        } else if (!((flags & 2) && (i >> 4) > (q >> 4))) {
+            for (int vb = v; vb < nvb; vb += 16) s += partial[(int64_t)vb * nslots + idx];
+        }
     }
-    out[idx] = s;
+    sums[v][sl] = s;
+    __syncthreads();
+    if (v == 0 && idx < nslots) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) tot += sums[w][sl];
+        out[idx] = tot;
+    }
 }
 
 // per-lane coefficient tiles of panel_gemm_mfma from device coefficients laid out [q][ldc][ED] (column-major k x q):
