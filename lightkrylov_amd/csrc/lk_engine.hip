@@ -118,6 +118,18 @@ struct lk_context_s {
         int j0 = 0, cnt = 0;
         std::vector<double> vals;
     } memo;
+    // Gram memo: the reference's gram_matrix asks X(i)%dot(X(j)), j = i..k, i = 1..k (AbstractVectors.fypp:651-656): self fixed,
+    // vec running, so the batched-dot memo above (vec fixed) never applies and is_orthonormal would cost k(k+1)/2 dot kernels.
+    // The second call of such a run computes X^H X of the written columns once on the matrix cores; the rest are hits.
+    struct {
+        bool valid = false;
+        const double *xbase = nullptr;
+        int cnt = 0;
+        std::vector<double> G;           // [j][i][ED] = conj(X_i) . X_j
+        const double *last_x = nullptr;  // the previous in-panel dot call (pattern detection)
+        int last_jx = -1, last_jy = -1;
+    } gmemo;
+    void forget_memos() { memo.valid = false; nmemo.valid = false; gmemo.valid = false; gmemo.last_x = nullptr; }
     // queue: pending  T <- [zeroed ? 0 : T] + sum_i a_i X(:, j0+i)  (linear_combination's loop).  `zeroed`: the queue
     // began with T%zero() (which was itself deferred), so T is DEFINED by the queue and can stay VIRTUAL -- never
     // written -- as long as nobody reads it: linear_combination's temporary is consumed by one y%sub(proj) and dies.
@@ -771,7 +783,7 @@ int apply_sub(lk_context_t c) {
     if (!c->sub.active) return LK_OK;
     auto &q = c->queue;
     c->sub.active = false;
-    c->memo.valid = false; c->nmemo.valid = false;
+    c->forget_memos();
     LKCHK(stage_coef(c, q.coef, q.cnt, q.Bx->ed(), c->sub.s[0], c->sub.s[1]));
     c->fusion_stats[1] += 1;
     return sweepm<3>(q.Bx, q.j0, q.cnt, c->sub.By->col(c->sub.jy), c->coef, nullptr, 1, nullptr);
@@ -791,7 +803,7 @@ int materialise_queue(lk_context_t c) {
         if (q.zeroed && q.cnt > 0) c->fusion_stats[2] += 1;
         return LK_OK;
     }
-    c->memo.valid = false; c->nmemo.valid = false;                  // a column changes: batched dots may have covered it
+    c->forget_memos();                  // a column changes: batched dots may have covered it
     double *T = q.By->col(q.jy);
     if (q.cnt == 1) {
         // a single queued term is a plain axpby (cg's x%axpby(alpha, p, 1), r%axpby(-alpha, Ap, 1): CG.fypp:125-131): the
@@ -830,7 +842,7 @@ int lazy_flush(lk_context_t c) {
 // Called at the top of every ABI entry that works on whole panels (or whose operands are not tracked).
 inline int lazy_enter(lk_context_t c, bool mutates) {
     if (!c->lazy) return LK_OK;
-    if (mutates) { c->memo.valid = false; c->nmemo.valid = false; }
+    if (mutates) { c->forget_memos(); }
     return lazy_flush(c);
 }
 
@@ -840,7 +852,7 @@ inline int lazy_enter(lk_context_t c, bool mutates) {
 struct VecRef { lk_basis_t B; int j; };
 int lazy_enter_vec(lk_context_t c, const VecRef *w, bool overwrite, const VecRef *r1, const VecRef *r2) {
     if (!c->lazy) return LK_OK;
-    if (w) { c->memo.valid = false; c->nmemo.valid = false; }
+    if (w) { c->forget_memos(); }
     if (c->sub.active && w && overwrite && w->B->col(w->j) == c->sub.By->col(c->sub.jy) &&
         !(r1 && r1->B->col(r1->j) == w->B->col(w->j)) && !(r2 && r2->B->col(r2->j) == w->B->col(w->j)))
         c->sub.active = false;                                      // the vector with the pending update is overwritten: nothing to apply
@@ -1060,7 +1072,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "stream_update")) { c->stream_update = value != 0; return LK_OK; }
     if (!strcmp(key, "lazy")) {
         LKCHK(lazy_flush(c));
-        c->memo.valid = false; c->nmemo.valid = false;
+        c->forget_memos();
         c->lazy = value != 0;
         return LK_OK;
     }
@@ -1187,7 +1199,7 @@ int lk_basis_destroy(lk_basis_t B) {
             const bool only_target = B->own && q.active && q.zeroed && q.By == B && q.Bx != B && !(c->sub.active && c->sub.By == B);
             if (only_target) q.By = nullptr;     // a virtual temporary dies unwritten; its coefficients may still serve `sub`
             else (void)lazy_flush(c);
-            c->memo.valid = false; c->nmemo.valid = false;
+            c->forget_memos();
         }
     }
     // hipFree waits for outstanding device work itself; the context may already be finalized.
@@ -1416,7 +1428,7 @@ int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta,
         // y%sub(proj) / x%add(dx) with the operand still virtual (gram_schmidt.fypp:145, gmres.fypp:202): y += s X a pending
         if (unit_beta && q.active && q.zeroed && q.cnt >= 1 && !c->sub.active && T && xp == T && yp != T && !in_xrange(yp) &&
             q.Bx->ctx == By->ctx && q.Bx->n == By->n) {
-            c->memo.valid = false; c->nmemo.valid = false;
+            c->forget_memos();
             c->sub.active = true; c->sub.By = By; c->sub.jy = jy;
             c->sub.s[0] = alpha[0]; c->sub.s[1] = cp ? alpha[1] : 0.0;
             return LK_OK;
@@ -1436,7 +1448,7 @@ int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta,
             } else if (q.cnt == 0) {
                 q.Bx = Bx; q.j0 = jx;
             }
-            c->memo.valid = false; c->nmemo.valid = false;       // y is (about to be) modified
+            c->forget_memos();       // y is (about to be) modified
             for (int e = 0; e < ED; ++e) q.coef.push_back(alpha[e]);
             q.cnt += 1;
             c->lazy_stats[2] += 1;
@@ -1478,6 +1490,42 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
         if (Bx->dtype == LK_C128) out[1] = 0.0;
         c->lazy_stats[0] += 1;
         return LK_OK;
+    }
+    if (c->lazy && c->xhy_mfma && Bx->data == By->data && Bx->ncols > 1) {
+        // gram_matrix's loop: see gmemo
+        auto &gm = c->gmemo;
+        const int ED = Bx->ed();
+        auto serve = [&]() {
+            for (int e = 0; e < ED; ++e) out[e] = gm.G[((size_t)jy * gm.cnt + jx) * ED + e];
+            c->lazy_stats[0] += 1;
+        };
+        if (gm.valid && gm.xbase == Bx->data && jx < gm.cnt && jy < gm.cnt) { serve(); return LK_OK; }
+        const bool run = gm.last_x == Bx->data && gm.last_jx == jx && gm.last_jy + 1 == jy;
+        gm.last_x = Bx->data; gm.last_jx = jx; gm.last_jy = jy;
+        int cnt = Bx->hwm < Bx->ncols ? Bx->hwm : Bx->ncols;
+        if (cnt > XHY_MAX) cnt = XHY_MAX;
+        if (run && !c->queue.active && !c->sub.active && cnt >= XHY_MIN_P && jx < cnt && jy < cnt) {
+            double *dev = nullptr;
+            LKCHK(dots_mfma(Bx, 0, cnt, Bx, 0, cnt, 1 | 2, 0, &dev));
+            std::vector<double> host((size_t)cnt * (cnt + 1) * ED);
+            HIPCHK(hipMemcpyAsync(host.data(), dev, host.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->prof) prof_collect(c);
+            gm.G.assign((size_t)cnt * cnt * ED, 0.0);
+            for (int j = 0; j < cnt; ++j)
+                for (int i = 0; i <= j; ++i)
+                    for (int e = 0; e < ED; ++e) {
+                        const double v = host[((size_t)j * (cnt + 1) + i) * ED + e];
+                        gm.G[((size_t)j * cnt + i) * ED + e] = v;
+                        gm.G[((size_t)i * cnt + j) * ED + e] = e ? -v : v;        // conj(X_j) . X_i = conj(conj(X_i) . X_j)
+                    }
+            if (ED == 2)
+                for (int j = 0; j < cnt; ++j) gm.G[((size_t)j * cnt + j) * 2 + 1] = 0.0;   // x . x is real (dotc sums exact zeros)
+            gm.valid = true; gm.xbase = Bx->data; gm.cnt = cnt;
+            c->lazy_stats[1] += 1;
+            serve();
+            return LK_OK;
+        }
     }
     if (c->lazy && Bx->ncols > 1) {
         // innerprod's loop (AbstractVectors.fypp:672-674, 690-694) asks X(1)%dot(y), X(2)%dot(y), ...:

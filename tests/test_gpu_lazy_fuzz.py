@@ -61,6 +61,17 @@ def _run(seed, dtype, lazy):
                         out.append(B[j].dot(_vec(B, S, y)))
                 elif k < 0.7:
                     out.append(_vec(B, S, y).dot(_vec(B, S, y)))
+        elif r < 0.36:                          # gram_matrix's loop over a sub-range (self fixed, vec running), cut by a write
+            i0 = int(rng.integers(0, NV - 3))
+            i1 = int(rng.integers(i0 + 2, NV))
+            cut = int(rng.integers(0, 40)) if rng.random() < 0.5 else -1
+            cnt = 0
+            for i in range(i0, i1 + 1):
+                for j in range(i, i1 + 1):
+                    out.append(B[i].dot(B[j]))
+                    cnt += 1
+                    if cnt == cut:
+                        B[int(rng.integers(0, NV))].scal(scalar())
         elif r < 0.40:
             a, b = rng.integers(0, NV + 2, 2)
             out.append(_vec(B, S, int(a)).dot(_vec(B, S, int(b))))

@@ -392,6 +392,37 @@ def test_many_right_hand_sides_on_the_matrix_cores(dtype, mfma, n, k, p):
         c.close()
 
 
+@pytest.mark.parametrize("dtype", KINDS)
+def test_lazy_gram_loop_of_the_reference_costs_one_pass(dtype):
+    """gram_matrix through the per-object calls an unchanged LightKrylov makes (AbstractVectors.fypp:651-656:
+    G(i,j) = X(i)%dot(X(j)), j = i..k; G(j,i) = G(i,j)) on a lazy context: the second call of the run computes X^H X on the
+    matrix cores, the other k(k+1)/2 - 2 are served from it -- against the oracle's Gram and an eager context; a write in
+    between invalidates."""
+    n, k = 20_011, 40
+    X = basis(n, k, dtype, 21)
+    Go = ora.gram(X)
+    res = {}
+    for lazy in (0, 1):
+        c = lk.Context(device=0)
+        c.set_tuning("lazy", lazy)
+        B = lk.krylov_basis_gpu(n, k, dtype, c); B.upload(X)
+        G = np.zeros((k, k), dtype=dtype)
+        for i in range(k):
+            for j in range(i, k):
+                G[i, j] = B[i].dot(B[j]); G[j, i] = G[i, j]
+        hits, sweeps, _q, _f = c.lazy_stats()
+        assert np.abs(G - Go).max() <= 1e-12 * np.linalg.norm(X, axis=0).max() ** 2
+        if lazy:
+            assert sweeps == 1 and hits >= k * (k + 1) // 2 - 2
+            B[3].scal(2.0)                                           # a write: the memo must not survive it
+            assert abs(B[3].dot(B[3]) - 4.0 * Go[3, 3]) <= 1e-12 * abs(Go[3, 3]) * 4
+            assert abs(B[2].dot(B[3]) - 2.0 * Go[2, 3]) <= 1e-12 * np.linalg.norm(X[:, 2]) * np.linalg.norm(X[:, 3]) * 2
+        res[lazy] = G
+        del B
+        c.close()
+    assert np.abs(res[0] - res[1]).max() <= 1e-12 * np.linalg.norm(X, axis=0).max() ** 2
+
+
 def test_arnoldi_beyond_the_fused_width_and_restarted_ranges(ctx):
     """kdim = 140 > 128: steps 1..128 run as one asynchronous batch, the rest through the wide (unfused) schedule; and a
     factorisation continued with kstart > 1 (what krylov_schur restarts do) equals the one-shot run.  H against the oracle."""
