@@ -966,7 +966,7 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     constexpr int CPP = 512 / CH;                // columns one block-wide pass stages
     constexpr int NXP = 128 / CPP, NYP = (16 * PJM + CPP - 1) / CPP;
     static_assert(TR == 64 || TR == 32, "tile rows");
-    extern __shared__ double xhy_lds[];
+    extern __shared__ __attribute__((aligned(16))) double xhy_lds[];   // 16-byte ds_write_b128 of the staged chunks
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int KP = (k + 15) >> 4, PJ = (p + 15) >> 4;
