@@ -377,7 +377,6 @@ __global__ __launch_bounds__(256) void panel_dot_cw(const double *__restrict__ X
             yv[u] = load_y<CPLX>(y, r0 + (int64_t)u * SEG, n, full);
             nrm += yv[u].x * yv[u].x + yv[u].y * yv[u].y;
         }
-#pragma unroll 2
         for (int j = 0; j < k; ++j) {
             const double *xc = X + (int64_t)j * colstride;
             v2d xv[U];
