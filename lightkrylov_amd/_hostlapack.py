@@ -48,14 +48,35 @@ def threaded() -> bool:
     return _load() is not None
 
 
+_controller = None
+
+
+def _all_blas():
+    """threadpoolctl's controller over EVERY BLAS loaded in the process (numpy and scipy each ship their own OpenBLAS, each
+    with its own worker threads), built once; None when threadpoolctl is not installed."""
+    global _controller
+    if _controller is None:
+        try:
+            import threadpoolctl
+            _controller = threadpoolctl.ThreadpoolController()
+        except Exception:  # noqa: BLE001
+            _controller = False
+    return _controller or None
+
+
 class blas_threads:
-    """Context manager: OpenBLAS' own worker threads off while WE parallelise over problems (its threading only slows
-    128 x 128 problems down: 2.3 s vs 1.3 s for the 128 problems of one cycle on 8 cores)."""
+    """Context manager: the BLAS libraries' own worker threads off while WE parallelise over problems (OpenBLAS' threading
+    only slows 128 x 128 problems down: 2.3 s vs 1.3 s for the 128 problems of one cycle on 8 cores)."""
 
     def __init__(self, n: int = 1):
-        self.n, self.prev = n, None
+        self.n, self.prev, self.cm = n, None, None
 
     def __enter__(self):
+        ctl = _all_blas()
+        if ctl is not None:
+            self.cm = ctl.limit(limits=self.n)
+            self.cm.__enter__()
+            return self
         lib = _load()
         if lib is not None and hasattr(lib, "scipy_openblas_set_num_threads"):
             self.prev = lib.scipy_openblas_get_num_threads()
@@ -63,9 +84,26 @@ class blas_threads:
         return self
 
     def __exit__(self, *exc):
-        if self.prev is not None:
+        if self.cm is not None:
+            self.cm.__exit__(*exc)
+            self.cm = None
+        elif self.prev is not None:
             _load().scipy_openblas_set_num_threads(C.c_int(self.prev))
         return False
+
+
+def small_problems(fn):
+    """Decorator for host routines whose LAPACK work is all on matrices of at most kdim x kdim (<= a few hundred): run them
+    with OpenBLAS' own threading off.  Its threading gains nothing at that size, and its workers busy-wait for a while after
+    every parallel call (numpy's copy as much as scipy's): on the GPU box (128 hardware threads) the Arnoldi batch of an `eigs` call that started right after
+    the previous call's Schur step took 98-116 ms instead of 74 -- the spinning workers delay the HIP runtime's threads."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        with blas_threads(1):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def _p(a: np.ndarray):

@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 from scipy.linalg import lapack as _lapack
 
-from . import _capi
+from . import _capi, _hostlapack
 from .constants import atol_dp, rtol_dp
 from .linops import _engine_linop, abstract_linop
 from .vectors import (Gram, abstract_vector, copy, dense_vector_gpu, innerprod, krylov_basis_gpu,
@@ -291,6 +291,7 @@ def _ordschur(T: np.ndarray, Q: np.ndarray, selected: np.ndarray):
     return out[0], out[1]
 
 
+@_hostlapack.small_problems
 def krylov_schur(X, H: np.ndarray, select_eigs) -> int:
     """Krylov-Schur restart: re-order the Schur form of H and compress the basis.
     src/Krylov/BaseKrylov.fypp:782-834.  Returns n, the number of selected eigenvalues."""

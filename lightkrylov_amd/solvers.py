@@ -203,6 +203,19 @@ def gmres(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float
 
 
 # ------------------------------------------------------------------------------------------
+_EIGS_SEGMENT = 16          # Arnoldi steps per asynchronous device batch of the pipelined eigs cycle
+_pools: dict = {}
+
+
+def _pool(name: str, nthreads: int) -> ThreadPoolExecutor:
+    """Host worker threads, created once (starting 32 threads costs ~15 ms: as much as the Schur step of a cycle)."""
+    key = (name, nthreads)
+    if key not in _pools:
+        _pools[key] = ThreadPoolExecutor(nthreads, thread_name_prefix="lk_" + name)
+    return _pools[key]
+
+
+@_hostlapack.small_problems
 def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | None = None,
          tolerance: float = rtol_dp, transpose: bool = False, write_intermediate: bool = False,
          max_restarts: int | None = None, pipelined: bool | None = None):
@@ -265,26 +278,42 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
         restarts += 1
         k_from, stopped = kstart, False
         if pipelined and kstart <= kdim_:
-            ainfo = arnoldi(A, Xwrk, H, kstart=kstart, kend=kdim_, transpose=transpose)
-            klast = ainfo if ainfo > 0 else kdim_                                  # an exhausted Krylov space ends the batch early
-            with _hostlapack.blas_threads(1), ThreadPoolExecutor(nthreads) as pool:
-                for c0 in range(kstart, klast + 1, nthreads):
-                    ks = range(c0, min(c0 + nthreads, klast + 1))
-                    for k, (_vals, r) in zip(ks, pool.map(ritz_test, ks)):
-                        res[:k] = r
-                        niter += 1
-                        conv = int(np.count_nonzero(res[:k] < tolerance))          # :1087
-                        if conv >= nev:
-                            stopped = True
+            # segments of _EIGS_SEGMENT steps: while the device runs segment s + 1 (one asynchronous lk_arnoldi call on a helper thread;
+            # ctypes drops the interpreter lock for its duration) the host tests the steps of segment s
+            bounds = [(a, min(a + _EIGS_SEGMENT - 1, kdim_)) for a in range(kstart, kdim_ + 1, _EIGS_SEGMENT)]
+            kdone = kstart - 1                                                     # last step any segment has computed
+            pool, device = _pool("geev", nthreads), _pool("device", 1)
+            with _hostlapack.blas_threads(1):
+                fut = device.submit(arnoldi, A, Xwrk, H, bounds[0][0], bounds[0][1], atol_dp, transpose)
+                for si, (a, b) in enumerate(bounds):
+                    ainfo = fut.result()
+                    fut = None
+                    klast = ainfo if ainfo > 0 else b                              # an exhausted Krylov space ends the batch early
+                    kdone = klast
+                    if ainfo == 0 and si + 1 < len(bounds):
+                        fut = device.submit(arnoldi, A, Xwrk, H, bounds[si + 1][0], bounds[si + 1][1], atol_dp, transpose)
+                    for c0 in range(a, klast + 1, nthreads):
+                        ks = range(c0, min(c0 + nthreads, klast + 1))
+                        for k, (_vals, r) in zip(ks, pool.map(ritz_test, ks)):
+                            res[:k] = r
+                            niter += 1
+                            conv = int(np.count_nonzero(res[:k] < tolerance))      # :1087
+                            if conv >= nev:
+                                stopped = True
+                                break
+                        if stopped:
                             break
-                    if stopped:
+                    if stopped or ainfo > 0:
                         break
-            if stopped and k < klast:
+                if fut is not None:                                                # a segment still in flight when the loop stopped
+                    ainfo = fut.result()
+                    kdone = ainfo if ainfo > 0 else bounds[si + 1][1]
+            if stopped and k < kdone:
                 # put the work arrays into the state the reference is in when it leaves the loop at step k (:1093):
                 # krylov_schur below acts on ALL of H and Xwrk
                 H[:, k:] = 0
                 zero_basis(Xwrk[k + 1:])
-            k_from = klast + 1                                                     # (breakdown without convergence: go on step by step)
+            k_from = kdone + 1                                                     # (breakdown without convergence: go on step by step)
         if not stopped:
             for k in range(k_from, kdim_ + 1):
                 arnoldi(A, Xwrk, H, kstart=k, kend=k, transpose=transpose)        # :1059
@@ -364,6 +393,7 @@ def cg(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float = 
     return info
 
 
+@_hostlapack.small_problems
 def eighs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | None = None,
           tolerance: float = rtol_dp, write_intermediate: bool = False):
     """Lanczos eigensolver for the leading len(X) eigenpairs of a symmetric / Hermitian operator.
@@ -403,6 +433,7 @@ def eighs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | N
     return vals[:nev].copy(), res[:nev].copy(), k
 
 
+@_hostlapack.small_problems
 def svds(A: abstract_linop, U, V, u0: abstract_vector | None = None, kdim: int | None = None,
          tolerance: float = rtol_dp, write_intermediate: bool = False):
     """Golub-Kahan solver for the leading len(U) singular triplets.  src/IterativeSolvers/SVDS/svd_solvers.fypp:44-150.
