@@ -304,6 +304,15 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
 int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend,
                double tol, int trans, int *info);
 
+/* ---- Lanczos tridiagonalisation (symmetric / Hermitian operators) ------------------------
+ * lanczos_tridiagonalization(A, X, T, info, kstart, kend, tol): src/Krylov/lanczos.fypp:7-64.
+ * Per step: X(k+1) = A X(k); T(i, k) = X(i)%dot(X(k+1)), X(k+1) -= T(i, k) X(i) for i = max(1, k-1), k (:57-60); full
+ * re-orthogonalisation by a double Gram-Schmidt step without beta (:62); T(k+1, k) = ||X(k+1)||; beta < tol => info = k and
+ * the loop exits WITHOUT scaling (:32-36), else X(k+1) is normalised.  All steps of a call are enqueued asynchronously
+ * (device-side stop flag), one host synchronisation per call.  T: host (ldt x m) column-major array of the basis dtype;
+ * only T(k-1:k+1, k) of each step is written.  kend <= 128. */
+int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, int kend, double tol, int *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,8 @@ struct lk_context_s {
     double *coef = nullptr;     // device coefficients for lincomb (KMAX_FUSED*2 doubles)
     double *scratch = nullptr;  // scratch vector (grown on demand), scratch_n doubles
     int64_t scratch_n = 0;
+    double *lz_red = nullptr, *lz_red_host = nullptr;   // lk_lanczos: per step 4 sections (two local passes x {dot, update})
+    int lz_cap = 0;
     double *xhy = nullptr;      // panel_xhy_mfma: [2 result sections][norm partials][partials], grown on demand
     int64_t xhy_n = 0;
     // communication
@@ -1001,6 +1003,8 @@ int lk_finalize(lk_context_t c) {
     if (c->coef) (void)hipFree(c->coef);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->xhy) (void)hipFree(c->xhy);
+    if (c->lz_red) (void)hipFree(c->lz_red);
+    if (c->lz_red_host) (void)hipHostFree(c->lz_red_host);
     if (c->red_host) (void)hipHostFree(c->red_host);
     if (c->coef_host) (void)hipHostFree(c->coef_host);
     if (c->coef_ev) (void)hipEventDestroy(c->coef_ev);
@@ -2322,6 +2326,100 @@ static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
     if (c->prof) prof_collect(c);
     const int stop_step = *c->stop_host;
     *done = stop_step ? stop_step : k1;
+    return LK_OK;
+}
+
+// Lanczos steps [k0, k1] (all <= KMAX_FUSED) enqueued back to back, as arnoldi_batch_async: operator; the two local
+// orthogonalisations of update_tridiag_matrix (lanczos.fypp:57-60) -- each T(i, k) = X(i)%dot(X(k+1)) with its
+// X(k+1)%axpby(-T(i, k), X(i), 1) is a one-column Gram-Schmidt pass: dot sweep, coefficient left on the device, update sweep --;
+// the full re-orthogonalisation (three fused sweeps); the normalise kernel with the device-side stop flag.
+static int lanczos_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, double tol, int *done) {
+    lk_context_t c = X->ctx;
+    const int nsteps = k1 - k0 + 1;
+    LKCHK(ensure_step_buffers(c, nsteps));
+    if (c->lz_cap < nsteps) {
+        if (c->lz_red) HIPCHK(hipFree(c->lz_red));
+        if (c->lz_red_host) HIPCHK(hipHostFree(c->lz_red_host));
+        c->lz_red = nullptr; c->lz_red_host = nullptr; c->lz_cap = 0;
+        const size_t bytes = (size_t)nsteps * 4 * RED_SECTION * sizeof(double);
+        HIPCHK(hipMalloc((void **)&c->lz_red, bytes));
+        HIPCHK(hipHostMalloc((void **)&c->lz_red_host, bytes, hipHostMallocDefault));
+        c->lz_cap = nsteps;
+    }
+    HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
+    const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
+    const int ED = X->ed();
+    c->guard_on = true;
+    c->prof_sweeps_only = true;
+    int rc = LK_OK;
+    for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
+        c->guard_step = k;
+        double *slot = c->step_red + (size_t)(k - k0) * RED_SECTIONS * RED_SECTION;
+        rc = lk_linop_apply(A, LK_OP_N, X, k - 1, X, k);
+        const int i0 = k > 1 ? k - 1 : 1;
+        for (int i = i0; i <= k && rc == LK_OK; ++i) {                       // lanczos.fypp:57-60
+            double *a = c->lz_red + ((size_t)(k - k0) * 4 + 2 * (i - i0)) * RED_SECTION;
+            rc = sweepm<1>(X, i - 1, 1, X->col(k), nullptr, nullptr, 1, a);
+            if (rc == LK_OK) rc = sweepm<3>(X, i - 1, 1, X->col(k), a, nullptr, 1, a + RED_SECTION);
+        }
+        if (rc != LK_OK) break;
+        rc = dgs_device(X, k, X->col(k), true, slot);                       // :62 (no beta)
+        if (rc != LK_OK) break;
+        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * RED_SECTION + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
+    }
+    c->guard_on = false;
+    c->guard_step = 0;
+    c->prof_sweeps_only = false;
+    LKCHK(rc);
+    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)nsteps * RED_SECTIONS * RED_SECTION * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->lz_red_host, c->lz_red, (size_t)nsteps * 4 * RED_SECTION * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->stop_host, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    const int stop_step = *c->stop_host;
+    *done = stop_step ? stop_step : k1;
+    return LK_OK;
+}
+
+int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, int kend, double tol, int *info) {
+    if (!A || !X || !T || !info) return fail(LK_ERR_INVALID, "lk_lanczos: null argument");
+    const int kdim = X->ncols - 1;                               // lanczos.fypp:20
+    if (kdim < 1) return fail(LK_ERR_INVALID, "lk_lanczos: basis needs at least 2 columns");
+    if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_lanczos: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
+    if (kend > KMAX_FUSED) return fail(LK_ERR_INVALID, "lk_lanczos: steps beyond %d basis columns are not fused (run them through the per-object calls)", KMAX_FUSED);
+    if (ldt < kdim + 1) return fail(LK_ERR_INVALID, "lk_lanczos: ldt too small");
+    lk_context_t c = X->ctx;
+    DevGuard dev_guard(c);
+    const int ED = X->ed();
+    *info = 0;
+    LKCHK(lazy_enter(c, true));
+    int k = kstart;
+    while (k <= kend) {
+        int done = 0;
+        LKCHK(lanczos_batch_async(A, X, k, kend, tol, &done));
+        const bool stopped_early = *c->stop_host != 0;
+        double beta = 0.0;
+        for (int s = k; s <= done; ++s) {
+            const double *r2 = c->step_red_host + ((size_t)(s - k) * RED_SECTIONS + 2) * RED_SECTION;
+            const int i0 = s > 1 ? s - 1 : 1;
+            double *Ts = T + (size_t)(s - 1) * ldt * ED;
+            for (int i = i0; i <= s; ++i) {
+                const double *a = c->lz_red_host + ((size_t)(s - k) * 4 + 2 * (i - i0)) * RED_SECTION;
+                for (int e = 0; e < ED; ++e) Ts[(size_t)(i - 1) * ED + e] = a[e];           // T(i, k)   :58
+            }
+            beta = std::sqrt(std::fabs(r2[(size_t)s * ED]));
+            if (beta != beta) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+            Ts[(size_t)s * ED] = beta;                                                      // T(k+1, k) :29
+            if (ED == 2) Ts[(size_t)s * ED + 1] = 0.0;
+        }
+        if (!stopped_early) break;
+        if (beta < tol) { *info = done; break; }                                            // :32-36 (no scaling)
+        // the device stops at max(tol, atol_dp); a caller's smaller tol lets the reference go on: normalise and resume
+        const double inv[2] = {1.0 / beta, 0.0};
+        LKCHK(lk_vec_scal(X, done, inv));
+        k = done + 1;
+    }
     return LK_OK;
 }
 

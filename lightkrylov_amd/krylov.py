@@ -219,6 +219,17 @@ def lanczos(A: abstract_linop, X, T: np.ndarray, kstart: int = 1, kend: int | No
     kdim = len(X) - 1
     kend = kdim if kend is None else kend
     info = 0
+    # whole step loop inside the engine (asynchronous, one synchronisation per call) for the first 128 basis columns
+    if (isinstance(X, krylov_basis_gpu) and isinstance(A, _engine_linop) and T.flags.f_contiguous and T.dtype == X.dtype
+            and T.shape[0] >= kdim + 1 and kstart <= min(kend, 128)):
+        k1 = min(kend, 128)
+        cinfo = C.c_int()
+        _capi.check(X._lib.lk_lanczos(A._h, X._h, T.ctypes.data_as(_DP), T.shape[0], int(kstart), int(k1), float(tol),
+                                      C.byref(cinfo)))
+        A.matvec_counter += (cinfo.value if cinfo.value else k1) - kstart + 1
+        if cinfo.value or k1 == kend:
+            return cinfo.value
+        kstart = k1 + 1
     for k in range(kstart, kend + 1):
         A.apply_matvec(X[k - 1], X[k])                                              # :26
         for i in range(max(1, k - 1), k + 1):                                       # :57-60

@@ -97,6 +97,49 @@ def test_lanczos_tridiagonal_matches_the_oracle(ctx, dtype):
     assert np.abs(G - np.eye(m + 1)).max() < 1e-12
 
 
+@pytest.mark.parametrize("dtype", KINDS)
+def test_fused_lanczos_breakdown_restart_ranges_and_the_per_object_loop(ctx, dtype):
+    """lk_lanczos (all steps of a call enqueued asynchronously) against the oracle and against the per-object loop of the
+    mirror (the reference's own sequence of dot / axpby / double_gram_schmidt_step / norm / scal calls):
+    breakdown -- a diagonal operator with three distinct values spans a 3-dimensional Krylov space: info = 3, T(4, 3) below
+    tol, X(4) left unscaled (lanczos.fypp:32-36); continued ranges kstart..kend equal the one-shot run; a caller's tolerance
+    below atol_dp resumes past the device-side stop."""
+    n, m = 20_003, 24
+    x0 = seeded(n, dtype, 5); x0 /= np.linalg.norm(x0)
+    # (a) breakdown
+    d3 = np.choose(np.arange(n) % 3, [1.0, 2.0, 3.5]).astype(dtype)
+    X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X.upload(x0.reshape(-1, 1), 0)
+    T = np.zeros((m + 1, m), dtype=dtype, order="F")
+    info = lk.lanczos(lk.diag_linop_gpu(d3, ctx), X, T)
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
+    To = np.zeros((m + 1, m), dtype=dtype, order="F")
+    info_o = ora.lanczos(ora.DiagOp(d3), Xo, To)
+    assert info == info_o == 3
+    assert np.abs(T[:3, :3] - To[:3, :3]).max() <= 1e-12 * np.abs(To[:3, :3]).max()
+    assert abs(T[3, 2]) < 1e-12 and not T[:, 3:].any()
+    # (b) ranges and the per-object loop
+    d = (1.0 + np.arange(n) / n).astype(dtype)
+    A = lk.diag_linop_gpu(d, ctx)
+    Xo[...] = 0; Xo[:, 0] = x0; To[...] = 0
+    assert ora.lanczos(ora.DiagOp(d), Xo, To) == 0
+    X.upload(np.zeros((n, m + 1), dtype=dtype)); X.upload(x0.reshape(-1, 1), 0); T[...] = 0
+    assert lk.lanczos(A, X, T, kstart=1, kend=7) == 0
+    assert lk.lanczos(A, X, T, kstart=8, kend=8) == 0
+    assert lk.lanczos(A, X, T, kstart=9, kend=m, tol=1e-300) == 0        # tol < atol_dp: same result, resumable path
+    for j in range(m):
+        assert np.abs(T[:, j] - To[:, j]).max() <= 1e-12 * np.abs(To[:, j]).max()
+    assert np.abs(X.download() - Xo).max() <= 1e-10                      # Krylov vectors (conditioning grows with the step)
+
+    class per_object(lk.abstract_linop):                                 # not an engine operator: the mirror's python loop runs
+        def matvec(self, vec_in, vec_out):
+            A.matvec(vec_in, vec_out)
+    X2 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X2.upload(x0.reshape(-1, 1), 0)
+    T2 = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.lanczos(per_object(), X2, T2) == 0
+    for j in range(m):
+        assert np.abs(T[:, j] - T2[:, j]).max() <= 1e-12 * np.abs(To[:, j]).max()
+
+
 # ----------------------------------------------------------------------------- f4: on-disk outputs from the GPU
 def test_eigs_on_gpu_writes_the_reference_outputs(ctx, tmp_path, monkeypatch):
     """eigs(write_intermediate=.true.) dumps eigs_output.txt every Arnoldi step (IterativeSolvers.fypp:1091, 899-922)
