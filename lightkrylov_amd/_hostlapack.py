@@ -35,7 +35,7 @@ def _load():
             cands = sorted(glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so*")))
             for path in cands:
                 lib = C.CDLL(path)
-                if hasattr(lib, "scipy_dgeev_") and hasattr(lib, "scipy_zgeev_"):
+                if all(hasattr(lib, f) for f in ("scipy_dgeev_", "scipy_zgeev_", "scipy_dsyev_", "scipy_zheev_")):
                     _lib = lib
                     break
         except Exception:  # noqa: BLE001
@@ -153,3 +153,37 @@ def geev(Hk: np.ndarray):
     if info.value != 0:
         raise RuntimeError(f"GEEV failed, info={info.value}")
     return vr, vals
+
+
+def syev(Tk: np.ndarray):
+    """(w, v) = eigenvalues (ascending) and orthonormal eigenvectors of the symmetric / Hermitian matrix whose UPPER triangle is
+    Tk's -- LAPACK syev / heev with a workspace query, i.e. what stdlib's `eigh(a, lambda, vectors)` (the routine `eighs` calls,
+    EIGHS/eighs.fypp:87; stdlib is not vendored with the reference: `upper_a` defaults to .true. there) does.  Callable from
+    several threads at once like geev(); falls back to scipy's wrapper of the same routine."""
+    lib = _load()
+    k = Tk.shape[0]
+    cplx = Tk.dtype == np.complex128
+    if lib is None or k == 0:
+        from scipy.linalg import eigh
+        return eigh(Tk, lower=False, driver="ev")
+    a = np.array(Tk, dtype=Tk.dtype, order="F", copy=True)          # overwritten by the eigenvectors
+    w = np.empty(k, dtype=np.float64)
+    n, lda, info = C.c_int(k), C.c_int(k), C.c_int(0)
+    jobz, uplo = C.c_char(b"V"), C.c_char(b"U")
+    one = C.c_size_t(1)
+    rwork = np.empty(max(1, 3 * k - 2), dtype=np.float64)
+
+    def call(work, lw):
+        if cplx:
+            lib.scipy_zheev_(C.byref(jobz), C.byref(uplo), C.byref(n), _p(a), C.byref(lda), _p(w), _p(work), C.byref(lw), _p(rwork),
+                             C.byref(info), one, one)
+        else:
+            lib.scipy_dsyev_(C.byref(jobz), C.byref(uplo), C.byref(n), _p(a), C.byref(lda), _p(w), _p(work), C.byref(lw),
+                             C.byref(info), one, one)
+    q = np.empty(1, dtype=Tk.dtype)
+    call(q, C.c_int(-1))                                             # workspace query
+    lw = C.c_int(max(1, int(q[0].real)))
+    call(np.empty(lw.value, dtype=Tk.dtype), lw)
+    if info.value != 0:
+        raise RuntimeError(f"SYEV/HEEV failed, info={info.value}")
+    return w, a

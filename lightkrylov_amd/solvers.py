@@ -395,10 +395,11 @@ def cg(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float = 
 
 @_hostlapack.small_problems
 def eighs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | None = None,
-          tolerance: float = rtol_dp, write_intermediate: bool = False):
+          tolerance: float = rtol_dp, write_intermediate: bool = False, pipelined: bool | None = None):
     """Lanczos eigensolver for the leading len(X) eigenpairs of a symmetric / Hermitian operator.
-    src/IterativeSolvers/EIGHS/eighs.fypp:46-140.  Returns (eigvals[nev], residuals[nev], info = Lanczos steps)."""
-    from scipy.linalg import eigh
+    src/IterativeSolvers/EIGHS/eighs.fypp:46-140.  Returns (eigvals[nev], residuals[nev], info = Lanczos steps).
+    (`pipelined`, engine extra as in eigs: the Lanczos steps are enqueued in asynchronous device segments while the host
+    runs the per-step `eigh` tests of the previous segment on several threads; same results.)"""
     nev = len(X)
     kdim_ = 4 * nev if kdim is None else kdim
     proto = X[0]
@@ -413,18 +414,53 @@ def eighs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | N
     vals = np.zeros(kdim_)
     vecs = np.zeros((kdim_, kdim_), dtype=dt)
     res = np.zeros(kdim_)
-    k = 0
-    for k in range(1, kdim_ + 1):
-        lanczos(A, Xwrk, T, kstart=k, kend=k)                                      # :84
-        vals[:] = 0
+
+    def ritz_test(k):
+        w, v = _hostlapack.syev(T[:k, :k])                                         # :87  (stdlib eigh = syev / heev: ascending)
+        return w, v, np.abs(T[k, k - 1] * v[k - 1, :k])                            # :93
+
+    def accept(k, w, v, r) -> bool:
+        vals[:] = 0                                                                # :86
         vecs[:] = 0
-        w, v = eigh(T[:k, :k])                                                     # :87  (syev / heev: ascending)
-        vals[:k], vecs[:k, :k] = w, v
-        res[:k] = np.abs(T[k, k - 1] * vecs[k - 1, :k])                            # :93
+        vals[:k], vecs[:k, :k], res[:k] = w, v, r
         if write_intermediate:
             write_results("eighs_output.txt", vals[:k].astype(complex), res[:k], tolerance)
-        if np.count_nonzero(res[:k] < tolerance) >= nev:                           # :96, :101
-            break
+        return np.count_nonzero(res[:k] < tolerance) >= nev                        # :96, :101
+
+    can_pipeline = (isinstance(Xwrk, krylov_basis_gpu) and isinstance(A, _engine_linop) and not write_intermediate
+                    and kdim_ <= 128)
+    pipelined = can_pipeline and (_hostlapack.threaded() if pipelined is None else bool(pipelined))
+    nthreads = max(1, min(32, os.cpu_count() or 1))
+    k, k_from, stopped = 0, 1, False
+    if pipelined:
+        bounds = [(a, min(a + _EIGS_SEGMENT - 1, kdim_)) for a in range(1, kdim_ + 1, _EIGS_SEGMENT)]
+        pool, device = _pool("geev", nthreads), _pool("device", 1)
+        fut = device.submit(lanczos, A, Xwrk, T, bounds[0][0], bounds[0][1])
+        klast = 0
+        for si, (a, b) in enumerate(bounds):
+            linfo = fut.result()
+            fut = None
+            klast = linfo if linfo > 0 else b                                      # a breakdown ends the batch: step by step from there
+            if linfo == 0 and si + 1 < len(bounds):
+                fut = device.submit(lanczos, A, Xwrk, T, bounds[si + 1][0], bounds[si + 1][1])
+            for c0 in range(a, klast + 1, nthreads):
+                ks = range(c0, min(c0 + nthreads, klast + 1))
+                for k, (w, v, r) in zip(ks, pool.map(ritz_test, ks)):
+                    if accept(k, w, v, r):
+                        stopped = True
+                        break
+                if stopped:
+                    break
+            if stopped or linfo > 0:
+                break
+        if fut is not None:
+            fut.result()                                                           # a segment in flight beyond the stop: only T(:, k+1:) and Xwrk(k+2:) changed
+        k_from = klast + 1
+    if not stopped:
+        for k in range(k_from, kdim_ + 1):
+            lanczos(A, Xwrk, T, kstart=k, kend=k)                                  # :84
+            if accept(k, *ritz_test(k)):
+                break
     idx = np.argsort(-vals, kind="stable")                                         # sort_index(..., reverse=.true.) over all kdim   :106
     vals, vecs, res = vals[idx], vecs[:, idx], res[idx]
     k = min(k, kdim_)

@@ -646,7 +646,7 @@ def eighs(A: _OpBase, x0: np.ndarray, nev: int, kdim: int | None = None, toleran
         lanczos(A, Xw, T, kstart=k, kend=k)
         vals[:] = 0
         vecs[:] = 0
-        w, v = eigh(T[:k, :k])                                           # stdlib eigh = syev / heev, ascending
+        w, v = eigh(T[:k, :k], lower=False, driver="ev")                 # stdlib eigh = syev / heev on the upper triangle (upper_a defaults to .true.), ascending
         vals[:k], vecs[:k, :k] = w, v
         res[:k] = np.abs(T[k, k - 1] * vecs[k - 1, :k])
         if np.count_nonzero(res[:k] < tolerance) >= nev:

@@ -734,6 +734,30 @@ def test_eighs_against_oracle_and_known_spectrum(ctx):
         assert np.linalg.norm(A @ V[:, i] - vals[i] * V[:, i]) <= 1e-8 * abs(vals[i])
 
 
+@pytest.mark.parametrize("dtype", KINDS)
+def test_pipelined_eighs_equals_the_step_by_step_one(ctx, dtype):
+    """eighs with the Lanczos steps enqueued in asynchronous device segments and the per-step eigh tests on host threads
+    (`pipelined=True`) against the reference's alternation of one step and one eigh (`pipelined=False`): same step count,
+    eigenvalues, residuals and eigenvectors bit for bit -- including an early stop in the middle of a segment -- and both
+    against the oracle."""
+    n, nev, kdim = 30_011, 4, 60
+    d = np.r_[np.linspace(1.0, 2.0, n - nev), 3.0 + 0.5 * np.arange(nev)].astype(dtype)     # nev separated leading eigenvalues
+    x0 = seeded(n, dtype, 9)
+    out = []
+    for pipe in (False, True):
+        X = lk.krylov_basis_gpu(n, nev, dtype, ctx)
+        vals, res, info = lk.eighs(lk.diag_linop_gpu(d, ctx), X, x0=lk.dense_vector_gpu.from_array(x0, ctx), kdim=kdim,
+                                   tolerance=1e-10, pipelined=pipe)
+        out.append((vals, res, info, X.download()))
+    (v0, r0, i0, X0), (v1, r1, i1, X1) = out
+    assert i0 == i1 and 5 < i0 < kdim                                     # converged before kdim: the pipeline stopped early
+    assert np.array_equal(v0, v1) and np.array_equal(r0, r1) and np.array_equal(X0, X1)
+    vo, ro, Xo, info_o = ora.eighs(ora.DiagOp(d), x0.copy(), nev, kdim=kdim, tolerance=1e-10)
+    assert info_o == i0
+    assert np.abs(v0 - vo).max() <= 1e-11 * np.abs(vo).max()
+    assert np.abs(v0 - (3.0 + 0.5 * np.arange(nev))[::-1]).max() <= 1e-9
+
+
 def test_svds_against_oracle_and_known_singular_values(ctx):
     """svds (SVDS/svd_solvers.fypp: Golub-Kahan bidiagonalisation, matvec + rmatvec, svd of B each step)."""
     n, nsv = 400, 3
