@@ -277,6 +277,31 @@ def test_grid_partition_covers_the_grid_in_whole_lines():
                 assert nj >= 1 and j0 + nj == j1
 
 
+def test_threadable_syev_is_bit_identical_to_scipys_wrapper():
+    """_hostlapack.syev = LAPACK syev / heev on the UPPER triangle (stdlib's eigh, EIGHS/eighs.fypp:87) through ctypes: the
+    bits of scipy.linalg.eigh(lower=False, driver="ev"), from one thread or from eight at once; the lower triangle is not read."""
+    from concurrent.futures import ThreadPoolExecutor
+    from scipy.linalg import eigh
+    from lightkrylov_amd import _hostlapack as hl
+    rng = np.random.default_rng(6)
+    Tr = rng.standard_normal((40, 40)); Tr = (Tr + Tr.T) / 2
+    Tz = rng.standard_normal((40, 40)) + 1j * rng.standard_normal((40, 40)); Tz = (Tz + Tz.conj().T) / 2
+
+    def check(k):
+        ok = True
+        for T in (Tr, Tz):
+            w, v = hl.syev(T[:k, :k])
+            w2, v2 = eigh(T[:k, :k], lower=False, driver="ev")
+            junk = np.triu(T[:k, :k]) + np.tril(np.random.default_rng(k).standard_normal((k, k)), -1)   # garbage below the diagonal
+            w3, v3 = hl.syev(junk.astype(T.dtype))
+            ok = ok and np.array_equal(w, w2) and np.array_equal(v, v2) and np.array_equal(w, w3) and np.array_equal(v, v3)
+        return ok
+
+    assert all(check(k) for k in range(1, 41))
+    with hl.blas_threads(1), ThreadPoolExecutor(8) as pool:
+        assert all(pool.map(check, list(range(1, 41)) * 2))
+
+
 def test_threadable_geev_is_bit_identical_to_scipys_wrapper():
     """lightkrylov_amd._hostlapack.geev calls the same OpenBLAS routine scipy.linalg.lapack.{d,z}geev calls, with the
     same workspace size, outside the interpreter lock: same bits, from one thread or from eight at once."""
