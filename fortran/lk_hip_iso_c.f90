@@ -358,6 +358,16 @@ module lightkrylov_hip_c
             integer(c_int), intent(out) :: info
             integer(c_int) :: rc
         end function
+        function lk_bidiag(A, U, V, B, ldb, kstart, kend, tol, info) bind(C, name="lk_bidiag") result(rc)
+            import :: c_int, c_ptr, c_double, c_int64_t
+            type(c_ptr), value :: A, U, V
+            real(c_double), intent(inout) :: B(*)
+            integer(c_int64_t), value :: ldb
+            integer(c_int), value :: kstart, kend
+            real(c_double), value :: tol
+            integer(c_int), intent(out) :: info
+            integer(c_int) :: rc
+        end function
         function lk_lanczos(A, X, T, ldt, kstart, kend, tol, info) bind(C, name="lk_lanczos") result(rc)
             import :: c_int, c_ptr, c_double, c_int64_t
             type(c_ptr), value :: A, X

@@ -313,6 +313,15 @@ int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, i
  * only T(k-1:k+1, k) of each step is written.  kend <= 128. */
 int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, int kend, double tol, int *info);
 
+/* ---- Golub-Kahan bidiagonalisation -----------------------------------------------------------
+ * lanczos_bidiagonalization(A, U, V, B, info, kstart, kend, tol): src/Krylov/golub_kahan.fypp:7-64.
+ * Per step: V(k) = A^H U(k), double Gram-Schmidt against V(:k-1) (k > 1), B(k, k) = alpha = ||V(k)||, normalise (:27-42);
+ * U(k+1) = A V(k), double Gram-Schmidt against U(:k), B(k+1, k) = beta = ||U(k+1)||, normalise (:45-58); a norm not above
+ * tol => info = k and the loop exits without scaling.  All steps of a call are enqueued asynchronously (device-side stop flag
+ * per half step), one host synchronisation per call.  U: kdim + 1 columns, V: >= kdim columns (two different bases); B: host
+ * (ldb x kdim) column-major array of the basis dtype, only B(k, k) and B(k+1, k) are written.  kend <= 128, tol >= atol_dp. */
+int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, int kstart, int kend, double tol, int *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,7 @@ SIGNATURES = {
     "lk_linop_apply": (_int, [_p, _int, _p, _int, _p, _int]),
     "lk_arnoldi": (_int, [_p, _p, _dp, _i64, _int, _int, C.c_double, _int, _ip]),
     "lk_lanczos": (_int, [_p, _p, _dp, _i64, _int, _int, C.c_double, _ip]),
+    "lk_bidiag": (_int, [_p, _p, _p, _dp, _i64, _int, _int, C.c_double, _ip]),
 }
 
 

@@ -35,7 +35,7 @@ def _load():
             cands = sorted(glob.glob(os.path.join(os.path.dirname(scipy.__file__), "..", "scipy.libs", "libscipy_openblas*.so*")))
             for path in cands:
                 lib = C.CDLL(path)
-                if all(hasattr(lib, f) for f in ("scipy_dgeev_", "scipy_zgeev_", "scipy_dsyev_", "scipy_zheev_")):
+                if all(hasattr(lib, f) for f in ("scipy_dgeev_", "scipy_zgeev_", "scipy_dsyev_", "scipy_zheev_", "scipy_dgesdd_", "scipy_zgesdd_")):
                     _lib = lib
                     break
         except Exception:  # noqa: BLE001
@@ -187,3 +187,39 @@ def syev(Tk: np.ndarray):
     if info.value != 0:
         raise RuntimeError(f"SYEV/HEEV failed, info={info.value}")
     return w, a
+
+
+def gesdd(Bk: np.ndarray):
+    """(u, s, vh) = full singular value decomposition of the square matrix Bk by LAPACK gesdd (jobz = 'A') with a workspace
+    query: what stdlib's `svd(a, s, u, vt)` (SVDS/svd_solvers.fypp:102) and scipy.linalg.svd's default driver call.  Callable
+    from several threads at once; bit-identical to scipy.linalg.svd(Bk) (tests/test_host_logic.py)."""
+    lib = _load()
+    k = Bk.shape[0]
+    if lib is None or k == 0:
+        from scipy.linalg import svd
+        return svd(Bk)
+    cplx = Bk.dtype == np.complex128
+    a = np.array(Bk, dtype=Bk.dtype, order="F", copy=True)
+    sv = np.empty(k, dtype=np.float64)
+    u = np.empty((k, k), dtype=Bk.dtype, order="F")
+    vt = np.empty((k, k), dtype=Bk.dtype, order="F")
+    n, ld, info = C.c_int(k), C.c_int(k), C.c_int(0)
+    jobz = C.c_char(b"A")
+    one = C.c_size_t(1)
+    iwork = np.empty(8 * k, dtype=np.int32)
+    rwork = np.empty(max(1, 5 * k * k + 5 * k), dtype=np.float64)
+
+    def call(work, lw):
+        if cplx:
+            lib.scipy_zgesdd_(C.byref(jobz), C.byref(n), C.byref(n), _p(a), C.byref(ld), _p(sv), _p(u), C.byref(ld), _p(vt), C.byref(ld),
+                              _p(work), C.byref(lw), _p(rwork), _p(iwork), C.byref(info), one)
+        else:
+            lib.scipy_dgesdd_(C.byref(jobz), C.byref(n), C.byref(n), _p(a), C.byref(ld), _p(sv), _p(u), C.byref(ld), _p(vt), C.byref(ld),
+                              _p(work), C.byref(lw), _p(iwork), C.byref(info), one)
+    q = np.empty(1, dtype=Bk.dtype)
+    call(q, C.c_int(-1))
+    lw = C.c_int(max(1, int(q[0].real)))
+    call(np.empty(lw.value, dtype=Bk.dtype), lw)
+    if info.value != 0:
+        raise RuntimeError(f"GESDD failed, info={info.value}")
+    return u, sv, vt

@@ -2347,7 +2347,7 @@ static int lanczos_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
         c->lz_cap = nsteps;
     }
     HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
-    const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
+    const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;     // below it: stop flag AND no scaling (lanczos.fypp:32-36)
     const int ED = X->ed();
     c->guard_on = true;
     c->prof_sweeps_only = true;
@@ -2365,7 +2365,7 @@ static int lanczos_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
         if (rc != LK_OK) break;
         rc = dgs_device(X, k, X->col(k), true, slot);                       // :62 (no beta)
         if (rc != LK_OK) break;
-        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * RED_SECTION + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
+        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * RED_SECTION + (size_t)k * ED, tol_break, c->stop_dev, tol_break);
     }
     c->guard_on = false;
     c->guard_step = 0;
@@ -2420,6 +2420,85 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
         LKCHK(lk_vec_scal(X, done, inv));
         k = done + 1;
     }
+    return LK_OK;
+}
+
+// Golub-Kahan steps [k0, k1] enqueued back to back (golub_kahan.fypp:25-60).  A step has two halves, each ending in a
+// normalise kernel that can raise the stop flag, so the guard counts HALF steps: 2k - 1 = right half (V(k) = A^H U(k), DGS
+// against V(:k-1), alpha), 2k = left half (U(k+1) = A V(k), DGS against U(:k), beta).  Half-step slots in step_red.
+static int bidiag_batch_async(lk_linop_t A, lk_basis_t U, lk_basis_t V, int k0, int k1, double tol, int *done_half) {
+    lk_context_t c = U->ctx;
+    const int nsteps = k1 - k0 + 1;
+    LKCHK(ensure_step_buffers(c, 2 * nsteps));
+    HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
+    const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
+    const int ED = U->ed();
+    c->guard_on = true;
+    c->prof_sweeps_only = true;
+    int rc = LK_OK;
+    for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
+        double *sv = c->step_red + (size_t)(2 * (k - k0)) * RED_SECTIONS * RED_SECTION;
+        double *su = sv + (size_t)RED_SECTIONS * RED_SECTION;
+        c->guard_step = 2 * k - 1;
+        rc = lk_linop_apply(A, LK_OP_H, U, k - 1, V, k - 1);                                   // :27
+        if (rc != LK_OK) break;
+        if (k > 1) rc = dgs_device(V, k - 1, V->col(k - 1), true, sv);                        // :30-33
+        else rc = dot_device(V, 0, V, 0, sv + 2 * RED_SECTION);                               // ||V(1)||^2 where the DGS would leave it
+        if (rc != LK_OK) break;
+        rc = scal_launch(V, k - 1, 1.0, 0.0, sv + 2 * RED_SECTION + (size_t)(k - 1) * ED, tol_break, c->stop_dev, tol_break);   // :36-42
+        if (rc != LK_OK) break;
+        c->guard_step = 2 * k;
+        rc = lk_linop_apply(A, LK_OP_N, V, k - 1, U, k);                                       // :45
+        if (rc != LK_OK) break;
+        rc = dgs_device(U, k, U->col(k), true, su);                                           // :48-49
+        if (rc != LK_OK) break;
+        rc = scal_launch(U, k, 1.0, 0.0, su + 2 * RED_SECTION + (size_t)k * ED, tol_break, c->stop_dev, tol_break);             // :52-58
+    }
+    c->guard_on = false;
+    c->guard_step = 0;
+    c->prof_sweeps_only = false;
+    LKCHK(rc);
+    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)2 * nsteps * RED_SECTIONS * RED_SECTION * sizeof(double),
+                          hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->stop_host, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    const int stop_half = *c->stop_host;
+    *done_half = stop_half ? stop_half : 2 * k1;
+    return LK_OK;
+}
+
+int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, int kstart, int kend, double tol, int *info) {
+    if (!A || !U || !V || !B || !info) return fail(LK_ERR_INVALID, "lk_bidiag: null argument");
+    LKCHK(check_pair(U, V, "lk_bidiag"));
+    const int kdim = U->ncols - 1;                               // golub_kahan.fypp:18
+    if (kdim < 1 || V->ncols < kdim) return fail(LK_ERR_INVALID, "lk_bidiag: U needs kdim + 1 columns and V kdim");
+    if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_bidiag: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
+    if (kend > KMAX_FUSED) return fail(LK_ERR_INVALID, "lk_bidiag: steps beyond %d basis columns are not fused (run them through the per-object calls)", KMAX_FUSED);
+    if (!(tol >= ATOL_DP)) return fail(LK_ERR_INVALID, "lk_bidiag: tol below atol_dp is not fused (the device-side stop is at max(tol, atol_dp))");
+    if (ldb < kdim + 1) return fail(LK_ERR_INVALID, "lk_bidiag: ldb too small");
+    if (U->data == V->data) return fail(LK_ERR_INVALID, "lk_bidiag: U and V must be different bases");
+    lk_context_t c = U->ctx;
+    DevGuard dev_guard(c);
+    const int ED = U->ed();
+    *info = 0;
+    if (kstart > kend) return LK_OK;
+    LKCHK(lazy_enter(c, true));
+    int done_half = 0;
+    LKCHK(bidiag_batch_async(A, U, V, kstart, kend, tol, &done_half));
+    const bool stopped_early = *c->stop_host != 0;
+    for (int hs = 2 * kstart - 1; hs <= done_half; ++hs) {
+        const int k = (hs + 1) / 2;
+        const bool right = hs & 1;
+        const double *r2 = c->step_red_host + ((size_t)(hs - (2 * kstart - 1)) * RED_SECTIONS + 2) * RED_SECTION;
+        const double nrm = std::sqrt(std::fabs(r2[(size_t)(right ? k - 1 : k) * ED]));
+        if (nrm != nrm) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+        double *Bk = B + (size_t)(k - 1) * ldb * ED;
+        const size_t row = right ? (size_t)(k - 1) : (size_t)k;                           // B(k, k) = alpha ; B(k+1, k) = beta
+        Bk[row * ED] = nrm;
+        if (ED == 2) Bk[row * ED + 1] = 0.0;
+    }
+    if (stopped_early) *info = (done_half + 1) / 2;                                        // :41, :57
     return LK_OK;
 }
 

@@ -253,6 +253,19 @@ def bidiagonalization(A: abstract_linop, U, V, B: np.ndarray, kstart: int = 1, k
     kend = kdim if kend is None else kend
     info = 0
     gpu = isinstance(U, krylov_basis_gpu) and isinstance(V, krylov_basis_gpu)
+    # whole step loop inside the engine (asynchronous, one synchronisation per call) for the first 128 basis columns
+    if (gpu and isinstance(A, _engine_linop) and B.flags.f_contiguous and B.dtype == U.dtype and B.shape[0] >= kdim + 1
+            and tol >= atol_dp and kstart <= min(kend, 128) and len(V) >= kdim):
+        k1 = min(kend, 128)
+        cinfo = C.c_int()
+        _capi.check(U._lib.lk_bidiag(A._h, U._h, V._h, B.ctypes.data_as(_DP), B.shape[0], int(kstart), int(k1), float(tol),
+                                     C.byref(cinfo)))
+        ksteps = (cinfo.value if cinfo.value else k1) - kstart + 1
+        A.rmatvec_counter += ksteps
+        A.matvec_counter += ksteps if not cinfo.value or B[cinfo.value - 1, cinfo.value - 1].real > tol else ksteps - 1
+        if cinfo.value or k1 == kend:
+            return cinfo.value
+        kstart = k1 + 1
     for k in range(kstart, kend + 1):
         A.apply_rmatvec(U[k - 1], V[k - 1])                                         # :27
         norms: list = []

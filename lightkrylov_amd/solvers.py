@@ -471,10 +471,9 @@ def eighs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | N
 
 @_hostlapack.small_problems
 def svds(A: abstract_linop, U, V, u0: abstract_vector | None = None, kdim: int | None = None,
-         tolerance: float = rtol_dp, write_intermediate: bool = False):
+         tolerance: float = rtol_dp, write_intermediate: bool = False, pipelined: bool | None = None):
     """Golub-Kahan solver for the leading len(U) singular triplets.  src/IterativeSolvers/SVDS/svd_solvers.fypp:44-150.
-    Returns (S[nsv], residuals[nsv], info)."""
-    from scipy.linalg import svd
+    Returns (S[nsv], residuals[nsv], info).  (`pipelined`: engine extra as in eigs / eighs, same results.)"""
     nsv = len(U)
     kdim_ = 4 * nsv if kdim is None else kdim
     dt = _dtype_of(U[0])
@@ -490,20 +489,55 @@ def svds(A: abstract_linop, U, V, u0: abstract_vector | None = None, kdim: int |
     um = np.zeros((kdim_, kdim_), dtype=dt)
     vm = np.zeros((kdim_, kdim_), dtype=dt)
     res = np.zeros(kdim_)
-    k = 0
-    for k in range(1, kdim_ + 1):
-        bidiagonalization(A, Uwrk, Vwrk, B, kstart=k, kend=k, tol=tolerance)      # :96
+
+    def ritz_test(k):
+        u, s_, vh = _hostlapack.gesdd(B[:k, :k])                                   # :102  (stdlib svd = gesdd)
+        v = vh.conj().T                                                            # vmat = hermitian(vmat)   :104
+        return u, s_, v, np.abs(B[k, k - 1] * v[k - 1, :k])                        # :106
+
+    def accept(k, u, s_, v, r) -> bool:
         sv[:] = 0
         um[:] = 0
         vm[:] = 0
-        u, s_, vh = svd(B[:k, :k])                                                 # :102
-        sv[:k], um[:k, :k] = s_, u
-        vm[:k, :k] = vh.conj().T                                                   # vmat = hermitian(vmat)   :104
-        res[:k] = np.abs(B[k, k - 1] * vm[k - 1, :k])                              # :106
+        sv[:k], um[:k, :k], vm[:k, :k], res[:k] = s_, u, v, r
         if write_intermediate:
             write_results("svds_output.txt", sv[:k].astype(complex), res[:k], tolerance)
-        if np.count_nonzero(res[:k] < tolerance) >= nsv:
-            break
+        return np.count_nonzero(res[:k] < tolerance) >= nsv
+
+    can_pipeline = (isinstance(Uwrk, krylov_basis_gpu) and isinstance(Vwrk, krylov_basis_gpu) and isinstance(A, _engine_linop)
+                    and not write_intermediate and kdim_ <= 128 and tolerance >= atol_dp)
+    pipelined = can_pipeline and (_hostlapack.threaded() if pipelined is None else bool(pipelined))
+    nthreads = max(1, min(32, os.cpu_count() or 1))
+    k, k_from, stopped = 0, 1, False
+    if pipelined:
+        bounds = [(a, min(a + _EIGS_SEGMENT - 1, kdim_)) for a in range(1, kdim_ + 1, _EIGS_SEGMENT)]
+        pool, device = _pool("geev", nthreads), _pool("device", 1)
+        fut = device.submit(bidiagonalization, A, Uwrk, Vwrk, B, bounds[0][0], bounds[0][1], tolerance)
+        klast = 0
+        for si, (a, b) in enumerate(bounds):
+            binfo = fut.result()
+            fut = None
+            klast = binfo if binfo > 0 else b                                      # a breakdown ends the batch: step by step from there
+            if binfo == 0 and si + 1 < len(bounds):
+                fut = device.submit(bidiagonalization, A, Uwrk, Vwrk, B, bounds[si + 1][0], bounds[si + 1][1], tolerance)
+            for c0 in range(a, klast + 1, nthreads):
+                ks = range(c0, min(c0 + nthreads, klast + 1))
+                for k, out in zip(ks, pool.map(ritz_test, ks)):
+                    if accept(k, *out):
+                        stopped = True
+                        break
+                if stopped:
+                    break
+            if stopped or binfo > 0:
+                break
+        if fut is not None:
+            fut.result()                                                           # a segment in flight beyond the stop: later columns only
+        k_from = klast + 1
+    if not stopped:
+        for k in range(k_from, kdim_ + 1):
+            bidiagonalization(A, Uwrk, Vwrk, B, kstart=k, kend=k, tol=tolerance)  # :96
+            if accept(k, *ritz_test(k)):
+                break
     k = min(k, kdim_)
     copy(U, linear_combination(Uwrk[:k], np.asfortranarray(um[:k, :nsv].astype(dt))))   # :121-127
     copy(V, linear_combination(Vwrk[:k], np.asfortranarray(vm[:k, :nsv].astype(dt))))

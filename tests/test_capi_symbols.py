@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_every_entry_point_cites_the_reference():
     text = open(os.path.join(ROOT, "include", "lightkrylov_hip.h")).read()
     for name in ("lk_vec_zero", "lk_vec_rand", "lk_vec_scal", "lk_vec_axpby", "lk_vec_dot", "lk_vec_norm",
-                 "lk_vec_copy", "lk_innerprod", "lk_lincomb", "lk_gram", "lk_orthogonalize", "lk_dgs", "lk_arnoldi", "lk_lanczos"):
+                 "lk_vec_copy", "lk_innerprod", "lk_lincomb", "lk_gram", "lk_orthogonalize", "lk_dgs", "lk_arnoldi", "lk_lanczos", "lk_bidiag"):
         head = text[:text.index(f"int {name}(")]
         last_comment = head[head.rindex("/*"):]
         assert re.search(r"\.fypp:\d+", last_comment), f"{name} lacks a reference file:line citation"

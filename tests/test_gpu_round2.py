@@ -776,3 +776,85 @@ def test_svds_against_oracle_and_known_singular_values(ctx):
     Uh, Vh = U.download(), V.download()
     for i in range(nsv):
         assert np.linalg.norm(G @ Vh[:, i] - S[i] * Uh[:, i]) <= 1e-8 * S[i]
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_fused_bidiagonalization_against_the_oracle_breakdown_and_ranges(ctx, dtype):
+    """lk_bidiag (golub_kahan.fypp:7-64, every step of a call enqueued asynchronously, stop flag per half step) against the
+    oracle: a dense non-normal operator (B, both bases), continued ranges, and breakdowns in the right half of a step (alpha
+    below tol, the left half of that step must not run) -- a rank-2 operator at step 3, a start vector in the kernel of A^H at
+    step 1 (info = 1, nothing of U(2) touched)."""
+    n, m = 1501, 20
+    rng = np.random.default_rng(3)
+    cplx = np.dtype(dtype).kind == "c"
+    G = rng.standard_normal((n, n)) / np.sqrt(n) + (1j * rng.standard_normal((n, n)) / np.sqrt(n) if cplx else 0)
+    G = np.asfortranarray(G.astype(dtype))
+    u0 = seeded(n, dtype, 4); u0 /= np.linalg.norm(u0)
+    A = lk.dense_linop_gpu(G, ctx)
+    U = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); U.upload(u0.reshape(-1, 1), 0)
+    V = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+    B = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.bidiagonalization(A, U, V, B, kstart=1, kend=6) == 0
+    assert lk.bidiagonalization(A, U, V, B, kstart=7, kend=7) == 0
+    assert lk.bidiagonalization(A, U, V, B, kstart=8, kend=m) == 0
+    Uo = np.zeros((n, m + 1), dtype=dtype, order="F"); Uo[:, 0] = u0
+    Vo = np.zeros((n, m + 1), dtype=dtype, order="F")
+    Bo = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.bidiagonalization(ora.DenseOp(G), ora.DenseOp(np.asfortranarray(G.conj().T)), Uo, Vo, Bo) == 0
+    assert np.abs(B - Bo).max() <= 1e-11 * np.abs(Bo).max()                 # dense gemv order differs too
+    Ud, Vd = U.download(), V.download()
+    assert np.abs(Ud.conj().T @ Ud - np.eye(m + 1)).max() < 1e-12 and np.abs(Vd[:, :m].conj().T @ Vd[:, :m] - np.eye(m)).max() < 1e-12
+    assert np.abs(G @ Vd[:, :m] - Ud @ B).max() <= 1e-11                    # A V = U B
+    # rank 2: the Krylov space of A A^H on u0 has dimension 2
+    a, b, c_, e = (seeded(n, dtype, s_) for s_ in (31, 32, 33, 34))
+    R = np.asfortranarray((np.outer(a, b.conj()) + np.outer(c_, e.conj())).astype(dtype) / n)
+    U.upload(np.zeros((n, m + 1), dtype=dtype)); U.upload(u0.reshape(-1, 1), 0); V.upload(np.zeros((n, m + 1), dtype=dtype)); B[...] = 0
+    info = lk.bidiagonalization(lk.dense_linop_gpu(R, ctx), U, V, B, tol=1e-10)
+    Uo[...] = 0; Uo[:, 0] = u0; Vo[...] = 0; Bo[...] = 0
+    info_o = ora.bidiagonalization(ora.DenseOp(R), ora.DenseOp(np.asfortranarray(R.conj().T)), Uo, Vo, Bo, tol=1e-10)
+    # v1, v2 span range(A^H) = span(b, e); u2, u3 use up what span(a, c) adds to u0: V(3) = A^H U(3) has nothing left
+    assert info == info_o == 3
+    assert np.abs(B[:3, :2] - Bo[:3, :2]).max() <= 1e-11 * np.abs(Bo).max() and abs(B[2, 2]) < 1e-10
+    assert not B[3:, :].any() and not B[:, 3:].any()
+    assert not U.download(3, m - 2).any() and not V.download(3, m - 2).any()          # nothing beyond the breakdown was touched
+    # u0 in the kernel of A^H: alpha = 0 at step 1
+    P = np.asfortranarray((np.outer(a, b.conj()) / n).astype(dtype))
+    w = u0 - a * (np.vdot(a, u0) / np.vdot(a, a)); w /= np.linalg.norm(w)              # w orthogonal to a: P^H w = 0
+    U.upload(np.zeros((n, m + 1), dtype=dtype)); U.upload(w.reshape(-1, 1), 0); V.upload(np.zeros((n, m + 1), dtype=dtype)); B[...] = 0
+    assert lk.bidiagonalization(lk.dense_linop_gpu(P, ctx), U, V, B, tol=1e-10) == 1
+    assert abs(B[0, 0]) < 1e-10 and not B[1:, :].any() and not U.download(1, m).any()
+    # the left half: u0 = a / |a| makes U(2) = A V(1) a multiple of U(1): beta below tol at step 1, V(1) normalised, U(2) not
+    ua = a / np.linalg.norm(a)
+    U.upload(np.zeros((n, m + 1), dtype=dtype)); U.upload(ua.reshape(-1, 1), 0); V.upload(np.zeros((n, m + 1), dtype=dtype)); B[...] = 0
+    info = lk.bidiagonalization(lk.dense_linop_gpu(P, ctx), U, V, B, tol=1e-10)
+    Uo[...] = 0; Uo[:, 0] = ua; Vo[...] = 0; Bo[...] = 0
+    assert info == ora.bidiagonalization(ora.DenseOp(P), ora.DenseOp(np.asfortranarray(P.conj().T)), Uo, Vo, Bo, tol=1e-10) == 1
+    assert abs(B[0, 0] - Bo[0, 0]) <= 1e-12 * abs(Bo[0, 0]) and abs(B[1, 0]) < 1e-10 and not B[:, 1:].any()
+    assert abs(np.linalg.norm(V.download(0, 1)) - 1.0) < 1e-14 and np.linalg.norm(U.download(1, 1)) < 1e-10 and not V.download(1, m).any()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_pipelined_svds_equals_the_step_by_step_one(ctx, dtype):
+    """svds with the Golub-Kahan steps in asynchronous device segments and the per-step svd tests on host threads against the
+    reference's alternation of one step and one svd: same step count, singular values, residuals and vectors bit for bit
+    (early stop inside a segment), and against the oracle."""
+    n, nsv, kdim = 3001, 3, 48
+    rng = np.random.default_rng(12)
+    cplx = np.dtype(dtype).kind == "c"
+    G = rng.standard_normal((n, n)) / np.sqrt(n) + (1j * rng.standard_normal((n, n)) / np.sqrt(n) if cplx else 0)
+    G[:3, :3] += np.diag([9.0, 7.0, 5.0])
+    G = np.asfortranarray(G.astype(dtype))
+    u0 = seeded(n, dtype, 8)
+    A = lk.dense_linop_gpu(G, ctx)
+    out = []
+    for pipe in (False, True):
+        U = lk.krylov_basis_gpu(n, nsv, dtype, ctx); V = lk.krylov_basis_gpu(n, nsv, dtype, ctx)
+        S, res, info = lk.svds(A, U, V, u0=lk.dense_vector_gpu.from_array(u0, ctx), kdim=kdim, tolerance=1e-10, pipelined=pipe)
+        out.append((S, res, info, U.download(), V.download()))
+    a, b = out
+    assert a[2] == b[2] and 3 < a[2] < kdim
+    assert all(np.array_equal(x, y) for x, y in zip(a, b) if isinstance(x, np.ndarray))
+    So, ro, Uo, Vo, info_o = ora.svds(ora.DenseOp(G), ora.DenseOp(np.asfortranarray(G.conj().T)), u0.copy(), nsv, kdim=kdim, tolerance=1e-10)
+    assert info_o == a[2] and np.abs(a[0] - So).max() <= 1e-11 * So[0]
+    assert np.abs(a[0] - np.linalg.svd(G, compute_uv=False)[:nsv]).max() <= 1e-9
+

@@ -277,6 +277,29 @@ def test_grid_partition_covers_the_grid_in_whole_lines():
                 assert nj >= 1 and j0 + nj == j1
 
 
+def test_threadable_gesdd_is_bit_identical_to_scipys_svd():
+    """_hostlapack.gesdd = LAPACK gesdd (jobz 'A', workspace query) through ctypes: the bits of scipy.linalg.svd on the lower
+    bidiagonal matrices svds decomposes, from one thread or from eight at once."""
+    from concurrent.futures import ThreadPoolExecutor
+    from scipy.linalg import svd
+    from lightkrylov_amd import _hostlapack as hl
+    rng = np.random.default_rng(8)
+    Br = np.tril(np.triu(rng.standard_normal((41, 40)), -1))
+    Bz = Br + 1j * np.tril(np.triu(rng.standard_normal((41, 40)), -1))
+
+    def check(k):
+        ok = True
+        for B in (Br, Bz):
+            u, s_, vh = hl.gesdd(np.asfortranarray(B[:k, :k]))
+            u2, s2, vh2 = svd(B[:k, :k])
+            ok = ok and np.array_equal(u, u2) and np.array_equal(s_, s2) and np.array_equal(vh, vh2)
+        return ok
+
+    assert all(check(k) for k in range(1, 41))
+    with hl.blas_threads(1), ThreadPoolExecutor(8) as pool:
+        assert all(pool.map(check, list(range(1, 41)) * 2))
+
+
 def test_threadable_syev_is_bit_identical_to_scipys_wrapper():
     """_hostlapack.syev = LAPACK syev / heev on the UPPER triangle (stdlib's eigh, EIGHS/eighs.fypp:87) through ctypes: the
     bits of scipy.linalg.eigh(lower=False, driver="ev"), from one thread or from eight at once; the lower triangle is not read."""
