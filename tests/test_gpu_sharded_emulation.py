@@ -113,6 +113,46 @@ def test_sharded_arnoldi_matches_single_context(ctx, dtype, nranks):
     assert np.abs(Xs.conj().T @ Xs - np.eye(m + 1)).max() <= 1e-12
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_lanczos_and_bidiagonalization_match_single_context(ctx, nranks):
+    """lk_lanczos and lk_bidiag row-sharded: every reduction of their asynchronous batches (the local one-column passes, the
+    first step's norm, the three sweeps, both halves of a Golub-Kahan step) must be all-reduced; T, B and the stitched bases
+    against a single context."""
+    n, m = 200_003, 24
+    dtype = np.float64
+
+    def dvals(row0, nl):
+        return 1.0 + (row0 + np.arange(nl)) / n
+
+    def body(rank, c, row0, nl):
+        A = lk.diag_linop_gpu(dvals(row0, nl), c)
+        X = lk.krylov_basis_gpu(nl, m + 1, dtype, c)
+        X[0].rand(True, seed=7)
+        T = np.zeros((m + 1, m), dtype=dtype, order="F")
+        i1 = lk.lanczos(A, X, T)
+        U = lk.krylov_basis_gpu(nl, m + 1, dtype, c); V = lk.krylov_basis_gpu(nl, m + 1, dtype, c)
+        U[0].rand(True, seed=9)
+        B = np.zeros((m + 1, m), dtype=dtype, order="F")
+        i2 = lk.bidiagonalization(A, U, V, B)
+        return i1, T, X.download(), i2, B, U.download(), V.download()
+
+    res, _grp = _sharded(n, nranks, body)
+    A1 = lk.diag_linop_gpu(dvals(0, n), ctx)
+    X1 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X1[0].rand(True, seed=7)
+    T1 = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.lanczos(A1, X1, T1) == 0
+    U1 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); V1 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); U1[0].rand(True, seed=9)
+    B1 = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.bidiagonalization(A1, U1, V1, B1) == 0
+    for i1, T, _x, i2, B, _u, _v in res:
+        assert i1 == 0 and i2 == 0
+        assert np.array_equal(T, res[0][1]) and np.array_equal(B, res[0][4])       # every rank holds the same T and B
+        assert np.abs(T - T1).max() <= 1e-13 * np.abs(T1).max() and np.abs(B - B1).max() <= 1e-13 * np.abs(B1).max()
+    for idx, ref in ((2, X1), (5, U1), (6, V1)):
+        stitched = np.concatenate([r[idx] for r in res], axis=0)
+        assert np.abs(stitched - ref.download()).max() <= 1e-11
+
+
 def test_sharded_blas1_and_gmres(ctx):
     n = 200_001
 
