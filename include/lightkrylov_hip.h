@@ -106,14 +106,15 @@ int lk_set_halo_exchange(lk_context_t ctx, lk_halo_fn fn, void *user);
 /* row block owned by this rank: global rows [row0, row0 + n_local) of n_global; only used
  * so that counter-based rand fills are identical for every partition. */
 int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
-/* tuning knobs (integers): "grid_mult" / "update_grid_mult" / "gemm_grid_mult" blocks per CU for the panel kernels;
- * "stream_update" (barrier-free single-coefficient update sweep); "recompute_update" (two-pass DGS: sweep 2 keeps y'
+/* tuning knobs (integers): "stream_update" (barrier-free single-coefficient update sweep); "recompute_update" (two-pass DGS: sweep 2 keeps y'
  * in registers and sweep 3 re-forms it, so y' is never written to HBM); "store_policy" (cache policy of the sweeps'
  * 16-byte y store: 0 plain, 1 nt, 2 sc1 = write-through [default], 3 sc0 sc1) and "store_split"; "async_arnoldi"
  * (default 1: lk_arnoldi enqueues all steps with a device-side breakdown flag, one host synchronisation per call; 0:
  * one host round trip per step); "cplx_wide" (complex sweeps on 8 waves x 16 columns when k exceeds this threshold, default 32, 0 = never); "pool_slab_cols" (columns per
  * pool slab); "lazy" (see lk_lazy_stats).  None of those changes a result bit (tests/test_gpu_round2.py).
- * Kernel selectors -- same results to rounding (different summation order), each checked against the oracle:
+ * Shapes and kernel selectors -- same results to rounding (different summation order), each checked against the oracle:
+ * "grid_mult" / "grid_mult_s2" / "update_grid_mult" / "gemm_grid_mult" (blocks per CU of the panel kernels: the number of
+ * per-block partial sums a dot is assembled from);
  * "dot_colwise" (default 1: DGS sweep 1 / innerprod one column at a time, panel_dot_cw; 0: all columns per tile) with
  * "cw_u" (16-byte loads per lane and column: 4, 8, 0 = by size) and "cw_grid_mult"; "xhy_mfma" (default 1: X^H Y with five or
  * more right-hand sides -- Gram, innerprod_matrix, block DGS -- in one pass over X on the FP64 matrix cores; 0: four

@@ -101,6 +101,7 @@ struct lk_context_s {
     // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
     int lap5_grid_mult = 8;    // persistent blocks per CU of the stencil operator
     int dot_colwise = 1;       // sweep 1 by panel_dot_cw (one column at a time, y in registers) instead of panel_sweep<DOT>
+    int grid_mult_s2 = 1;      // blocks per CU of the update + dot sweep (0: grid_mult).  1 is never slower than 2 and +1-6 % at small n or small k
     int cw_u = 0;              // its 16-byte loads per lane and column: 4, 8, or 0 = by size (8 on 2 blocks per CU for long panels)
     int cw_grid_mult = 3;      // its blocks per CU (A/B at n = 10^8: 3 > 4 > 6)
     int xcd_map = 0;           // A/B: contiguous eighth of the rows per XCD instead of grid-cyclic tiles (null: DESIGN tuning log)
@@ -333,10 +334,10 @@ int allreduce(lk_context_t c, double *dev, int64_t count) {
 }
 
 // ---- sweep launcher ---------------------------------------------------------------------
-struct SweepCfg { int WC, kcw, grid; };
+struct SweepCfg { int WC, kcw, grid; int64_t ntiles; };
 
 template <bool CPLX, int KC, int NW>
-SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n) {
+SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n, int mult = 0) {
     SweepCfg s;
     int wc = (k + KC - 1) / KC;  // waves needed across columns
     if (wc < 1) wc = 1;
@@ -348,11 +349,12 @@ SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n) {
     if (s.kcw < 1) s.kcw = 1;
     const int64_t tile_rows = (int64_t)(NW / WC) * 64 * K<CPLX>::ROWS;
     int64_t ntiles = (n + tile_rows - 1) / tile_rows;
-    int64_t g = (int64_t)c->num_cu * c->grid_mult;
+    int64_t g = (int64_t)c->num_cu * (mult > 0 ? mult : c->grid_mult);
     if (g > ntiles) g = ntiles;
     if (g > MAX_GRID) g = MAX_GRID;
     if (g < 1) g = 1;
     s.grid = (int)g;
+    s.ntiles = ntiles;
     return s;
 }
 
@@ -369,7 +371,7 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr bool UPDATE = MODE != 1, DOT = MODE <= 2;
     static_assert(KC * NW == KMAX_FUSED, "fused capacity");
-    SweepCfg s = sweep_cfg<CPLX, KC, NW>(c, k, n);
+    SweepCfg s = sweep_cfg<CPLX, KC, NW>(c, k, n, MODE == 2 ? c->grid_mult_s2 : 0);
     // ALGORITHMIC bytes of the three-sweep schedule: k+1 | k+2 | k+2 columns
     const double bytes = (double)n * ED * 8.0 * (k + 1 + (UPDATE ? 1 : 0));
     int nblocks = s.grid;
@@ -1047,6 +1049,7 @@ int lk_set_partition(lk_context_t c, int64_t row0, int64_t n_global) {
 
 int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!c || !key) return fail(LK_ERR_INVALID, "lk_set_tuning: null argument");
+    if (!strcmp(key, "grid_mult_s2")) { c->grid_mult_s2 = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
     if (!strcmp(key, "grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "grid_mult must be in [1,16]");
         c->grid_mult = value;
