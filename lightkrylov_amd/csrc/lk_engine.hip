@@ -101,6 +101,7 @@ struct lk_context_s {
     // through the type-bound procedures -- k consecutive X(i)%dot(y), then k consecutive y%axpby(a_i, X(i), 1).
     int lap5_grid_mult = 8;    // persistent blocks per CU of the stencil operator
     int dot_colwise = 1;       // sweep 1 by panel_dot_cw (one column at a time, y in registers) instead of panel_sweep<DOT>
+    int grid_mult_s3 = 0;      // blocks per CU of the two-coefficient update sweep (0: grid_mult)
     int grid_mult_s2 = 1;      // blocks per CU of the update + dot sweep (0: grid_mult).  1 is never slower than 2 and +1-6 % at small n or small k
     int cw_u = 0;              // its 16-byte loads per lane and column: 4, 8, or 0 = by size (8 on 2 blocks per CU for long panels)
     int cw_grid_mult = 3;      // its blocks per CU (A/B at n = 10^8: 3 > 4 > 6)
@@ -371,7 +372,7 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr bool UPDATE = MODE != 1, DOT = MODE <= 2;
     static_assert(KC * NW == KMAX_FUSED, "fused capacity");
-    SweepCfg s = sweep_cfg<CPLX, KC, NW>(c, k, n, MODE == 2 ? c->grid_mult_s2 : 0);
+    SweepCfg s = sweep_cfg<CPLX, KC, NW>(c, k, n, MODE == 2 ? c->grid_mult_s2 : (MODE == 4 ? c->grid_mult_s3 : 0));
     // ALGORITHMIC bytes of the three-sweep schedule: k+1 | k+2 | k+2 columns
     const double bytes = (double)n * ED * 8.0 * (k + 1 + (UPDATE ? 1 : 0));
     int nblocks = s.grid;
@@ -1049,6 +1050,7 @@ int lk_set_partition(lk_context_t c, int64_t row0, int64_t n_global) {
 
 int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!c || !key) return fail(LK_ERR_INVALID, "lk_set_tuning: null argument");
+    if (!strcmp(key, "grid_mult_s3")) { c->grid_mult_s3 = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
     if (!strcmp(key, "grid_mult_s2")) { c->grid_mult_s2 = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
     if (!strcmp(key, "grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "grid_mult must be in [1,16]");
