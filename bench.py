@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- Arnoldi-iteration throughput + DGS sweep bandwidth on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W            (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus N --steps K --warmup W            (any N: for N > 1 without a launcher's environment it starts
+                                                            `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+                                                            as a child process, relays its output and exits with its code)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form for N > 1)
 
 A "step" is ONE Arnoldi factorisation of the workload (m Arnoldi iterations: operator kernel,
 three fused DGS panel sweeps, normalise), run through the C ABI (lk_arnoldi).  Workload at every N:
@@ -33,6 +35,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+# Reduction order of the N > 1 all-reduce: RCCL picks ring / tree (and the protocol) per call from the message size and the
+# topology it detects; pinning the algorithm makes the summation order of the <= 129 scalars a function of (N, rank order) only,
+# so a run is bit-reproducible from launch to launch.  A caller's own setting wins.
+NCCL_PIN = {"NCCL_ALGO": "Ring"}
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _self_launch(ngpus: int) -> int:
+    """--gpus N > 1 without a launcher: run this script under torch.distributed.run in a FRESH child process (decided before
+    anything in this process touches the GPU; never an exec), relay its output, return its exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k, v in NCCL_PIN.items():
+        env.setdefault(k, v)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, cwd=ROOT)
+    return proc.returncode
+
+
+def kernel_source_hash() -> str:
+    """SHA-256 over the device code and its launcher: what a PMC traffic record must have been measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("lk_kernels.hip.h", "lk_engine.hip"):
+        h.update(open(os.path.join(ROOT, "lightkrylov_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def _oracle_sample(n: int, m: int, threads: int, fused: bool, repeat: int = 1):
@@ -141,6 +178,11 @@ def main() -> None:
                     help="diagnostic: leave the library's per-kernel HIP events off (value only; roofline fields are then zero)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(_self_launch(args.gpus))
+    for k, v in NCCL_PIN.items():
+        os.environ.setdefault(k, v)
+
     import torch
     import lightkrylov_amd as lk
 
@@ -153,11 +195,8 @@ def main() -> None:
     backend = os.environ.get("LK_DIST_BACKEND", "nccl")
     if "LK_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["LK_FORCE_DEVICE"])
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+    if world != args.gpus and rank == 0:       # under a launcher its world size wins
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running on {world} rank(s)", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:      # under torch.distributed.run: RCCL path even for one rank
@@ -236,7 +275,7 @@ def main() -> None:
 
     n_sweeps, sweep_ms, sweep_bytes = ctx.profile_get("dgs_sweep*")
     n_dgs, dgs_ms, dgs_bytes = ctx.profile_get("dgs")
-    n_mv, mv_ms, _ = ctx.profile_get("matvec")
+    n_mv, mv_ms, mv_bytes = ctx.profile_get("matvec")
     per_sweep = {}
     for i, what in ((1, "h1 = X^H y"), (2, "y' = y - X h1 (registers); h2 = X^H y'"), (3, "y'' = (y - X h1) - X h2, stored")):
         cnt, ms, by = ctx.profile_get(f"dgs_sweep{i}")
@@ -248,16 +287,25 @@ def main() -> None:
     if rank == 0:
         iters = args.steps * m
         achieved = (sweep_bytes / 1e9) / (sweep_ms / 1e3) if sweep_ms > 0 else 0.0
+        # `traffic` comes from separate rocprofv3 --pmc passes (counters cannot be collected from inside this process); the
+        # record names the SHA-256 of the kernel sources it was measured on.  A record made on other kernels is refused
+        # loudly -- traffic = null and a line on stderr -- instead of being quoted as if it described this build.
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc))
                 if rec.get("n_local") == n_local and rec.get("m") == m and rec.get("dtype") == args.dtype:
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_src = {k: rec.get(k) for k in ("commit", "source", "method") if k in rec}
-            except Exception:  # noqa: BLE001
-                traffic = None
+                    have = kernel_source_hash()
+                    if rec.get("kernel_source_sha256") == have:
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        traffic_src = {k: rec.get(k) for k in ("commit", "kernel_source_sha256", "source", "method") if k in rec}
+                    else:
+                        traffic_src = (f"STALE: profiles/pmc_traffic.json was measured on kernel sources {str(rec.get('kernel_source_sha256'))[:12]}..., "
+                                       f"this build is {have[:12]}...; re-run tools/run_profiles.sh")
+                        print("bench.py: " + traffic_src, file=sys.stderr)
+            except Exception as exc:  # noqa: BLE001
+                traffic, traffic_src = None, f"profiles/pmc_traffic.json unreadable: {exc!r}"
         out = {
             "metric": "Arnoldi iterations/s (+ DGS sweep HBM GB/s, % of 8 TB/s roofline)",
             "value": iters / elapsed,
@@ -277,12 +325,13 @@ def main() -> None:
                 "n_global": n, "n_local": n_local, "m": m, "parallelism": f"row-shard x{world} (RCCL all-reduce of <=129 scalars/sweep)",
                 "info": int(info), "H_fro": float(np.linalg.norm(H)), "H_last_subdiag": float(abs(H[m, m - 1])),
                 "all_reduce": reduce_path,
+                "nccl_algo": os.environ.get("NCCL_ALGO") if world > 1 or dist is not None else None,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "the three DGS sweeps: lk::panel_dot_cw (DOT, one column at a time) | lk::panel_sweep (UPDATE+DOT, y' kept in registers) | lk::panel_sweep (UPDATE with two coefficient sets)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_source": traffic_src if traffic is not None else
+                "traffic_source": traffic_src if traffic_src is not None else
                                   "rocprofv3 --pmc passes cannot run inside bench.py; see profiles/ (no record for this workload)",
                 "bytes_priced": "ALGORITHMIC three-sweep schedule, s*n_local*(k+1 | k+2 | k+2) = s*n*(3k+5) per DGS (SURVEY 8d); "
                                 "the shipped schedule moves 3k+4 columns (y' is never written), so HBM-level bandwidth is "
@@ -292,7 +341,10 @@ def main() -> None:
                 "per_sweep": per_sweep,
                 "dgs_call_GBps": (dgs_bytes / 1e9) / (dgs_ms / 1e3) if dgs_ms > 0 else 0.0,
                 "dgs_frac_of_step_time": (dgs_ms / 1e3) / elapsed if elapsed > 0 else 0.0,
-                "matvec_ms_total": mv_ms,
+                "matvec": {"launches": int(n_mv), "ms_total": mv_ms, "avg_ms": mv_ms / max(n_mv, 1),
+                           "algorithmic_bytes_per_launch": mv_bytes / max(n_mv, 1),
+                           "GBps": (mv_bytes / mv_ms / 1e6) if mv_ms > 0 else None,
+                           "measured": "HIP events on the operator's own dispatch inside the asynchronous batch" if n_mv else "not measured"},
             },
         }
         if world == 1 and not args.no_cpu_baseline:

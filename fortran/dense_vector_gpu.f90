@@ -27,7 +27,11 @@
 !>   Limit: a sourced copy shares its source's column until it is first written through.  Every sourced allocation
 !>   in LightKrylov's Krylov layer and solvers is followed by `zero()` / `zero_basis()` or an overwrite (gmres.fypp:
 !>   110-115, IterativeSolvers.fypp:1032-1034, AbstractVectors.fypp:595-598, 628-630, qr.fypp:186); user code that
-!>   needs an independent copy should assign (`y = x`), not source-allocate.
+!>   needs an independent copy should assign (`y = x`), not source-allocate.  The limit is ENFORCED, not silent: every
+!>   pool column carries a generation counter that the pool increments each time it hands the column out, and a handle
+!>   remembers the generation it was bound at.  If the source of a sourced copy dies and another object is created at its
+!>   address (`allocate(b, source=dense_vector_gpu(x))`: the constructor's result is such a temporary), the copy's generation
+!>   no longer matches and every use of it stops with an error instead of reading the new occupant's data.
 !> Lazy batching.  Columns are handed out in the order objects are first written -- V(1), V(2), ... for
 !> `allocate(V(kdim+1), source=b); call zero_basis(V)` -- and the engine runs in "lazy" mode (lk_lazy_stats,
 !> lk_lazy_fusion_stats): the k calls `X(i)%dot(y)` of `innerprod` cost one panel sweep; `linear_combination`'s
@@ -35,6 +39,7 @@
 !> one pass over the basis per Gram-Schmidt pass.  The fully fused three-sweep DGS is reached through `gpu_arnoldi_rdp`.
 module lightkrylov_gpu
     use, intrinsic :: iso_c_binding
+    use, intrinsic :: iso_fortran_env, only: error_unit
     use lightkrylov_hip_c
     use LightKrylov_Constants, only: dp
     use LightKrylov_Logger, only: stop_error, type_error
@@ -65,6 +70,7 @@ module lightkrylov_gpu
         integer(c_int) :: dtype = -1
         integer(c_int64_t) :: n = -1
         integer(c_intptr_t) :: owner = 0               !! address of the handle this column is registered to
+        integer(c_int64_t) :: gen = 0                  !! the column's generation when this handle was bound (lk_pool_column_info)
     contains
         procedure, private :: handle_assign
         generic :: assignment(=) => handle_assign
@@ -225,23 +231,54 @@ contains
         integer(c_int), intent(in) :: dtype
         integer(c_int64_t), intent(in) :: n
         integer(c_intptr_t) :: tag, reg
+        integer(c_int64_t) :: gen
         own = .false.
         if (.not. c_associated(h%buf)) return
         tag = transfer(c_loc(h), tag)
         if (h%owner /= tag .or. h%dtype /= dtype .or. h%n /= n) return
-        call chk(lk_pool_owner(ctx, h%buf, h%col, reg), 'handle_is_own')
-        own = (reg == tag)
+        call chk(lk_pool_column_info(ctx, h%buf, h%col, reg, gen), 'handle_is_own')
+        own = (reg == tag .and. gen == h%gen)
     end function
 
-    !> .true. when `h` points at a registered pool column (own or shared): safe to read
+    !> .true. when `h` points at a registered pool column (own or shared) that has not been handed out again since `h` was
+    !> bound: safe to read.  A bit copy whose source object died and was replaced at the same address (the source of
+    !> `allocate(b, source=dense_vector_gpu(x))` is such a temporary) fails the generation test: the caller stops with an
+    !> error instead of reading the new occupant's data.
     logical function handle_is_readable(h) result(ok)
         type(gpu_handle), intent(in) :: h
         integer(c_intptr_t) :: reg
+        integer(c_int64_t) :: gen
         ok = .false.
         if (.not. c_associated(h%buf)) return
-        call chk(lk_pool_owner(ctx, h%buf, h%col, reg), 'handle_is_readable')
-        ok = (reg /= 0)
+        call chk(lk_pool_column_info(ctx, h%buf, h%col, reg, gen), 'handle_is_readable')
+        ok = (reg /= 0 .and. gen == h%gen)
     end function
+
+    !> .true. when `h` points at a pool column that has been handed out AGAIN since `h` was bound (see handle_is_readable)
+    logical function handle_is_stale_copy(h) result(stale)
+        type(gpu_handle), intent(in) :: h
+        integer(c_intptr_t) :: reg
+        integer(c_int64_t) :: gen
+        stale = .false.
+        if (.not. c_associated(h%buf)) return
+        call chk(lk_pool_column_info(ctx, h%buf, h%col, reg, gen), 'handle_is_stale_copy')
+        stale = (reg /= 0 .and. gen /= h%gen)
+    end function
+
+    !> Stop unless `h` can be read: "stale bit copy" when its column has been handed out again since (see handle_is_readable),
+    !> "<what> holds no data" when it was never bound or the pool was released.
+    subroutine require_readable(h, what, procedure)
+        type(gpu_handle), intent(in) :: h
+        character(len=*), intent(in) :: what, procedure
+        character(len=*), parameter :: stale = ' is a stale bit copy: the object it was source-allocated from has been '// &
+            're-initialised or replaced; make independent copies by assignment (y = x), not by allocate(y, source=x)'
+        if (handle_is_readable(h)) return
+        if (handle_is_stale_copy(h)) then
+            write (error_unit, '(a)') this_module//' % '//procedure//': '//what//stale    ! stop_error logs the text only at debug level
+            call stop_error(what//stale, this_module, procedure)
+        end if
+        call stop_error(what//' holds no data', this_module, procedure)
+    end subroutine
 
     !> Make `h` own a column of shape (dtype, n); keep=.true. preserves what it could read before.
     subroutine handle_bind(h, dtype, n, keep)
@@ -251,7 +288,7 @@ contains
         logical, intent(in) :: keep
         type(c_ptr) :: fresh, old_buf
         integer(c_int) :: fresh_col, old_col
-        integer(c_intptr_t) :: tag
+        integer(c_intptr_t) :: tag, reg
         logical :: copy_old
         if (n <= 0) call stop_error('vector size not set (set %n or upload first)', this_module, 'bind')
         if (handle_is_own(h, dtype, n)) then
@@ -259,7 +296,12 @@ contains
             return
         end if
         copy_old = .false.
-        if (keep .and. h%dtype == dtype .and. h%n == n) copy_old = handle_is_readable(h)
+        if (keep .and. h%dtype == dtype .and. h%n == n) then
+            copy_old = handle_is_readable(h)
+            if (.not. copy_old .and. handle_is_stale_copy(h)) call stop_error( &
+                'stale bit copy: the object this vector was source-allocated from has been re-initialised; assign (y = x) instead', &
+                this_module, 'bind')
+        end if
         old_buf = h%buf; old_col = h%col
         tag = transfer(c_loc(h), tag)
         call chk(lk_pool_acquire(ctx, dtype, n, tag, fresh, fresh_col), 'bind')
@@ -268,6 +310,7 @@ contains
                 call chk(lk_vec_copy(fresh, fresh_col, old_buf, old_col), 'bind')
         end if
         h%buf = fresh; h%col = fresh_col; h%dtype = dtype; h%n = n; h%owner = tag
+        call chk(lk_pool_column_info(ctx, fresh, fresh_col, reg, h%gen), 'bind')
         last_n = int(n)
     end subroutine
 
@@ -276,11 +319,11 @@ contains
         class(gpu_handle), intent(inout), target :: lhs
         class(gpu_handle), intent(in) :: rhs
         if (.not. c_associated(rhs%buf)) then          ! unbound source: unbound copy
-            lhs%buf = c_null_ptr; lhs%col = -1; lhs%dtype = rhs%dtype; lhs%n = rhs%n; lhs%owner = 0
+            lhs%buf = c_null_ptr; lhs%col = -1; lhs%dtype = rhs%dtype; lhs%n = rhs%n; lhs%owner = 0; lhs%gen = 0
             return
         end if
         if (.not. handle_is_readable(rhs)) then        ! stale source (pool released): nothing to copy
-            lhs%buf = c_null_ptr; lhs%col = -1; lhs%dtype = rhs%dtype; lhs%n = rhs%n; lhs%owner = 0
+            lhs%buf = c_null_ptr; lhs%col = -1; lhs%dtype = rhs%dtype; lhs%n = rhs%n; lhs%owner = 0; lhs%gen = 0
             return
         end if
         select type (lhs)
@@ -339,7 +382,7 @@ contains
             ! dense_axpby's `if (.not. allocated(self%data)) allocate(self%data(m))` (AbstractVectors.fypp:521-524)
             if (.not. c_associated(self%h%buf)) self%n = vec%n
             if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'axpby')
-            if (.not. handle_is_readable(vec%h)) call stop_error("vec holds no data", this_module, 'axpby')
+            call require_readable(vec%h, 'vec', 'axpby')
             call handle_bind(self%h, LK_F64, int(self%n, c_int64_t), beta /= 0.0_dp)   ! beta == 0: old contents are not read
             call chk(lk_vec_axpby([alpha], vec%h%buf, vec%h%col, [beta], self%h%buf, self%h%col), 'axpby')
         class default
@@ -356,8 +399,8 @@ contains
         select type (vec)
         class is (dense_vector_gpu_rdp)
             if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'dot')
-            if (.not. (handle_is_readable(self%h) .and. handle_is_readable(vec%h))) &
-                call stop_error("vector holds no data", this_module, 'dot')
+            call require_readable(self%h, 'self', 'dot')
+            call require_readable(vec%h, 'vec', 'dot')
             call chk(lk_vec_dot(self%h%buf, self%h%col, vec%h%buf, vec%h%col, res), 'dot')
             alpha = res(1)
         class default
@@ -387,7 +430,7 @@ contains
     function gpu_ptr_in(self) result(p)
         class(dense_vector_gpu_rdp), intent(in) :: self
         type(c_ptr) :: p
-        if (.not. handle_is_readable(self%h)) call stop_error("vector holds no data", this_module, 'device_ptr_in')
+        call require_readable(self%h, 'vector', 'device_ptr_in')
         call chk(lk_vec_device_ptr(self%h%buf, self%h%col, LK_ACCESS_READ, p), 'device_ptr_in')
     end function
     function gpu_ptr_out(self) result(p)
@@ -400,7 +443,7 @@ contains
     function gpuz_ptr_in(self) result(p)
         class(dense_vector_gpu_cdp), intent(in) :: self
         type(c_ptr) :: p
-        if (.not. handle_is_readable(self%h)) call stop_error("vector holds no data", this_module, 'device_ptr_in')
+        call require_readable(self%h, 'vector', 'device_ptr_in')
         call chk(lk_vec_device_ptr(self%h%buf, self%h%col, LK_ACCESS_READ, p), 'device_ptr_in')
     end function
     function gpuz_ptr_out(self) result(p)
@@ -414,7 +457,7 @@ contains
     subroutine gpu_download(self, x)
         class(dense_vector_gpu_rdp), intent(in) :: self
         real(dp), intent(out), target :: x(:)
-        if (.not. handle_is_readable(self%h)) call stop_error("vector holds no data", this_module, 'download')
+        call require_readable(self%h, 'vector', 'download')
         call chk(lk_basis_download(self%h%buf, self%h%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'download')
     end subroutine
 
@@ -453,7 +496,7 @@ contains
         class is (dense_vector_gpu_cdp)
             if (.not. c_associated(self%h%buf)) self%n = vec%n
             if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'axpby')
-            if (.not. handle_is_readable(vec%h)) call stop_error("vec holds no data", this_module, 'axpby')
+            call require_readable(vec%h, 'vec', 'axpby')
             call handle_bind(self%h, LK_C128, int(self%n, c_int64_t), beta /= (0.0_dp, 0.0_dp))
             call chk(lk_vec_axpby([real(alpha, dp), aimag(alpha)], vec%h%buf, vec%h%col, [real(beta, dp), aimag(beta)], &
                                   self%h%buf, self%h%col), 'axpby')
@@ -471,8 +514,8 @@ contains
         select type (vec)
         class is (dense_vector_gpu_cdp)
             if (vec%n /= self%n) call stop_error("Inconsistent size between the two vectors.", this_module, 'dot')
-            if (.not. (handle_is_readable(self%h) .and. handle_is_readable(vec%h))) &
-                call stop_error("vector holds no data", this_module, 'dot')
+            call require_readable(self%h, 'self', 'dot')
+            call require_readable(vec%h, 'vec', 'dot')
             call chk(lk_vec_dot(self%h%buf, self%h%col, vec%h%buf, vec%h%col, res), 'dot')   ! conj on self, like dotc
             alpha = cmplx(res(1), res(2), kind=dp)
         class default
@@ -497,7 +540,7 @@ contains
     subroutine gpuz_download(self, x)
         class(dense_vector_gpu_cdp), intent(in) :: self
         complex(dp), intent(out), target :: x(:)
-        if (.not. handle_is_readable(self%h)) call stop_error("vector holds no data", this_module, 'download')
+        call require_readable(self%h, 'vector', 'download')
         call chk(lk_basis_download(self%h%buf, self%h%col, 1_c_int, c_loc(x), int(self%n, c_int64_t)), 'download')
     end subroutine
 
@@ -512,7 +555,7 @@ contains
         class is (dense_vector_gpu_rdp)
             select type (vec_out)
             class is (dense_vector_gpu_rdp)
-                if (.not. handle_is_readable(vec_in%h)) call stop_error("vec_in holds no data", this_module, procedure)
+                call require_readable(vec_in%h, 'vec_in', procedure)
                 vec_out%n = vec_in%n
                 call handle_bind(vec_out%h, LK_F64, int(vec_out%n, c_int64_t), .false.)
                 call chk(lk_linop_apply(op, trans, vec_in%h%buf, vec_in%h%col, vec_out%h%buf, vec_out%h%col), procedure)
@@ -534,7 +577,7 @@ contains
         class is (dense_vector_gpu_cdp)
             select type (vec_out)
             class is (dense_vector_gpu_cdp)
-                if (.not. handle_is_readable(vec_in%h)) call stop_error("vec_in holds no data", this_module, procedure)
+                call require_readable(vec_in%h, 'vec_in', procedure)
                 vec_out%n = vec_in%n
                 call handle_bind(vec_out%h, LK_C128, int(vec_out%n, c_int64_t), .false.)
                 call chk(lk_linop_apply(op, trans, vec_in%h%buf, vec_in%h%col, vec_out%h%buf, vec_out%h%col), procedure)

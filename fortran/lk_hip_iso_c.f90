@@ -249,6 +249,14 @@ module lightkrylov_hip_c
             integer(c_intptr_t), intent(out) :: owner_tag
             integer(c_int) :: rc
         end function
+        function lk_pool_column_info(ctx, slab, col, owner_tag, generation) bind(C, name="lk_pool_column_info") result(rc)
+            import :: c_int, c_ptr, c_intptr_t, c_int64_t
+            type(c_ptr), value :: ctx, slab
+            integer(c_int), value :: col
+            integer(c_intptr_t), intent(out) :: owner_tag
+            integer(c_int64_t), intent(out) :: generation
+            integer(c_int) :: rc
+        end function
         function lk_pool_release(ctx, slab, col) bind(C, name="lk_pool_release") result(rc)
             import :: c_int, c_ptr
             type(c_ptr), value :: ctx, slab

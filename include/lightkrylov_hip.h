@@ -118,7 +118,9 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * "dot_colwise" (default 1: DGS sweep 1 / innerprod one column at a time, panel_dot_cw; 0: all columns per tile) with
  * "cw_u" (16-byte loads per lane and column: 4, 8, 0 = by size) and "cw_grid_mult"; "xhy_mfma" (default 1: X^H Y with five or
  * more right-hand sides -- Gram, innerprod_matrix, block DGS -- in one pass over X on the FP64 matrix cores; 0: four
- * right-hand sides per pass on the vector units) and "xhy_small"; "gemm_mfma" likewise for the tall-skinny product. */
+ * right-hand sides per pass on the vector units) and "xhy_small"; "gemm_mfma" likewise for the tall-skinny product, from "gemm_mfma_min" output columns on (default 5; narrower
+ * products stream X through the vector units with 1 / 2 / 4 accumulators per lane); "gemm_store_policy" (cache policy of its
+ * output stores, as "store_policy"). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
 
 /* Lazy batching of the per-object path (tuning key "lazy", off by default).  When on, k consecutive
@@ -179,7 +181,9 @@ int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh
  * LightKrylov creates vectors one object at a time, by sourced allocation, polymorphic assignment and
  * intent(out) dummies, and never frees them explicitly (AbstractVectors.fypp:595-598, gmres.fypp:110-115,155;
  * SURVEY 8b "Ownership").  A plugin type therefore cannot own device memory through allocate/final; it asks
- * this pool for a COLUMN of a shared slab (a panel of `pool_slab_cols` columns, tuning key, default 160) keyed
+ * this pool for a COLUMN of a shared slab (a panel of `pool_slab_cols` columns, tuning key, default 160; a single-rank
+ * context takes fewer when that would exceed a quarter of the free memory, a row-sharded one never does -- the slab geometry
+ * must be the same on every rank, so there an allocation that does not fit FAILS with LK_ERR_NOMEM) keyed
  * by an owner tag -- the address of the Fortran object:
  *   lk_pool_acquire  returns the column already registered to `owner_tag` (an object that reappears at the
  *                    address of a dead one re-uses its column: temporaries such as linear_combination's `proj`
@@ -188,12 +192,18 @@ int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh
  *                    of one panel and the lazy per-object path (lk_lazy_stats) can batch it;
  *   lk_pool_owner    tag a column is registered to (0: free or not a pool column; `slab` is validated
  *                    against the pool before it is dereferenced, so stale handles are safe to ask about);
+ *   lk_pool_column_info  the same plus the column's GENERATION, which lk_pool_acquire increments every time it hands the
+ *                    column out (first use, re-use by tag, re-use after a release).  A plugin stores the generation in its
+ *                    handle: a bit copy of a handle whose source object has since died and been replaced at the same address
+ *                    (`allocate(b, source=dense_vector_gpu(x))` followed by another temporary) carries an old generation and
+ *                    is refused instead of silently reading the new occupant's data;
  *   lk_pool_release  returns one column; lk_pool_release_all destroys every slab (after a solver call);
  *   lk_pool_stats    out4 = {slabs, columns ever carved, columns currently registered, acquisitions served by
  *                    re-use}. */
 int lk_pool_acquire(lk_context_t ctx, int dtype, int64_t n_local, uint64_t owner_tag, lk_basis_t *slab,
                     int *col);
 int lk_pool_owner(lk_context_t ctx, lk_basis_t slab, int col, uint64_t *owner_tag);
+int lk_pool_column_info(lk_context_t ctx, lk_basis_t slab, int col, uint64_t *owner_tag, uint64_t *generation);
 int lk_pool_release(lk_context_t ctx, lk_basis_t slab, int col);
 int lk_pool_release_all(lk_context_t ctx);
 int lk_pool_stats(lk_context_t ctx, int64_t *out4);
@@ -243,7 +253,10 @@ int lk_gram(lk_basis_t Bx, int k, double *G);
 int lk_orthogonalize(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, int *info);
 /* double_gram_schmidt_step(y, X(:k), info, if_chk_orthonormal=.false., beta=h)
  * src/Krylov/gram_schmidt.fypp:12-57; interface src/Krylov/BaseKrylov.fypp:634-712.
- * Three fused panel sweeps (h1 = X^H y | y' = y - X h1, h2 = X^H y' | y'' = y' - X h2);
+ * Three fused panel sweeps (h1 = X^H y | y' = y - X h1, h2 = X^H y' | y'' = y' - X h2) for k <= 512 basis columns: 3k+4
+ * columns of traffic (129..512 columns: the lanes of a wave are split over column groups so that a block still holds all k
+ * columns of its tile); 513..2048 columns run as column panels of 512 on the device (4k - |last panel| columns, one host
+ * synchronisation), wider bases panel by panel with a host round trip each.
  * h = h1 + h2 on the host (k scalars, may be NULL).
  * norms[0..2] = ||y||, ||y'||, ||y''|| (may be NULL).  info = 1 when ||y'|| < atol_dp (the
  * reference's pass-2 zero-vector flag, gram_schmidt.fypp:126-127), else 0. */
@@ -301,7 +314,8 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
  * src/Krylov/arnoldi.fypp:8-76 (+ the 1-column qr_no_pivoting, src/Krylov/qr.fypp:116-167).
  * X: basis with m+1 columns; H: host (ldh x m) column-major array of the basis dtype;
  * kstart/kend 1-based inclusive; tol: breakdown tolerance (reference default atol_dp).
- * info = 0, or k when |H(k+1,k)| < tol (invariant subspace, loop exits). */
+ * info = 0, or k when |H(k+1,k)| < tol (invariant subspace, loop exits).  Steps up to 512 basis columns are enqueued
+ * asynchronously (one host synchronisation per call); beyond that one round trip per step. */
 int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend,
                double tol, int trans, int *info);
 
@@ -311,7 +325,7 @@ int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, i
  * re-orthogonalisation by a double Gram-Schmidt step without beta (:62); T(k+1, k) = ||X(k+1)||; beta < tol => info = k and
  * the loop exits WITHOUT scaling (:32-36), else X(k+1) is normalised.  All steps of a call are enqueued asynchronously
  * (device-side stop flag), one host synchronisation per call.  T: host (ldt x m) column-major array of the basis dtype;
- * only T(k-1:k+1, k) of each step is written.  kend <= 128. */
+ * only T(k-1:k+1, k) of each step is written.  kend <= 512. */
 int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, int kend, double tol, int *info);
 
 /* ---- Golub-Kahan bidiagonalisation -----------------------------------------------------------
@@ -320,7 +334,7 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
  * U(k+1) = A V(k), double Gram-Schmidt against U(:k), B(k+1, k) = beta = ||U(k+1)||, normalise (:45-58); a norm not above
  * tol => info = k and the loop exits without scaling.  All steps of a call are enqueued asynchronously (device-side stop flag
  * per half step), one host synchronisation per call.  U: kdim + 1 columns, V: >= kdim columns (two different bases); B: host
- * (ldb x kdim) column-major array of the basis dtype, only B(k, k) and B(k+1, k) are written.  kend <= 128, tol >= atol_dp. */
+ * (ldb x kdim) column-major array of the basis dtype, only B(k, k) and B(k+1, k) are written.  kend <= 512, tol >= atol_dp. */
 int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, int kstart, int kend, double tol, int *info);
 
 #ifdef __cplusplus

@@ -57,6 +57,7 @@ SIGNATURES = {
     "lk_basis_download": (_int, [_p, _int, _int, _p, _i64]),
     "lk_pool_acquire": (_int, [_p, _int, _i64, C.c_uint64, _pp, _ip]),
     "lk_pool_owner": (_int, [_p, _p, _int, C.POINTER(C.c_uint64)]),
+    "lk_pool_column_info": (_int, [_p, _p, _int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "lk_pool_release": (_int, [_p, _p, _int]),
     "lk_pool_release_all": (_int, [_p]),
     "lk_pool_stats": (_int, [_p, C.POINTER(_i64)]),

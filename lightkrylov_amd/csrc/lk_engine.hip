@@ -20,7 +20,8 @@ using namespace lk;
 namespace {
 
 constexpr double ATOL_DP = 1.0e-15;  // src/Constants.f90:35  atol_dp = 10**(-precision(1.0_dp))
-constexpr int KMAX_FUSED = 128;      // columns one fused sweep can hold (KC * NW)
+constexpr int KMAX_FUSED = 128;      // columns one fused sweep can hold (KC * NW) without the lane split
+constexpr int KMAX_WIDE = 512;       // ... with the lanes of a wave split 4 ways over column groups (panel_sweep's SC)
 constexpr int MAX_GRID = 4096;       // upper bound on sweep blocks (partial buffer stride)
 
 thread_local char g_err[512] = "";
@@ -74,6 +75,8 @@ struct lk_context_s {
     int update_grid_mult = 4;
     int gemm_grid_mult = 4;    // panel_gemm blocks per CU
     int gemm_mfma = 1;         // tall-skinny product on the FP64 matrix cores (0: FP64 VALU kernel)
+    int gemm_mfma_min = 5;     // ... for at least this many output columns; narrower products stream through the VALU kernel
+    int gemm_store_policy = 2; // cache policy of the product's output stores (as store_policy: 2 = sc1 write-through)
     int stream_two = 0;        // sweep 3 with two coefficient sets: barrier-free streaming kernel instead of the LDS/barrier one
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
@@ -164,7 +167,7 @@ struct lk_context_s {
     int guard_step = 0;
     double *step_red = nullptr;            // device: nsteps x RED_SECTIONS x RED_SECTION doubles
     double *step_red_host = nullptr;       // pinned mirror
-    int step_red_cap = 0;                  // steps the two buffers hold
+    int64_t step_red_cap = 0;              // doubles the two buffers hold
     int async_arnoldi = 1;                 // tuning key: 0 = one host round trip per step (the round-1 schedule)
     Guard guard() const { return Guard{guard_on ? stop_dev : nullptr, guard_step}; }
     // column pool (lk_pool_*): slabs handed out to per-object hosts
@@ -172,6 +175,7 @@ struct lk_context_s {
         lk_basis_t B = nullptr;
         int used = 0;                          // columns carved so far
         std::vector<uint64_t> owner;           // owner tag per column (0 = free)
+        std::vector<uint64_t> gen;             // generation per column: +1 every time lk_pool_acquire hands the column out
     };
     std::vector<PoolSlab> pool;
     std::map<uint64_t, std::pair<int, int>> pool_by_tag;   // owner tag -> (slab index, column)
@@ -232,6 +236,8 @@ struct lk_linop_s {
 namespace {
 
 constexpr int RED_SECTION = (KMAX_FUSED + 1) * 2;  // doubles per result section
+constexpr int RED_SECTION_WIDE = (KMAX_WIDE + 1) * 2;   // ... of a sweep over a wide basis (129..512 columns)
+inline int red_stride(int k) { return k <= KMAX_FUSED ? RED_SECTION : RED_SECTION_WIDE; }
 constexpr int RED_SECTIONS = 3;                     // h1 | h2 | ||y''||^2 of one vector DGS (also the per-step slot of lk_arnoldi)
 constexpr int RED_MULTI = 4;                        // sections one multi-RHS dot pass fills: a flat [4][k+1] buffer
 constexpr int RED_TOTAL = 2 * RED_MULTI + 1;        // sections of c->red: two such passes (block DGS keeps both on the device); the
@@ -245,7 +251,7 @@ struct ProfScope {
     ProfRec rec;
     bool ext = false;   // the launch itself carries the two events (hipExtLaunchKernelGGL): nothing is recorded on the stream
     ProfScope(lk_context_t ctx, const char *tag, double bytes, bool ext_launch = false) : c(ctx), on(ctx->prof), ext(ext_launch) {
-        if (on && c->prof_sweeps_only && strncmp(tag, "dgs_sweep", 9) != 0) on = false;
+        if (on && c->prof_sweeps_only && strncmp(tag, "dgs_sweep", 9) != 0 && strcmp(tag, "matvec") != 0) on = false;
         if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -337,18 +343,19 @@ int allreduce(lk_context_t c, double *dev, int64_t count) {
 // ---- sweep launcher ---------------------------------------------------------------------
 struct SweepCfg { int WC, kcw, grid; int64_t ntiles; };
 
-template <bool CPLX, int KC, int NW>
+template <bool CPLX, int KC, int NW, int SC = 1>
 SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n, int mult = 0) {
     SweepCfg s;
-    int wc = (k + KC - 1) / KC;  // waves needed across columns
+    int cg = (k + KC - 1) / KC;              // column groups needed (one per wave, or per lane group of a wave when SC > 1)
+    int wc = (cg + SC - 1) / SC;             // waves needed across columns
     if (wc < 1) wc = 1;
     int WC = 1;
     while (WC < wc) WC <<= 1;    // power of two so it divides NW
     if (WC > NW) WC = NW;
     s.WC = WC;
-    s.kcw = (k + WC - 1) / WC;
+    s.kcw = (k + WC * SC - 1) / (WC * SC);
     if (s.kcw < 1) s.kcw = 1;
-    const int64_t tile_rows = (int64_t)(NW / WC) * 64 * K<CPLX>::ROWS;
+    const int64_t tile_rows = (int64_t)(NW / WC) * (64 / SC) * K<CPLX>::ROWS;
     int64_t ntiles = (n + tile_rows - 1) / tile_rows;
     int64_t g = (int64_t)c->num_cu * (mult > 0 ? mult : c->grid_mult);
     if (g > ntiles) g = ntiles;
@@ -366,13 +373,14 @@ SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n, int mult = 0) {
 //   MODE 4: y'' = (y - X hin) - X hin2      (UPDATE, two coefficient sets; pairs with MODE 2, store = 0)
 // out == nullptr (update-only modes): the norm of the result is not wanted -- no finish kernel, and above all NO
 // all-reduce (the lazy flush runs at rank-dependent times; a collective there could mismatch across ranks).
-template <bool CPLX, int MODE, int KC = (CPLX ? 8 : 16), int NW = (CPLX ? 16 : 8)>
+template <bool CPLX, int MODE, int KC = (CPLX ? 8 : 16), int NW = (CPLX ? 16 : 8), int SC = 1>
 int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y, int64_t n, const double *hin,
                  const double *hin2, int store, double *out) {
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr bool UPDATE = MODE != 1, DOT = MODE <= 2;
-    static_assert(KC * NW == KMAX_FUSED, "fused capacity");
-    SweepCfg s = sweep_cfg<CPLX, KC, NW>(c, k, n, MODE == 2 ? c->grid_mult_s2 : (MODE == 4 ? c->grid_mult_s3 : 0));
+    static_assert(KC * NW * SC == KMAX_FUSED * SC && KMAX_FUSED * SC <= KMAX_WIDE, "fused capacity");
+    if (k > KC * NW * SC) return fail(LK_ERR_INVALID, "internal: sweep of %d columns on a block that holds %d", k, KC * NW * SC);
+    SweepCfg s = sweep_cfg<CPLX, KC, NW, SC>(c, k, n, MODE == 2 ? c->grid_mult_s2 : (MODE == 4 ? c->grid_mult_s3 : 0));
     // ALGORITHMIC bytes of the three-sweep schedule: k+1 | k+2 | k+2 columns
     const double bytes = (double)n * ED * 8.0 * (k + 1 + (UPDATE ? 1 : 0));
     int nblocks = s.grid;
@@ -425,11 +433,11 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
         } else {
             const int st = (store ? (1 | (c->store_policy << 1) | (c->store_split ? 8 : 0)) : 0) | (c->xcd_map ? 16 : 0);
             if (ps.on && ps.ext)
-                hipExtLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream,
+                hipExtLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4, SC>), dim3(s.grid), dim3(NW * 64), 0, c->stream,
                                       ps.rec.e0, ps.rec.e1, 0, X, ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st,
                                       c->guard());
             else
-                hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
+                hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4, SC>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
                                    ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st, c->guard());
         }
     }
@@ -448,6 +456,17 @@ template <int MODE>
 int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const double *hin2, int store, double *out) {
     lk_context_t c = Bx->ctx;
     const double *X = Bx->col(c0);
+    if (k > KMAX_FUSED) {
+        // wide basis (129..512 columns): 8 waves x 16 columns with the lanes of every wave split 2 / 4 ways over column
+        // groups, so that the block still holds ALL k columns of its (shorter) tile: one pass over X per sweep.  The split
+        // depends on k only, so the three sweeps of one DGS share it (sweep 3 re-forms y' in sweep 2's order).
+        const bool two = k <= 2 * KMAX_FUSED;
+        if (Bx->dtype == LK_C128)
+            return two ? launch_sweep<true, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
+                       : launch_sweep<true, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        return two ? launch_sweep<false, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
+                   : launch_sweep<false, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+    }
     if (Bx->dtype == LK_C128) {
         // complex block shape: 16 waves x 8 columns for narrow bases, 8 waves x 16 columns beyond 32 columns (half the
         // waves per barrier and per LDS exchange: +1-9 % per sweep at k >= 64, A/B in DESIGN.md; "cplx_wide" = threshold, 0 disables).
@@ -622,27 +641,45 @@ int gemm_launch_valu(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q
     lk_context_t c = Bx->ctx;
     const bool cp = Bx->dtype == LK_C128;
     const int ED = Bx->ed();
-    const int total = (int)gemm_packed_doubles(k, q, ED);
+    // accumulators per lane: the smallest of 1 / 2 / 4 / 8 / 16 that holds the product (q <= 16), 16 beyond
+    const int QB = q <= 1 ? 1 : (q <= 2 ? 2 : (q <= 4 ? 4 : (q <= 8 ? 8 : GEMM_QB)));
+    const int total = ((q + QB - 1) / QB) * k * QB * ED;
     hipLaunchKernelGGL(pack_coef, dim3((total + 255) / 256 > 64 ? 64 : (total + 255) / 256), dim3(256), 0, c->stream, Cdev, ldc, k, q,
-                       GEMM_QB, ED, sign, pack);
+                       QB, ED, sign, pack);
     HIPCHK(hipGetLastError());
-    for (int q0 = 0; q0 < q; q0 += GEMM_QB * GEMM_NQG) {
-        const int qn = (q - q0) < GEMM_QB * GEMM_NQG ? (q - q0) : GEMM_QB * GEMM_NQG;
-        const int groups = (qn + GEMM_QB - 1) / GEMM_QB;
+    for (int q0 = 0; q0 < q; q0 += QB * GEMM_NQG) {
+        const int qn = (q - q0) < QB * GEMM_NQG ? (q - q0) : QB * GEMM_NQG;
+        const int groups = (qn + QB - 1) / QB;
         const int QGB = groups <= 1 ? 1 : (groups == 2 ? 2 : 4);
         const int64_t tile_rows = (int64_t)(4 / QGB) * 64 * (cp ? 1 : 2);
         int64_t g = (Bx->n + tile_rows - 1) / tile_rows;
         const int64_t cap = (int64_t)c->num_cu * c->gemm_grid_mult;
         if (g > cap) g = cap;
         if (g < 1) g = 1;
-        const double *Cp = pack + (int64_t)(q0 / GEMM_QB) * k * GEMM_QB * ED;
+        const double *Cp = pack + (int64_t)(q0 / QB) * k * QB * ED;
         ProfScope ps(c, "lincomb", (double)Bx->n * ED * 8.0 * (k + qn * (accumulate ? 2 : 1)));
-        if (cp)
-            hipLaunchKernelGGL((panel_gemm<true, 4, GEMM_QB>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, k,
-                               By->col(jy0 + q0), By->ld, qn, Cp, Bx->n, accumulate, QGB);
-        else
-            hipLaunchKernelGGL((panel_gemm<false, 8, GEMM_QB>), dim3((unsigned)g), dim3(256), 0, c->stream, Bx->col(c0), Bx->ld, k,
-                               By->col(jy0 + q0), By->ld, qn, Cp, Bx->n, accumulate, QGB);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(256), 0, c->stream, (const double *)Bx->col(c0), Bx->ld, k, By->col(jy0 + q0), By->ld, qn,
+                               Cp, Bx->n, accumulate, QGB, c->gemm_store_policy);
+        };
+        // columns in flight per lane: 16 (real) / 8 (complex) loads of 16 B for the narrow shapes, half that beside 8-16 accumulators
+        if (cp) {
+            switch (QB) {
+            case 1: go(&panel_gemm<true, 8, 1>); break;
+            case 2: go(&panel_gemm<true, 8, 2>); break;
+            case 4: go(&panel_gemm<true, 8, 4>); break;
+            case 8: go(&panel_gemm<true, 4, 8>); break;
+            default: go(&panel_gemm<true, 4, GEMM_QB>);
+            }
+        } else {
+            switch (QB) {
+            case 1: go(&panel_gemm<false, 16, 1>); break;
+            case 2: go(&panel_gemm<false, 16, 2>); break;
+            case 4: go(&panel_gemm<false, 16, 4>); break;
+            case 8: go(&panel_gemm<false, 8, 8>); break;
+            default: go(&panel_gemm<false, 8, GEMM_QB>);
+            }
+        }
         HIPCHK(hipGetLastError());
     }
     return LK_OK;
@@ -663,7 +700,8 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     const int64_t cap = (int64_t)c->num_cu * (NG >= 8 ? 1 : (NG >= 4 && CPLX ? 2 : c->gemm_grid_mult));
     if (g > cap) g = cap;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate);
+    hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                       c->gemm_store_policy);
     HIPCHK(hipGetLastError());
     return LK_OK;
 }
@@ -709,8 +747,9 @@ int gemm_launch_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q
 
 int gemm_launch(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, const double *Cdev, int64_t ldc, double sign,
                 int accumulate, double *pack) {
-    // the MFMA kernel needs >= 2 useful output groups to beat the VALU one's one-wave-per-16-outputs layout on tiny q
-    if (Bx->ctx->gemm_mfma && q >= 2) return gemm_launch_mfma(Bx, c0, k, By, jy0, q, Cdev, ldc, sign, accumulate, pack);
+    // narrow products (q < gemm_mfma_min) stream X through the VALU kernel with q accumulators per lane; wider ones go to the
+    // matrix cores (crossover from profiles/r03_lincomb.jsonl)
+    if (Bx->ctx->gemm_mfma && q >= Bx->ctx->gemm_mfma_min) return gemm_launch_mfma(Bx, c0, k, By, jy0, q, Cdev, ldc, sign, accumulate, pack);
     return gemm_launch_valu(Bx, c0, k, By, jy0, q, Cdev, ldc, sign, accumulate, pack);
 }
 
@@ -734,10 +773,10 @@ int dot_device(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out_dev) {
     return allreduce(c, out_dev, 2);
 }
 
-int fetch(lk_context_t c, int section0, int nsections) {
+int fetch(lk_context_t c, int section0, int nsections, int stride = RED_SECTION) {
     // copy result sections to the pinned mirror and wait
-    HIPCHK(hipMemcpyAsync(c->red_host + (size_t)section0 * RED_SECTION, c->red + (size_t)section0 * RED_SECTION,
-                          (size_t)nsections * RED_SECTION * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->red_host + (size_t)section0 * stride, c->red + (size_t)section0 * stride,
+                          (size_t)nsections * stride * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->prof) prof_collect(c);
     return LK_OK;
@@ -899,11 +938,12 @@ int fused_sub_with_dots(lk_context_t c) {
 
 // Core of double_gram_schmidt_step for one vector; results stay in c->red (device):
 //   section 0: h1[0..k), nrm2(y)    section 1: h2[0..k), nrm2(y')   section 2 (slot k): nrm2(y'')
-int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass, double *red_base = nullptr) {
+int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass, double *red_base = nullptr, int stride = 0) {
     lk_context_t c = Bx->ctx;
     double *base = red_base ? red_base : c->red;
-    double *r0 = base, *r1 = base + RED_SECTION, *r2 = base + 2 * RED_SECTION;
-    if (k <= KMAX_FUSED) {
+    if (!stride) stride = red_stride(k);
+    double *r0 = base, *r1 = base + stride, *r2 = base + 2 * stride;
+    if (k <= KMAX_WIDE) {
         LKCHK((sweepm<1>(Bx, 0, k, y, nullptr, nullptr, 1, r0)));    // h1 = X^H y ; ||y||^2
         if (two_pass && c->recompute_update) {
             LKCHK((sweepm<2>(Bx, 0, k, y, r0, nullptr, 0, r1)));     // y' = y - X h1 (registers only); h2 = X^H y'; ||y'||^2
@@ -916,7 +956,7 @@ int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass, double *red_base 
         }
         return LK_OK;
     }
-    return fail(LK_ERR_INVALID, "internal: dgs_device called with k=%d > %d", k, KMAX_FUSED);
+    return fail(LK_ERR_INVALID, "internal: dgs_device called with k=%d > %d", k, KMAX_WIDE);
 }
 
 }  // namespace
@@ -952,9 +992,10 @@ int lk_init(int device, void *stream, lk_context_t *ctx) {
             c->own_stream = true;
         }
         HIPCHK(hipMalloc((void **)&c->partial, (size_t)PARTIAL_SECTIONS * RED_SECTION * MAX_GRID * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&c->red, (size_t)RED_TOTAL * RED_SECTION * sizeof(double)));
-        HIPCHK(hipMemsetAsync(c->red, 0, (size_t)RED_TOTAL * RED_SECTION * sizeof(double), c->stream));
-        HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)RED_TOTAL * RED_SECTION * sizeof(double), hipHostMallocDefault));
+        // sized for the wide layouts too: 9 sections of RED_SECTION_WIDE (the narrow layouts use the head of the same buffer)
+        HIPCHK(hipMalloc((void **)&c->red, (size_t)RED_TOTAL * RED_SECTION_WIDE * sizeof(double)));
+        HIPCHK(hipMemsetAsync(c->red, 0, (size_t)RED_TOTAL * RED_SECTION_WIDE * sizeof(double), c->stream));
+        HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)RED_TOTAL * RED_SECTION_WIDE * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **)&c->coef, (size_t)KMAX_FUSED * 2 * sizeof(double)));
         HIPCHK(hipHostMalloc((void **)&c->coef_host, (size_t)KMAX_FUSED * 2 * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **)&c->stop_dev, sizeof(int)));
@@ -1101,6 +1142,12 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "gemm_mfma")) { c->gemm_mfma = value != 0; return LK_OK; }
+    if (!strcmp(key, "gemm_mfma_min")) { c->gemm_mfma_min = value < 1 ? 1 : value; return LK_OK; }
+    if (!strcmp(key, "gemm_store_policy")) {
+        if (value < 0 || value > 3) return fail(LK_ERR_INVALID, "gemm_store_policy must be in [0,3]");
+        c->gemm_store_policy = value;
+        return LK_OK;
+    }
     if (!strcmp(key, "gemm_grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "gemm_grid_mult must be in [1,16]");
         c->gemm_grid_mult = value;
@@ -1203,6 +1250,7 @@ int lk_basis_destroy(lk_basis_t B) {
         std::lock_guard<std::mutex> lock(g_ctx_mu);
         if (g_live_ctx.count(B->ctx)) {          // a queued update may still target / read this panel
             lk_context_t c = B->ctx;
+            DevGuard dev_guard(c);               // the flush below launches on c->stream: run it on the context's device
             auto &q = c->queue;
             // (a non-owning handle is a VIEW of memory that lives on: what is pending there must be written)
             const bool only_target = B->own && q.active && q.zeroed && q.By == B && q.Bx != B && !(c->sub.active && c->sub.By == B);
@@ -1295,6 +1343,7 @@ int lk_pool_acquire(lk_context_t c, int dtype, int64_t n_local, uint64_t tag, lk
         const int si = it->second.first, cj = it->second.second;
         if (matches(si)) {                                   // the object that lived at this address is gone: re-use
             *slab = c->pool[si].B; *col = cj;
+            c->pool[si].gen[cj] += 1;                        // bit copies of the previous occupant's handle are stale from here on
             c->pool_stats[1] += 1;
             return LK_OK;
         }
@@ -1307,6 +1356,7 @@ int lk_pool_acquire(lk_context_t c, int dtype, int64_t n_local, uint64_t tag, lk
         const int si = f->first, cj = f->second;
         c->pool_free.erase(f);
         c->pool[si].owner[cj] = tag;
+        c->pool[si].gen[cj] += 1;
         c->pool_by_tag[tag] = {si, cj};
         *slab = c->pool[si].B; *col = cj;
         c->pool_stats[1] += 1;
@@ -1316,23 +1366,38 @@ int lk_pool_acquire(lk_context_t c, int dtype, int64_t n_local, uint64_t tag, lk
     for (int i = (int)c->pool.size() - 1; i >= 0; --i)
         if (matches(i) && c->pool[i].used < c->pool[i].B->ncols) { si = i; break; }
     if (si < 0) {
-        // new slab: pool_slab_cols columns, fewer when that would take more than a quarter of the free memory
+        // new slab: pool_slab_cols columns.  A single-rank context takes fewer when that would exceed a quarter of the free
+        // memory.  A row-sharded context (nranks > 1) NEVER derives the geometry from its own free memory: that differs from
+        // rank to rank, V(k) would fall into a second slab at a different k on different ranks, and the lazy path's batched
+        // sweeps (column counts from the slab's written columns) would issue all-reduces of different lengths.  There the
+        // slab has exactly pool_slab_cols columns on every rank, and an allocation that does not fit fails loudly.
         int ncols = c->pool_slab_cols;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        if (c->nranks == 1 && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const double colbytes = (double)(n_local > 0 ? n_local : 1) * (dtype == LK_C128 ? 16.0 : 8.0);
             const double fit = 0.25 * (double)free_b / colbytes;
             if (fit < ncols) ncols = fit < 8.0 ? 8 : (int)fit;
         }
         lk_context_s::PoolSlab ps;
-        LKCHK(lk_basis_create(c, dtype, n_local, ncols, &ps.B));
+        {
+            const int rc_slab = lk_basis_create(c, dtype, n_local, ncols, &ps.B);
+            if (rc_slab != LK_OK && c->nranks > 1) {
+                char keep[sizeof(g_err)];
+                memcpy(keep, g_err, sizeof(keep));
+                return fail(rc_slab, "lk_pool_acquire: a slab of pool_slab_cols = %d columns of %lld rows does not fit on rank %d (%.400s); "
+                            "set the SAME smaller pool_slab_cols on every rank (lk_set_tuning)", ncols, (long long)n_local, c->rank, keep);
+            }
+            LKCHK(rc_slab);
+        }
         ps.owner.assign((size_t)ncols, 0);
+        ps.gen.assign((size_t)ncols, 0);
         c->pool.push_back(ps);
         si = (int)c->pool.size() - 1;
     }
     auto &ps = c->pool[si];
     const int cj = ps.used++;
     ps.owner[cj] = tag;
+    ps.gen[cj] += 1;
     c->pool_by_tag[tag] = {si, cj};
     c->pool_stats[0] += 1;
     *slab = ps.B; *col = cj;
@@ -1348,8 +1413,20 @@ int lk_pool_owner(lk_context_t c, lk_basis_t slab, int col, uint64_t *tag) {
     return LK_OK;
 }
 
+int lk_pool_column_info(lk_context_t c, lk_basis_t slab, int col, uint64_t *tag, uint64_t *generation) {
+    if (!c) return fail(LK_ERR_INVALID, "lk_pool_column_info: null context");
+    if (tag) *tag = 0;
+    if (generation) *generation = 0;
+    const int si = pool_find_slab(c, slab);
+    if (si < 0 || col < 0 || col >= c->pool[si].used) return LK_OK;
+    if (tag) *tag = c->pool[si].owner[col];
+    if (generation) *generation = c->pool[si].gen[col];
+    return LK_OK;
+}
+
 int lk_pool_release(lk_context_t c, lk_basis_t slab, int col) {
     if (!c) return fail(LK_ERR_INVALID, "lk_pool_release: null context");
+    DevGuard dev_guard(c);
     const int si = pool_find_slab(c, slab);
     if (si < 0 || col < 0 || col >= c->pool[si].used) return fail(LK_ERR_INVALID, "lk_pool_release: not a pool column");
     const uint64_t tag = c->pool[si].owner[col];
@@ -1674,13 +1751,18 @@ static int innerprod_impl(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, d
     }
     for (int j = 0; j < p; j += 4) {
         const int pn = (p - j) < 4 ? (p - j) : 4;
+        if (pn == 1) {                                 // one vector: up to KMAX_WIDE columns per sweep
+            for (int c0 = 0; c0 < k; c0 += KMAX_WIDE) {
+                const int kk = (k - c0) < KMAX_WIDE ? (k - c0) : KMAX_WIDE;
+                LKCHK((sweepm<1>(Bx, c0, kk, By->col(jy0 + j), nullptr, nullptr, 0, c->red)));
+                LKCHK(fetch(c, 0, 1, red_stride(kk)));
+                memcpy(M + ((size_t)j * k + c0) * ED, c->red_host, (size_t)kk * ED * sizeof(double));
+            }
+            continue;
+        }
         for (int c0 = 0; c0 < k; c0 += KMAX_FUSED) {
             const int kk = (k - c0) < KMAX_FUSED ? (k - c0) : KMAX_FUSED;
-            if (pn == 1) {
-                LKCHK((sweepm<1>(Bx, c0, kk, By->col(jy0 + j), nullptr, nullptr, 0, c->red)));
-                LKCHK(fetch(c, 0, 1));
-                memcpy(M + ((size_t)j * k + c0) * ED, c->red_host, (size_t)kk * ED * sizeof(double));
-            } else {                                   // up to four columns of Y per pass over X
+            {                                   // up to four columns of Y per pass over X
                 LKCHK(dots_p(Bx, c0, kk, By, jy0 + j, pn));
                 LKCHK(fetch(c, 0, RED_MULTI));
                 for (int q = 0; q < pn; ++q)
@@ -1750,32 +1832,34 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
     }
     double n0 = 0, n1 = 0, n2 = 0;
     ProfScope ps(c, "dgs", (double)Bx->n * ED * 8.0 * (two_pass ? (3.0 * k + 5.0) : (2.0 * k + 3.0)));
-    if (k <= KMAX_FUSED) {
+    if (k <= KMAX_WIDE) {
+        const int rs = red_stride(k);
         LKCHK(dgs_device(Bx, k, y, two_pass));
         const int last = two_pass ? 2 : 1;
         if (flags & LK_DGS_NORMALIZE)
-            LKCHK(scal_launch(By, jy, 1.0, 0.0, c->red + last * RED_SECTION + (size_t)k * ED, ATOL_DP));
+            LKCHK(scal_launch(By, jy, 1.0, 0.0, c->red + last * rs + (size_t)k * ED, ATOL_DP));
         ps.end();
-        LKCHK(fetch(c, 0, 3));
-        const double *r0 = c->red_host, *r1 = c->red_host + RED_SECTION, *r2 = c->red_host + 2 * RED_SECTION;
+        LKCHK(fetch(c, 0, 3, rs));
+        const double *r0 = c->red_host, *r1 = c->red_host + rs, *r2 = c->red_host + 2 * rs;
         if (h)
             for (int i = 0; i < k * ED; ++i) h[i] = two_pass ? (r0[i] + r1[i]) : r0[i];   // gram_schmidt.fypp:49
         n0 = r0[k * ED];
         n1 = r1[k * ED];
         n2 = two_pass ? r2[k * ED] : n1;
-    } else if (k <= 4 * KMAX_FUSED) {
-        // wide basis, up to four column panels of KMAX_FUSED: everything stays on the device, ONE copy + synchronisation.
+    } else if (k <= 4 * KMAX_WIDE) {
+        // very wide basis, up to four column panels of KMAX_WIDE: everything stays on the device, ONE copy + synchronisation.
         //   sweep 1 : h1_p = X_p^H y for every panel                                   (k columns)
         //   pass B  : y' = y - X h1 -- update-only sweeps for all panels but the last, whose sweep is the fused update + dot
         //             (h2 of that panel, ||y'||^2); then dot sweeps of the OTHER panels against the finished y'   (2k - |last| columns)
         //   pass C  : y'' = y' - X h2, panel by panel, ||y''||^2 from the last                      (k columns)
         // = 4k - |last panel| columns against 4k (+ a host round trip per panel) for the schedule below.
-        const int npan = (k + KMAX_FUSED - 1) / KMAX_FUSED, last = npan - 1;
-        auto c0 = [&](int p) { return p * KMAX_FUSED; };
-        auto kk = [&](int p) { return (k - c0(p)) < KMAX_FUSED ? (k - c0(p)) : KMAX_FUSED; };
-        auto r1 = [&](int p) { return c->red + (size_t)p * RED_SECTION; };
-        auto r2 = [&](int p) { return c->red + (size_t)(npan + p) * RED_SECTION; };
-        double *r3 = c->red + (size_t)(2 * npan) * RED_SECTION;
+        const int npan = (k + KMAX_WIDE - 1) / KMAX_WIDE, last = npan - 1;
+        constexpr int RS = RED_SECTION_WIDE;
+        auto c0 = [&](int p) { return p * KMAX_WIDE; };
+        auto kk = [&](int p) { return (k - c0(p)) < KMAX_WIDE ? (k - c0(p)) : KMAX_WIDE; };
+        auto r1 = [&](int p) { return c->red + (size_t)p * RS; };
+        auto r2 = [&](int p) { return c->red + (size_t)(npan + p) * RS; };
+        double *r3 = c->red + (size_t)(2 * npan) * RS;
         for (int p = 0; p < npan; ++p) LKCHK((sweepm<1>(Bx, c0(p), kk(p), y, nullptr, nullptr, 0, r1(p))));
         if (two_pass) {
             for (int p = 0; p < last; ++p) LKCHK((sweepm<3>(Bx, c0(p), kk(p), y, r1(p), nullptr, 1, nullptr)));
@@ -1789,7 +1873,7 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
         }
         if (flags & LK_DGS_NORMALIZE) LKCHK(scal_launch(By, jy, 1.0, 0.0, r3 + (size_t)kk(last) * ED, ATOL_DP));
         ps.end();
-        LKCHK(fetch(c, 0, 2 * npan + 1));
+        LKCHK(fetch(c, 0, 2 * npan + 1, RS));
         auto host = [&](double *dev) { return c->red_host + (dev - c->red); };
         if (h)
             for (int p = 0; p < npan; ++p)
@@ -1996,6 +2080,13 @@ int lk_linop_lap5_create_sharded(lk_context_t c, int64_t N, int64_t j0, int64_t 
     lk_linop_t o = new lk_linop_s();
     o->ctx = c; o->kind = OP_LAP5; o->dtype = LK_F64; o->n = nj * N; o->N = N; o->NJ = nj;
     o->has_lo = j0 > 0; o->has_hi = j0 + nj < N;
+    // the halo exchange addresses its peers by RANK ORDER (rank - 1 below, rank + 1 above): a partition that does not follow
+    // it would skip a send on one side and leave the neighbour waiting
+    if (c->nranks > 1 && (o->has_lo != (c->rank > 0) || o->has_hi != (c->rank < c->nranks - 1))) {
+        delete o;
+        return fail(LK_ERR_INVALID, "lk_linop_lap5_create_sharded: grid lines [%lld, %lld) of %lld on rank %d/%d do not follow rank order "
+                    "(rank r must own the r-th consecutive block)", (long long)j0, (long long)(j0 + nj), (long long)N, c->rank, c->nranks);
+    }
     if (o->has_lo || o->has_hi) {
         hipError_t e = hipMalloc((void **)&o->halo, (size_t)2 * N * sizeof(double));
         if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
@@ -2018,6 +2109,11 @@ int lk_linop_gl_create_sharded(lk_context_t c, int64_t n_global, int64_t row0, i
     o->ctx = c; o->kind = OP_GL; o->dtype = LK_C128; o->n = n_local; o->tau = tau; o->nsub = nsub;
     o->row0 = row0; o->n_global = n_global;
     o->has_lo = row0 > 0; o->has_hi = row0 + n_local < n_global;
+    if (c->nranks > 1 && (o->has_lo != (c->rank > 0) || o->has_hi != (c->rank < c->nranks - 1))) {
+        delete o;
+        return fail(LK_ERR_INVALID, "lk_linop_gl_create_sharded: rows [%lld, %lld) of %lld on rank %d/%d do not follow rank order "
+                    "(rank r must own the r-th consecutive block)", (long long)row0, (long long)(row0 + n_local), (long long)n_global, c->rank, c->nranks);
+    }
     o->gl[0] = dx; o->gl[1] = 0.5 * dx * (double)(n_global + 1);   // L = dx (n+1), x = linspace(-L/2, L/2, n+2)
     o->gl[2] = nu[0]; o->gl[3] = nu[1]; o->gl[4] = gamma[0]; o->gl[5] = gamma[1]; o->gl[6] = mu_c; o->gl[7] = mu2;
     hipError_t e = hipMalloc((void **)&o->wk, ((size_t)3 * n_local * 2 + 8) * sizeof(double));
@@ -2145,14 +2241,26 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
     const bool cp = op->dtype == LK_C128;
     const int64_t n = op->n;
     const int64_t nv = n * Bx->ed() / 2 + 1;
-    ProfScope ps(c, "matvec", 0.0);
+    // algorithmic bytes of the operator (diagonal: d, x read, y written; generated diagonal: x read, y written); 0 = not priced
+    const double mv_bytes = op->kind == OP_DIAG ? 3.0 * n * Bx->ed() * 8.0 : (op->kind == OP_DIAG_LIN ? 2.0 * n * 8.0 : 0.0);
+    // the diagonal operators (one kernel) carry their two events on the dispatch itself, like the sweeps: no marker packets
+    const bool one_kernel = op->kind == OP_DIAG || op->kind == OP_DIAG_LIN;
+    ProfScope ps(c, "matvec", mv_bytes, one_kernel && c->prof_ext);
     switch (op->kind) {
     case OP_DIAG:
+        if (ps.on && ps.ext) {
+            if (cp) hipExtLaunchKernelGGL(k_diag<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, ps.rec.e0, ps.rec.e1, 0, (const double *)op->dev, x, y, n, (int)(trans == LK_OP_H), c->guard());
+            else hipExtLaunchKernelGGL(k_diag<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, ps.rec.e0, ps.rec.e1, 0, (const double *)op->dev, x, y, n, 0, c->guard());
+            break;
+        }
         if (cp) hipLaunchKernelGGL(k_diag<true>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->dev, x, y, n, trans == LK_OP_H, c->guard());
         else hipLaunchKernelGGL(k_diag<false>, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->dev, x, y, n, 0, c->guard());
         break;
     case OP_DIAG_LIN:
-        hipLaunchKernelGGL(k_diag_linspace, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->d0, op->dstep, op->row0, x, y, n, c->guard());
+        if (ps.on && ps.ext)
+            hipExtLaunchKernelGGL(k_diag_linspace, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, ps.rec.e0, ps.rec.e1, 0, op->d0, op->dstep, op->row0, x, y, n, c->guard());
+        else
+            hipLaunchKernelGGL(k_diag_linspace, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->d0, op->dstep, op->row0, x, y, n, c->guard());
         break;
     case OP_DENSE:
         if (trans == LK_OP_N) {
@@ -2278,26 +2386,29 @@ static int arnoldi_step_sync(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh,
     return LK_OK;
 }
 
-static int ensure_step_buffers(lk_context_t c, int nsteps) {
-    if (c->step_red_cap >= nsteps) return LK_OK;
+// per-step result slots of an asynchronous batch: nsteps x RED_SECTIONS sections of `stride` doubles (red_stride(last step))
+static int ensure_step_buffers(lk_context_t c, int nsteps, int stride) {
+    const int64_t need = (int64_t)nsteps * RED_SECTIONS * stride;
+    if (c->step_red_cap >= need) return LK_OK;
     if (c->step_red) HIPCHK(hipFree(c->step_red));
     if (c->step_red_host) HIPCHK(hipHostFree(c->step_red_host));
     c->step_red = nullptr; c->step_red_host = nullptr; c->step_red_cap = 0;
-    const size_t bytes = (size_t)nsteps * RED_SECTIONS * RED_SECTION * sizeof(double);
+    const size_t bytes = (size_t)need * sizeof(double);
     HIPCHK(hipMalloc((void **)&c->step_red, bytes));
     HIPCHK(hipHostMalloc((void **)&c->step_red_host, bytes, hipHostMallocDefault));
-    c->step_red_cap = nsteps;
+    c->step_red_cap = need;
     return LK_OK;
 }
 
-// Steps [k0, k1] (all <= KMAX_FUSED) enqueued back to back with NO host round trip: operator, three fused sweeps and
+// Steps [k0, k1] (all <= KMAX_WIDE) enqueued back to back with NO host round trip: operator, three fused sweeps and
 // the normalise of step s write their reduction results into step slot s - k0; the normalise kernel raises the device
 // stop flag on breakdown (||y''|| < max(tol, atol_dp)) or NaN, which turns every kernel of a later step into a
 // no-op.  One D2H copy + one synchronisation per batch.  *done = last step whose results are valid.
 static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, double tol, int trans, int *done) {
     lk_context_t c = X->ctx;
     const int nsteps = k1 - k0 + 1;
-    LKCHK(ensure_step_buffers(c, nsteps));
+    const int rs = red_stride(k1);                  // one section size for every step of the batch
+    LKCHK(ensure_step_buffers(c, nsteps, rs));
     HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
     const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
     const int ED = X->ed();
@@ -2306,11 +2417,11 @@ static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
     int rc = LK_OK;
     for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
         c->guard_step = k;
-        double *slot = c->step_red + (size_t)(k - k0) * RED_SECTIONS * RED_SECTION;
+        double *slot = c->step_red + (size_t)(k - k0) * RED_SECTIONS * rs;
         rc = lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, k - 1, X, k);
         if (rc != LK_OK) break;
         c->span_first = nullptr;
-        rc = dgs_device(X, k, X->col(k), true, slot);
+        rc = dgs_device(X, k, X->col(k), true, slot, rs);
         if (rc != LK_OK) break;
         if (c->prof && c->span_first) {          // "dgs" = first sweep's start .. last sweep's stop, no events of its own
             ProfRec span;
@@ -2318,13 +2429,13 @@ static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
             span.bytes = (double)X->n * ED * 8.0 * (3.0 * k + 5.0);
             c->prof_pending.push_back(span);
         }
-        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * RED_SECTION + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
+        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
     }
     c->guard_on = false;
     c->guard_step = 0;
     c->prof_sweeps_only = false;
     LKCHK(rc);
-    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)nsteps * RED_SECTIONS * RED_SECTION * sizeof(double),
+    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)nsteps * RED_SECTIONS * rs * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->stop_host, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2334,14 +2445,15 @@ static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
     return LK_OK;
 }
 
-// Lanczos steps [k0, k1] (all <= KMAX_FUSED) enqueued back to back, as arnoldi_batch_async: operator; the two local
+// Lanczos steps [k0, k1] (all <= KMAX_WIDE) enqueued back to back, as arnoldi_batch_async: operator; the two local
 // orthogonalisations of update_tridiag_matrix (lanczos.fypp:57-60) -- each T(i, k) = X(i)%dot(X(k+1)) with its
 // X(k+1)%axpby(-T(i, k), X(i), 1) is a one-column Gram-Schmidt pass: dot sweep, coefficient left on the device, update sweep --;
 // the full re-orthogonalisation (three fused sweeps); the normalise kernel with the device-side stop flag.
 static int lanczos_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, double tol, int *done) {
     lk_context_t c = X->ctx;
     const int nsteps = k1 - k0 + 1;
-    LKCHK(ensure_step_buffers(c, nsteps));
+    const int rs = red_stride(k1);
+    LKCHK(ensure_step_buffers(c, nsteps, rs));
     if (c->lz_cap < nsteps) {
         if (c->lz_red) HIPCHK(hipFree(c->lz_red));
         if (c->lz_red_host) HIPCHK(hipHostFree(c->lz_red_host));
@@ -2359,7 +2471,7 @@ static int lanczos_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
     int rc = LK_OK;
     for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
         c->guard_step = k;
-        double *slot = c->step_red + (size_t)(k - k0) * RED_SECTIONS * RED_SECTION;
+        double *slot = c->step_red + (size_t)(k - k0) * RED_SECTIONS * rs;
         rc = lk_linop_apply(A, LK_OP_N, X, k - 1, X, k);
         const int i0 = k > 1 ? k - 1 : 1;
         for (int i = i0; i <= k && rc == LK_OK; ++i) {                       // lanczos.fypp:57-60
@@ -2368,15 +2480,15 @@ static int lanczos_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
             if (rc == LK_OK) rc = sweepm<3>(X, i - 1, 1, X->col(k), a, nullptr, 1, a + RED_SECTION);
         }
         if (rc != LK_OK) break;
-        rc = dgs_device(X, k, X->col(k), true, slot);                       // :62 (no beta)
+        rc = dgs_device(X, k, X->col(k), true, slot, rs);                   // :62 (no beta)
         if (rc != LK_OK) break;
-        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * RED_SECTION + (size_t)k * ED, tol_break, c->stop_dev, tol_break);
+        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, tol_break, c->stop_dev, tol_break);
     }
     c->guard_on = false;
     c->guard_step = 0;
     c->prof_sweeps_only = false;
     LKCHK(rc);
-    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)nsteps * RED_SECTIONS * RED_SECTION * sizeof(double),
+    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)nsteps * RED_SECTIONS * rs * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->lz_red_host, c->lz_red, (size_t)nsteps * 4 * RED_SECTION * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->stop_host, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -2392,7 +2504,7 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
     const int kdim = X->ncols - 1;                               // lanczos.fypp:20
     if (kdim < 1) return fail(LK_ERR_INVALID, "lk_lanczos: basis needs at least 2 columns");
     if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_lanczos: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
-    if (kend > KMAX_FUSED) return fail(LK_ERR_INVALID, "lk_lanczos: steps beyond %d basis columns are not fused (run them through the per-object calls)", KMAX_FUSED);
+    if (kend > KMAX_WIDE) return fail(LK_ERR_INVALID, "lk_lanczos: steps beyond %d basis columns are not fused (run them through the per-object calls)", KMAX_WIDE);
     if (ldt < kdim + 1) return fail(LK_ERR_INVALID, "lk_lanczos: ldt too small");
     lk_context_t c = X->ctx;
     DevGuard dev_guard(c);
@@ -2405,8 +2517,9 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
         LKCHK(lanczos_batch_async(A, X, k, kend, tol, &done));
         const bool stopped_early = *c->stop_host != 0;
         double beta = 0.0;
+        const int rs = red_stride(kend);
         for (int s = k; s <= done; ++s) {
-            const double *r2 = c->step_red_host + ((size_t)(s - k) * RED_SECTIONS + 2) * RED_SECTION;
+            const double *r2 = c->step_red_host + ((size_t)(s - k) * RED_SECTIONS + 2) * rs;
             const int i0 = s > 1 ? s - 1 : 1;
             double *Ts = T + (size_t)(s - 1) * ldt * ED;
             for (int i = i0; i <= s; ++i) {
@@ -2434,7 +2547,8 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
 static int bidiag_batch_async(lk_linop_t A, lk_basis_t U, lk_basis_t V, int k0, int k1, double tol, int *done_half) {
     lk_context_t c = U->ctx;
     const int nsteps = k1 - k0 + 1;
-    LKCHK(ensure_step_buffers(c, 2 * nsteps));
+    const int rs = red_stride(k1);
+    LKCHK(ensure_step_buffers(c, 2 * nsteps, rs));
     HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
     const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
     const int ED = U->ed();
@@ -2442,28 +2556,28 @@ static int bidiag_batch_async(lk_linop_t A, lk_basis_t U, lk_basis_t V, int k0, 
     c->prof_sweeps_only = true;
     int rc = LK_OK;
     for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
-        double *sv = c->step_red + (size_t)(2 * (k - k0)) * RED_SECTIONS * RED_SECTION;
-        double *su = sv + (size_t)RED_SECTIONS * RED_SECTION;
+        double *sv = c->step_red + (size_t)(2 * (k - k0)) * RED_SECTIONS * rs;
+        double *su = sv + (size_t)RED_SECTIONS * rs;
         c->guard_step = 2 * k - 1;
         rc = lk_linop_apply(A, LK_OP_H, U, k - 1, V, k - 1);                                   // :27
         if (rc != LK_OK) break;
-        if (k > 1) rc = dgs_device(V, k - 1, V->col(k - 1), true, sv);                        // :30-33
-        else rc = dot_device(V, 0, V, 0, sv + 2 * RED_SECTION);                               // ||V(1)||^2 where the DGS would leave it
+        if (k > 1) rc = dgs_device(V, k - 1, V->col(k - 1), true, sv, rs);                    // :30-33
+        else rc = dot_device(V, 0, V, 0, sv + 2 * rs);                                        // ||V(1)||^2 where the DGS would leave it
         if (rc != LK_OK) break;
-        rc = scal_launch(V, k - 1, 1.0, 0.0, sv + 2 * RED_SECTION + (size_t)(k - 1) * ED, tol_break, c->stop_dev, tol_break);   // :36-42
+        rc = scal_launch(V, k - 1, 1.0, 0.0, sv + 2 * rs + (size_t)(k - 1) * ED, tol_break, c->stop_dev, tol_break);   // :36-42
         if (rc != LK_OK) break;
         c->guard_step = 2 * k;
         rc = lk_linop_apply(A, LK_OP_N, V, k - 1, U, k);                                       // :45
         if (rc != LK_OK) break;
-        rc = dgs_device(U, k, U->col(k), true, su);                                           // :48-49
+        rc = dgs_device(U, k, U->col(k), true, su, rs);                                       // :48-49
         if (rc != LK_OK) break;
-        rc = scal_launch(U, k, 1.0, 0.0, su + 2 * RED_SECTION + (size_t)k * ED, tol_break, c->stop_dev, tol_break);             // :52-58
+        rc = scal_launch(U, k, 1.0, 0.0, su + 2 * rs + (size_t)k * ED, tol_break, c->stop_dev, tol_break);             // :52-58
     }
     c->guard_on = false;
     c->guard_step = 0;
     c->prof_sweeps_only = false;
     LKCHK(rc);
-    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)2 * nsteps * RED_SECTIONS * RED_SECTION * sizeof(double),
+    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)2 * nsteps * RED_SECTIONS * rs * sizeof(double),
                           hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->stop_host, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -2479,7 +2593,7 @@ int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, 
     const int kdim = U->ncols - 1;                               // golub_kahan.fypp:18
     if (kdim < 1 || V->ncols < kdim) return fail(LK_ERR_INVALID, "lk_bidiag: U needs kdim + 1 columns and V kdim");
     if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_bidiag: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
-    if (kend > KMAX_FUSED) return fail(LK_ERR_INVALID, "lk_bidiag: steps beyond %d basis columns are not fused (run them through the per-object calls)", KMAX_FUSED);
+    if (kend > KMAX_WIDE) return fail(LK_ERR_INVALID, "lk_bidiag: steps beyond %d basis columns are not fused (run them through the per-object calls)", KMAX_WIDE);
     if (!(tol >= ATOL_DP)) return fail(LK_ERR_INVALID, "lk_bidiag: tol below atol_dp is not fused (the device-side stop is at max(tol, atol_dp))");
     if (ldb < kdim + 1) return fail(LK_ERR_INVALID, "lk_bidiag: ldb too small");
     if (U->data == V->data) return fail(LK_ERR_INVALID, "lk_bidiag: U and V must be different bases");
@@ -2492,10 +2606,11 @@ int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, 
     int done_half = 0;
     LKCHK(bidiag_batch_async(A, U, V, kstart, kend, tol, &done_half));
     const bool stopped_early = *c->stop_host != 0;
+    const int rs = red_stride(kend);
     for (int hs = 2 * kstart - 1; hs <= done_half; ++hs) {
         const int k = (hs + 1) / 2;
         const bool right = hs & 1;
-        const double *r2 = c->step_red_host + ((size_t)(hs - (2 * kstart - 1)) * RED_SECTIONS + 2) * RED_SECTION;
+        const double *r2 = c->step_red_host + ((size_t)(hs - (2 * kstart - 1)) * RED_SECTIONS + 2) * rs;
         const double nrm = std::sqrt(std::fabs(r2[(size_t)(right ? k - 1 : k) * ED]));
         if (nrm != nrm) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
         double *Bk = B + (size_t)(k - 1) * ldb * ED;
@@ -2521,21 +2636,22 @@ int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, i
     int k = kstart;
     while (k <= kend) {
         int stop = 0;
-        if (!c->async_arnoldi || k > KMAX_FUSED || k == kend) {
-            // single step, wide basis, or the round-1 schedule: one host round trip per step
+        if (!c->async_arnoldi || k > KMAX_WIDE || k == kend) {
+            // single step, a basis beyond KMAX_WIDE columns, or the round-1 schedule: one host round trip per step
             LKCHK(arnoldi_step_sync(A, X, H, ldh, k, tol, trans, h, info, &stop));
             if (stop) break;
             ++k;
             continue;
         }
-        const int k1 = kend < KMAX_FUSED ? kend : KMAX_FUSED;
+        const int k1 = kend < KMAX_WIDE ? kend : KMAX_WIDE;
+        const int rs = red_stride(k1);
         LKCHK(lazy_enter(c, true));
         int done = 0;
         LKCHK(arnoldi_batch_async(A, X, k, k1, tol, trans, &done));
         const bool stopped_early = *c->stop_host != 0;
         for (int s = k; s <= done; ++s) {
-            const double *slot = c->step_red_host + (size_t)(s - k) * RED_SECTIONS * RED_SECTION;
-            const double *r0 = slot, *r1 = slot + RED_SECTION, *r2 = slot + 2 * RED_SECTION;
+            const double *slot = c->step_red_host + (size_t)(s - k) * RED_SECTIONS * rs;
+            const double *r0 = slot, *r1 = slot + rs, *r2 = slot + 2 * rs;
             double *Hk = H + (size_t)(s - 1) * ldh * ED;
             for (int i = 0; i < s * ED; ++i) Hk[i] = r0[i] + r1[i];                 // gram_schmidt.fypp:49
             const double beta = std::sqrt(std::fabs(r2[s * ED]));

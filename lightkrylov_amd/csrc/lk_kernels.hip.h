@@ -53,6 +53,28 @@ __device__ __forceinline__ double wave_sum(double v) {
     return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
+// The same DPP tree, but the 64 lanes are SC lane groups of 64/SC consecutive lanes (panel_sweep's lane split for wide
+// bases): out[g] = sum over group g, wave-uniform.  SC = 1 is wave_sum.
+template <int SC>
+__device__ __forceinline__ void group_sums(double v, double (&out)[SC]) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    const double r0 = lane_value(v, 0), r1 = lane_value(v, 16), r2 = lane_value(v, 32), r3 = lane_value(v, 48);
+    if constexpr (SC == 1) out[0] = (r0 + r1) + (r2 + r3);
+    else if constexpr (SC == 2) { out[0] = r0 + r1; out[1] = r2 + r3; }
+    else { out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3; }
+}
+// v + (the same value of the lanes 32 / 16 away): after it every lane group of a wave split SC ways holds the sum over the
+// groups.  Addition is commutative, so all groups end with the same bits.
+template <int SC>
+__device__ __forceinline__ double across_groups(double v) {
+    if constexpr (SC == 4) v += __shfl_xor(v, 16, 64);
+    if constexpr (SC >= 2) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
 // Early-exit guard of the ASYNCHRONOUS Arnoldi pipeline (lk_arnoldi enqueues every step without waiting for the
 // host): when step s finds an invariant subspace / a colinear vector / a NaN, its normalise kernel records
 // *stop_step = s; every kernel of a LATER step returns at once, so the basis beyond the breakdown stays untouched
@@ -110,12 +132,14 @@ __device__ __forceinline__ v2d load_y(const double *__restrict__ y, int64_t r, i
     }
 }
 
-template <bool CPLX, int KC>
+// UNIFORM = false: nc differs between the lanes of a wave (lane-split sweeps): one predicated load per column, no
+// wave-uniform fast path.
+template <bool CPLX, int KC, bool UNIFORM = true>
 __device__ __forceinline__ void load_cols(const double *__restrict__ Xw, int64_t colstride, int64_t r, int64_t n,
                                           bool full, int nc, v2d (&xv)[KC]) {
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     if (full) {
-        if (nc == KC) {
+        if (UNIFORM && nc == KC) {
 #pragma unroll
             for (int jj = 0; jj < KC; ++jj)
                 xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Xw + jj * colstride + r * ED));
@@ -144,11 +168,11 @@ __device__ __forceinline__ void load_cols(const double *__restrict__ Xw, int64_t
     }
 }
 
-template <bool CPLX, int KC>
+template <bool CPLX, int KC, bool UNIFORM = true>
 __device__ __forceinline__ void load_tile(const double *__restrict__ Xw, int64_t colstride, const double *__restrict__ y,
                                           int64_t r, int64_t n, bool full, int nc, v2d (&xv)[KC], v2d &yv) {
     yv = load_y<CPLX>(y, r, n, full);
-    load_cols<CPLX, KC>(Xw, colstride, r, n, full, nc, xv);
+    load_cols<CPLX, KC, UNIFORM>(Xw, colstride, r, n, full, nc, xv);
 }
 
 // 16-byte store with an explicit gfx950 cache policy.  `policy` is block-uniform:
@@ -180,7 +204,13 @@ __device__ __forceinline__ void store_rows(double *__restrict__ y, int64_t r, in
 // original y exactly as sweep 2 formed it (same wave split, same summation order), then
 // y'' = y' - X h2 is written.  That lets sweep 2 run with store = 0 (y' never goes to HBM): the
 // y' write was ~1% of sweep 2's bytes but cost it 5-13% (HBM read/write mixing).
-template <bool CPLX, int KC, int NW, bool UPDATE, bool DOT, bool TWO>
+// SC (lane split, wide bases): the 64 lanes of a wave form SC groups of 64/SC lanes; group g of wave-column wc holds column
+// group wc*SC + g for the SAME 64/SC * ROWS rows, so a block holds KC*NW*SC columns (256 / 512 for SC = 2 / 4) of a tile
+// 1/SC as tall -- a column still arrives as contiguous 512 / 256 bytes per group.  That keeps the tile of X on chip between
+// the update and the dot phase for up to 512 basis columns: ONE pass over X per sweep, 3k+4 columns per DGS, where column
+// panels of 128 cost 4k - |last panel|.  The groups' partial products meet by two cross-lane adds before the LDS exchange,
+// dots reduce per group.  SC = 1 is the narrow kernel, instruction for instruction.
+template <bool CPLX, int KC, int NW, bool UPDATE, bool DOT, bool TWO, int SC = 1>
 __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict__ X, int64_t ldx, int k,
                                                         double *__restrict__ y, int64_t n,
                                                         const double *__restrict__ hin,
@@ -188,10 +218,12 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
                                                         double *__restrict__ partial, int64_t pstride,
                                                         int WC, int kcw, int store, Guard guard) {
     static_assert(!TWO || (UPDATE && !DOT), "TWO is the update-only sweep with two coefficient sets");
+    static_assert(SC == 1 || SC == 2 || SC == 4, "lane split");
     if (stopped(guard)) return;
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
-    constexpr int WROWS = 64 * ROWS;  // rows one wave covers per tile
+    constexpr int LG = 64 / SC;          // lanes per group
+    constexpr int WROWS = LG * ROWS;     // rows one wave covers per tile
     constexpr int NU = TWO ? 2 : 1;
 
     const int lane = threadIdx.x & 63;
@@ -199,17 +231,31 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     const int wc = wave % WC;
     const int wr = wave / WC;
     const int WR = NW / WC;
-    const int c0 = wc * kcw;
+    const int lg = SC > 1 ? lane / LG : 0;            // lane group (per lane)
+    const int rl = SC > 1 ? lane % LG : lane;         // lane within its group = row pair / row index
+    const int c0 = (wc * SC + lg) * kcw;
     int nc = k - c0;
     nc = nc > kcw ? kcw : nc;
     nc = nc < 0 ? 0 : nc;
 
     __shared__ v2d u_lds[UPDATE ? 2 * NU * NW * 64 : 1];
-    __shared__ double red_lds[NW * (KC * ED + 1)];
+    __shared__ double red_lds[NW * SC * (KC * ED + 1)];
 
-    // projection coefficients of this wave's columns (wave-uniform)
-    v2d hc[KC], hc2[TWO ? KC : 1];
-    if constexpr (UPDATE) {
+    // projection coefficients of this wave's columns: wave-uniform (scalar registers) for SC = 1.  With the lane split they
+    // differ from lane group to lane group and would take 2-4 VGPRs per column and coefficient set on top of the tile
+    // itself (the complex two-coefficient sweep spilled): they live in LDS instead, zero padded to the block's capacity, and
+    // are read back per use -- every lane of a group reads the same address (broadcast).
+    constexpr bool HLDS = SC > 1 && UPDATE;
+    constexpr int CAP = KC * NW * SC;
+    __shared__ double hc_lds[HLDS ? NU * CAP * ED : 1];
+    v2d hc[HLDS ? 1 : KC], hc2[(TWO && !HLDS) ? KC : 1];
+    if constexpr (HLDS) {
+        for (int i = threadIdx.x; i < CAP * ED; i += NW * 64) {
+            hc_lds[i] = i < k * ED ? hin[i] : 0.0;
+            if constexpr (TWO) hc_lds[CAP * ED + i] = i < k * ED ? hin2[i] : 0.0;
+        }
+        __syncthreads();
+    } else if constexpr (UPDATE) {
 #pragma unroll
         for (int jj = 0; jj < KC; ++jj) {
             if (jj < nc) {
@@ -225,6 +271,19 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
             }
         }
     }
+    // coefficient jj of set `set` of this lane's column group (columns beyond k read the zero padding; c0 + jj < CAP always
+    // holds for the groups that own columns, and the others are clamped onto the padding's last entry)
+    auto hcoef = [&](int set, int jj) -> v2d {
+        if constexpr (HLDS) {
+            int idx = c0 + jj;
+            idx = idx < CAP ? idx : CAP - 1;
+            if constexpr (CPLX) return *reinterpret_cast<const v2d *>(&hc_lds[(set * CAP + idx) * 2]);
+            else return v2d{hc_lds[set * CAP + idx], 0.0};
+        } else {
+            if constexpr (TWO) return set ? hc2[jj] : hc[jj];
+            else return hc[jj];
+        }
+    };
 
     v2d acc[KC];  // real: (sum over even rows, sum over odd rows) ; complex: (re, im)
 #pragma unroll
@@ -235,7 +294,7 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
     const double *Xw = X + (int64_t)c0 * ldx * ED;
     const int64_t colstride = ldx * ED;  // doubles between consecutive columns
-    const int64_t roff = (int64_t)wr * WROWS + (int64_t)lane * ROWS;
+    const int64_t roff = (int64_t)wr * WROWS + (int64_t)rl * ROWS;
     int buf = 0;
 
     // tile order.  Default: cyclic over the whole grid (block b takes tiles b, b + G, ...).  Bit 4 of `store` (A/B knob
@@ -251,20 +310,28 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
         const bool full = (t + 1) * tile_rows <= n;   // block-uniform
         v2d xv[KC];
         v2d yv;
-        load_tile<CPLX, KC>(Xw, colstride, y, r, n, full, nc, xv, yv);
+        load_tile<CPLX, KC, SC == 1>(Xw, colstride, y, r, n, full, nc, xv, yv);
 
         if constexpr (UPDATE) {
             v2d u = v2d{0.0, 0.0}, u2 = v2d{0.0, 0.0};
 #pragma unroll
             for (int jj = 0; jj < KC; ++jj) {
-                if constexpr (CPLX) u += cmul(xv[jj], hc[jj]);
-                else u += xv[jj] * hc[jj].x;
+                if constexpr (CPLX) u += cmul(xv[jj], hcoef(0, jj));
+                else u += xv[jj] * hcoef(0, jj).x;
             }
             if constexpr (TWO) {
 #pragma unroll
                 for (int jj = 0; jj < KC; ++jj) {
-                    if constexpr (CPLX) u2 += cmul(xv[jj], hc2[jj]);
-                    else u2 += xv[jj] * hc2[jj].x;
+                    if constexpr (CPLX) u2 += cmul(xv[jj], hcoef(1, jj));
+                    else u2 += xv[jj] * hcoef(1, jj).x;
+                }
+            }
+            if constexpr (SC > 1) {                    // the lane groups of this wave hold the same rows: add their shares
+                u.x = across_groups<SC>(u.x);
+                u.y = across_groups<SC>(u.y);
+                if constexpr (TWO) {
+                    u2.x = across_groups<SC>(u2.x);
+                    u2.y = across_groups<SC>(u2.y);
                 }
             }
             if (WC > 1) {
@@ -287,7 +354,9 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
             // (instead of the wc == 0 wave storing all 64 lanes).
             if (store & 1) {
                 const int pol = (store >> 1) & 3;
-                if (store & 8) {
+                if constexpr (SC > 1) {
+                    if (wc == 0 && lg == 0) store_rows<CPLX>(y, r, n, full, yv, pol);
+                } else if (store & 8) {
                     const int per = 64 / WC;
                     if (lane / per == wc) store_rows<CPLX>(y, r, n, full, yv, pol);
                 } else if (wc == 0) {
@@ -302,7 +371,7 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
                 else acc[jj] += xv[jj] * yv;
             }
         }
-        if (wc == 0) nrm += yv.x * yv.x + yv.y * yv.y;
+        if (wc == 0 && lg == 0) nrm += yv.x * yv.x + yv.y * yv.y;
     }
 
     // ---- block reduction: lanes (shuffle) -> waves sharing a column set (LDS) -> partial
@@ -310,34 +379,55 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     if constexpr (DOT) {
 #pragma unroll
         for (int jj = 0; jj < KC; ++jj) {
-            if constexpr (CPLX) {
-                double re = wave_sum(acc[jj].x), im = wave_sum(acc[jj].y);
-                if (lane == 0) { red_lds[wave * SLOTS + 2 * jj] = re; red_lds[wave * SLOTS + 2 * jj + 1] = im; }
+            if constexpr (SC == 1) {
+                if constexpr (CPLX) {
+                    double re = wave_sum(acc[jj].x), im = wave_sum(acc[jj].y);
+                    if (lane == 0) { red_lds[wave * SLOTS + 2 * jj] = re; red_lds[wave * SLOTS + 2 * jj + 1] = im; }
+                } else {
+                    double s = wave_sum(acc[jj].x + acc[jj].y);
+                    if (lane == 0) red_lds[wave * SLOTS + jj] = s;
+                }
             } else {
-                double s = wave_sum(acc[jj].x + acc[jj].y);
-                if (lane == 0) red_lds[wave * SLOTS + jj] = s;
+                double a[SC], b[SC];
+                if constexpr (CPLX) {
+                    group_sums<SC>(acc[jj].x, a);
+                    group_sums<SC>(acc[jj].y, b);
+                } else {
+                    group_sums<SC>(acc[jj].x + acc[jj].y, a);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int gq = 0; gq < SC; ++gq) {
+                        if constexpr (CPLX) {
+                            red_lds[(wave * SC + gq) * SLOTS + 2 * jj] = a[gq];
+                            red_lds[(wave * SC + gq) * SLOTS + 2 * jj + 1] = b[gq];
+                        } else {
+                            red_lds[(wave * SC + gq) * SLOTS + jj] = a[gq];
+                        }
+                    }
+                }
             }
         }
     }
     {
         double s = wave_sum(nrm);
-        if (lane == 0) red_lds[wave * SLOTS + KC * ED] = s;
+        if (lane == 0) red_lds[(wave * SC) * SLOTS + KC * ED] = s;
     }
     __syncthreads();
-    // thread tid < k*ED handles one output double: column j = tid/ED lives in wave column wc_j
+    // thread tid < k*ED handles one output double: column j = tid/ED lives in column group j / kcw
     const int tid = threadIdx.x;
     if constexpr (DOT) {
-        if (tid < k * ED) {
-            const int j = tid / ED, part = tid % ED;
-            const int wcj = j / kcw, jj = j - wcj * kcw;
+        for (int o = tid; o < k * ED; o += NW * 64) {
+            const int j = o / ED, part = o % ED;
+            const int cgj = j / kcw, jj = j - cgj * kcw;
             double s = 0.0;
-            for (int w = 0; w < WR; ++w) s += red_lds[(w * WC + wcj) * SLOTS + jj * ED + part];
+            for (int w = 0; w < WR; ++w) s += red_lds[(w * WC * SC + cgj) * SLOTS + jj * ED + part];
             partial[((int64_t)j * ED + part) * pstride + blockIdx.x] = s;
         }
     }
     if (tid == 0) {
         double s = 0.0;
-        for (int w = 0; w < WR; ++w) s += red_lds[(w * WC) * SLOTS + KC * ED];
+        for (int w = 0; w < WR; ++w) s += red_lds[(w * WC * SC) * SLOTS + KC * ED];
         partial[((int64_t)k * ED) * pstride + blockIdx.x] = s;
         if constexpr (CPLX) partial[((int64_t)k * ED + 1) * pstride + blockIdx.x] = 0.0;
     }
@@ -756,7 +846,11 @@ __device__ __forceinline__ void gemm_cols(const double *__restrict__ Xj, int64_t
 template <bool CPLX, int KC, int QB>
 __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, int64_t ldx, int k,
                                                   double *__restrict__ Y, int64_t ldy, int qn,
-                                                  const double *__restrict__ Cp, int64_t n, int accumulate, int QGB) {
+                                                  const double *__restrict__ Cp, int64_t n, int accumulate, int QGB,
+                                                  int policy) {
+    // QB = accumulators per lane = output columns per wave: 16 for wide products; 1 / 2 / 4 / 8 for narrow ones, where the
+    // kernel is a pure stream over X (q = 1: the GMRES solution update, gmres.fypp:201, and every X * v) -- with QB = 16 a
+    // single output column paid 16x the FMAs and ran VALU-limited at 4.9 TB/s.
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;
@@ -793,7 +887,7 @@ __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, 
                 double *yc = Y + (int64_t)(q0 + qq) * ystride;
                 v2d out = acc[qq];
                 if (accumulate) out += load_y<CPLX>(yc, r, n, full);
-                store_rows<CPLX>(yc, r, n, full, out);
+                store_rows<CPLX>(yc, r, n, full, out, policy);
             }
         }
     }
@@ -821,7 +915,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 template <bool CPLX, int NG>
 __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                        double *__restrict__ Y, int64_t ldy, int qn,
-                                                       const double *__restrict__ Cp, int64_t n, int accumulate) {
+                                                       const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
     constexpr int QB = CPLX ? 8 : 16;            // output columns per group
     constexpr int RG = CPLX ? 16 : 32;           // rows per row group (one MFMA N extent; x2 rows per lane for real)
     constexpr int NACC = CPLX ? 1 : 2;
@@ -915,7 +1009,7 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                             double *yc = Y + (int64_t)qq * ystride;
                             v2d out = v2d{acc[g][g2][0][h2], acc[g][g2][0][h2 + 2]};
                             if (accumulate) out += load_y<CPLX>(yc, r, n, full);
-                            store_rows<CPLX>(yc, r, n, full, out);
+                            store_rows<CPLX>(yc, r, n, full, out, policy);
                         }
                     }
                 } else {
@@ -926,7 +1020,7 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                             double *yc = Y + (int64_t)qq * ystride;
                             v2d out = v2d{acc[g][g2][0][reg], acc[g][g2][1][reg]};
                             if (accumulate) out += load_y<CPLX>(yc, r, n, full);
-                            store_rows<CPLX>(yc, r, n, full, out);
+                            store_rows<CPLX>(yc, r, n, full, out, policy);
                         }
                     }
                 }

@@ -219,10 +219,10 @@ def lanczos(A: abstract_linop, X, T: np.ndarray, kstart: int = 1, kend: int | No
     kdim = len(X) - 1
     kend = kdim if kend is None else kend
     info = 0
-    # whole step loop inside the engine (asynchronous, one synchronisation per call) for the first 128 basis columns
+    # whole step loop inside the engine (asynchronous, one synchronisation per call) for the first 512 basis columns
     if (isinstance(X, krylov_basis_gpu) and isinstance(A, _engine_linop) and T.flags.f_contiguous and T.dtype == X.dtype
-            and T.shape[0] >= kdim + 1 and kstart <= min(kend, 128)):
-        k1 = min(kend, 128)
+            and T.shape[0] >= kdim + 1 and kstart <= min(kend, 512)):
+        k1 = min(kend, 512)
         cinfo = C.c_int()
         _capi.check(X._lib.lk_lanczos(A._h, X._h, T.ctypes.data_as(_DP), T.shape[0], int(kstart), int(k1), float(tol),
                                       C.byref(cinfo)))
@@ -253,10 +253,10 @@ def bidiagonalization(A: abstract_linop, U, V, B: np.ndarray, kstart: int = 1, k
     kend = kdim if kend is None else kend
     info = 0
     gpu = isinstance(U, krylov_basis_gpu) and isinstance(V, krylov_basis_gpu)
-    # whole step loop inside the engine (asynchronous, one synchronisation per call) for the first 128 basis columns
+    # whole step loop inside the engine (asynchronous, one synchronisation per call) for the first 512 basis columns
     if (gpu and isinstance(A, _engine_linop) and B.flags.f_contiguous and B.dtype == U.dtype and B.shape[0] >= kdim + 1
-            and tol >= atol_dp and kstart <= min(kend, 128) and len(V) >= kdim):
-        k1 = min(kend, 128)
+            and tol >= atol_dp and kstart <= min(kend, 512) and len(V) >= kdim):
+        k1 = min(kend, 512)
         cinfo = C.c_int()
         _capi.check(U._lib.lk_bidiag(A._h, U._h, V._h, B.ctypes.data_as(_DP), B.shape[0], int(kstart), int(k1), float(tol),
                                      C.byref(cinfo)))

@@ -1,0 +1,348 @@
+"""GPU tests added in round 3 (all through the C ABI).
+
+  * bases of 129..512 columns on the lane-split fused sweeps (one pass over X per sweep, 3k+4 columns per DGS) and the
+    asynchronous Arnoldi / Lanczos / Golub-Kahan pipelines beyond 128 columns -- reference: `kdim = (size(X) - p) / p` has no
+    cap (src/Krylov/arnoldi.fypp:26);
+  * narrow tall-skinny products (q = 1..4: the GMRES solution update, gmres.fypp:200-214, and every X * v of
+    linear_combination, AbstractVectors.fypp:571-643) on the streaming kernel with q accumulators per lane;
+  * the column pool's slab geometry on row-sharded contexts and its generation counter;
+  * the operator's own time inside the asynchronous batch (`matvec` profile tag).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import lightkrylov_amd as lk
+from lightkrylov_amd import _capi
+from oracle import oracle as ora
+
+pytestmark = pytest.mark.gpu
+KINDS = [np.float64, np.complex128]
+
+
+def seeded(n, dtype, seed):
+    x = np.empty(n, dtype=dtype)
+    ora.fill_counter(x, seed)
+    return x
+
+
+def basis(n, k, dtype, seed):
+    X = np.empty((n, k), dtype=dtype, order="F")
+    for j in range(k):
+        ora.fill_counter(X[:, j], seed + j)
+    return X
+
+
+def orthonormal_basis(n, k, dtype, seed):
+    Q, _ = np.linalg.qr(basis(n, k, dtype, seed))
+    return np.asfortranarray(Q)
+
+
+# ----------------------------------------------------------------------------- wide bases: the fused sweeps
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("n,k", [(20_011, 129), (20_011, 200), (16_384, 256), (9001, 257), (9001, 384), (8192, 512),
+                                 (6007, 511), (600, 512), (131, 130), (4099, 513), (3001, 700), (2500, 1100)])
+def test_wide_dgs_against_oracle_and_traffic(dtype, n, k):
+    """double_gram_schmidt_step against 129..512 (and, as column panels of 512, up to 1100) basis columns vs the oracle:
+    coefficients and vector normwise 1e-12, orthogonality 1e-13, and -- from the library's own byte accounting -- exactly three
+    sweep launches per DGS for k <= 512 (the panel schedule it replaces took 3 + 2 (npanels - 1))."""
+    c = lk.Context(device=0)
+    Q = orthonormal_basis(n, k, dtype, 3)
+    y = seeded(n, dtype, 77)
+    B = lk.krylov_basis_gpu(n, k + 1, dtype, c)
+    B.upload(Q, 0)
+    B.upload(y.reshape(-1, 1), k)
+    beta = np.zeros(k, dtype=dtype)
+    c.profile_reset(); c.profile_enable(True)
+    info = lk.double_gram_schmidt_step(B[k], B[:k], if_chk_orthonormal=False, beta=beta)
+    c.sync()
+    launches = [c.profile_get(f"dgs_sweep{i}")[0] for i in (1, 2, 3)]
+    by = sum(c.profile_get(f"dgs_sweep{i}")[2] for i in (1, 2, 3))
+    c.profile_enable(False)
+    yo = y.copy()
+    ho, info_o = ora.double_gram_schmidt_step(yo, Q)
+    assert info == info_o
+    ynorm = np.linalg.norm(y)
+    assert np.abs(beta - ho).max() <= 1e-12 * ynorm
+    yg = B.download(k, 1)[:, 0]
+    assert np.abs(yg - yo).max() <= 1e-12 * ynorm
+    assert np.abs(Q.conj().T @ yg).max() <= 1e-13 * ynorm
+    if k <= 512:
+        s = np.dtype(dtype).itemsize
+        assert launches == [1, 1, 1]
+        assert by == pytest.approx(s * n * (3 * k + 5))                 # priced on the algorithmic 3k+5 columns
+    # single pass (orthogonalize_against_basis) on the same shapes
+    B.upload(y.reshape(-1, 1), k)
+    b1 = np.zeros(k, dtype=dtype)
+    lk.orthogonalize_against_basis(B[k], B[:k], if_chk_orthonormal=False, beta=b1)
+    y1 = y.copy()
+    h1, _ = ora.orthogonalize_against_basis(y1, Q)
+    assert np.abs(b1 - h1).max() <= 1e-12 * ynorm
+    assert np.abs(B.download(k, 1)[:, 0] - y1).max() <= 1e-12 * ynorm
+    del B
+    c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_wide_sweep_knobs_are_result_invariant(dtype):
+    """Store policy, y' recomputation and the sweep-1 kernel choice change no result bit on a wide basis either (the lane-split
+    sweep 3 must re-form y' in exactly sweep 2's summation order)."""
+    n, k = 7001, 300
+    Q = orthonormal_basis(n, k, dtype, 5)
+    y = seeded(n, dtype, 9)
+    ref = None
+    for knobs in (dict(), dict(store_policy=0), dict(store_policy=1), dict(recompute_update=0), dict(dot_colwise=0)):
+        c = lk.Context(device=0)
+        for kk, v in knobs.items():
+            c.set_tuning(kk, v)
+        B = lk.krylov_basis_gpu(n, k + 1, dtype, c)
+        B.upload(Q, 0); B.upload(y.reshape(-1, 1), k)
+        beta = np.zeros(k, dtype=dtype)
+        lk.double_gram_schmidt_step(B[k], B[:k], if_chk_orthonormal=False, beta=beta)
+        got = (beta.tobytes(), B.download(k, 1).tobytes())
+        if "dot_colwise" in knobs or "recompute_update" in knobs:
+            # another kernel for sweep 1 / a stored y': same results to rounding
+            b0 = np.frombuffer(ref[0], dtype=dtype)
+            assert np.abs(beta - b0).max() <= 1e-13 * np.linalg.norm(y)
+        else:
+            if ref is None:
+                ref = got
+            assert got == ref
+        del B
+        c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_arnoldi_with_256_basis_columns_is_one_asynchronous_batch(dtype):
+    """kdim = 256: every step runs as three fused sweeps inside ONE asynchronous batch (one host synchronisation per call);
+    H against the oracle column by column, orthonormality, and bit-identity with the one-round-trip-per-step schedule."""
+    n, m = 12_007, 256
+    g = np.arange(n) / n
+    d = (1.0 + g).astype(dtype) if np.dtype(dtype).kind == "f" else ((1.0 + g) * np.exp(1j * g)).astype(dtype)
+    x0 = seeded(n, dtype, 7); x0 /= np.linalg.norm(x0)
+    out = {}
+    for mode in (1, 0):
+        c = lk.Context(device=0)
+        c.set_tuning("async_arnoldi", mode)
+        X = lk.krylov_basis_gpu(n, m + 1, dtype, c); X.upload(x0.reshape(-1, 1), 0)
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        c.profile_reset(); c.profile_enable(True)
+        assert lk.arnoldi(lk.diag_linop_gpu(d, c), X, H) == 0
+        c.sync()
+        cnt = [c.profile_get(f"dgs_sweep{i}")[0] for i in (1, 2, 3)]
+        c.profile_enable(False)
+        assert cnt == [m, m, m]                                             # three launches per step, whatever the width
+        out[mode] = (H.copy(), X.download())
+        if mode == 1:
+            G = lk.Gram(X[:128]); G2 = lk.innerprod(X[:128], X[128:m + 1])
+            assert np.abs(G - np.eye(128)).max() <= 1e-12 and np.abs(G2).max() <= 1e-12
+        del X
+        c.close()
+    assert out[0][0].tobytes() == out[1][0].tobytes() and out[0][1].tobytes() == out[1][1].tobytes()
+    H = out[1][0]
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.arnoldi(ora.DiagOp(d), Xo, Ho) == 0
+    for j in range(m):
+        assert np.abs(H[:, j] - Ho[:, j]).max() <= 1e-12 * np.abs(Ho[:, j]).max()
+
+
+def test_arnoldi_breakdown_beyond_128_columns_leaves_the_rest_untouched():
+    """Invariant subspace at step 150 of a 200-step call: info = 150 and the columns beyond stay as they were (arnoldi.fypp:58-71)
+    -- the device-side stop flag of the asynchronous batch on the wide kernels."""
+    c = lk.Context(device=0)
+    n, m, r = 9001, 200, 150
+    d = 1.0 + (np.arange(n) % r) / r                                      # r distinct eigenvalues in [1, 2)
+    X = lk.krylov_basis_gpu(n, m + 1, np.float64, c)
+    X[0].rand(True, seed=9)
+    marker = seeded(n, np.float64, 123)
+    for j in range(r + 1, m + 1):
+        X.upload(marker.reshape(-1, 1), j)
+    H = np.zeros((m + 1, m), order="F")
+    info = lk.arnoldi(lk.diag_linop_gpu(d, c), X, H, tol=1e-7)
+    assert info == r
+    assert np.array_equal(X.download(m, 1)[:, 0], marker) and np.array_equal(X.download(r + 1, 1)[:, 0], marker)
+    G = lk.Gram(X[:r])
+    assert np.abs(G - np.eye(r)).max() <= 1e-10
+    del X
+    c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_lanczos_and_bidiagonalization_beyond_128_columns(ctx, dtype):
+    """lk_lanczos / lk_bidiag with kend = 200: the whole call is one asynchronous batch; T and B against the oracle."""
+    n, m = 6007, 200
+    d = (1.0 + np.arange(n) / n).astype(dtype)
+    x0 = seeded(n, dtype, 21); x0 /= np.linalg.norm(x0)
+    X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X.upload(x0.reshape(-1, 1), 0)
+    T = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.lanczos(lk.diag_linop_gpu(d, ctx), X, T) == 0
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
+    To = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.lanczos(ora.DiagOp(d), Xo, To) == 0
+    for j in range(m):
+        assert np.abs(T[:, j] - To[:, j]).max() <= 1e-12 * np.abs(To[:, j]).max()
+    # Golub-Kahan on a non-normal diagonal-times-shift operator is not available among the engine operators; the diagonal one
+    # (complex: non-Hermitian) exercises both bases
+    g = np.arange(n) / n
+    dz = (1.0 + g).astype(dtype) if np.dtype(dtype).kind == "f" else ((1.0 + g) * np.exp(1j * g)).astype(dtype)
+    A = lk.diag_linop_gpu(dz, ctx)
+    U = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); U.upload(x0.reshape(-1, 1), 0)
+    V = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+    B = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.bidiagonalization(A, U, V, B) == 0
+    Uo = np.zeros((n, m + 1), dtype=dtype, order="F"); Uo[:, 0] = x0
+    Vo = np.zeros((n, m + 1), dtype=dtype, order="F")
+    Bo = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.bidiagonalization(ora.DiagOp(dz), ora.DiagOp(dz.conj()), Uo, Vo, Bo) == 0
+    for j in range(m):
+        assert np.abs(B[:, j] - Bo[:, j]).max() <= 1e-12 * np.abs(Bo[:, j]).max()
+
+
+# ----------------------------------------------------------------------------- narrow tall-skinny products
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("mfma_min", [5, 1, 2, 100])
+@pytest.mark.parametrize("n,k,q", [(1, 1, 1), (4099, 128, 1), (20_011, 64, 1), (2051, 200, 1), (777, 300, 2), (4097, 128, 2),
+                                   (4097, 17, 3), (5003, 128, 4), (5003, 33, 5), (1023, 64, 8), (3001, 128, 9)])
+def test_narrow_linear_combinations_on_every_kernel_choice(dtype, mfma_min, n, k, q):
+    """linear_combination with 1..9 output columns through the streaming kernel (q accumulators per lane) and through the
+    matrix-core kernel (`gemm_mfma_min` moves the crossover): each output column against the oracle's loop of axpbys."""
+    c = lk.Context(device=0)
+    c.set_tuning("gemm_mfma_min", mfma_min)
+    X = basis(n, k, dtype, 10)
+    Cm = basis(k, q, dtype, 900)
+    Bx = lk.krylov_basis_gpu(n, k, dtype, c); Bx.upload(X)
+    Yg = lk.linear_combination(Bx, Cm if q > 1 else np.ascontiguousarray(Cm[:, 0]))
+    Yh = Yg.download() if q > 1 else Yg.to_array().reshape(-1, 1)
+    for j in range(q):
+        ref = ora.linear_combination(X, np.ascontiguousarray(Cm[:, j]))
+        assert np.abs(Yh[:, j] - ref).max() <= 1e-13 * np.abs(ref).max() * max(1, k) ** 0.5
+    del Bx, Yg
+    c.close()
+
+
+def test_gmres_update_uses_the_streaming_kernel(ctx):
+    """The GMRES solution update dx = V(:, :k) y (gmres.fypp:200-201) is a q = 1 product: priced at k + 1 columns and run by
+    the one-accumulator kernel (same profile tag, one launch)."""
+    n, k = 100_003, 30
+    Bx = lk.krylov_basis_gpu(n, k, np.float64, ctx); Bx.upload(basis(n, k, np.float64, 4))
+    v = seeded(k, np.float64, 8)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    y = lk.linear_combination(Bx, v)
+    ctx.sync()
+    cnt, _ms, by = ctx.profile_get("lincomb")
+    ctx.profile_enable(False)
+    assert cnt == 1 and by == pytest.approx(8.0 * n * (k + 1))
+    ref = ora.linear_combination(Bx.download(), v)
+    assert np.abs(y.to_array() - ref).max() <= 1e-13 * np.abs(ref).max() * k ** 0.5
+
+
+# ----------------------------------------------------------------------------- column pool
+def _pool_fns(ctx):
+    lib = _capi.load()
+
+    def acquire(dtype, n, tag):
+        slab, col = C.c_void_p(), C.c_int()
+        _capi.check(lib.lk_pool_acquire(ctx._h, dtype, n, C.c_uint64(tag), C.byref(slab), C.byref(col)))
+        return slab.value, col.value
+
+    def info(slab, col):
+        t, g = C.c_uint64(), C.c_uint64()
+        _capi.check(lib.lk_pool_column_info(ctx._h, C.c_void_p(slab), col, C.byref(t), C.byref(g)))
+        return t.value, g.value
+
+    return lib, acquire, info
+
+
+def test_pool_generation_counter_exposes_stale_bit_copies():
+    """A column's generation goes up every time the pool hands it out: first use, re-use by the same owner tag (an object
+    re-created at a dead one's address), re-use after a release.  A handle that remembers the generation it was bound at --
+    the Fortran plugin's does -- can tell that its column now belongs to something else."""
+    c = lk.Context(device=0)
+    lib, acquire, info = _pool_fns(c)
+    c.set_tuning("pool_slab_cols", 8)
+    a = acquire(_capi.LK_F64, 1000, 0x1000)
+    assert info(*a) == (0x1000, 1)
+    b = acquire(_capi.LK_F64, 1000, 0x2000)
+    assert info(*b) == (0x2000, 1)
+    assert acquire(_capi.LK_F64, 1000, 0x1000) == a and info(*a) == (0x1000, 2)      # same address again: same column, next generation
+    _capi.check(lib.lk_pool_release(c._h, C.c_void_p(b[0]), b[1]))
+    assert info(*b) == (0, 1)
+    assert acquire(_capi.LK_F64, 1000, 0x3000) == b and info(*b) == (0x3000, 2)      # released column handed to another owner
+    assert info(a[0], 7) == (0, 0) and info(0xdead0, 0) == (0, 0)                     # never carved / not a slab: safe to ask
+    _capi.check(lib.lk_pool_release_all(c._h))
+    c.close()
+
+
+def test_pool_slab_geometry_is_rank_independent_on_sharded_contexts():
+    """On a single-rank context a slab shrinks to a quarter of the free memory; on a row-sharded one it must not (free memory
+    differs between ranks; unequal slabs would desynchronise the lazy path's batched all-reduces): there a slab has exactly
+    pool_slab_cols columns, or the acquisition fails."""
+    import torch
+    free_b, _total = torch.cuda.mem_get_info(0)
+    want = 2048
+    n = int(0.3 * free_b / (8.0 * want))                    # `want` columns = 0.3 of the free memory: more than a quarter, and it fits
+    lib = _capi.load()
+
+    def slab_cols(ctx):
+        slab, col = C.c_void_p(), C.c_int()
+        _capi.check(lib.lk_pool_acquire(ctx._h, _capi.LK_F64, n, C.c_uint64(0x1000), C.byref(slab), C.byref(col)))
+        nc = C.c_int()
+        _capi.check(lib.lk_basis_info(slab, None, None, C.byref(nc), None, None))
+        _capi.check(lib.lk_pool_release_all(ctx._h))
+        return nc.value
+
+    single = lk.Context(device=0)
+    single.set_tuning("pool_slab_cols", want)
+    got1 = slab_cols(single)
+    single.close()
+    assert got1 < want                                      # single rank: memory-derived
+    cb = _capi.ALLREDUCE_FN(lambda _u, _p, _n, _s: 0)       # a 2-rank context (the reduction itself is not exercised here)
+    sharded = lk.Context(device=0)
+    _capi.check(lib.lk_set_allreduce(sharded._h, cb, None, 2, 0))
+    sharded.set_tuning("pool_slab_cols", want)
+    got2 = slab_cols(sharded)
+    assert got2 == want                                     # sharded: exactly the configured geometry
+    # ... and an impossible geometry fails loudly instead of shrinking
+    sharded.set_tuning("pool_slab_cols", 4096)
+    big = int(free_b / (8.0 * 4096) * 1.5)
+    slab, col = C.c_void_p(), C.c_int()
+    rc = lib.lk_pool_acquire(sharded._h, _capi.LK_F64, big, C.c_uint64(0x2000), C.byref(slab), C.byref(col))
+    assert rc != 0 and b"pool_slab_cols" in lib.lk_last_error()
+    _capi.check(lib.lk_set_allreduce(sharded._h, None, None, 1, 0))
+    sharded.close()
+
+
+def test_sharded_stencil_operators_reject_partitions_out_of_rank_order():
+    """The halo exchange addresses neighbours by rank: rank r must own the r-th block."""
+    lib = _capi.load()
+    cb = _capi.ALLREDUCE_FN(lambda _u, _p, _n, _s: 0)
+    c = lk.Context(device=0)
+    _capi.check(lib.lk_set_allreduce(c._h, cb, None, 2, 0))             # this context is rank 0 of 2
+    op = C.c_void_p()
+    assert lib.lk_linop_lap5_create_sharded(c._h, 64, 32, 32, C.byref(op)) != 0        # the UPPER half on rank 0
+    assert b"rank order" in lib.lk_last_error()
+    _capi.check(lib.lk_linop_lap5_create_sharded(c._h, 64, 0, 32, C.byref(op)))
+    _capi.check(lib.lk_linop_destroy(op))
+    nu = (C.c_double * 2)(2.0, 0.2); ga = (C.c_double * 2)(1.0, -1.0)
+    assert lib.lk_linop_gl_create_sharded(c._h, 1000, 500, 500, 0.4, 0.01, 1, nu, ga, 0.34, -0.01, C.byref(op)) != 0
+    assert b"rank order" in lib.lk_last_error()
+    _capi.check(lib.lk_set_allreduce(c._h, None, None, 1, 0))
+    c.close()
+
+
+# ----------------------------------------------------------------------------- measurement hygiene
+def test_operator_time_is_measured_inside_the_asynchronous_batch(ctx):
+    """bench.py's `matvec` figure: the operator launches of an asynchronous Arnoldi batch carry profiling events too."""
+    n, m = 1_000_003, 12
+    X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
+    X[0].rand(True, seed=7)
+    H = np.zeros((m + 1, m), order="F")
+    A = lk.diag_linop_gpu(n_local=n, row0=0, d0=1.0, dstep=1.0 / n, ctx=ctx)
+    ctx.profile_reset(); ctx.profile_enable(True)
+    assert lk.arnoldi(A, X, H) == 0
+    ctx.sync()
+    cnt, ms, by = ctx.profile_get("matvec")
+    ctx.profile_enable(False)
+    assert cnt == m and ms > 0.0 and by == pytest.approx(m * 2 * 8.0 * n)

@@ -18,6 +18,10 @@ src, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(ROOT, "profiles")
 commit = open(os.path.join(src, "commit.txt")).read().strip() if os.path.exists(os.path.join(src, "commit.txt")) else "unknown"
+# SHA-256 of the kernel sources the profiled binary was built from (written on the GPU box by tools/run_profiles.sh);
+# bench.py refuses a traffic record whose hash is not that of the sources it sits beside
+khash = (open(os.path.join(src, "kernel_source_sha256.txt")).read().strip()
+         if os.path.exists(os.path.join(src, "kernel_source_sha256.txt")) else None)
 
 
 def find(sub, suffix):
@@ -83,7 +87,7 @@ if ff and fw:
     alg = 8.0 * n_local * sum(3 * k + 5 for k in range(1, m + 1)) / (3.0 * m)
     must = 8.0 * n_local * sum(3 * k + 4 for k in range(1, m + 1)) / (3.0 * m)
     pm = {
-        "commit": commit, "n_local": n_local, "m": m, "dtype": "f64",
+        "commit": commit, "kernel_source_sha256": khash, "n_local": n_local, "m": m, "dtype": "f64",
         "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
         "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
         "method": "separate --pmc passes; KB units; FETCH_SIZE doubled (gfx950 reports 1/2 of a 16 B/lane streaming read, MI355X_MICROARCH.md); "
@@ -100,7 +104,7 @@ if ff and fw:
     json.dump(pm, open(os.path.join(out, f"{tag}_pmc_n1e8_m128.json"), "w"), indent=1)
     json.dump({"n_local": n_local, "m": m, "dtype": "f64", "hbm_bytes_per_launch": fetch_b + write_b,
                "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_b + write_b) / alg,
-               "commit": commit, "source": f"profiles/{tag}_pmc_n1e8_m128.json", "method": pm["method"]},
+               "commit": commit, "kernel_source_sha256": khash, "source": f"profiles/{tag}_pmc_n1e8_m128.json", "method": pm["method"]},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     rec["pmc"] = {"traffic_over_algorithmic": pm["traffic_over_algorithmic"], "calibration": calib}
 print(json.dumps(rec))

@@ -24,7 +24,7 @@ typedef struct mock_op { int kind; int dtype; int64_t n; double *a; } mock_op;  
 #define MAX_SLABS 64
 static int g_in_pool = 0;   /* slabs are created / destroyed by the pool itself: not ABI calls of the plugin */
 typedef struct mock_ctx {
-    mock_basis *slab[MAX_SLABS]; int used[MAX_SLABS]; uint64_t *owner[MAX_SLABS]; int nslabs;
+    mock_basis *slab[MAX_SLABS]; int used[MAX_SLABS]; uint64_t *owner[MAX_SLABS]; uint64_t *gen[MAX_SLABS]; int nslabs;
     int slab_cols; int64_t carved, reused; int64_t row0;
 } mock_ctx;
 
@@ -92,13 +92,13 @@ int lk_pool_acquire(mock_ctx *c, int dtype, int64_t n, uint64_t tag, mock_basis 
     for (int i = 0; i < c->nslabs; ++i)
         for (int j = 0; j < c->used[i]; ++j)
             if (c->owner[i][j] == tag) {
-                if (c->slab[i]->dtype == dtype && c->slab[i]->n == n) { *slab = c->slab[i]; *colo = j; c->reused++; TR("pool_acquire %d %lld %llu -> %d %d\n", dtype, (long long)n, (unsigned long long)tag, idof(*slab), j); return LK_OK; }
+                if (c->slab[i]->dtype == dtype && c->slab[i]->n == n) { *slab = c->slab[i]; *colo = j; c->reused++; c->gen[i][j]++; TR("pool_acquire %d %lld %llu -> %d %d\n", dtype, (long long)n, (unsigned long long)tag, idof(*slab), j); return LK_OK; }
                 c->owner[i][j] = 0;
             }
     for (int i = 0; i < c->nslabs; ++i)
         if (c->slab[i]->dtype == dtype && c->slab[i]->n == n)
             for (int j = 0; j < c->used[i]; ++j)
-                if (c->owner[i][j] == 0) { c->owner[i][j] = tag; *slab = c->slab[i]; *colo = j; c->reused++; TR("pool_acquire %d %lld %llu -> %d %d\n", dtype, (long long)n, (unsigned long long)tag, idof(*slab), j); return LK_OK; }
+                if (c->owner[i][j] == 0) { c->owner[i][j] = tag; c->gen[i][j]++; *slab = c->slab[i]; *colo = j; c->reused++; TR("pool_acquire %d %lld %llu -> %d %d\n", dtype, (long long)n, (unsigned long long)tag, idof(*slab), j); return LK_OK; }
     int si = -1;
     for (int i = c->nslabs - 1; i >= 0; --i)
         if (c->slab[i]->dtype == dtype && c->slab[i]->n == n && c->used[i] < c->slab[i]->ncols) { si = i; break; }
@@ -107,10 +107,11 @@ int lk_pool_acquire(mock_ctx *c, int dtype, int64_t n, uint64_t tag, mock_basis 
         si = c->nslabs++;
         g_in_pool = 1; lk_basis_create(c, dtype, n, c->slab_cols, &c->slab[si]); g_in_pool = 0;
         c->owner[si] = calloc((size_t)c->slab_cols, sizeof(uint64_t));
+        c->gen[si] = calloc((size_t)c->slab_cols, sizeof(uint64_t));
         c->used[si] = 0;
     }
     const int j = c->used[si]++;
-    c->owner[si][j] = tag; c->carved++;
+    c->owner[si][j] = tag; c->gen[si][j]++; c->carved++;
     *slab = c->slab[si]; *colo = j;
     TR("pool_acquire %d %lld %llu -> %d %d\n", dtype, (long long)n, (unsigned long long)tag, idof(*slab), j);
     return LK_OK;
@@ -121,6 +122,13 @@ int lk_pool_owner(mock_ctx *c, mock_basis *slab, int j, uint64_t *tag) {
     if (si >= 0 && j >= 0 && j < c->used[si]) *tag = c->owner[si][j];
     return LK_OK;
 }
+int lk_pool_column_info(mock_ctx *c, mock_basis *slab, int j, uint64_t *tag, uint64_t *gen) {
+    if (tag) *tag = 0;
+    if (gen) *gen = 0;
+    const int si = find_slab(c, slab);
+    if (si >= 0 && j >= 0 && j < c->used[si]) { if (tag) *tag = c->owner[si][j]; if (gen) *gen = c->gen[si][j]; }
+    return LK_OK;
+}
 int lk_pool_release(mock_ctx *c, mock_basis *slab, int j) {
     const int si = find_slab(c, slab);
     if (si < 0) return fail("not a pool column");
@@ -129,7 +137,7 @@ int lk_pool_release(mock_ctx *c, mock_basis *slab, int j) {
 int lk_pool_release_all(mock_ctx *c) {
     TR("pool_release_all\n");
     g_in_pool = 1;
-    for (int i = 0; i < c->nslabs; ++i) { lk_basis_destroy(c->slab[i]); free(c->owner[i]); }
+    for (int i = 0; i < c->nslabs; ++i) { lk_basis_destroy(c->slab[i]); free(c->owner[i]); free(c->gen[i]); }
     g_in_pool = 0;
     c->nslabs = 0; return LK_OK;
 }

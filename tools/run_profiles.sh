@@ -7,6 +7,7 @@ TAG=${1:?tag}; COMMIT=${2:-unknown}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 D=$R/gpurun_out/$TAG
 mkdir -p "$D"; echo "$COMMIT" > "$D/commit.txt"
+python3 -c "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_source_hash())" > "$D/kernel_source_sha256.txt"
 cd /tmp; export TMPDIR=/tmp
 python3 "$R/bench.py" > "$D/bench_default.log" 2> "$D/bench_default.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -o bench -- python3 "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$D/stats.log" 2>&1
