@@ -13,6 +13,11 @@ real(dp) rows, m = 128, x0 from the shared counter RNG -- row-sharded over the N
 scaling: total work fixed), the only cross-rank traffic being the RCCL all-reduce of the <= 129
 reduction scalars after each sweep.  Inputs are generated in HBM before the timed region.
 
+`--operator dense | lap5 | csr` run the same factorisation on the other synthetic operators north_star names (dense matvec,
+5-point stencil, the same Laplacian as a CSR matrix; defaults: n = 65536 / 4096^2 / 4096^2), each row-sharded over the N ranks
+(dense, CSR: row block of A + all-gather of x; stencil: one grid line to each neighbour).  The headline line is the default
+(diagonal) operator.
+
 Prints ONE JSON line on rank 0; `value` = Arnoldi iterations per second, whole job.
   roofline   : the DGS sweep kernels (lk::panel_dot_cw for sweep 1, lk::panel_sweep for sweeps 2 and 3) -- algorithmic bytes s*n_local*(k+1|k+2)
                per launch (s*n*(3k+5) per DGS) / HIP-event duration on the kernel's
@@ -161,12 +166,63 @@ def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int) -> dict
     }
 
 
+def cpu_baseline_operator(operator: str, n_full: int, m_full: int) -> dict:
+    """cpu_baseline of the operator legs: the oracle's Arnoldi in the reference's schedule, ONE thread, on a bounded sample of
+    the same operator family, scaled to the full workload by a byte model (matvec bytes + (14k+20)*s*n per DGS)."""
+    from oracle import oracle as ora
+    ora.set_threads(1)
+    dgs = lambda nn, mm: sum(8.0 * nn * (14 * k + 20) for k in range(1, mm + 1))   # noqa: E731
+    if operator == "dense":
+        ns, ms = 8192, 12
+        rng = np.random.default_rng(0)
+        op = ora.DenseOp(np.asfortranarray(rng.uniform(-1.0, 1.0, (ns, ns))))
+        mvb = lambda nn: 8.0 * nn * nn                                                # noqa: E731
+        what = f"dense {ns} x {ns} (the stdlib gemv loop of the reference, AbstractLinops.fypp:623)"
+    else:
+        Ns = 1448                                                                     # ~2.1e6 rows
+        ns, ms = Ns * Ns, 16
+        op = ora.Lap5Op(Ns)
+        mvb = lambda nn: 16.0 * nn                                                    # noqa: E731
+        what = f"5-point Laplacian {Ns} x {Ns} (the oracle's stencil loop; the reference has no sparse type of its own)"
+    X = np.zeros((ns, ms + 1), order="F")
+    H = np.zeros((ms + 1, ms), order="F")
+    ora.fill_counter(X[:, 0], 7)
+    ora.scal(X[:, 0], 1.0 / ora.norm(X[:, 0]))
+    t0 = time.perf_counter()
+    info = ora.arnoldi(op, X, H)
+    dt = time.perf_counter() - t0
+    bw = (ms * mvb(ns) + dgs(ns, ms)) / dt
+    t_full = (m_full * mvb(n_full) + dgs(n_full, m_full)) / bw
+    return {"value": m_full / t_full, "unit": "Arnoldi iterations/s", "cores": 1, "kind": "port", "info": int(info), "host_cpus": os.cpu_count(),
+            "sample_seconds": dt, "effective_GBps_on_reference_schedule": bw / 1e9,
+            "sample": f"oracle (C restatement of the reference schedule, 1 thread) arnoldi, {what}, m={ms}: {dt:.2f} s; scaled to n={n_full}, "
+                      f"m={m_full} by bytes (operator + (14k+20)*8*n per DGS)"}
+
+
+def _laplacian_csr_rows(N: int, row0: int, n_local: int):
+    """Rows [row0, row0 + n_local) of the 5-point Laplacian on an N x N grid (Dirichlet, scaled by (N+1)^2) as
+    (rowptr, colind, vals) with global column indices in ascending order per row -- the stencil operator's matrix."""
+    i = np.arange(row0, row0 + n_local, dtype=np.int64)
+    ix, jy = i % N, i // N
+    sc = float((N + 1) ** 2)
+    cols = np.stack([i - N, i - 1, i, i + 1, i + N], axis=1)
+    ok = np.stack([jy > 0, ix > 0, np.ones_like(i, dtype=bool), ix < N - 1, jy < N - 1], axis=1)
+    vals = np.broadcast_to(np.array([-sc, -sc, 4.0 * sc, -sc, -sc]), cols.shape)
+    rowptr = np.zeros(n_local + 1, dtype=np.int64)
+    np.cumsum(ok.sum(axis=1), out=rowptr[1:])
+    return rowptr, cols[ok].astype(np.int32), np.ascontiguousarray(vals[ok])
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", dest="n", type=int, default=100_000_000, help="global rows (metric config: 1e8)")
+    ap.add_argument("--operator", default="diag", choices=["diag", "dense", "lap5", "csr"],
+                    help="synthetic operator: diag (the metric's configuration), dense (n x n matrix: GEMV), lap5 (5-point stencil), "
+                         "csr (the same Laplacian as an explicit sparse matrix)")
+    ap.add_argument("--rows", dest="n", type=int, default=None,
+                    help="global rows (default: 1e8 for diag = the metric config; 65536 for dense; 4096^2 for lap5 / csr)")
     ap.add_argument("--kdim", dest="m", type=int, default=128, help="Krylov dimension (metric config: 128)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "c128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -231,18 +287,52 @@ def main() -> None:
         ctx.set_tuning(key, int(val))
 
     dtype = np.float64 if args.dtype == "f64" else np.complex128
+    if args.n is None:
+        args.n = {"diag": 100_000_000, "dense": 65_536, "lap5": 4096 * 4096, "csr": 4096 * 4096}[args.operator]
     n, m = args.n, args.m
-    row0, n_local = lk.row_partition(n, world, rank)
-    ctx.set_partition(row0, n)
     s = 8 if args.dtype == "f64" else 16
+    if args.operator != "diag" and args.dtype != "f64":
+        raise SystemExit("bench.py: --operator dense / lap5 / csr run in real(dp)")
+    N = int(round(n ** 0.5))
+    if args.operator in ("lap5", "csr"):
+        if N * N != n:
+            raise SystemExit("bench.py: --operator lap5 / csr need --rows = N^2")
+        j0, nj = lk.grid_partition(N, world, rank)          # whole grid lines per rank
+        row0, n_local = j0 * N, nj * N
+        row_starts = [lk.grid_partition(N, world, r)[0] * N for r in range(world)] + [n]
+    else:
+        row0, n_local = lk.row_partition(n, world, rank)
+        row_starts = [lk.row_partition(n, world, r)[0] for r in range(world)] + [n]
+    ctx.set_partition(row0, n)
 
     # ---- inputs resident in HBM before the timed region
     X = lk.krylov_basis_gpu(n_local, m + 1, dtype, ctx)
-    if args.dtype == "f64":
-        A = lk.diag_linop_gpu(n_local=n_local, row0=row0, d0=1.0, dstep=1.0 / n, ctx=ctx)
+    keep = None
+    if args.operator == "diag":
+        if args.dtype == "f64":
+            A = lk.diag_linop_gpu(n_local=n_local, row0=row0, d0=1.0, dstep=1.0 / n, ctx=ctx)
+        else:
+            g = (row0 + np.arange(n_local)) / n
+            A = lk.diag_linop_gpu(((1.0 + g) * np.exp(1j * g)).astype(dtype), ctx)
+        op_desc = "synthetic diagonal linop d_i=1+i/n"
+        mv_bytes_model = (2 if args.dtype == "f64" else 3) * s * n_local
+    elif args.operator == "dense":
+        # A(i, j) = 2 u(seed = j, counter = i) - 1 generated in HBM column by column (the shared counter RNG: identical for
+        # every partition); this rank holds rows [row0, row0 + n_local)
+        keep = lk.krylov_basis_gpu(n_local, n, dtype, ctx)
+        for j in range(n):
+            keep[j].rand(False, seed=1000 + j)
+        A = lk.dense_linop_gpu.from_device_panel(keep, n_global=n, row_starts=row_starts)
+        op_desc = "synthetic dense linop A_ij = 2u(j, i)-1 (GEMV; row block per rank + all-gather of x)"
+        mv_bytes_model = s * n_local * n + s * (n + n_local)
+    elif args.operator == "lap5":
+        A = lk.laplacian2d_linop_gpu(N, ctx, j0=j0, nj=nj) if world > 1 else lk.laplacian2d_linop_gpu(N, ctx)
+        op_desc = f"5-point Laplacian stencil, {N} x {N} grid (grid lines per rank + one-line halo exchange)"
+        mv_bytes_model = 2 * s * n_local
     else:
-        g = (row0 + np.arange(n_local)) / n
-        A = lk.diag_linop_gpu(((1.0 + g) * np.exp(1j * g)).astype(dtype), ctx)
+        A = lk.csr_linop_gpu(_laplacian_csr_rows(N, row0, n_local), ctx, n_global=n, row_starts=row_starts)
+        op_desc = f"5-point Laplacian as a CSR matrix, {N} x {N} grid, {A.nnz} non-zeros on rank 0 (row block per rank + all-gather of x)"
+        mv_bytes_model = (s + 4) * A.nnz + 8 * (n_local + 1) + s * (n + n_local)
     H = np.zeros((m + 1, m), dtype=dtype, order="F")
 
     def one_factorisation() -> int:
@@ -320,8 +410,9 @@ def main() -> None:
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"arnoldi, synthetic diagonal linop d_i=1+i/n, n={n} {'real' if s == 8 else 'complex'}(dp), "
+                "workload": f"arnoldi, {op_desc}, n={n} {'real' if s == 8 else 'complex'}(dp), "
                             f"m={m}, one step = one m-step factorisation",
+                "operator": args.operator,
                 "n_global": n, "n_local": n_local, "m": m, "parallelism": f"row-shard x{world} (RCCL all-reduce of <=129 scalars/sweep)",
                 "info": int(info), "H_fro": float(np.linalg.norm(H)), "H_last_subdiag": float(abs(H[m, m - 1])),
                 "all_reduce": reduce_path,
@@ -342,12 +433,33 @@ def main() -> None:
                 "dgs_call_GBps": (dgs_bytes / 1e9) / (dgs_ms / 1e3) if dgs_ms > 0 else 0.0,
                 "dgs_frac_of_step_time": (dgs_ms / 1e3) / elapsed if elapsed > 0 else 0.0,
                 "matvec": {"launches": int(n_mv), "ms_total": mv_ms, "avg_ms": mv_ms / max(n_mv, 1),
-                           "algorithmic_bytes_per_launch": mv_bytes / max(n_mv, 1),
-                           "GBps": (mv_bytes / mv_ms / 1e6) if mv_ms > 0 else None,
-                           "measured": "HIP events on the operator's own dispatch inside the asynchronous batch" if n_mv else "not measured"},
+                           "algorithmic_bytes_per_launch": mv_bytes_model,
+                           "GBps": (mv_bytes_model * n_mv / mv_ms / 1e6) if mv_ms > 0 else None,
+                           "frac_of_hbm_peak": (mv_bytes_model * n_mv / mv_ms / 1e6 / HBM_PEAK_GBS) if mv_ms > 0 else None,
+                           "frac_of_step_time": (mv_ms / 1e3) / elapsed if elapsed > 0 else 0.0,
+                           "measured": ("HIP events around the operator (its own dispatch for the one-kernel diagonal operators; stream "
+                                        "markers around kernels + exchange otherwise) inside the asynchronous batch") if n_mv else "not measured"},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if mv_ms > sweep_ms and mv_ms > 0:
+            # the operator, not the orthogonalisation, is the dominant kernel of this workload (dense GEMV): its roofline leads
+            r = out["roofline"]
+            r["dominant"] = "matvec"
+            r["dgs_sweeps"] = {"achieved": r["achieved"], "frac": r["frac"], "launches": r["launches"], "avg_launch_ms": r["avg_launch_ms"],
+                               "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"]}
+            r["kernel"] = {"dense": "lk::k_gemv_n (y = A_rows x: 16 B per lane along rows, 8 columns in flight, split-K in chunks of 256 columns) + lk::k_gemv_n_finish"}.get(args.operator, "operator")
+            r["achieved"] = r["matvec"]["GBps"]
+            r["frac"] = r["matvec"]["frac_of_hbm_peak"]
+            r["launches"], r["avg_launch_ms"] = int(n_mv), mv_ms / max(n_mv, 1)
+            r["algorithmic_bytes_per_launch"] = mv_bytes_model
+            r["bytes_priced"] = "ALGORITHMIC bytes of one operator application: s*n_local*n (the matrix) + s*(n + n_local) (x read, y written)"
+            r["traffic"], r["traffic_source"] = None, "no PMC record for this workload"
+        if world == 1 and not args.no_cpu_baseline and args.operator != "diag":
+            try:
+                out["cpu_baseline"] = cpu_baseline_operator(args.operator, n, m)
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "Arnoldi iterations/s", "cores": 1, "kind": "port", "sample": f"failed: {exc!r}"}
+        elif world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, m, args.cpu_n, args.cpu_m)
             except Exception as exc:  # noqa: BLE001
@@ -355,7 +467,7 @@ def main() -> None:
                                        "sample": f"failed: {exc!r}"}
         print(json.dumps(out))
     # orderly teardown: device objects, then the library's own communicator (lk_finalize), then torch's group
-    del X, A
+    del X, A, keep
     if dist is not None:
         dist.barrier()
     ctx.close()

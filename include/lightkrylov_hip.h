@@ -103,6 +103,15 @@ typedef int (*lk_halo_fn)(void *user, const void *send_lo, const void *send_hi, 
                           int64_t count, void *stream);
 int lk_set_halo_exchange(lk_context_t ctx, lk_halo_fn fn, void *user);
 
+/* All-gather of row blocks, needed only by the row-sharded dense and CSR operators (their matvec needs the whole input
+ * vector): rank r contributes counts[r] doubles -- this rank's at device address `send` --, and on return the device buffer
+ * `recv` holds every rank's block, rank r's at recv + displs[r] (doubles).  Ordered on `stream`.  lk_comm_init_rank
+ * installs the native one (ncclAllGather for equal blocks, else ncclSend / ncclRecv in one group); lk_set_allgather lets a host
+ * bring its own (MPI_Allgatherv, tests). */
+typedef int (*lk_allgather_fn)(void *user, const void *send, void *recv, const int64_t *counts, const int64_t *displs,
+                               int nranks, void *stream);
+int lk_set_allgather(lk_context_t ctx, lk_allgather_fn fn, void *user);
+
 /* row block owned by this rank: global rows [row0, row0 + n_local) of n_global; only used
  * so that counter-based rand fills are identical for every partition. */
 int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
@@ -277,15 +286,32 @@ int lk_linop_diag_create(lk_context_t ctx, int dtype, int64_t n_local, const voi
 int lk_linop_diag_linspace_create(lk_context_t ctx, int64_t n_local, int64_t row0, double d0,
                                   double dstep, lk_linop_t *op);
 /* dense_linop: y = A x ('N') or A^H x ('H'); A is n x n column-major on the host.
- * AbstractLinops.fypp:265-271, 608-660.  Single-rank only. */
+ * AbstractLinops.fypp:265-271, 608-660.  Whole matrix on one rank (row-sharded: the _sharded variants below). */
 int lk_linop_dense_create(lk_context_t ctx, int dtype, int64_t n, const void *A_host, int64_t lda,
                           lk_linop_t *op);
+/* row-sharded dense_linop ("row block of A + allgather of x"): rank r owns rows [row_starts[r], row_starts[r+1]) of
+ * the n_global x n_global matrix and of every vector (row_starts: nranks + 1 entries, the same on every rank; the context's
+ * rank picks the block).  A_rows: this rank's n_local x n_global block, column-major, leading dimension lda >= n_local.
+ *   matvec  : x is all-gathered over the ranks (lk_allgather_fn), y_local = A_rows x -- the same products and the same
+ *             summation order per row as the single-rank operator;
+ *   rmatvec : z = A_rows^H x_local has n_global entries on every rank; their sum over the ranks (the all-reduce hook) is A^H x,
+ *             of which each rank keeps its rows (to rounding: the single-rank operator sums a column in one piece).
+ * _wrap_ takes the block where it already lies in DEVICE memory (16-byte aligned, lda even for LK_F64; not copied, not freed). */
+int lk_linop_dense_create_sharded(lk_context_t ctx, int dtype, int64_t n_global, const int64_t *row_starts, const void *A_rows,
+                                  int64_t lda, lk_linop_t *op);
+int lk_linop_dense_wrap_sharded(lk_context_t ctx, int dtype, int64_t n_global, const int64_t *row_starts, void *dev_ptr,
+                                int64_t lda, lk_linop_t *op);
 /* sparse operator in CSR: y = A x ('N') or A^H x ('H'), A n x n, 0-based `rowptr[n+1]` / `colind[nnz]`, values of
  * `dtype` -- a user's sparse `abstract_linop` (AbstractLinops.fypp:58-87; the reference has no sparse type of its own:
  * its Poisson / Ginzburg-Landau examples write the stencil by hand).  The arrays are copied; A^H is built once on the
- * host so that rmatvec is a row-parallel product too.  Single-rank. */
+ * host so that rmatvec is a row-parallel product too.  Whole matrix on one rank (row-sharded: below). */
 int lk_linop_csr_create(lk_context_t ctx, int dtype, int64_t n, const int64_t *rowptr, const int32_t *colind,
                         const void *vals, lk_linop_t *op);
+/* row-sharded CSR operator: rank r owns rows [row_starts[r], row_starts[r+1]); rowptr (n_local + 1 entries, 0-based) / colind /
+ * vals describe those rows with GLOBAL column indices.  matvec all-gathers x, rmatvec sums the ranks' full-length products of
+ * their blocks' conjugate transposes and keeps the local rows -- as lk_linop_dense_create_sharded. */
+int lk_linop_csr_create_sharded(lk_context_t ctx, int dtype, int64_t n_global, const int64_t *row_starts, const int64_t *rowptr,
+                                const int32_t *colind, const void *vals, lk_linop_t *op);
 /* 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (BASELINE config 3).
  * F64; whole grid on one rank (row-sharded: the _sharded variant below). */
 int lk_linop_lap5_create(lk_context_t ctx, int64_t N, lk_linop_t *op);

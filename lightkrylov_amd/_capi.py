@@ -20,6 +20,7 @@ LK_COMM_ID_BYTES = 128
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_void_p)
 
 _p = C.c_void_p
 _pp = C.POINTER(C.c_void_p)
@@ -37,6 +38,7 @@ SIGNATURES = {
     "lk_sync": (_int, [_p]),
     "lk_set_allreduce": (_int, [_p, ALLREDUCE_FN, _p, _int, _int]),
     "lk_set_halo_exchange": (_int, [_p, HALO_FN, _p]),
+    "lk_set_allgather": (_int, [_p, ALLGATHER_FN, _p]),
     "lk_context_info": (_int, [_p, _ip, _pp]),
     "lk_comm_get_unique_id": (_int, [_p]),
     "lk_comm_init_rank": (_int, [_p, _int, _int, _p]),
@@ -78,7 +80,10 @@ SIGNATURES = {
     "lk_linop_diag_create": (_int, [_p, _int, _i64, _p, _pp]),
     "lk_linop_diag_linspace_create": (_int, [_p, _i64, _i64, C.c_double, C.c_double, _pp]),
     "lk_linop_dense_create": (_int, [_p, _int, _i64, _p, _i64, _pp]),
+    "lk_linop_dense_create_sharded": (_int, [_p, _int, _i64, C.POINTER(_i64), _p, _i64, _pp]),
+    "lk_linop_dense_wrap_sharded": (_int, [_p, _int, _i64, C.POINTER(_i64), _p, _i64, _pp]),
     "lk_linop_csr_create": (_int, [_p, _int, _i64, _p, _p, _p, _pp]),
+    "lk_linop_csr_create_sharded": (_int, [_p, _int, _i64, C.POINTER(_i64), _p, _p, _p, _pp]),
     "lk_linop_lap5_create": (_int, [_p, _i64, _pp]),
     "lk_linop_lap5_create_sharded": (_int, [_p, _i64, _i64, _i64, _pp]),
     "lk_linop_gl_create_sharded": (_int, [_p, _i64, _i64, _i64, C.c_double, C.c_double, _int, _dp, _dp, C.c_double, C.c_double, _pp]),

@@ -20,6 +20,11 @@ class _DevMem:
             "shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
+def _null_ctx():
+    import contextlib
+    return contextlib.nullcontext()
+
+
 def row_partition(n_global: int, nranks: int, rank: int):
     """Contiguous row block of `rank`: (row0, n_local).  Every block but the last has an even
     number of rows (n_global // nranks rounded down to even); the last takes the remainder."""
@@ -95,6 +100,30 @@ class Context:
         self._cb = _capi.ALLREDUCE_FN(_allreduce)
         _capi.check(self._lib.lk_set_allreduce(self._h, self._cb, None, self.nranks, self.rank))
 
+        def _allgather(_user, send_ptr, recv_ptr, counts, displs, nranks, stream_ptr):
+            # every rank's row block of a vector to every rank (row-sharded dense / CSR matvec): one broadcast per block, which
+            # every backend supports for unequal blocks
+            try:
+                sp = int(stream_ptr or 0)
+                st = torch.cuda.ExternalStream(sp, device=self.device) if sp else None
+                with (torch.cuda.stream(st) if st is not None else _null_ctx()):
+                    mine = int(counts[self.rank])
+                    if mine:
+                        src = torch.as_tensor(_DevMem(int(send_ptr), mine), device=f"cuda:{self.device}")
+                        torch.as_tensor(_DevMem(int(recv_ptr) + 8 * int(displs[self.rank]), mine), device=f"cuda:{self.device}").copy_(src)
+                    for r in range(int(nranks)):
+                        if int(counts[r]):
+                            blk = torch.as_tensor(_DevMem(int(recv_ptr) + 8 * int(displs[r]), int(counts[r])), device=f"cuda:{self.device}")
+                            dist.broadcast(blk, src=dist.get_global_rank(pg, r) if pg is not None and pg is not dist.group.WORLD else r, group=pg)
+                return 0
+            except Exception as exc:  # noqa: BLE001 - must not propagate through C
+                import sys
+                print(f"[lightkrylov_amd] all-gather callback failed: {exc!r}", file=sys.stderr)
+                return 1
+
+        self._ag_cb = _capi.ALLGATHER_FN(_allgather)
+        _capi.check(self._lib.lk_set_allgather(self._h, self._ag_cb, None))
+
     # -- multi-GPU, native: ncclAllReduce issued by the library itself (no interpreter in the path) ------
     @staticmethod
     def comm_unique_id() -> bytes:
@@ -135,6 +164,12 @@ class Context:
         communicator installs its own (ncclSend / ncclRecv)."""
         self._halo_cb = fn
         _capi.check(self._lib.lk_set_halo_exchange(self._h, fn, None))
+
+    def set_allgather(self, fn) -> None:
+        """Install a host-provided all-gather of row blocks (`_capi.ALLGATHER_FN`) for the row-sharded dense / CSR operators; the
+        native communicator and `set_process_group` install their own."""
+        self._ag_cb = fn
+        _capi.check(self._lib.lk_set_allgather(self._h, fn, None))
 
     def set_partition(self, row0: int, n_global: int) -> None:
         _capi.check(self._lib.lk_set_partition(self._h, int(row0), int(n_global)))

@@ -32,6 +32,7 @@ struct Rccl {
     decltype(&ncclRecv) recv = nullptr;
     decltype(&ncclGroupStart) group_start = nullptr;
     decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
 };
 static_assert(sizeof(ncclUniqueId) == LK_COMM_ID_BYTES, "LK_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
 Rccl g_rccl;
@@ -58,8 +59,9 @@ int load_rccl() {
     g_rccl.recv = (decltype(g_rccl.recv))dlsym(h, "ncclRecv");
     g_rccl.group_start = (decltype(g_rccl.group_start))dlsym(h, "ncclGroupStart");
     g_rccl.group_end = (decltype(g_rccl.group_end))dlsym(h, "ncclGroupEnd");
+    g_rccl.all_gather = (decltype(g_rccl.all_gather))dlsym(h, "ncclAllGather");
     if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.comm_destroy || !g_rccl.all_reduce || !g_rccl.send ||
-        !g_rccl.recv || !g_rccl.group_start || !g_rccl.group_end)
+        !g_rccl.recv || !g_rccl.group_start || !g_rccl.group_end || !g_rccl.all_gather)
         return lk_fail_(LK_ERR_COMM, "lk_comm: librccl lacks a required symbol");
     g_rccl.handle = h;
     return LK_OK;
@@ -81,6 +83,31 @@ int rccl_halo(void *user, const void *send_lo, const void *send_hi, void *recv_l
     if (recv_lo && st->rank > 0) ok = ok && g_rccl.recv(recv_lo, (size_t)count, ncclDouble, st->rank - 1, st->comm, s) == ncclSuccess;
     if (send_hi && st->rank + 1 < st->nranks) ok = ok && g_rccl.send(send_hi, (size_t)count, ncclDouble, st->rank + 1, st->comm, s) == ncclSuccess;
     if (recv_hi && st->rank + 1 < st->nranks) ok = ok && g_rccl.recv(recv_hi, (size_t)count, ncclDouble, st->rank + 1, st->comm, s) == ncclSuccess;
+    ok = (g_rccl.group_end() == ncclSuccess) && ok;
+    return ok ? 0 : 1;
+}
+
+// every rank's row block of a vector to every rank (the input of a row-sharded dense / CSR matvec).  Equal blocks laid out in
+// rank order are one ncclAllGather; otherwise (the last rank of row_partition holds the remainder) every pair exchanges its
+// blocks by ncclSend / ncclRecv in one group and the own block is a device copy.
+int rccl_allgatherv(void *user, const void *send, void *recv, const int64_t *counts, const int64_t *displs, int nranks, void *stream) {
+    CommState *st = (CommState *)user;
+    hipStream_t s = (hipStream_t)stream;
+    if (nranks != st->nranks) return 1;
+    bool uniform = true;
+    for (int r = 0; r < nranks; ++r) uniform = uniform && counts[r] == counts[0] && displs[r] == (int64_t)r * counts[0];
+    if (uniform)
+        return g_rccl.all_gather(send, recv, (size_t)counts[0], ncclDouble, st->comm, s) == ncclSuccess ? 0 : 1;
+    double *out = (double *)recv;
+    if (counts[st->rank] > 0 &&
+        hipMemcpyAsync(out + displs[st->rank], send, (size_t)counts[st->rank] * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        return 1;
+    bool ok = g_rccl.group_start() == ncclSuccess;
+    for (int r = 0; r < nranks; ++r) {
+        if (r == st->rank) continue;
+        if (counts[st->rank] > 0) ok = ok && g_rccl.send(send, (size_t)counts[st->rank], ncclDouble, r, st->comm, s) == ncclSuccess;
+        if (counts[r] > 0) ok = ok && g_rccl.recv(out + displs[r], (size_t)counts[r], ncclDouble, r, st->comm, s) == ncclSuccess;
+    }
     ok = (g_rccl.group_end() == ncclSuccess) && ok;
     return ok ? 0 : 1;
 }
@@ -120,6 +147,7 @@ int lk_comm_init_rank(lk_context_t ctx, int nranks, int rank, const void *id) {
     CommState *st = new CommState{comm, nranks, rank};
     rc = lk_set_allreduce(ctx, rccl_sum, st, nranks, rank);
     if (rc == LK_OK) rc = lk_set_halo_exchange(ctx, rccl_halo, st);
+    if (rc == LK_OK) rc = lk_set_allgather(ctx, rccl_allgatherv, st);
     if (rc != LK_OK) {
         (void)g_rccl.comm_destroy(comm);
         delete st;
@@ -137,6 +165,7 @@ int lk_comm_destroy(lk_context_t ctx) {
     (void)lk_sync(ctx);
     (void)lk_set_allreduce(ctx, nullptr, nullptr, 1, 0);
     (void)lk_set_halo_exchange(ctx, nullptr, nullptr);
+    (void)lk_set_allgather(ctx, nullptr, nullptr);
     const ncclResult_t nrc = g_rccl.comm_destroy(it->second->comm);
     delete it->second;
     g_comms.erase(it);

@@ -75,7 +75,8 @@ struct lk_context_s {
     int update_grid_mult = 4;
     int gemm_grid_mult = 4;    // panel_gemm blocks per CU
     int gemm_mfma = 1;         // tall-skinny product on the FP64 matrix cores (0: FP64 VALU kernel)
-    int gemm_mfma_min = 5;     // ... for at least this many output columns; narrower products stream through the VALU kernel
+    int gemm_mfma_min = 0;     // ... for at least this many output columns (0: 5 real / 9 complex, from profiles/r03_lincomb_scan.txt);
+                               // narrower products stream X through the VALU kernel with 1 / 2 / 4 / 8 accumulators per lane
     int gemm_store_policy = 2; // cache policy of the product's output stores (as store_policy: 2 = sc1 write-through)
     int stream_two = 0;        // sweep 3 with two coefficient sets: barrier-free streaming kernel instead of the LDS/barrier one
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
@@ -98,6 +99,8 @@ struct lk_context_s {
     void *allreduce_user = nullptr;
     lk_halo_fn halo = nullptr;
     void *halo_user = nullptr;
+    lk_allgather_fn allgather = nullptr;
+    void *allgather_user = nullptr;
     int nranks = 1, rank = 0;
     int64_t row0 = 0, n_global = -1;  // this rank's row block [row0, row0 + n_local) of n_global rows
     // lazy batching of the PER-OBJECT path (opt-in, tuning key "lazy"): what an unchanged LightKrylov drives
@@ -211,7 +214,14 @@ struct lk_linop_s {
     int dtype;
     int64_t n;
     double *dev = nullptr;  // diag values / dense matrix
+    bool own_dev = true;    // dense: the matrix memory belongs to the operator (false: wrapped caller memory)
     int64_t lda = 0;
+    // row-sharded dense / CSR: this rank holds rows [rstart[rank], rstart[rank+1]) of an ncols_g x ncols_g operator
+    int64_t ncols_g = 0;                  // global size (= n on a single rank)
+    std::vector<int64_t> gcounts, gdispls;   // all-gather layout in DOUBLES (per rank)
+    double *xfull = nullptr;              // the gathered input vector / the full-length adjoint product (ncols_g elements)
+    double *gpart = nullptr;              // k_gemv_n's per-chunk partial sums
+    int gchunks = 1;
     int64_t row0 = 0;
     double d0 = 0, dstep = 0;
     int64_t N = 0;
@@ -749,7 +759,8 @@ int gemm_launch(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, con
                 int accumulate, double *pack) {
     // narrow products (q < gemm_mfma_min) stream X through the VALU kernel with q accumulators per lane; wider ones go to the
     // matrix cores (crossover from profiles/r03_lincomb.jsonl)
-    if (Bx->ctx->gemm_mfma && q >= Bx->ctx->gemm_mfma_min) return gemm_launch_mfma(Bx, c0, k, By, jy0, q, Cdev, ldc, sign, accumulate, pack);
+    const int mfma_min = Bx->ctx->gemm_mfma_min > 0 ? Bx->ctx->gemm_mfma_min : (Bx->dtype == LK_C128 ? 9 : 5);
+    if (Bx->ctx->gemm_mfma && q >= mfma_min) return gemm_launch_mfma(Bx, c0, k, By, jy0, q, Cdev, ldc, sign, accumulate, pack);
     return gemm_launch_valu(Bx, c0, k, By, jy0, q, Cdev, ldc, sign, accumulate, pack);
 }
 
@@ -1142,7 +1153,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "gemm_mfma")) { c->gemm_mfma = value != 0; return LK_OK; }
-    if (!strcmp(key, "gemm_mfma_min")) { c->gemm_mfma_min = value < 1 ? 1 : value; return LK_OK; }
+    if (!strcmp(key, "gemm_mfma_min")) { c->gemm_mfma_min = value < 0 ? 0 : value; return LK_OK; }
     if (!strcmp(key, "gemm_store_policy")) {
         if (value < 0 || value > 3) return fail(LK_ERR_INVALID, "gemm_store_policy must be in [0,3]");
         c->gemm_store_policy = value;
@@ -2043,20 +2054,113 @@ int lk_linop_diag_linspace_create(lk_context_t c, int64_t n_local, int64_t row0,
     return LK_OK;
 }
 
-int lk_linop_dense_create(lk_context_t c, int dtype, int64_t n, const void *A_host, int64_t lda, lk_linop_t *op) {
-    if (!c || !A_host || !op) return fail(LK_ERR_INVALID, "lk_linop_dense_create: null argument");
+// layout of a row partition for the all-gather of x (counts and displacements in doubles) + the workspaces of a sharded operator
+static int shard_setup(lk_linop_t o, lk_context_t c, int64_t n_global, const int64_t *row_starts, const char *what) {
+    const int ED = o->dtype == LK_C128 ? 2 : 1;
+    if (!row_starts) return fail(LK_ERR_INVALID, "%s: null row_starts", what);
+    if (row_starts[0] != 0 || row_starts[c->nranks] != n_global) return fail(LK_ERR_INVALID, "%s: row_starts must run from 0 to n_global", what);
+    for (int r = 0; r < c->nranks; ++r)
+        if (row_starts[r + 1] < row_starts[r]) return fail(LK_ERR_INVALID, "%s: row_starts decreases at rank %d", what, r);
+    o->ncols_g = n_global;
+    o->n = row_starts[c->rank + 1] - row_starts[c->rank];
+    o->row0 = row_starts[c->rank];
+    o->gcounts.resize(c->nranks);
+    o->gdispls.resize(c->nranks);
+    for (int r = 0; r < c->nranks; ++r) {
+        o->gcounts[r] = (row_starts[r + 1] - row_starts[r]) * ED;
+        o->gdispls[r] = row_starts[r] * ED;
+    }
+    if (c->nranks > 1) HIPCHK(hipMalloc((void **)&o->xfull, (size_t)(n_global > 0 ? n_global : 1) * ED * sizeof(double)));
+    return LK_OK;
+}
+
+constexpr int64_t GEMV_COLS_PER_CHUNK = 256;
+
+static int dense_finish(lk_linop_t o, lk_context_t c) {
+    // split-K of y = A x in chunks of GEMV_COLS_PER_CHUNK columns: the chunking depends on the GLOBAL column count only, so a
+    // row's products are added in the same order whatever the row partition (sharded matvec = single-rank matvec bit for bit)
+    (void)c;
+    int64_t chunks = (o->ncols_g + GEMV_COLS_PER_CHUNK - 1) / GEMV_COLS_PER_CHUNK;
+    if (chunks < 1) chunks = 1;
+    o->gchunks = (int)chunks;
+    const int ED = o->dtype == LK_C128 ? 2 : 1;
+    HIPCHK(hipMalloc((void **)&o->gpart, (size_t)chunks * (o->n > 0 ? o->n : 1) * ED * sizeof(double)));
+    return LK_OK;
+}
+
+int lk_linop_dense_wrap_sharded(lk_context_t c, int dtype, int64_t n_global, const int64_t *row_starts, void *dev_ptr, int64_t lda,
+                                lk_linop_t *op) {
+    if (!c || !dev_ptr || !op) return fail(LK_ERR_INVALID, "lk_linop_dense_wrap_sharded: null argument");
     DevGuard dev_guard(c);
     if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "bad dtype");
-    if (lda < n) return fail(LK_ERR_INVALID, "lda < n");
-    if (c->nranks > 1) return fail(LK_ERR_INVALID, "dense_linop is single-rank only");
+    if (((uintptr_t)dev_ptr & 15) != 0) return fail(LK_ERR_INVALID, "lk_linop_dense_wrap_sharded: pointer must be 16-byte aligned");
+    if (dtype == LK_F64 && (lda & 1)) return fail(LK_ERR_INVALID, "lk_linop_dense_wrap_sharded: lda must be even for LK_F64");
     lk_linop_t o = new lk_linop_s();
-    o->ctx = c; o->kind = OP_DENSE; o->dtype = dtype; o->n = n; o->lda = n;
-    const size_t es = (dtype == LK_C128 ? 2 : 1) * sizeof(double);
-    hipError_t e = hipMalloc((void **)&o->dev, (size_t)n * n * es + 16);
-    if (e != hipSuccess) { delete o; return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
-    e = hipMemcpy2D(o->dev, (size_t)n * es, A_host, (size_t)lda * es, (size_t)n * es, n, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { (void)hipFree(o->dev); delete o; return fail(LK_ERR_HIP, "hipMemcpy2D failed: %s", hipGetErrorString(e)); }
+    o->ctx = c; o->kind = OP_DENSE; o->dtype = dtype; o->dev = (double *)dev_ptr; o->own_dev = false; o->lda = lda;
+    int rc = shard_setup(o, c, n_global, row_starts, "lk_linop_dense_wrap_sharded");
+    if (rc == LK_OK && lda < o->n) rc = fail(LK_ERR_INVALID, "lk_linop_dense_wrap_sharded: lda < local rows");
+    if (rc == LK_OK) rc = dense_finish(o, c);
+    if (rc != LK_OK) { (void)lk_linop_destroy(o); return rc; }
     *op = o;
+    return LK_OK;
+}
+
+int lk_linop_dense_create_sharded(lk_context_t c, int dtype, int64_t n_global, const int64_t *row_starts, const void *A_rows, int64_t lda,
+                                  lk_linop_t *op) {
+    if (!c || !A_rows || !op || !row_starts) return fail(LK_ERR_INVALID, "lk_linop_dense_create_sharded: null argument");
+    DevGuard dev_guard(c);
+    if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "bad dtype");
+    const int64_t n_local = row_starts[c->rank + 1] - row_starts[c->rank];
+    if (n_local < 0 || lda < n_local) return fail(LK_ERR_INVALID, "lk_linop_dense_create_sharded: lda < local rows");
+    const size_t es = (dtype == LK_C128 ? 2 : 1) * sizeof(double);
+    const int64_t ldd = ((n_local + 31) / 32) * 32 + (n_local == 0 ? 32 : 0);          // 256-byte columns on the device
+    double *dev = nullptr;
+    hipError_t e = hipMalloc((void **)&dev, (size_t)ldd * (n_global > 0 ? n_global : 1) * es);
+    if (e != hipSuccess) return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    if (n_local > 0 && n_global > 0) {
+        e = hipMemcpy2D(dev, (size_t)ldd * es, A_rows, (size_t)lda * es, (size_t)n_local * es, n_global, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(dev); return fail(LK_ERR_HIP, "hipMemcpy2D failed: %s", hipGetErrorString(e)); }
+    }
+    const int rc = lk_linop_dense_wrap_sharded(c, dtype, n_global, row_starts, dev, ldd, op);
+    if (rc != LK_OK) { (void)hipFree(dev); return rc; }
+    (*op)->own_dev = true;
+    return LK_OK;
+}
+
+int lk_linop_dense_create(lk_context_t c, int dtype, int64_t n, const void *A_host, int64_t lda, lk_linop_t *op) {
+    if (!c || !A_host || !op) return fail(LK_ERR_INVALID, "lk_linop_dense_create: null argument");
+    if (lda < n) return fail(LK_ERR_INVALID, "lda < n");
+    if (c->nranks > 1) return fail(LK_ERR_INVALID, "dense_linop over several ranks: use lk_linop_dense_create_sharded (a row block per rank)");
+    const int64_t starts[2] = {0, n};
+    return lk_linop_dense_create_sharded(c, dtype, n, starts, A_host, lda, op);
+}
+
+// x (this rank's rows) -> the operator's full-length buffer, rank r's block at its global offset
+static int gather_x(lk_linop_t op, const double *x, const double **xg) {
+    lk_context_t c = op->ctx;
+    if (c->nranks == 1) { *xg = x; return LK_OK; }
+    if (!c->allgather) return fail(LK_ERR_COMM, "row-sharded dense / CSR operator but no all-gather installed (lk_comm_init_rank / lk_set_allgather)");
+    const int rc = c->allgather(c->allgather_user, x, op->xfull, op->gcounts.data(), op->gdispls.data(), c->nranks, (void *)c->stream);
+    if (rc != 0) return fail(LK_ERR_COMM, "all-gather callback returned %d", rc);
+    *xg = op->xfull;
+    return LK_OK;
+}
+
+// adjoint products of a row block are full-length partial sums: summed over the ranks, then this rank keeps its own rows
+static int reduce_to_slice(lk_linop_t op, double *zfull, double *y) {
+    lk_context_t c = op->ctx;
+    const int ED = op->dtype == LK_C128 ? 2 : 1;
+    LKCHK(allreduce(c, zfull, op->ncols_g * ED));
+    const int64_t nd = op->n * ED;
+    hipLaunchKernelGGL(k_copy_guarded, dim3(blas1_grid(c, nd / 2 + 1)), dim3(256), 0, c->stream, (const double *)(zfull + op->row0 * ED), y, nd, c->guard());
+    HIPCHK(hipGetLastError());
+    return LK_OK;
+}
+
+int lk_set_allgather(lk_context_t c, lk_allgather_fn fn, void *user) {
+    if (!c) return fail(LK_ERR_INVALID, "lk_set_allgather: null context");
+    c->allgather = fn;
+    c->allgather_user = user;
     return LK_OK;
 }
 
@@ -2166,26 +2270,27 @@ static int csr_upload(lk_linop_t o, int which, int64_t n, const int64_t *rowptr,
     return LK_OK;
 }
 
-int lk_linop_csr_create(lk_context_t c, int dtype, int64_t n, const int64_t *rowptr, const int32_t *colind, const void *vals,
-                        lk_linop_t *op) {
-    if (!c || !rowptr || !op) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null argument");
+int lk_linop_csr_create_sharded(lk_context_t c, int dtype, int64_t n_global, const int64_t *row_starts, const int64_t *rowptr,
+                                const int32_t *colind, const void *vals, lk_linop_t *op) {
+    if (!c || !rowptr || !op || !row_starts) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null argument");
     DevGuard dev_guard(c);
     if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "lk_linop_csr_create: bad dtype %d", dtype);
-    if (c->nranks > 1) return fail(LK_ERR_INVALID, "lk_linop_csr_create: single-rank operator");
-    if (n < 0 || n > 2147483647LL) return fail(LK_ERR_INVALID, "lk_linop_csr_create: bad size %lld", (long long)n);
+    if (n_global < 0 || n_global > 2147483647LL) return fail(LK_ERR_INVALID, "lk_linop_csr_create: bad size %lld", (long long)n_global);
+    const int64_t n = row_starts[c->rank + 1] - row_starts[c->rank];      // rows held here; column indices are GLOBAL
+    if (n < 0) return fail(LK_ERR_INVALID, "lk_linop_csr_create: row_starts decreases");
     if (rowptr[0] != 0) return fail(LK_ERR_INVALID, "lk_linop_csr_create: rowptr must be 0-based");
     const int64_t nnz = rowptr[n];
     if (nnz > 0 && (!colind || !vals)) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null colind / vals");
     for (int64_t i = 0; i < n; ++i)
         if (rowptr[i + 1] < rowptr[i]) return fail(LK_ERR_INVALID, "lk_linop_csr_create: rowptr decreases at row %lld", (long long)i);
     for (int64_t p = 0; p < nnz; ++p)
-        if (colind[p] < 0 || colind[p] >= n) return fail(LK_ERR_INVALID, "lk_linop_csr_create: column index %d out of range at entry %lld", colind[p], (long long)p);
+        if (colind[p] < 0 || colind[p] >= n_global) return fail(LK_ERR_INVALID, "lk_linop_csr_create: column index %d out of range at entry %lld", colind[p], (long long)p);
     const int ED = dtype == LK_C128 ? 2 : 1;
     const double *v = (const double *)vals;
-    // conjugate transpose by counting sort over the column indices
-    std::vector<int64_t> tp((size_t)n + 1, 0);
+    // conjugate transpose of the row block (n_global rows, LOCAL column indices) by counting sort over the column indices
+    std::vector<int64_t> tp((size_t)n_global + 1, 0);
     for (int64_t p = 0; p < nnz; ++p) tp[(size_t)colind[p] + 1] += 1;
-    for (int64_t j = 0; j < n; ++j) tp[(size_t)j + 1] += tp[(size_t)j];
+    for (int64_t j = 0; j < n_global; ++j) tp[(size_t)j + 1] += tp[(size_t)j];
     std::vector<int32_t> tc((size_t)(nnz > 0 ? nnz : 1));
     std::vector<double> tv((size_t)(nnz > 0 ? nnz : 1) * ED);
     {
@@ -2199,12 +2304,21 @@ int lk_linop_csr_create(lk_context_t c, int dtype, int64_t n, const int64_t *row
             }
     }
     lk_linop_t o = new lk_linop_s();
-    o->ctx = c; o->kind = OP_CSR; o->dtype = dtype; o->n = n;
-    int rc = csr_upload(o, 0, n, rowptr, colind, v, ED);
-    if (rc == LK_OK) rc = csr_upload(o, 1, n, tp.data(), tc.data(), tv.data(), ED);
+    o->ctx = c; o->kind = OP_CSR; o->dtype = dtype;
+    int rc = shard_setup(o, c, n_global, row_starts, "lk_linop_csr_create");
+    if (rc == LK_OK) rc = csr_upload(o, 0, n, rowptr, colind, v, ED);
+    if (rc == LK_OK) rc = csr_upload(o, 1, n_global, tp.data(), tc.data(), tv.data(), ED);
     if (rc != LK_OK) { (void)lk_linop_destroy(o); return rc; }
     *op = o;
     return LK_OK;
+}
+
+int lk_linop_csr_create(lk_context_t c, int dtype, int64_t n, const int64_t *rowptr, const int32_t *colind, const void *vals,
+                        lk_linop_t *op) {
+    if (!c || !rowptr || !op) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null argument");
+    if (c->nranks > 1) return fail(LK_ERR_INVALID, "lk_linop_csr_create over several ranks: use lk_linop_csr_create_sharded (a row block per rank)");
+    const int64_t starts[2] = {0, n};
+    return lk_linop_csr_create_sharded(c, dtype, n, starts, rowptr, colind, vals, op);
 }
 
 int lk_linop_destroy(lk_linop_t op) {
@@ -2217,7 +2331,9 @@ int lk_linop_destroy(lk_linop_t op) {
     }
     if (op->kind == OP_LAP5 && op->halo) (void)hipFree(op->halo);
     if (op->wk) (void)hipFree(op->wk);
-    if (op->dev) (void)hipFree(op->dev);  // synchronises; the context may already be finalized
+    if (op->xfull) (void)hipFree(op->xfull);
+    if (op->gpart) (void)hipFree(op->gpart);
+    if (op->dev && op->own_dev) (void)hipFree(op->dev);  // synchronises; the context may already be finalized
     delete op;
     return LK_OK;
 }
@@ -2262,43 +2378,71 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
         else
             hipLaunchKernelGGL(k_diag_linspace, dim3(blas1_grid(c, nv)), dim3(256), 0, c->stream, op->d0, op->dstep, op->row0, x, y, n, c->guard());
         break;
-    case OP_DENSE:
+    case OP_DENSE: {
+        const int ED = Bx->ed();
         if (trans == LK_OP_N) {
-            if (cp) hipLaunchKernelGGL(k_gemv_n<true>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y, c->guard());
-            else hipLaunchKernelGGL(k_gemv_n<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y, c->guard());
+            const double *xg = nullptr;
+            LKCHK(gather_x(op, x, &xg));                                                  // sharded: all-gather of x
+            const int64_t cpc = GEMV_COLS_PER_CHUNK;
+            const dim3 grid((unsigned)((n + (cp ? 255 : 511)) / (cp ? 256 : 512)), (unsigned)op->gchunks);
+            if (n > 0) {
+                if (cp) hipLaunchKernelGGL(k_gemv_n<true>, grid, dim3(256), 0, c->stream, op->dev, op->lda, n, op->ncols_g, xg, op->gpart, cpc, c->guard());
+                else hipLaunchKernelGGL(k_gemv_n<false>, grid, dim3(256), 0, c->stream, op->dev, op->lda, n, op->ncols_g, xg, op->gpart, cpc, c->guard());
+                hipLaunchKernelGGL(k_gemv_n_finish, dim3(blas1_grid(c, n * ED)), dim3(256), 0, c->stream, (const double *)op->gpart, n * ED, op->gchunks, y, c->guard());
+            }
         } else {
-            if (cp) hipLaunchKernelGGL(k_gemv_h<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y, c->guard());
-            else hipLaunchKernelGGL(k_gemv_h<false>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, x, y, c->guard());
+            // y = A^H x.  Sharded: z = A_rows^H x_rows has n_global entries on every rank; their sum over the ranks is the
+            // product, of which this rank keeps its rows.
+            double *z = c->nranks > 1 ? op->xfull : y;
+            if (op->ncols_g > 0) {
+                if (cp) hipLaunchKernelGGL(k_gemv_h<true>, dim3((unsigned)((op->ncols_g + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, op->ncols_g, x, z, c->guard());
+                else hipLaunchKernelGGL(k_gemv_h<false>, dim3((unsigned)((op->ncols_g + 3) / 4)), dim3(256), 0, c->stream, op->dev, op->lda, n, op->ncols_g, x, z, c->guard());
+            }
+            if (c->nranks > 1) LKCHK(reduce_to_slice(op, z, y));
         }
         break;
+    }
     case OP_CSR: {
         auto m = op->csr[trans == LK_OP_N ? 0 : 1];
-        if (c->csr_stream && n > 0 && (double)m.nnz_hint / (double)n <= 32.0 && !c->csr_lanes) {
+        // row-sharded: 'N' multiplies this rank's rows with the all-gathered x; 'H' applies the conjugate transpose of the row
+        // block (n_global rows) to this rank's x, sums the full-length results over the ranks and keeps this rank's rows
+        const bool shard = c->nranks > 1;
+        const int64_t nr = trans == LK_OP_N ? n : op->ncols_g;          // rows of the product computed here
+        const double *xin = x;
+        double *yout = y;
+        if (shard && trans == LK_OP_N) LKCHK(gather_x(op, x, &xin));
+        if (shard && trans != LK_OP_N) yout = op->xfull;
+        bool launched = false;
+        if (c->csr_stream && nr > 0 && (double)m.nnz_hint / (double)nr <= 32.0 && !c->csr_lanes) {
             // short rows: stream the entries through LDS (k_csr_stream)
             int64_t g = m.nblocks;
             const int64_t cap = (int64_t)c->num_cu * 16;
             if (g > cap) g = cap;
             if (g < 1) g = 1;
-            if (cp) hipLaunchKernelGGL(k_csr_stream<true>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, x, y, m.nblocks, c->guard());
-            else hipLaunchKernelGGL(k_csr_stream<false>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, x, y, m.nblocks, c->guard());
-            break;
+            if (cp) hipLaunchKernelGGL(k_csr_stream<true>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, xin, yout, m.nblocks, c->guard());
+            else hipLaunchKernelGGL(k_csr_stream<false>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, xin, yout, m.nblocks, c->guard());
+            launched = true;
         }
-        if (c->csr_lanes) m.W = c->csr_lanes;
-        const int64_t rows_per_block = 256 / m.W;
-        int64_t g = (n + rows_per_block - 1) / rows_per_block;
-        const int64_t cap = (int64_t)c->num_cu * 16;
-        if (g > cap) g = cap;
-        if (g < 1) g = 1;
+        if (!launched) {
+            if (c->csr_lanes) m.W = c->csr_lanes;
+            const int64_t rows_per_block = 256 / m.W;
+            int64_t g = (nr + rows_per_block - 1) / rows_per_block;
+            const int64_t cap = (int64_t)c->num_cu * 16;
+            if (g > cap) g = cap;
+            if (g < 1) g = 1;
 #define LK_CSR_LAUNCH(WW)                                                                                                  \
     case WW:                                                                                                               \
-        if (cp) hipLaunchKernelGGL((k_csr<true, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, x, y, n, c->guard()); \
-        else hipLaunchKernelGGL((k_csr<false, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, x, y, n, c->guard());   \
+        if (cp) hipLaunchKernelGGL((k_csr<true, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, xin, yout, nr, c->guard()); \
+        else hipLaunchKernelGGL((k_csr<false, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, xin, yout, nr, c->guard());   \
         break;
-        switch (m.W) {
-            LK_CSR_LAUNCH(1) LK_CSR_LAUNCH(2) LK_CSR_LAUNCH(4) LK_CSR_LAUNCH(8) LK_CSR_LAUNCH(16) LK_CSR_LAUNCH(32) LK_CSR_LAUNCH(64)
-        default: return fail(LK_ERR_INVALID, "internal: CSR lanes per row %d", m.W);
-        }
+            switch (m.W) {
+                LK_CSR_LAUNCH(1) LK_CSR_LAUNCH(2) LK_CSR_LAUNCH(4) LK_CSR_LAUNCH(8) LK_CSR_LAUNCH(16) LK_CSR_LAUNCH(32) LK_CSR_LAUNCH(64)
+            default: return fail(LK_ERR_INVALID, "internal: CSR lanes per row %d", m.W);
+            }
 #undef LK_CSR_LAUNCH
+        }
+        HIPCHK(hipGetLastError());
+        if (shard && trans != LK_OP_N) LKCHK(reduce_to_slice(op, yout, y));
         break;
     }
     case OP_GL: {

@@ -1597,59 +1597,113 @@ __global__ __launch_bounds__(256) void k_csr_stream(const int64_t *__restrict__ 
     }
 }
 
-// y = A x, A n x n column-major.  Block = 4 waves x 64 rows; wave w sums columns j == w (mod 4).
+// Dense operator (dense_linop, AbstractLinops.fypp:608-660): A is nrows x ncols column-major on the device, leading dimension
+// lda EVEN for the real kind and the base 16-byte aligned (the launcher pads), so that a lane reads 16 bytes of a column.
+// Square on one rank; the row-sharded operator holds the row block of a rank (nrows = n_local, ncols = n_global).
+//
+// y = A x: lanes along rows (16 B per lane: a block of 256 threads owns 512 real / 256 complex rows), the columns of the
+// block's chunk (split over gridDim.y so that short matrices still fill the chip) walked 8 at a time -- 8 independent
+// non-temporal loads per lane in flight, x(j) a wave-uniform scalar load.  Chunk c writes its partial sums to
+// part[c][row]; k_gemv_n_finish adds the chunks in index order (deterministic: no atomics).
 template <bool CPLX>
-__global__ __launch_bounds__(256) void k_gemv_n(const double *__restrict__ A, int64_t lda, int64_t n,
-                                                const double *__restrict__ x, double *__restrict__ y, Guard guard) {
+__global__ __launch_bounds__(256) void k_gemv_n(const double *__restrict__ A, int64_t lda, int64_t nrows, int64_t ncols,
+                                                const double *__restrict__ x, double *__restrict__ part, int64_t cols_per_chunk,
+                                                Guard guard) {
     if (stopped(guard)) return;
+    constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    constexpr int U = 8;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) * ROWS;
+    const int64_t j0 = (int64_t)blockIdx.y * cols_per_chunk;
+    int64_t j1 = j0 + cols_per_chunk;
+    j1 = j1 < ncols ? j1 : ncols;
+    const bool full = r + ROWS <= nrows;
+    const int64_t cs = lda * ED;
     v2d acc = v2d{0.0, 0.0};
-    if (i < n) {
-        for (int64_t j = wave; j < n; j += 4) {
-            if constexpr (CPLX) {
-                v2d a = *reinterpret_cast<const v2d *>(A + (j * lda + i) * 2);
-                v2d b = *reinterpret_cast<const v2d *>(x + j * 2);
-                acc += cmul(a, b);
-            } else {
-                acc.x += A[j * lda + i] * x[j];
+    if (r < nrows) {
+        const double *__restrict__ Ar = A + r * ED;
+        int64_t j = j0;
+        if (full) {
+            for (; j + U <= j1; j += U) {
+                v2d a[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) a[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Ar + (j + u) * cs));
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if constexpr (CPLX) acc += cmul(a[u], v2d{x[2 * (j + u)], x[2 * (j + u) + 1]});
+                    else acc += a[u] * x[j + u];
+                }
             }
         }
-    }
-    __shared__ v2d red[256];
-    red[threadIdx.x] = acc;
-    __syncthreads();
-    if (wave == 0 && i < n) {
-        v2d s = (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
-        if constexpr (CPLX) *reinterpret_cast<v2d *>(y + i * ED) = s;
-        else y[i] = s.x;
+        for (; j < j1; ++j) {
+            const v2d a = load_y<CPLX>(A + j * cs, r, nrows, full);
+            if constexpr (CPLX) acc += cmul(a, v2d{x[2 * j], x[2 * j + 1]});
+            else acc += a * x[j];
+        }
+        store_rows<CPLX>(part + (int64_t)blockIdx.y * nrows * ED, r, nrows, full, acc);
     }
 }
 
-// y = A^H x: one wave per column j, lanes over rows.
+// y(i) = sum over chunks of part[c][i] in index order
+__global__ __launch_bounds__(256) void k_gemv_n_finish(const double *__restrict__ part, int64_t nd, int nchunks, double *__restrict__ y,
+                                                       Guard guard) {
+    if (stopped(guard)) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * nd + i];
+        y[i] = s;
+    }
+}
+
+// y = A^H x (y: ncols entries, x: nrows): one wave per column, lanes along rows with 16-byte loads, four in flight; x comes
+// from the caches (every wave re-reads it).  DPP wave sum: fixed order.
 template <bool CPLX>
-__global__ __launch_bounds__(256) void k_gemv_h(const double *__restrict__ A, int64_t lda, int64_t n,
+__global__ __launch_bounds__(256) void k_gemv_h(const double *__restrict__ A, int64_t lda, int64_t nrows, int64_t ncols,
                                                 const double *__restrict__ x, double *__restrict__ y, Guard guard) {
     if (stopped(guard)) return;
+    constexpr int ROWS = K<CPLX>::ROWS;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int U = 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t j = (int64_t)blockIdx.x * 4 + wave;
-    if (j >= n) return;
+    if (j >= ncols) return;                       // whole waves leave: the DPP sum below sees full waves only
+    const double *__restrict__ Aj = A + j * lda * ED;
     v2d acc = v2d{0.0, 0.0};
-    for (int64_t i = lane; i < n; i += 64) {
-        if constexpr (CPLX) {
-            v2d a = *reinterpret_cast<const v2d *>(A + (j * lda + i) * 2);
-            v2d b = *reinterpret_cast<const v2d *>(x + i * 2);
-            acc += cmulconj(a, b);
-        } else {
-            acc.x += A[j * lda + i] * x[i];
+    const int64_t step = 64 * ROWS;
+    int64_t r = (int64_t)lane * ROWS;
+    const int64_t nfull = nrows - (nrows % ROWS);
+    for (; r + (U - 1) * step + ROWS <= nfull; r += U * step) {
+        v2d a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a[u] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(Aj + (r + u * step) * ED));
+            b[u] = *reinterpret_cast<const v2d *>(x + (r + u * step) * ED);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (CPLX) acc += cmulconj(a[u], b[u]);
+            else acc += a[u] * b[u];
         }
     }
-    double re = wave_sum(acc.x), im = wave_sum(acc.y);
-    if (lane == 0) {
-        if constexpr (CPLX) { y[2 * j] = re; y[2 * j + 1] = im; }
-        else y[j] = re;
+    for (; r < nrows; r += step) {
+        const v2d a = load_y<CPLX>(Aj, r, nrows, false), b = load_y<CPLX>(x, r, nrows, false);
+        if constexpr (CPLX) acc += cmulconj(a, b);
+        else acc += a * b;
     }
+    if constexpr (CPLX) {
+        const double re = wave_sum(acc.x), im = wave_sum(acc.y);
+        if (lane == 0) { y[2 * j] = re; y[2 * j + 1] = im; }
+    } else {
+        const double re = wave_sum(acc.x + acc.y);
+        if (lane == 0) y[j] = re;
+    }
+}
+
+// y(0:nd) = z(0:nd) (doubles) under the asynchronous pipeline's guard: the slice of an all-reduced full-length vector that
+// this rank owns (row-sharded rmatvec)
+__global__ __launch_bounds__(256) void k_copy_guarded(const double *__restrict__ z, double *__restrict__ y, int64_t nd, Guard guard) {
+    if (stopped(guard)) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += (int64_t)gridDim.x * blockDim.x) y[i] = z[i];
 }
 
 // 5-point Laplacian, N x N grid, Dirichlet, scale s = (N+1)^2.  One thread per 2 grid points

@@ -160,44 +160,100 @@ class _engine_linop(abstract_linop):
             pass
 
 
-class dense_linop_gpu(_engine_linop):
-    """dense_linop_{rdp,cdp}: y = A x via gemv('N') / ('T'|'C').  AbstractLinops.fypp:265-271, 608-660"""
+def _row_starts(ctx: Context, n_global: int, row_starts):
+    """(nranks + 1) int64 row offsets of the contiguous row blocks; default = `row_partition` of the context's ranks."""
+    from .context import row_partition
+    if row_starts is None:
+        row_starts = [row_partition(n_global, ctx.nranks, r)[0] for r in range(ctx.nranks)] + [n_global]
+    rs = np.ascontiguousarray(row_starts, dtype=np.int64)
+    if rs.shape != (ctx.nranks + 1,):
+        raise ValueError(f"row_starts needs nranks + 1 = {ctx.nranks + 1} entries")
+    return rs
 
-    def __init__(self, A: np.ndarray, ctx: Context | None = None):
+
+class dense_linop_gpu(_engine_linop):
+    """dense_linop_{rdp,cdp}: y = A x via gemv('N') / ('T'|'C').  AbstractLinops.fypp:265-271, 608-660.
+    Row-sharded (one process per GPU): pass this rank's ROW BLOCK `A[row0:row0 + n_local, :]` and `n_global`; x is
+    all-gathered for matvec, the ranks' A_rows^H x_rows are summed for rmatvec (lk_linop_dense_create_sharded)."""
+
+    def __init__(self, A: np.ndarray, ctx: Context | None = None, n_global: int | None = None, row_starts=None):
         super().__init__(ctx)
         A = np.asfortranarray(A)
-        if A.dtype not in _DT or A.ndim != 2 or A.shape[0] != A.shape[1]:
-            raise TypeError("dense_linop_gpu needs a square float64/complex128 matrix")
-        self.dtype, self.n = A.dtype, A.shape[0]
-        _capi.check(self._lib.lk_linop_dense_create(self.ctx._h, _DT[A.dtype], self.n,
-                                                    A.ctypes.data_as(C.c_void_p), A.shape[0], C.byref(self._h)))
+        if A.dtype not in _DT or A.ndim != 2:
+            raise TypeError("dense_linop_gpu needs a float64/complex128 matrix")
+        self.dtype = A.dtype
+        if n_global is None and self.ctx.nranks == 1:
+            if A.shape[0] != A.shape[1]:
+                raise TypeError("dense_linop_gpu needs a square matrix")
+            self.n = A.shape[0]
+            _capi.check(self._lib.lk_linop_dense_create(self.ctx._h, _DT[A.dtype], self.n,
+                                                        A.ctypes.data_as(C.c_void_p), A.shape[0], C.byref(self._h)))
+            return
+        n_global = A.shape[1] if n_global is None else int(n_global)
+        rs = _row_starts(self.ctx, n_global, row_starts)
+        self.n = int(rs[self.ctx.rank + 1] - rs[self.ctx.rank])
+        if A.shape != (self.n, n_global):
+            raise TypeError(f"this rank's block must be {self.n} x {n_global}, got {A.shape}")
+        _capi.check(self._lib.lk_linop_dense_create_sharded(self.ctx._h, _DT[A.dtype], n_global, rs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                            A.ctypes.data_as(C.c_void_p), max(A.shape[0], 1), C.byref(self._h)))
+
+    @classmethod
+    def from_device_panel(cls, panel, n_global: int | None = None, row_starts=None):
+        """The operator on a matrix that already lies in HBM: `panel` is a krylov_basis_gpu whose columns are the COLUMNS of
+        this rank's row block (n_local rows x n_global columns).  Not copied; the panel must outlive the operator."""
+        self = cls.__new__(cls)
+        _engine_linop.__init__(self, panel.ctx)
+        self.dtype = np.dtype(panel.dtype)
+        n_global = panel.ncols if n_global is None else int(n_global)
+        rs = _row_starts(self.ctx, n_global, row_starts)
+        self.n = int(rs[self.ctx.rank + 1] - rs[self.ctx.rank])
+        if panel.n_local != self.n or panel.ncols != n_global:
+            raise TypeError("panel shape does not match this rank's row block")
+        dt, nl, nc, ld, ptr = C.c_int(), C.c_int64(), C.c_int(), C.c_int64(), C.c_void_p()
+        _capi.check(self._lib.lk_basis_info(panel._h, C.byref(dt), C.byref(nl), C.byref(nc), C.byref(ld), C.byref(ptr)))
+        _capi.check(self._lib.lk_linop_dense_wrap_sharded(self.ctx._h, dt.value, n_global, rs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                          ptr, ld.value, C.byref(self._h)))
+        self._panel = panel
+        return self
 
 
 class csr_linop_gpu(_engine_linop):
     """A user's sparse `abstract_linop` (AbstractLinops.fypp:58-87) in CSR: y = A x / A^H x on the device.
     `A`: anything with `.indptr`, `.indices`, `.data`, `.shape` in CSR layout (a scipy.sparse.csr_matrix / csr_array), or
-    a tuple (rowptr, colind, vals) with 0-based indices."""
+    a tuple (rowptr, colind, vals) with 0-based indices.  Row-sharded: pass this rank's rows (GLOBAL column indices) and
+    `n_global` (lk_linop_csr_create_sharded)."""
 
-    def __init__(self, A, ctx: Context | None = None):
+    def __init__(self, A, ctx: Context | None = None, n_global: int | None = None, row_starts=None):
         super().__init__(ctx)
         if isinstance(A, tuple):
             rowptr, colind, vals = A
             n = len(rowptr) - 1
+            ncols = n if n_global is None else int(n_global)
         else:
             if getattr(A, "format", "csr") != "csr":
                 A = A.tocsr()
-            if A.shape[0] != A.shape[1]:
-                raise TypeError("csr_linop_gpu needs a square matrix")
-            rowptr, colind, vals, n = A.indptr, A.indices, A.data, A.shape[0]
+            rowptr, colind, vals, n, ncols = A.indptr, A.indices, A.data, A.shape[0], A.shape[1]
+            if n_global is not None and ncols != n_global:
+                raise TypeError("csr_linop_gpu: the block's column count must be n_global")
         vals = np.ascontiguousarray(vals)
         if vals.dtype not in _DT:
             raise TypeError("csr_linop_gpu needs float64 / complex128 values")
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
         colind = np.ascontiguousarray(colind, dtype=np.int32)
         self.dtype, self.n, self.nnz = vals.dtype, int(n), int(rowptr[-1])
-        _capi.check(self._lib.lk_linop_csr_create(self.ctx._h, _DT[vals.dtype], self.n, rowptr.ctypes.data_as(C.c_void_p),
-                                                  colind.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
-                                                  C.byref(self._h)))
+        if n_global is None and self.ctx.nranks == 1:
+            if n != ncols:
+                raise TypeError("csr_linop_gpu needs a square matrix")
+            _capi.check(self._lib.lk_linop_csr_create(self.ctx._h, _DT[vals.dtype], self.n, rowptr.ctypes.data_as(C.c_void_p),
+                                                      colind.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
+                                                      C.byref(self._h)))
+            return
+        rs = _row_starts(self.ctx, int(ncols), row_starts)
+        if int(rs[self.ctx.rank + 1] - rs[self.ctx.rank]) != self.n:
+            raise TypeError("csr_linop_gpu: the number of rows passed is not this rank's block")
+        _capi.check(self._lib.lk_linop_csr_create_sharded(self.ctx._h, _DT[vals.dtype], int(ncols), rs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                          rowptr.ctypes.data_as(C.c_void_p), colind.ctypes.data_as(C.c_void_p),
+                                                          vals.ctypes.data_as(C.c_void_p), C.byref(self._h)))
 
 
 class diag_linop_gpu(_engine_linop):

@@ -56,7 +56,24 @@ def test_two_processes_sharing_one_gpu_reproduce_the_single_process_factorisatio
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                 "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + args,
                LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
+    # ... and through the PLAIN entry: `python bench.py --gpus 2` starts the launcher itself as a child process
+    plain2 = _run([sys.executable, "bench.py", "--gpus", "2"] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
+    assert plain2["n_gpus"] == 2 and plain2["config"]["H_fro"] == two["config"]["H_fro"]
+    assert plain2["config"]["nccl_algo"] == "Ring"                      # the reduction algorithm is pinned
     assert two["n_gpus"] == 2 and two["config"]["all_reduce"].startswith("gloo")
     assert two["config"]["n_local"] == 1500000 and two["config"]["info"] == 0
     assert abs(two["config"]["H_fro"] - plain["config"]["H_fro"]) <= 1e-13 * plain["config"]["H_fro"]
     assert abs(two["config"]["H_last_subdiag"] - plain["config"]["H_last_subdiag"]) <= 1e-12 * plain["config"]["H_last_subdiag"]
+
+
+@pytest.mark.parametrize("operator,rows", [("dense", "2051"), ("csr", "3721")])
+def test_two_processes_on_the_row_sharded_dense_and_csr_operators(operator, rows):
+    """bench.py --operator dense / csr with two processes (gloo standing in for RCCL, both ranks on one GPU): a row block of A per
+    rank, x all-gathered per matvec.  Same factorisation as the single process to rounding."""
+    args = ["--operator", operator, "--rows", rows, "--kdim", "12", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + args)
+    two = _run([sys.executable, "bench.py", "--gpus", "2"] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
+    assert two["n_gpus"] == 2 and two["config"]["operator"] == operator and two["config"]["info"] == one["config"]["info"] == 0
+    assert abs(two["config"]["H_fro"] - one["config"]["H_fro"]) <= 1e-12 * one["config"]["H_fro"]
+    assert abs(two["config"]["H_last_subdiag"] - one["config"]["H_last_subdiag"]) <= 1e-11 * one["config"]["H_last_subdiag"]
+    assert one["roofline"]["matvec"]["launches"] == 12

@@ -354,3 +354,182 @@ def test_sharded_per_object_arnoldi_in_lazy_mode_matches_single_context(ctx):
         assert np.array_equal(H, res[0][1])
         for j in range(m):
             assert np.abs(H[:, j] - H1[:, j]).max() <= 1e-12 * np.abs(H1[:, j]).max()
+
+
+# ----------------------------------------------------------------------------- dense and CSR operators with an all-gather of x
+class _EmulatedAllGather:
+    """All-gather of row blocks between `nranks` threads (lk_allgather_fn): what ncclAllGather / ncclSend+ncclRecv do on a node."""
+
+    def __init__(self, nranks):
+        import torch
+        self.torch = torch
+        self.n = nranks
+        self.barrier = threading.Barrier(nranks)
+        self.sends = [None] * nranks
+        self.calls = 0
+
+    def hook(self, rank, ctx):
+        torch = self.torch
+
+        def _cb(_user, send, recv, counts, displs, nranks, _stream):
+            try:
+                ctx.sync_stream_only()
+                cnt = [int(counts[r]) for r in range(nranks)]
+                dsp = [int(displs[r]) for r in range(nranks)]
+                self.sends[rank] = torch.as_tensor(_DevMem(int(send), cnt[rank]), device="cuda:0") if cnt[rank] else None
+                self.barrier.wait(timeout=120)
+                for r in range(nranks):
+                    if cnt[r]:
+                        torch.as_tensor(_DevMem(int(recv) + 8 * dsp[r], cnt[r]), device="cuda:0").copy_(self.sends[r])
+                torch.cuda.synchronize()
+                if rank == 0:
+                    self.calls += 1
+                self.barrier.wait(timeout=120)
+                return 0
+            except Exception as exc:  # noqa: BLE001
+                print("emulated all-gather failed:", repr(exc))
+                self.barrier.abort()
+                return 1
+        return _capi.ALLGATHER_FN(_cb)
+
+
+def _sharded_with_allgather(n, nranks, body):
+    lib = _capi.load()
+    grp, ag = _EmulatedGroup(nranks), _EmulatedAllGather(nranks)
+    out, errs = [None] * nranks, []
+
+    def worker(rank):
+        try:
+            ctx = lk.Context(device=0, use_torch_stream=False)
+            ctx.sync_stream_only = lambda: _capi.check(lib.lk_sync(ctx._h))
+            cb = grp.hook(rank, ctx)
+            _capi.check(lib.lk_set_allreduce(ctx._h, cb, None, nranks, rank))
+            ctx._cb, ctx.nranks, ctx.rank = cb, nranks, rank
+            ctx.set_allgather(ag.hook(rank, ctx))
+            row0, nl = lk.row_partition(n, nranks, rank)
+            ctx.set_partition(row0, n)
+            out[rank] = body(rank, ctx, row0, nl)
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+            grp.barrier.abort(); ag.barrier.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    [t.start() for t in ts]
+    [t.join(600) for t in ts]
+    assert not errs, errs
+    return out, ag
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_dense_linop_matvec_rmatvec_and_arnoldi(ctx, dtype, nranks):
+    """dense_linop (AbstractLinops.fypp:608-660) row-sharded: a row block of A per rank, x all-gathered for matvec, the ranks'
+    A_rows^H x_rows summed for rmatvec.  matvec is bit-identical to the single-context operator (same products, same order per
+    row), rmatvec and a whole Arnoldi factorisation agree to rounding; also against numpy."""
+    n, m = 2051, 12
+    rng = np.random.default_rng(5)
+    cplx = np.dtype(dtype).kind == "c"
+    Afull = rng.standard_normal((n, n)) / np.sqrt(n) + (1j * rng.standard_normal((n, n)) / np.sqrt(n) if cplx else 0)
+    Afull = np.asfortranarray(Afull.astype(dtype))
+    from oracle import oracle as ora
+    x_full = np.empty(n, dtype=dtype); ora.fill_counter(x_full, 13); x_full /= np.linalg.norm(x_full)
+
+    def body(rank, c, row0, nl):
+        A = lk.dense_linop_gpu(Afull[row0:row0 + nl, :], c, n_global=n)
+        v = lk.dense_vector_gpu.from_array(x_full[row0:row0 + nl], c)
+        w = v.zeros_like(); wt = v.zeros_like()
+        A.apply_matvec(v, w); A.apply_rmatvec(v, wt)
+        X = lk.krylov_basis_gpu(nl, m + 1, dtype, c)
+        X.upload(x_full[row0:row0 + nl].reshape(-1, 1), 0)
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        info = lk.arnoldi(A, X, H)
+        Ht = np.zeros((m + 1, m), dtype=dtype, order="F")
+        Xt = lk.krylov_basis_gpu(nl, m + 1, dtype, c)
+        Xt.upload(x_full[row0:row0 + nl].reshape(-1, 1), 0)
+        info_t = lk.arnoldi(A, Xt, Ht, transpose=True)
+        return w.to_array(), wt.to_array(), info, H, info_t, Ht
+
+    res, ag = _sharded_with_allgather(n, nranks, body)
+    A1 = lk.dense_linop_gpu(Afull, ctx)
+    v1 = lk.dense_vector_gpu.from_array(x_full, ctx)
+    w1 = v1.zeros_like(); wt1 = v1.zeros_like()
+    A1.apply_matvec(v1, w1); A1.apply_rmatvec(v1, wt1)
+    ws, wts = np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+    assert np.array_equal(ws, w1.to_array())
+    assert np.abs(wts - wt1.to_array()).max() <= 1e-14 * np.abs(wt1.to_array()).max() * np.sqrt(n)
+    assert np.abs(ws - Afull @ x_full).max() <= 1e-13 and np.abs(wts - Afull.conj().T @ x_full).max() <= 1e-13
+    X1 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X1.upload(x_full.reshape(-1, 1), 0)
+    H1 = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.arnoldi(A1, X1, H1) == 0
+    X1.upload(np.zeros((n, m + 1), dtype=dtype)); X1.upload(x_full.reshape(-1, 1), 0)
+    H1t = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.arnoldi(A1, X1, H1t, transpose=True) == 0
+    for r in res:
+        assert r[2] == 0 and r[4] == 0
+        for j in range(m):
+            assert np.abs(r[3][:, j] - H1[:, j]).max() <= 1e-12 * np.abs(H1[:, j]).max()
+            assert np.abs(r[5][:, j] - H1t[:, j]).max() <= 1e-12 * np.abs(H1t[:, j]).max()
+    assert ag.calls == 1 + m                                       # one all-gather per matvec; rmatvec uses the all-reduce
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_csr_linop_matvec_rmatvec_and_gmres(ctx, dtype, nranks):
+    """A user's sparse operator row-sharded (rows of A per rank with global column indices): matvec / rmatvec against scipy and
+    the single-context operator; the 5-point Laplacian as a sharded CSR matrix reproduces the single-context GMRES run."""
+    import scipy.sparse as sp
+    n = 3001
+    rng = np.random.default_rng(2)
+    cplx = np.dtype(dtype).kind == "c"
+    M = sp.random(n, n, density=0.004, format="csr", random_state=3, dtype=np.float64)
+    if cplx:
+        M = (M + 1j * sp.random(n, n, density=0.004, format="csr", random_state=4, dtype=np.float64)).tocsr()
+    M = (M + sp.diags(np.linspace(1.0, 2.0, n))).tocsr().astype(dtype)
+    M.sort_indices()
+    from oracle import oracle as ora
+    x_full = np.empty(n, dtype=dtype); ora.fill_counter(x_full, 17)
+
+    def body(rank, c, row0, nl):
+        A = lk.csr_linop_gpu(M[row0:row0 + nl, :], c, n_global=n)
+        v = lk.dense_vector_gpu.from_array(x_full[row0:row0 + nl], c)
+        w = v.zeros_like(); wt = v.zeros_like()
+        A.apply_matvec(v, w); A.apply_rmatvec(v, wt)
+        return w.to_array(), wt.to_array()
+
+    res, _ag = _sharded_with_allgather(n, nranks, body)
+    A1 = lk.csr_linop_gpu(M, ctx)
+    v1 = lk.dense_vector_gpu.from_array(x_full, ctx)
+    w1 = v1.zeros_like(); wt1 = v1.zeros_like()
+    A1.apply_matvec(v1, w1); A1.apply_rmatvec(v1, wt1)
+    ws, wts = np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+    assert np.array_equal(ws, w1.to_array())                        # a row's entries are summed in the same order
+    scale = np.abs(x_full).max() * 4
+    assert np.abs(wts - wt1.to_array()).max() <= 1e-14 * scale
+    assert np.abs(ws - M @ x_full).max() <= 1e-13 * scale and np.abs(wts - M.conj().T @ x_full).max() <= 1e-13 * scale
+    if cplx:
+        return
+    # the Laplacian of config 3 as a sharded CSR matrix in GMRES
+    N = 61
+    nn = N * N
+    T = sp.diags([-1.0, 4.0, -1.0], [-1, 0, 1], shape=(N, N))
+    L = ((sp.kron(sp.identity(N), T) + sp.kron(sp.diags([-1.0, -1.0], [-1, 1], shape=(N, N)), sp.identity(N))) * float((N + 1) ** 2)).tocsr()
+    L.sort_indices()
+    b_full = np.empty(nn); ora.fill_counter(b_full, 11)
+
+    def body2(rank, c, row0, nl):
+        A = lk.csr_linop_gpu(L[row0:row0 + nl, :], c, n_global=nn)
+        b = lk.dense_vector_gpu.from_array(b_full[row0:row0 + nl], c)
+        x = b.zeros_like()
+        meta = lk.gmres_dp_metadata()
+        info = lk.gmres(A, b, x, rtol=1e-8, options=lk.gmres_dp_opts(kdim=20, maxiter=1), meta=meta)
+        return x.to_array(), info, np.array(meta.res)
+
+    res2, _ = _sharded_with_allgather(nn, nranks, body2)
+    A1 = lk.laplacian2d_linop_gpu(N, ctx)
+    b1 = lk.dense_vector_gpu.from_array(b_full, ctx)
+    x1 = b1.zeros_like(); m1 = lk.gmres_dp_metadata()
+    info1 = lk.gmres(A1, b1, x1, rtol=1e-8, options=lk.gmres_dp_opts(kdim=20, maxiter=1), meta=m1)
+    xs = np.concatenate([r[0] for r in res2])
+    assert all(r[1] == info1 for r in res2)
+    assert np.abs(res2[0][2] - np.array(m1.res)).max() <= 1e-11 * m1.res[0]
+    assert np.abs(xs - x1.to_array()).max() <= 1e-10 * np.abs(x1.to_array()).max()

@@ -11,6 +11,9 @@ for kv in sys.argv[1:]:
     ctx.set_tuning(key, int(val))
 shapes = ((np.complex128, 1_000_000, 128, 64), (np.complex128, 1_000_000, 128, 16), (np.complex128, 1_000_000, 64, 32),
           (np.float64, 10_000_000, 128, 64), (np.float64, 10_000_000, 64, 32), (np.float64, 10_000_000, 128, 1))
+if os.environ.get("LK_LINCOMB_SCAN"):      # narrow products: q = 1..32 for the crossover table (set gemm_mfma_min=1 / 100 on the command line)
+    shapes = tuple((dt, nn, k, q) for dt, nn in ((np.float64, 10_000_000), (np.complex128, 5_000_000)) for k in (32, 64, 128)
+                   for q in (1, 2, 3, 4, 5, 8, 16, 32))
 for dtype, n, k, q in shapes:
     X = lk.krylov_basis_gpu(n, k, dtype, ctx)
     for j in range(k):
