@@ -48,6 +48,29 @@ def cfg1_matrix():
     return np.asfortranarray(A), x0 / np.linalg.norm(x0)
 
 
+GL_REF = dict(n=512, dx=200.0 / 513.0, tau=0.01, nsub=1, nu=2.0 + 0.2j, gamma=1.0 - 1.0j, mu_c=0.38 - 0.2 ** 2, mu2=-0.01,
+              nev=8, kdim=16, seed=13)
+
+
+def gl_reference_size():
+    """SURVEY 8(c) fixture (5): the reference's Ginzburg-Landau example at ITS OWN size and parameters
+    (example/ginzburg_landau/Ginzburg_Landau.f90:23-33: nx = 512, L = 200, nu = 2 + 0.2i, gamma = 1 - i, mu_0 = 0.38, c_mu = 0.2,
+    mu_2 = -0.01; main.f90:20,27,66: tau = 0.01, nev = 8, kdim = 2 nev = 16), operator = one classical RK4 step of the reference
+    right-hand side incl. its boundary rows (:126-136) -- the reference integrates with rklib's adaptive scheme, an un-vendored
+    dependency.  Stored: H(:17, :16) of the first 16-step Arnoldi factorisation, its Ritz values, and what
+    eigs(nev = 8, kdim = 16, tolerance = rtol_dp) returns (8 leading eigenvalues, residuals, info)."""
+    g = GL_REF
+    A = ora.GLOp(g["n"], g["dx"], g["tau"], g["nsub"], g["nu"], g["gamma"], g["mu_c"], g["mu2"])
+    x0 = seeded(g["n"], np.complex128, g["seed"])
+    m = g["kdim"]
+    X = np.zeros((g["n"], m + 1), dtype=np.complex128, order="F")
+    X[:, 0] = x0 / np.linalg.norm(x0)
+    H = np.zeros((m + 1, m), dtype=np.complex128, order="F")
+    info = ora.arnoldi(A, X, H)
+    vals, res, _V, niter = ora.eigs(A, x0, g["nev"], m)
+    return dict(H=H, info=info, ritz=np.linalg.eigvals(H[:m, :m]), eig_vals=vals, eig_res=res, eig_niter=niter)
+
+
 def main():
     for n, m in ((1000, 8), (100_000, 64), (20_011, 128)):
         for dtype, tag in ((np.float64, "rdp"), (np.complex128, "cdp")):
@@ -65,6 +88,7 @@ def main():
     x = np.zeros(N * N)
     ginfo, hist = ora.gmres(ora.Lap5Op(N), b, x, rtol=1e-8, kdim=30, maxiter=2)
     np.savez(os.path.join(OUT, "gmres_poisson64_k30.npz"), info=ginfo, res=hist, x_norm=np.linalg.norm(x), x_head=x[:64])
+    np.savez(os.path.join(OUT, "gl_nx512_kdim16_cdp.npz"), **gl_reference_size())
     # reference-run values recorded by the survey: reference arnoldi,
     # n=1000, m=8, d_i = 1+(i-1)/n, x0_i = sin(i)/||.||
     np.savez(os.path.join(OUT, "survey_reference_run_n1000_m8.npz"), H11=1.4991929804973552,

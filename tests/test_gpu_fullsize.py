@@ -18,6 +18,7 @@ import pytest
 import lightkrylov_amd as lk
 from lightkrylov_amd import _capi
 from oracle import oracle as ora
+from tests._tol import assert_columns_close, assert_ritz_close, ritz_condition
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -158,9 +159,8 @@ def test_config3_full_size_gmres_against_live_oracle(ctx):
 
 def test_config4_size_complex_arnoldi_against_live_oracle(ctx):
     """The complex(dp) kind at configs[3]'s size (n = 10^6, m = 128) on a well-conditioned (diagonal, complex) operator,
-    against a live multi-threaded oracle run: H columns and Ritz values within 1e-12.  (With configs[3]'s own operator,
-    one small RK4 step of Ginzburg-Landau, the Krylov vectors are nearly dependent and an entry-wise comparison would
-    measure that conditioning -- see DESIGN.md section 4; its full-size test checks invariants instead.)"""
+    against a live multi-threaded oracle run: H columns and Ritz values within 1e-12.  (configs[3]'s own operator: the next
+    test.)"""
     n, m = 1_000_000, 128
     g = np.arange(n) / n
     d = ((1.0 + g) * np.exp(1j * g)).astype(np.complex128)
@@ -182,11 +182,53 @@ def test_config4_size_complex_arnoldi_against_live_oracle(ctx):
         assert ora.arnoldi(ora.DiagOp(d), Xo, Ho, fast=True) == 0
     finally:
         ora.set_threads(1)
-    assert colerr(H, Ho) <= TOL
-    w, wo = np.linalg.eigvals(H[:m, :m]), np.linalg.eigvals(Ho[:m, :m])
-    # Ritz values of a normal operator are well conditioned; match each to its nearest oracle value
-    dist = np.abs(w[:, None] - wo[None, :]).min(axis=1)
-    assert dist.max() <= 1e-11 * np.abs(wo).max(), dist.max()
+    assert_columns_close(H, Ho, "configs[3] size, complex diagonal operator, n = 1e6, m = 128")
+    assert_ritz_close(np.linalg.eigvals(H[:m, :m]), np.linalg.eigvals(Ho[:m, :m]), H[:m, :m],
+                      "configs[3] size, complex diagonal operator, n = 1e6, m = 128")
+
+
+def test_config4_on_its_own_operator_against_live_oracle(ctx, capsys):
+    """BASELINE configs[3] ON ITS OWN OPERATOR at full size: the Ginzburg-Landau stepper of SURVEY 8(d) (one classical RK4 step of
+    tau = 0.01 of the reference right-hand side, example/ginzburg_landau/Ginzburg_Landau.f90:126-136; main.f90:20), complex(dp),
+    n = 10^6, a 128-step Arnoldi factorisation (what one `eigs(nev = 8, kdim = 128)` cycle computes, IterativeSolvers.fypp:
+    1059-1083) -- engine against a LIVE run of the oracle (the reference's arithmetic, multi-threaded bit-identically; its own numpy
+    restatement of the operator): every column of H normwise within 1e-12, the Ritz values within 1e-12 * kappa_i * ||H||
+    (kappa_i = the condition number of the Ritz value, computed from H and printed; the 8 leading ones are what eigs asks
+    for).  The step-to-step amplification ||H(:, j)|| / |H(j+1, j)| is printed too: the Krylov vectors of A = I + tau L are
+    close to dependent (each step keeps ~1/5 of the new vector), which is why this comparison was expected to need a
+    conditioning allowance -- measured, it does not (max column error ~1e-14)."""
+    n, m = 1_000_000, 128
+    A = lk.ginzburg_landau_linop_gpu(n, ctx, tau=0.01, nsub=1)
+    p = A.params
+    Ao = ora.GLOp(n, p["dx"], 0.01, 1, p["nu"], p["gamma"], p["mu_c"], p["mu2"])
+    x0 = np.empty(n, dtype=np.complex128)
+    ora.fill_counter(x0, 13)
+    x0 /= np.linalg.norm(x0)
+    X = lk.krylov_basis_gpu(n, m + 1, np.complex128, ctx)
+    X.upload(x0.reshape(-1, 1), 0)
+    H = np.zeros((m + 1, m), dtype=np.complex128, order="F")
+    assert lk.arnoldi(A, X, H) == 0
+    del X
+    ora.set_threads(min(64, ora.max_threads()))
+    try:
+        Xo = np.zeros((n, m + 1), dtype=np.complex128, order="F")
+        Xo[:, 0] = x0
+        Ho = np.zeros((m + 1, m), dtype=np.complex128, order="F")
+        assert ora.arnoldi(Ao, Xo, Ho, fast=True) == 0
+    finally:
+        ora.set_threads(1)
+    del Xo
+    worst = assert_columns_close(H, Ho, "configs[3] own operator (Ginzburg-Landau RK4 step), n = 1e6, m = 128")
+    w, kap = ritz_condition(H[:m, :m])
+    amp = np.array([np.linalg.norm(H[:j + 2, j]) / abs(H[j + 1, j]) for j in range(m)])
+    # all 128 Ritz values at the kappa-stated bound, and the 8 leading ones (the ones eigs(nev = 8) is after) separately
+    wo = np.linalg.eigvals(Ho[:m, :m])
+    wall, kmax = assert_ritz_close(np.linalg.eigvals(H[:m, :m]), wo, H[:m, :m], "configs[3] own operator, all 128 Ritz values")
+    w8, k8 = assert_ritz_close(np.linalg.eigvals(H[:m, :m]), wo, H[:m, :m], "configs[3] own operator, 8 leading Ritz values", top=8)
+    with capsys.disabled():
+        print(f"\n  GL n = 1e6, kdim = 128: max normwise |dH| per column {worst:.2e}; step amplification ||H(:,j)||/|H(j+1,j)| max "
+              f"{amp.max():.2f}; Ritz condition numbers: max {kap.max():.2e} (8 leading: {k8:.2e}); Ritz differences / ||H||: all "
+              f"{wall:.2e}, 8 leading {w8:.2e}")
 
 
 @pytest.mark.parametrize("dtype,ncol", [(np.float64, 5), (np.complex128, 3)])

@@ -11,6 +11,7 @@ import pytest
 
 import lightkrylov_amd as lk
 from oracle import oracle as ora
+from tests._tol import assert_columns_close, assert_ritz_close
 
 pytestmark = pytest.mark.gpu
 
@@ -302,8 +303,7 @@ def test_arnoldi_dense_linop_cfg1_shape(ctx, dtype):
     Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
     Ho = np.zeros((m + 1, m), dtype=dtype, order="F")
     assert ora.arnoldi(ora.DenseOp(A), Xo, Ho) == 0
-    for j in range(m):
-        assert np.abs(H[:, j] - Ho[:, j]).max() <= 1e-11 * np.abs(Ho[:, j]).max()   # gemv order differs too
+    assert_columns_close(H, Ho, f"arnoldi dense 1000 x 1000 {np.dtype(dtype)}")
     # rmatvec: A^H x   (test/TestLinops.fypp:48-184)
     v, w = lk.dense_vector_gpu.from_array(x0, ctx), lk.dense_vector_gpu(n, dtype, ctx)
     op.apply_rmatvec(v, w)
@@ -359,7 +359,7 @@ def test_eigs_leading_pairs_against_oracle(ctx):
                               tolerance=1e-10)
     vo, ro, Vo, info_o = ora.eigs(ora.DenseOp(A), x0, nev, kdim, 1e-10)
     assert info == info_o
-    assert np.abs(vals - vo).max() <= 1e-10 * np.abs(vo).max()
+    assert_ritz_close(vals, vo, A, "eigs dense 1000 x 1000, nev = 4 (kappa from A)")
     V = X.download()
     for i in range(nev):
         r = A @ V[:, i] - vals[i].real * V[:, i] if abs(vals[i].imag) < 1e-14 else None
@@ -444,7 +444,9 @@ def test_eigs_ginzburg_landau_reference_size_against_oracle(ctx):
     vals, res, info = lk.eigs(A, X, x0=lk.dense_vector_gpu.from_array(x0, ctx), kdim=kdim, tolerance=1e-10)
     vo, ro, Vo, info_o = ora.eigs(Ao, x0, nev, kdim, 1e-10)
     assert info == info_o
-    assert np.abs(vals - vo).max() <= 1e-9 * np.abs(vo).max()
+    # 1e-12 * kappa_i * ||P||: kappa_i from the propagator's own matrix (the operator is non-normal: kappa_i > 1, printed)
+    P = np.stack([Ao.apply(e) for e in np.eye(n, dtype=np.complex128)], axis=1)
+    assert_ritz_close(vals, vo, P, "eigs Ginzburg-Landau nx = 512, unit-time propagator (kappa from the propagator)")
     V = X.download()
     for i in range(nev):
         assert np.linalg.norm(Ao.apply(V[:, i]) - vals[i] * V[:, i]) <= 1e-7 * abs(vals[i])
@@ -827,8 +829,7 @@ def test_arnoldi_and_gmres_with_transpose(ctx, dtype):
         H = np.zeros((m + 1, m), dtype=dtype, order="F")
         assert lk.arnoldi(A_, X, H, transpose=True) == 0
         assert A_.rmatvec_counter == m and A_.matvec_counter == 0
-        for j in range(m):
-            assert np.abs(H[:, j] - Ho[:, j]).max() <= 1e-11 * np.abs(Ho[:, j]).max()
+        assert_columns_close(H, Ho, f"arnoldi transpose dense 400 x 400 {np.dtype(dtype)}")
     b = seeded(n, dtype, 4)
     x = lk.dense_vector_gpu(n, dtype, ctx)
     info = lk.gmres(op, lk.dense_vector_gpu.from_array(b, ctx), x, rtol=1e-10, transpose=True,

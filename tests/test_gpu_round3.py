@@ -315,7 +315,7 @@ def test_pool_slab_geometry_is_rank_independent_on_sharded_contexts():
     slab, col = C.c_void_p(), C.c_int()
     rc = lib.lk_pool_acquire(sharded._h, _capi.LK_F64, big, C.c_uint64(0x2000), C.byref(slab), C.byref(col))
     assert rc != 0 and b"pool_slab_cols" in lib.lk_last_error()
-    _capi.check(lib.lk_set_allreduce(sharded._h, None, None, 1, 0))
+    _capi.check(lib.lk_set_allreduce(sharded._h, _capi.ALLREDUCE_FN(), None, 1, 0))
     sharded.close()
 
 
@@ -333,7 +333,7 @@ def test_sharded_stencil_operators_reject_partitions_out_of_rank_order():
     nu = (C.c_double * 2)(2.0, 0.2); ga = (C.c_double * 2)(1.0, -1.0)
     assert lib.lk_linop_gl_create_sharded(c._h, 1000, 500, 500, 0.4, 0.01, 1, nu, ga, 0.34, -0.01, C.byref(op)) != 0
     assert b"rank order" in lib.lk_last_error()
-    _capi.check(lib.lk_set_allreduce(c._h, None, None, 1, 0))
+    _capi.check(lib.lk_set_allreduce(c._h, _capi.ALLREDUCE_FN(), None, 1, 0))
     c.close()
 
 

@@ -14,6 +14,9 @@ shapes = ((np.complex128, 1_000_000, 128, 64), (np.complex128, 1_000_000, 128, 1
 if os.environ.get("LK_LINCOMB_SCAN"):      # narrow products: q = 1..32 for the crossover table (set gemm_mfma_min=1 / 100 on the command line)
     shapes = tuple((dt, nn, k, q) for dt, nn in ((np.float64, 10_000_000), (np.complex128, 5_000_000)) for k in (32, 64, 128)
                    for q in (1, 2, 3, 4, 5, 8, 16, 32))
+if os.environ.get("LK_LINCOMB_SHAPE"):     # one shape: "f64,10000000,64,32"
+    dt, nn, kk, qq = os.environ["LK_LINCOMB_SHAPE"].split(",")
+    shapes = ((np.float64 if dt == "f64" else np.complex128, int(nn), int(kk), int(qq)),)
 for dtype, n, k, q in shapes:
     X = lk.krylov_basis_gpu(n, k, dtype, ctx)
     for j in range(k):
