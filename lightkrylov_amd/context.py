@@ -124,6 +124,35 @@ class Context:
         self._ag_cb = _capi.ALLGATHER_FN(_allgather)
         _capi.check(self._lib.lk_set_allgather(self._h, self._ag_cb, None))
 
+        def _halo(_user, send_lo, send_hi, recv_lo, recv_hi, count, stream_ptr):
+            # nearest-neighbour exchange of the stencil operators through collectives every backend has: all ranks gather
+            # every rank's two edge blocks and keep their neighbours' (the native communicator uses ncclSend / ncclRecv)
+            try:
+                sp = int(stream_ptr or 0)
+                st = torch.cuda.ExternalStream(sp, device=self.device) if sp else None
+                with (torch.cuda.stream(st) if st is not None else _null_ctx()):
+                    cnt = int(count)
+                    dev = f"cuda:{self.device}"
+                    mine = torch.zeros(2 * cnt, dtype=torch.float64, device=dev)
+                    if send_lo:
+                        mine[:cnt].copy_(torch.as_tensor(_DevMem(int(send_lo), cnt), device=dev))
+                    if send_hi:
+                        mine[cnt:].copy_(torch.as_tensor(_DevMem(int(send_hi), cnt), device=dev))
+                    every = [torch.empty_like(mine) for _ in range(self.nranks)]
+                    dist.all_gather(every, mine, group=pg)
+                    if recv_lo and self.rank > 0:
+                        torch.as_tensor(_DevMem(int(recv_lo), cnt), device=dev).copy_(every[self.rank - 1][cnt:])
+                    if recv_hi and self.rank + 1 < self.nranks:
+                        torch.as_tensor(_DevMem(int(recv_hi), cnt), device=dev).copy_(every[self.rank + 1][:cnt])
+                return 0
+            except Exception as exc:  # noqa: BLE001 - must not propagate through C
+                import sys
+                print(f"[lightkrylov_amd] halo-exchange callback failed: {exc!r}", file=sys.stderr)
+                return 1
+
+        self._halo_cb = _capi.HALO_FN(_halo)
+        _capi.check(self._lib.lk_set_halo_exchange(self._h, self._halo_cb, None))
+
     # -- multi-GPU, native: ncclAllReduce issued by the library itself (no interpreter in the path) ------
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -31,8 +31,10 @@ thread_local char g_err[512] = "";
 #define HIPCHK(expr)                                                                         \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess) return fail(LK_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
-                                          hipGetErrorString(e_), __FILE__, __LINE__);        \
+        if (e_ != hipSuccess) {                                                              \
+            (void)hipGetLastError(); /* the runtime's last-error state is sticky: report once */ \
+            return fail(LK_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        }                                                                                    \
     } while (0)
 
 #define LKCHK(expr)            \
@@ -604,8 +606,11 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     if (g > ntiles) g = ntiles;
     if (g < 1) g = 1;
     const int grid = (int)g, nvb = grid * WR;
-    const int64_t need = 2 * sect + npart_n + (int64_t)nvb * nslots;
+    int64_t need = 2 * sect + npart_n + (int64_t)nvb * nslots;
     if (c->xhy_n < need) {
+        // (also room for the fused block pass, one block per CU, so that it never has to grow the buffer between passes)
+        const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * nslots;
+        if (need < fused) need = fused;
         if (c->xhy) HIPCHK(hipFree(c->xhy));
         c->xhy = nullptr;
         c->xhy_n = 0;
@@ -628,6 +633,46 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, part, nvb, npart, grid, k, p, ED, flags, out);
+    HIPCHK(hipGetLastError());
+    if (out_dev) *out_dev = out;
+    return allreduce(c, out, nslots);
+}
+
+// Pass B of the block DGS with many right-hand sides, fused (panel_xhy_upd_mfma): Y(:, jy0 : jy0+p) -= X(:, :k) H1, stored, and
+// M2 = X^H Y', ||Y'_q||^2 into result section `sec` of c->xhy (panel_dot_p's layout, all-reduced).  k <= 128, p <= 32.
+int upd_dots_mfma(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, const double *H1dev, int sec, double **out_dev) {
+    lk_context_t c = Bx->ctx;
+    const bool cp = Bx->dtype == LK_C128;
+    const int ED = Bx->ed();
+    const int KG = (k + 31) / 32;
+    const int64_t nslots = (int64_t)p * (k + 1) * ED;
+    const int64_t sect = (int64_t)XHY_MAX * (XHY_MAX + 1) * 2;
+    const int64_t npart_n = (int64_t)c->num_cu * 4 * XHY_MAX;
+    const int64_t ntiles = (Bx->n * ED + 63) / 64;
+    int64_t g = c->num_cu;                                   // 119 / 154 KB of LDS: one block per CU
+    if (g > ntiles) g = ntiles;
+    if (g < 1) g = 1;
+    const int grid = (int)g;
+    const int64_t need = 2 * sect + npart_n + (int64_t)grid * nslots;
+    if (c->xhy_n < need) {
+        // the coefficients of pass A live in this buffer: grow it BEFORE pass A ran (lk_dgs_block sizes it up front), never here
+        return fail(LK_ERR_INVALID, "internal: xhy workspace too small for the fused block pass (%lld < %lld)", (long long)c->xhy_n, (long long)need);
+    }
+    double *out = c->xhy + (int64_t)sec * sect, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
+    const size_t lds = (size_t)(KG * 32 * 66 + 32 * 66 + KG * 32 * 34 * (cp ? 2 : 1)) * sizeof(double);
+    {
+        ProfScope ps(c, "xhy_upd_mfma", (double)Bx->n * ED * 8.0 * (k + 2 * p));
+        auto go = [&](auto kern) -> int {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, (const double *)Bx->col(0), Bx->ld, k, By->col(jy0), By->ld, p, Bx->n,
+                               H1dev, part, npart, c->gemm_store_policy);
+            return LK_OK;
+        };
+        if (cp) LKCHK(go(&panel_xhy_upd_mfma<true>));
+        else LKCHK(go(&panel_xhy_upd_mfma<false>));
+    }
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, part, grid, npart, grid, k, p, ED, 0, out);
     HIPCHK(hipGetLastError());
     if (out_dev) *out_dev = out;
     return allreduce(c, out, nslots);
@@ -1235,7 +1280,11 @@ int lk_basis_create(lk_context_t c, int dtype, int64_t n_local, int ncols, lk_ba
     b->ctx = c; b->dtype = dtype; b->n = n_local; b->ld = ld; b->ncols = ncols; b->own = true; b->data = nullptr;
     const size_t bytes = (size_t)ld * ncols * ed * sizeof(double);
     hipError_t e = hipMalloc((void **)&b->data, bytes);
-    if (e != hipSuccess) { delete b; return fail(LK_ERR_NOMEM, "lk_basis_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();      // clear the runtime's sticky last-error state: the NEXT launch check must not report this
+        delete b;
+        return fail(LK_ERR_NOMEM, "lk_basis_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
     e = hipMemsetAsync(b->data, 0, bytes, c->stream);
     if (e != hipSuccess) { (void)hipFree(b->data); delete b; return fail(LK_ERR_HIP, "memset failed: %s", hipGetErrorString(e)); }
     *B = b;
@@ -1958,17 +2007,22 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
         lk_context_t c = Bx->ctx;
         LKCHK(lazy_enter(c, true));
         if (c->xhy_mfma && p >= XHY_MIN_P) {
-            // many right-hand sides: coefficients AND updates on the matrix cores, FOUR passes over X per group of up to 32
-            // columns of Y (H1 = X^H Y | Y -= X H1 | H2 = X^H Y | Y -= X H2), one copy + synchronisation per group
+            // many right-hand sides: coefficients AND updates on the matrix cores, THREE passes over X per group of up to 32
+            // columns of Y (H1 = X^H Y | Y' = Y - X H1 with H2 = X^H Y' in the same pass | Y'' = Y' - X H2); "block_fused" = 0
+            // keeps the four-pass schedule (H1 | update | H2 | update).  One copy + synchronisation per group
             std::vector<double> host((size_t)2 * XHY_GROUP * (k + 1) * ED);
             for (int j = 0; j < p; j += XHY_GROUP) {
                 const int pn = (p - j) < XHY_GROUP ? (p - j) : XHY_GROUP;
                 const size_t cnt = (size_t)pn * (k + 1) * ED;
                 double *o1 = nullptr, *o2 = nullptr;
-                LKCHK(dots_mfma(Bx, 0, k, By, jy0 + j, pn, 0, 0, &o1));
-                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, o1, (int64_t)(k + 1)));
-                LKCHK(dots_mfma(Bx, 0, k, By, jy0 + j, pn, 0, 1, &o2));
-                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, o2, (int64_t)(k + 1)));
+                LKCHK(dots_mfma(Bx, 0, k, By, jy0 + j, pn, 0, 0, &o1));                         // H1 = X^H Y
+                if (c->block_fused) {
+                    LKCHK(upd_dots_mfma(Bx, k, By, jy0 + j, pn, o1, 1, &o2));                   // Y' = Y - X H1 ; H2 = X^H Y'   (one pass)
+                } else {
+                    LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, o1, (int64_t)(k + 1)));
+                    LKCHK(dots_mfma(Bx, 0, k, By, jy0 + j, pn, 0, 1, &o2));
+                }
+                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, o2, (int64_t)(k + 1)));             // Y'' = Y' - X H2
                 HIPCHK(hipMemcpyAsync(host.data(), o1, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(hipMemcpyAsync(host.data() + cnt, o2, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(hipStreamSynchronize(c->stream));

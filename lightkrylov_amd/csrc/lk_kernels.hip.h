@@ -1192,6 +1192,218 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     }
 }
 
+// Pass B of the block Gram-Schmidt with many right-hand sides, FUSED on the matrix cores (gram_schmidt.fypp:59-105):
+//     Y' = Y - X H1   (stored)      M2 = X^H Y'      ||Y'_q||^2
+// in ONE pass over X(:, :k) (k <= 128) and Y(:, :p) (p <= 32) -- the update and the second coefficient pass of
+// DGS_basis_against_basis used to be two passes (MFMA update, then panel_xhy_mfma), four per group of 32 columns in all;
+// with this kernel a group costs three (panel_xhy_mfma | this | MFMA update).
+// A block stages a tile of 64 real rows x all columns of X and Y in LDS exactly as panel_xhy_mfma does (same strides, the next
+// tile prefetched into registers), plus -- once -- the coefficients H1 as B operands.  Per tile:
+//   update : D(16 rows x 16 rhs) += A(16 rows x 4 cols) B(4 cols x 16 rhs), wave w owning row block w & 3 and rhs tile w >> 2 of
+//            the 64 x 32 tile of U = X H1.  A k-step takes the columns c = 32 g + t + 8 kk (kk = 0..3), not 4 consecutive ones:
+//            with the column stride S = 66 (== 2 mod 32) that makes the A read (16 rows x 4 columns) and the B read of H1
+//            conflict free for the two 32-lane groups of a ds_read_b64.  Y' = Y - U goes back INTO the LDS tile;
+//   store  : every thread writes the 16 bytes of Y' it staged (coalesced along the rows) and adds them to the norms;
+//   dots   : as panel_xhy_mfma (wave w owns tile row I = w of X, contraction over the 64 rows).
+// complex kind: the panel is read as a real one of 2n rows (re, im interleaved).  U(rho, q) = sum_c X(rho, c) Hr(c, q) + s(rho)
+// X(rho^1, c) Hi(c, q), s = -1 on the even (real-part) rows: a second MFMA per k-step whose A operand is the partner row
+// with that sign and whose B operand is the imaginary plane of H1.
+// H1: device coefficients in panel_dot_p's layout [q][k + 1][ED].  Results as panel_xhy_mfma (partial[block][slot], norms in
+// npartial[block][q]).
+template <bool CPLX>
+__global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restrict__ X, int64_t ldx, int k,
+                                                          double *__restrict__ Y, int64_t ldy, int p, int64_t n,
+                                                          const double *__restrict__ H1, double *__restrict__ partial,
+                                                          double *__restrict__ npartial, int policy) {
+    constexpr int ER = CPLX ? 2 : 1;
+    constexpr int TR = 64, S = TR + 2, CH = TR / 2, CHS = 5, CPP = 512 / CH;   // as panel_xhy_mfma<., 2, 64>
+    constexpr int PJM = 2, NXP = 128 / CPP, NYP = (16 * PJM + CPP - 1) / CPP;
+    constexpr int RL = 16 * PJM + 2;             // row length of the staged coefficients (8 RL == 16 mod 32)
+    extern __shared__ __attribute__((aligned(16))) double xu_lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int KP = (k + 15) >> 4, PJ = (p + 15) >> 4, KG = (k + 31) >> 5;
+    const int KS = (k + CPP - 1) / CPP, PS = (p + CPP - 1) / CPP;
+    double *Xt = xu_lds;                                     // [32 KG columns][S]  (columns >= 16 KP stay zero)
+    double *Yt = Xt + KG * 32 * S;                           // [16 PJM columns][S]
+    double *Hr = Yt + 16 * PJM * S;                          // [32 KG columns][RL]  (+ the imaginary plane for the complex kind)
+    double *Hi = Hr + KG * 32 * RL;
+    const int64_t nr = n * ER;
+    const int64_t ntiles = (nr + TR - 1) / TR;
+    const int64_t xcs = ldx * ER, ycs = ldy * ER;
+    const int arow = lane >> 4, acol = lane & 15;
+
+    // ---- once: zero the padding columns of X's tile, stage H1 (zero beyond k / p)
+    for (int i = t; i < (KG * 32 - KP * 16) * S; i += 512) Xt[KP * 16 * S + i] = 0.0;
+    for (int i = t; i < KG * 32 * RL; i += 512) {
+        const int c = i / RL, q = i - c * RL;
+        double hr = 0.0, hi = 0.0;
+        if (c < k && q < p) {
+            hr = H1[((int64_t)q * (k + 1) + c) * ER];
+            if constexpr (CPLX) hi = H1[((int64_t)q * (k + 1) + c) * ER + 1];
+        }
+        Hr[i] = hr;
+        if constexpr (CPLX) Hi[i] = hi;
+    }
+
+    v4d acc_re[PJM], acc_im[PJM];
+#pragma unroll
+    for (int J = 0; J < PJM; ++J) { acc_re[J] = v4d{0.0, 0.0, 0.0, 0.0}; acc_im[J] = v4d{0.0, 0.0, 0.0, 0.0}; }
+    double nacc[NYP];
+#pragma unroll
+    for (int s = 0; s < NYP; ++s) nacc[s] = 0.0;
+    v2d xs[NXP], ys[NYP];
+
+    auto gload = [&](int64_t T) {
+        const int64_t rbase = T * TR;
+#pragma unroll
+        for (int s = 0; s < NXP; ++s) {
+            xs[s] = v2d{0.0, 0.0};
+            if (s < KS) {
+                const int c = t + 512 * s, col = c >> CHS;
+                const int64_t rr = rbase + 2 * (c & (CH - 1));
+                if (col < k) {
+                    const double *pc = X + (int64_t)col * xcs;
+                    if (rr + 1 < nr) xs[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(pc + rr));
+                    else if (rr < nr) xs[s].x = pc[rr];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NYP; ++s) {
+            ys[s] = v2d{0.0, 0.0};
+            if (s < PS) {
+                const int c = t + 512 * s, col = c >> CHS;
+                const int64_t rr = rbase + 2 * (c & (CH - 1));
+                if (col < p) {
+                    const double *pc = Y + (int64_t)col * ycs;
+                    if (rr + 1 < nr) ys[s] = *reinterpret_cast<const v2d *>(pc + rr);
+                    else if (rr < nr) ys[s].x = pc[rr];
+                }
+            }
+        }
+    };
+
+    int64_t T = blockIdx.x;
+    if (T < ntiles) gload(T);
+    for (; T < ntiles; T += gridDim.x) {
+        __syncthreads();                                            // the previous tile's operands have been read
+#pragma unroll
+        for (int s = 0; s < NXP; ++s)
+            if (s < KS) {
+                const int c = t + 512 * s;
+                if ((c >> CHS) < KP * 16) *reinterpret_cast<v2d *>(Xt + (c >> CHS) * S + 2 * (c & (CH - 1))) = xs[s];
+            }
+#pragma unroll
+        for (int s = 0; s < NYP; ++s)
+            if (s < PS) {
+                const int c = t + 512 * s;
+                if ((c >> CHS) < PJ * 16) *reinterpret_cast<v2d *>(Yt + (c >> CHS) * S + 2 * (c & (CH - 1))) = ys[s];
+            }
+        __syncthreads();
+        const int64_t Tcur = T;
+        if (T + gridDim.x < ntiles) gload(T + gridDim.x);           // in flight while this tile's MFMAs run
+
+        // ---- update: this wave's 16 x 16 tile of U = X H1, then Y' = Y - U into the LDS tile
+        {
+            const int rb = wave & 3, J = wave >> 2;
+            if (J < PJ) {
+                v4d u = v4d{0.0, 0.0, 0.0, 0.0};
+                const int r0 = rb * 16 + acol;                     // A operand: row of the tile (lane & 15), column step kk = lane >> 4
+                for (int g = 0; g < KG; ++g) {
+#pragma unroll
+                    for (int tt = 0; tt < 8; ++tt) {
+                        const int c = g * 32 + tt + 8 * arow;
+                        const double a = Xt[c * S + r0];
+                        const double b = Hr[c * RL + J * 16 + acol];
+                        u = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, u, 0, 0, 0);
+                        if constexpr (CPLX) {
+                            double a2 = Xt[c * S + (r0 ^ 1)];
+                            a2 = (r0 & 1) ? a2 : -a2;
+                            const double b2 = Hi[c * RL + J * 16 + acol];
+                            u = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, u, 0, 0, 0);
+                        }
+                    }
+                }
+                // D[row = (lane >> 4) + 4 reg][col = lane & 15]: rows of the tile, right-hand side J*16 + acol
+                double *yc = Yt + (J * 16 + acol) * S + rb * 16 + arow;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yc[4 * r] -= u[r];
+            }
+        }
+        __syncthreads();                                            // Y' is complete in LDS
+
+        // ---- store Y' (every thread the 16 bytes it staged) and its norms
+        {
+            const int64_t rbase = Tcur * TR;
+#pragma unroll
+            for (int s = 0; s < NYP; ++s)
+                if (s < PS) {
+                    const int c = t + 512 * s, col = c >> CHS;
+                    if (col < p) {
+                        const v2d v = *reinterpret_cast<const v2d *>(Yt + col * S + 2 * (c & (CH - 1)));
+                        const int64_t rr = rbase + 2 * (c & (CH - 1));
+                        double *pc = Y + (int64_t)col * ycs;
+                        if (rr + 1 < nr) { store16(reinterpret_cast<v2d *>(pc + rr), v, policy); nacc[s] += v.x * v.x + v.y * v.y; }
+                        else if (rr < nr) { pc[rr] = v.x; nacc[s] += v.x * v.x; }
+                    }
+                }
+        }
+
+        // ---- dots: M2 += X_tile^H Y'_tile (wave w = tile row I of X)
+        if (wave < KP) {
+            for (int step = 0; step < TR / 4; ++step) {
+                const int ro = 4 * step + arow;
+                const double a = Xt[(16 * wave + acol) * S + ro];
+#pragma unroll
+                for (int J = 0; J < PJM; ++J) {
+                    if (J < PJ) {
+                        const double b = Yt[(16 * J + acol) * S + ro];
+                        acc_re[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc_re[J], 0, 0, 0);
+                        if constexpr (CPLX) {
+                            double b2 = Yt[(16 * J + acol) * S + (ro ^ 1)];
+                            b2 = (ro & 1) ? -b2 : b2;
+                            acc_im[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc_im[J], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const int64_t nslots = (int64_t)p * (k + 1) * ER;
+    double *pb = partial + (int64_t)blockIdx.x * nslots;
+    if (wave < KP) {
+#pragma unroll
+        for (int J = 0; J < PJM; ++J) {
+            if (J < PJ) {
+                const int q = 16 * J + acol;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * wave + arow + 4 * r;
+                    if (i < k && q < p) {
+                        pb[((int64_t)q * (k + 1) + i) * ER] = acc_re[J][r];
+                        if constexpr (CPLX) pb[((int64_t)q * (k + 1) + i) * ER + 1] = acc_im[J][r];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NYP; ++s) {
+        if (s < PS) {
+            double v = nacc[s];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            const int col = (t >> CHS) + CPP * s;
+            if ((t & (CH - 1)) == 0 && col < p) npartial[(int64_t)blockIdx.x * p + col] = v;
+        }
+    }
+}
+
 // out[slot] = sum over vb of partial[vb][slot]; norm slots (i = k) from npartial; tiles panel_xhy_mfma skipped (flag 2:
 // I > J) read as zero.  16 slots x 16 lanes per block: lane v adds the entries vb = v, v + 16, ... in order, then the 16 lane
 // sums are added in lane order -- a fixed summation order whatever the grid (there can be thousands of partial blocks for a

@@ -66,10 +66,11 @@ def test_two_processes_sharing_one_gpu_reproduce_the_single_process_factorisatio
     assert abs(two["config"]["H_last_subdiag"] - plain["config"]["H_last_subdiag"]) <= 1e-12 * plain["config"]["H_last_subdiag"]
 
 
-@pytest.mark.parametrize("operator,rows", [("dense", "2051"), ("csr", "3721")])
+@pytest.mark.parametrize("operator,rows", [("dense", "2051"), ("csr", "3721"), ("lap5", "3721")])
 def test_two_processes_on_the_row_sharded_dense_and_csr_operators(operator, rows):
-    """bench.py --operator dense / csr with two processes (gloo standing in for RCCL, both ranks on one GPU): a row block of A per
-    rank, x all-gathered per matvec.  Same factorisation as the single process to rounding."""
+    """bench.py --operator dense / csr / lap5 with two PROCESSES (gloo standing in for RCCL, both ranks on one GPU): a row block
+    of A per rank and x all-gathered per matvec (dense, CSR); whole grid lines per rank and one line exchanged with the
+    neighbour (stencil).  Same factorisation as the single process to rounding."""
     args = ["--operator", operator, "--rows", rows, "--kdim", "12", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py", "--gpus", "1"] + args)
     two = _run([sys.executable, "bench.py", "--gpus", "2"] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")

@@ -18,8 +18,8 @@ for dtype in (np.float64, np.complex128):
         for j in range(p):
             Y[j].rand(True, seed=500 + j)
         res = {}
-        for mf, small in ((0, 1), (1, 1)):
-            ctx.set_tuning("xhy_mfma", mf); ctx.set_tuning("xhy_small", small)
+        for mf, fused in ((0, 1), (1, 0), (1, 1)):
+            ctx.set_tuning("xhy_mfma", mf); ctx.set_tuning("block_fused", fused)
             out = {}
             for name, fn in (("gram", lambda: lk.Gram(B)), ("innerprod", lambda: lk.innerprod(B, Y)),
                              ("block_dgs", lambda: lk.double_gram_schmidt_step(Y, B, if_chk_orthonormal=False))):
@@ -29,7 +29,7 @@ for dtype in (np.float64, np.complex128):
                     fn()
                 ctx.sync()
                 out[name + "_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
-            res["mfma" if mf else "valu"] = out
+            res[("mfma_3pass" if fused else "mfma_4pass") if mf else "valu"] = out
         one_pass_ms = nn * s * k / 6.5e12 * 1e3
         print(json.dumps({"dtype": np.dtype(dtype).name, "n": nn, "k": k, "p": p, "one_pass_over_X_ms_at_6.5TBps": round(one_pass_ms, 3), **res}), flush=True)
         del B, Y
