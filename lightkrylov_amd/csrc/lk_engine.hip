@@ -609,7 +609,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     int64_t need = 2 * sect + npart_n + (int64_t)nvb * nslots;
     if (c->xhy_n < need) {
         // (also room for the fused block pass, one block per CU, so that it never has to grow the buffer between passes)
-        const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * nslots;
+        const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
         if (need < fused) need = fused;
         if (c->xhy) HIPCHK(hipFree(c->xhy));
         c->xhy = nullptr;
@@ -648,8 +648,8 @@ int upd_dots_mfma(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, const dou
     const int64_t nslots = (int64_t)p * (k + 1) * ED;
     const int64_t sect = (int64_t)XHY_MAX * (XHY_MAX + 1) * 2;
     const int64_t npart_n = (int64_t)c->num_cu * 4 * XHY_MAX;
-    const int64_t ntiles = (Bx->n * ED + 63) / 64;
-    int64_t g = c->num_cu;                                   // 119 / 154 KB of LDS: one block per CU
+    const int64_t ntiles = (Bx->n * ED + 31) / 32;
+    int64_t g = (int64_t)c->num_cu * (cp ? 1 : 2);           // 78 KB (real) / 113 KB (complex) of LDS at k = 128: two / one blocks of 4 waves per CU
     if (g > ntiles) g = ntiles;
     if (g < 1) g = 1;
     const int grid = (int)g;
@@ -659,12 +659,12 @@ int upd_dots_mfma(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, const dou
         return fail(LK_ERR_INVALID, "internal: xhy workspace too small for the fused block pass (%lld < %lld)", (long long)c->xhy_n, (long long)need);
     }
     double *out = c->xhy + (int64_t)sec * sect, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
-    const size_t lds = (size_t)(KG * 32 * 66 + 32 * 66 + KG * 32 * 34 * (cp ? 2 : 1)) * sizeof(double);
+    const size_t lds = (size_t)(KG * 32 * 34 + 32 * 34 + KG * 32 * 34 * (cp ? 2 : 1)) * sizeof(double);
     {
         ProfScope ps(c, "xhy_upd_mfma", (double)Bx->n * ED * 8.0 * (k + 2 * p));
         auto go = [&](auto kern) -> int {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, (const double *)Bx->col(0), Bx->ld, k, By->col(jy0), By->ld, p, Bx->n,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, (const double *)Bx->col(0), Bx->ld, k, By->col(jy0), By->ld, p, Bx->n,
                                H1dev, part, npart, c->gemm_store_policy);
             return LK_OK;
         };
@@ -1163,7 +1163,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "xhy_small")) { c->xhy_small = value != 0; return LK_OK; }
     if (!strcmp(key, "xhy_grid_mult")) { c->xhy_grid_mult = value < 0 ? 0 : (value > 4 ? 4 : value); return LK_OK; }
     if (!strcmp(key, "xhy_mfma")) { c->xhy_mfma = value != 0; return LK_OK; }
-    if (!strcmp(key, "block_fused")) { c->block_fused = value != 0; return LK_OK; }
+    if (!strcmp(key, "block_fused")) { c->block_fused = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "csr_stream")) { c->csr_stream = value != 0; return LK_OK; }
     if (!strcmp(key, "csr_lanes")) {
         if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(LK_ERR_INVALID, "lk_set_tuning: csr_lanes must be 0 or a power of two in [1, 64]");
@@ -2016,7 +2016,7 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
                 const size_t cnt = (size_t)pn * (k + 1) * ED;
                 double *o1 = nullptr, *o2 = nullptr;
                 LKCHK(dots_mfma(Bx, 0, k, By, jy0 + j, pn, 0, 0, &o1));                         // H1 = X^H Y
-                if (c->block_fused) {
+                if (c->block_fused == 2 || (c->block_fused && Bx->dtype == LK_F64)) {   // complex: the 4-pass schedule is faster (2 = force)
                     LKCHK(upd_dots_mfma(Bx, k, By, jy0 + j, pn, o1, 1, &o2));                   // Y' = Y - X H1 ; H2 = X^H Y'   (one pass)
                 } else {
                     LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, o1, (int64_t)(k + 1)));

@@ -1197,26 +1197,30 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
 // in ONE pass over X(:, :k) (k <= 128) and Y(:, :p) (p <= 32) -- the update and the second coefficient pass of
 // DGS_basis_against_basis used to be two passes (MFMA update, then panel_xhy_mfma), four per group of 32 columns in all;
 // with this kernel a group costs three (panel_xhy_mfma | this | MFMA update).
-// A block stages a tile of 64 real rows x all columns of X and Y in LDS exactly as panel_xhy_mfma does (same strides, the next
-// tile prefetched into registers), plus -- once -- the coefficients H1 as B operands.  Per tile:
-//   update : D(16 rows x 16 rhs) += A(16 rows x 4 cols) B(4 cols x 16 rhs), wave w owning row block w & 3 and rhs tile w >> 2 of
-//            the 64 x 32 tile of U = X H1.  A k-step takes the columns c = 32 g + t + 8 kk (kk = 0..3), not 4 consecutive ones:
-//            with the column stride S = 66 (== 2 mod 32) that makes the A read (16 rows x 4 columns) and the B read of H1
+// A block of FOUR waves stages a tile of 32 real rows x all columns of X and Y in LDS as panel_xhy_mfma does (same strides, the
+// next tile prefetched into registers), plus -- once -- the coefficients H1 as B operands: 78 KB for k = 128, p = 32 in the
+// real kind, so two blocks share a CU and one block's staging / barriers / stores run under the other's MFMAs (a first version
+// with one 8-wave block per CU and 64-row tiles spent 40 % of its time outside the matrix pipe).  Per tile:
+//   update : D(16 rows x 16 rhs) += A(16 rows x 4 cols) B(4 cols x 16 rhs), wave w owning row block w & 1 and rhs tile w >> 1 of
+//            the 32 x 32 tile of U = X H1.  A k-step takes the columns c = 32 g + t + 8 kk (kk = 0..3), not 4 consecutive ones:
+//            with the column stride S = 34 (== 2 mod 32) that makes the A read (16 rows x 4 columns) and the B read of H1
 //            conflict free for the two 32-lane groups of a ds_read_b64.  Y' = Y - U goes back INTO the LDS tile;
 //   store  : every thread writes the 16 bytes of Y' it staged (coalesced along the rows) and adds them to the norms;
-//   dots   : as panel_xhy_mfma (wave w owns tile row I = w of X, contraction over the 64 rows).
+//   dots   : as panel_xhy_mfma (wave w owns tile rows I = w and w + 4 of X, contraction over the 32 rows).
 // complex kind: the panel is read as a real one of 2n rows (re, im interleaved).  U(rho, q) = sum_c X(rho, c) Hr(c, q) + s(rho)
 // X(rho^1, c) Hi(c, q), s = -1 on the even (real-part) rows: a second MFMA per k-step whose A operand is the partner row
-// with that sign and whose B operand is the imaginary plane of H1.
+// with that sign and whose B operand is the imaginary plane of H1 (113 KB: one block per CU -- the launcher keeps the
+// four-pass schedule for the complex kind, which is faster there).
 // H1: device coefficients in panel_dot_p's layout [q][k + 1][ED].  Results as panel_xhy_mfma (partial[block][slot], norms in
 // npartial[block][q]).
 template <bool CPLX>
-__global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restrict__ X, int64_t ldx, int k,
+__global__ __launch_bounds__(256) void panel_xhy_upd_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                           double *__restrict__ Y, int64_t ldy, int p, int64_t n,
                                                           const double *__restrict__ H1, double *__restrict__ partial,
                                                           double *__restrict__ npartial, int policy) {
     constexpr int ER = CPLX ? 2 : 1;
-    constexpr int TR = 64, S = TR + 2, CH = TR / 2, CHS = 5, CPP = 512 / CH;   // as panel_xhy_mfma<., 2, 64>
+    constexpr int NT = 256;                                                   // threads per block
+    constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = NT / CH;   // 16 columns staged per block-wide pass
     constexpr int PJM = 2, NXP = 128 / CPP, NYP = (16 * PJM + CPP - 1) / CPP;
     constexpr int RL = 16 * PJM + 2;             // row length of the staged coefficients (8 RL == 16 mod 32)
     extern __shared__ __attribute__((aligned(16))) double xu_lds[];
@@ -1234,8 +1238,8 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
     const int arow = lane >> 4, acol = lane & 15;
 
     // ---- once: zero the padding columns of X's tile, stage H1 (zero beyond k / p)
-    for (int i = t; i < (KG * 32 - KP * 16) * S; i += 512) Xt[KP * 16 * S + i] = 0.0;
-    for (int i = t; i < KG * 32 * RL; i += 512) {
+    for (int i = t; i < (KG * 32 - KP * 16) * S; i += NT) Xt[KP * 16 * S + i] = 0.0;
+    for (int i = t; i < KG * 32 * RL; i += NT) {
         const int c = i / RL, q = i - c * RL;
         double hr = 0.0, hi = 0.0;
         if (c < k && q < p) {
@@ -1246,9 +1250,11 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
         if constexpr (CPLX) Hi[i] = hi;
     }
 
-    v4d acc_re[PJM], acc_im[PJM];
+    v4d acc_re[2][PJM], acc_im[2][PJM];          // tile rows I = wave, wave + 4 of X
 #pragma unroll
-    for (int J = 0; J < PJM; ++J) { acc_re[J] = v4d{0.0, 0.0, 0.0, 0.0}; acc_im[J] = v4d{0.0, 0.0, 0.0, 0.0}; }
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int J = 0; J < PJM; ++J) { acc_re[h][J] = v4d{0.0, 0.0, 0.0, 0.0}; acc_im[h][J] = v4d{0.0, 0.0, 0.0, 0.0}; }
     double nacc[NYP];
 #pragma unroll
     for (int s = 0; s < NYP; ++s) nacc[s] = 0.0;
@@ -1260,7 +1266,7 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
         for (int s = 0; s < NXP; ++s) {
             xs[s] = v2d{0.0, 0.0};
             if (s < KS) {
-                const int c = t + 512 * s, col = c >> CHS;
+                const int c = t + NT * s, col = c >> CHS;
                 const int64_t rr = rbase + 2 * (c & (CH - 1));
                 if (col < k) {
                     const double *pc = X + (int64_t)col * xcs;
@@ -1273,7 +1279,7 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
         for (int s = 0; s < NYP; ++s) {
             ys[s] = v2d{0.0, 0.0};
             if (s < PS) {
-                const int c = t + 512 * s, col = c >> CHS;
+                const int c = t + NT * s, col = c >> CHS;
                 const int64_t rr = rbase + 2 * (c & (CH - 1));
                 if (col < p) {
                     const double *pc = Y + (int64_t)col * ycs;
@@ -1291,13 +1297,13 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
 #pragma unroll
         for (int s = 0; s < NXP; ++s)
             if (s < KS) {
-                const int c = t + 512 * s;
+                const int c = t + NT * s;
                 if ((c >> CHS) < KP * 16) *reinterpret_cast<v2d *>(Xt + (c >> CHS) * S + 2 * (c & (CH - 1))) = xs[s];
             }
 #pragma unroll
         for (int s = 0; s < NYP; ++s)
             if (s < PS) {
-                const int c = t + 512 * s;
+                const int c = t + NT * s;
                 if ((c >> CHS) < PJ * 16) *reinterpret_cast<v2d *>(Yt + (c >> CHS) * S + 2 * (c & (CH - 1))) = ys[s];
             }
         __syncthreads();
@@ -1306,25 +1312,33 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
 
         // ---- update: this wave's 16 x 16 tile of U = X H1, then Y' = Y - U into the LDS tile
         {
-            const int rb = wave & 3, J = wave >> 2;
+            const int rb = wave & 1, J = wave >> 1;
             if (J < PJ) {
-                v4d u = v4d{0.0, 0.0, 0.0, 0.0};
+                // four independent accumulator chains (k-steps tt, tt + 4 of every column group share one)
+                v4d ua[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ua[i] = v4d{0.0, 0.0, 0.0, 0.0};
                 const int r0 = rb * 16 + acol;                     // A operand: row of the tile (lane & 15), column step kk = lane >> 4
                 for (int g = 0; g < KG; ++g) {
+                    double av[8], bv[8], av2[CPLX ? 8 : 1], bv2[CPLX ? 8 : 1];
 #pragma unroll
-                    for (int tt = 0; tt < 8; ++tt) {
+                    for (int tt = 0; tt < 8; ++tt) {               // all LDS reads of the column group first, then its MFMAs
                         const int c = g * 32 + tt + 8 * arow;
-                        const double a = Xt[c * S + r0];
-                        const double b = Hr[c * RL + J * 16 + acol];
-                        u = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, u, 0, 0, 0);
+                        av[tt] = Xt[c * S + r0];
+                        bv[tt] = Hr[c * RL + J * 16 + acol];
                         if constexpr (CPLX) {
-                            double a2 = Xt[c * S + (r0 ^ 1)];
-                            a2 = (r0 & 1) ? a2 : -a2;
-                            const double b2 = Hi[c * RL + J * 16 + acol];
-                            u = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, u, 0, 0, 0);
+                            const double a2 = Xt[c * S + (r0 ^ 1)];
+                            av2[tt] = (r0 & 1) ? a2 : -a2;
+                            bv2[tt] = Hi[c * RL + J * 16 + acol];
                         }
                     }
+#pragma unroll
+                    for (int tt = 0; tt < 8; ++tt) {
+                        ua[tt & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[tt], bv[tt], ua[tt & 3], 0, 0, 0);
+                        if constexpr (CPLX) ua[tt & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(av2[tt], bv2[tt], ua[tt & 3], 0, 0, 0);
+                    }
                 }
+                const v4d u = (ua[0] + ua[1]) + (ua[2] + ua[3]);
                 // D[row = (lane >> 4) + 4 reg][col = lane & 15]: rows of the tile, right-hand side J*16 + acol
                 double *yc = Yt + (J * 16 + acol) * S + rb * 16 + arow;
 #pragma unroll
@@ -1339,7 +1353,7 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
 #pragma unroll
             for (int s = 0; s < NYP; ++s)
                 if (s < PS) {
-                    const int c = t + 512 * s, col = c >> CHS;
+                    const int c = t + NT * s, col = c >> CHS;
                     if (col < p) {
                         const v2d v = *reinterpret_cast<const v2d *>(Yt + col * S + 2 * (c & (CH - 1)));
                         const int64_t rr = rbase + 2 * (c & (CH - 1));
@@ -1350,20 +1364,36 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
                 }
         }
 
-        // ---- dots: M2 += X_tile^H Y'_tile (wave w = tile row I of X)
-        if (wave < KP) {
-            for (int step = 0; step < TR / 4; ++step) {
-                const int ro = 4 * step + arow;
-                const double a = Xt[(16 * wave + acol) * S + ro];
+        // ---- dots: M2 += X_tile^H Y'_tile (tile rows I = wave, wave + 4 of X); the LDS reads of four row steps, then their MFMAs
 #pragma unroll
-                for (int J = 0; J < PJM; ++J) {
-                    if (J < PJ) {
-                        const double b = Yt[(16 * J + acol) * S + ro];
-                        acc_re[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc_re[J], 0, 0, 0);
-                        if constexpr (CPLX) {
-                            double b2 = Yt[(16 * J + acol) * S + (ro ^ 1)];
-                            b2 = (ro & 1) ? -b2 : b2;
-                            acc_im[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc_im[J], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+            const int I = wave + 4 * h;
+            if (I < KP) {
+                for (int s0 = 0; s0 < TR / 4; s0 += 4) {
+                    double a[4], b[4][PJM], b2[4][CPLX ? PJM : 1];
+#pragma unroll
+                    for (int ss = 0; ss < 4; ++ss) {
+                        const int ro = 4 * (s0 + ss) + arow;
+                        a[ss] = Xt[(16 * I + acol) * S + ro];
+#pragma unroll
+                        for (int J = 0; J < PJM; ++J) {
+                            if (J < PJ) {
+                                b[ss][J] = Yt[(16 * J + acol) * S + ro];
+                                if constexpr (CPLX) {
+                                    const double v = Yt[(16 * J + acol) * S + (ro ^ 1)];
+                                    b2[ss][J] = (ro & 1) ? -v : v;
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int ss = 0; ss < 4; ++ss) {
+#pragma unroll
+                        for (int J = 0; J < PJM; ++J) {
+                            if (J < PJ) {
+                                acc_re[h][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ss], b[ss][J], acc_re[h][J], 0, 0, 0);
+                                if constexpr (CPLX) acc_im[h][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ss], b2[ss][J], acc_im[h][J], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -1373,17 +1403,21 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
 
     const int64_t nslots = (int64_t)p * (k + 1) * ER;
     double *pb = partial + (int64_t)blockIdx.x * nslots;
-    if (wave < KP) {
 #pragma unroll
-        for (int J = 0; J < PJM; ++J) {
-            if (J < PJ) {
-                const int q = 16 * J + acol;
+    for (int h = 0; h < 2; ++h) {
+        const int I = wave + 4 * h;
+        if (I < KP) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * wave + arow + 4 * r;
-                    if (i < k && q < p) {
-                        pb[((int64_t)q * (k + 1) + i) * ER] = acc_re[J][r];
-                        if constexpr (CPLX) pb[((int64_t)q * (k + 1) + i) * ER + 1] = acc_im[J][r];
+            for (int J = 0; J < PJM; ++J) {
+                if (J < PJ) {
+                    const int q = 16 * J + acol;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * I + arow + 4 * r;
+                        if (i < k && q < p) {
+                            pb[((int64_t)q * (k + 1) + i) * ER] = acc_re[h][J][r];
+                            if constexpr (CPLX) pb[((int64_t)q * (k + 1) + i) * ER + 1] = acc_im[h][J][r];
+                        }
                     }
                 }
             }
@@ -1393,7 +1427,6 @@ __global__ __launch_bounds__(512) void panel_xhy_upd_mfma(const double *__restri
     for (int s = 0; s < NYP; ++s) {
         if (s < PS) {
             double v = nacc[s];
-            v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 8);
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 2);

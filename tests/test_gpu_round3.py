@@ -351,3 +351,37 @@ def test_operator_time_is_measured_inside_the_asynchronous_batch(ctx):
     cnt, ms, by = ctx.profile_get("matvec")
     ctx.profile_enable(False)
     assert cnt == m and ms > 0.0 and by == pytest.approx(m * 2 * 8.0 * n)
+
+
+# ----------------------------------------------------------------------------- block DGS with many right-hand sides: three passes
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("fused", [0, 1, 2])
+@pytest.mark.parametrize("n,k,p", [(70_001, 128, 32), (5003, 100, 17), (4099, 17, 6), (3001, 64, 8), (2051, 33, 5), (777, 128, 33),
+                                   (63, 16, 32), (20_000, 96, 70)])
+def test_block_dgs_three_pass_schedule_on_the_matrix_cores(dtype, fused, n, k, p):
+    """DGS_basis_against_basis (gram_schmidt.fypp:59-105) with >= 5 right-hand sides: H1 = X^H Y | Y' = Y - X H1 AND H2 = X^H Y' in
+    one fused pass (panel_xhy_upd_mfma) | Y'' = Y' - X H2 -- three passes over X per group of 32 columns (`block_fused` = 1: real
+    kind, 2: both kinds) against the four-pass schedule (0); every column against the oracle's double Gram-Schmidt."""
+    c = lk.Context(device=0)
+    c.set_tuning("block_fused", fused)
+    Q = orthonormal_basis(n, k, dtype, 5)
+    Y = basis(n, p, dtype, 200)
+    B = lk.krylov_basis_gpu(n, k, dtype, c); B.upload(Q)
+    Z = lk.krylov_basis_gpu(n, p, dtype, c); Z.upload(Y)
+    beta = np.zeros((k, p), dtype=dtype, order="F")
+    c.profile_reset(); c.profile_enable(True)
+    assert lk.double_gram_schmidt_step(Z, B, False, beta) == 0
+    c.sync()
+    n_fused = c.profile_get("xhy_upd_mfma")[0]
+    c.profile_enable(False)
+    groups = (p + 31) // 32
+    assert n_fused == (groups if (fused == 2 or (fused == 1 and np.dtype(dtype).kind == "f")) else 0)
+    Yg = Z.download()
+    for j in range(p):
+        yo = Y[:, j].copy()
+        ho, _ = ora.double_gram_schmidt_step(yo, Q)
+        assert np.abs(beta[:, j] - ho).max() <= 1e-12 * np.linalg.norm(Y[:, j])
+        assert np.abs(Yg[:, j] - yo).max() <= 1e-12 * np.linalg.norm(Y[:, j])
+    assert np.abs(Q.conj().T @ Yg).max() <= 1e-13 * np.linalg.norm(Y, axis=0).max()
+    del B, Z
+    c.close()
