@@ -145,8 +145,11 @@ module lightkrylov_gpu
     interface dense_vector_gpu
         module procedure dense_vector_gpu_from_rdp, dense_vector_gpu_from_cdp
     end interface
+    !> dense_linop_gpu(A): the whole matrix on one rank.  dense_linop_gpu(A_rows, row_starts): ROW-SHARDED -- this rank passes its
+    !> n_local x n_global row block and the 0-based offsets row_starts(0:nranks) of every rank's block (lk_gpu_comm_init first):
+    !> matvec all-gathers x, rmatvec sums the ranks' products of their blocks' conjugate transposes (lightkrylov_hip.h).
     interface dense_linop_gpu
-        module procedure dense_linop_gpu_from_rdp, dense_linop_gpu_from_cdp
+        module procedure dense_linop_gpu_from_rdp, dense_linop_gpu_from_cdp, dense_linop_gpu_rows_rdp, dense_linop_gpu_rows_cdp
     end interface
     interface diag_linop_gpu
         module procedure diag_linop_gpu_from_rdp, diag_linop_gpu_from_cdp
@@ -648,6 +651,20 @@ contains
         type(dense_linop_gpu_cdp) :: L
         call chk(lk_linop_dense_create(ctx, LK_C128, int(size(A, 1), c_int64_t), c_loc(A), int(size(A, 1), c_int64_t), L%op), &
                  'dense_linop_gpu')
+    end function
+    function dense_linop_gpu_rows_rdp(A_rows, row_starts) result(L)
+        real(dp), intent(in), target :: A_rows(:, :)
+        integer(c_int64_t), intent(in) :: row_starts(0:)
+        type(dense_linop_gpu_rdp) :: L
+        call chk(lk_linop_dense_create_sharded(ctx, LK_F64, int(size(A_rows, 2), c_int64_t), row_starts, c_loc(A_rows), &
+                                               int(max(size(A_rows, 1), 1), c_int64_t), L%op), 'dense_linop_gpu (row block)')
+    end function
+    function dense_linop_gpu_rows_cdp(A_rows, row_starts) result(L)
+        complex(dp), intent(in), target :: A_rows(:, :)
+        integer(c_int64_t), intent(in) :: row_starts(0:)
+        type(dense_linop_gpu_cdp) :: L
+        call chk(lk_linop_dense_create_sharded(ctx, LK_C128, int(size(A_rows, 2), c_int64_t), row_starts, c_loc(A_rows), &
+                                               int(max(size(A_rows, 1), 1), c_int64_t), L%op), 'dense_linop_gpu (row block)')
     end function
     function csr_linop_gpu_from_rdp(rowptr, colind, vals) result(L)
         integer, intent(in) :: rowptr(:), colind(:)

@@ -328,6 +328,46 @@ module lightkrylov_hip_c
             type(c_funptr), value :: fn
             integer(c_int) :: rc
         end function
+        !> all-gather of row blocks for the row-sharded dense / CSR operators (lk_allgather_fn in the header); a host with MPI
+        !> passes c_funloc of a bind(C) wrapper around MPI_Allgatherv, lk_comm_init_rank installs the native RCCL one
+        function lk_set_allgather(ctx, fn, user) bind(C, name="lk_set_allgather") result(rc)
+            import :: c_int, c_ptr, c_funptr
+            type(c_ptr), value :: ctx, user
+            type(c_funptr), value :: fn
+            integer(c_int) :: rc
+        end function
+        !> row-sharded dense_linop: row_starts(0:nranks) (the same on every rank), A_rows = this rank's n_local x n_global block
+        function lk_linop_dense_create_sharded(ctx, dtype, n_global, row_starts, A_rows, lda, op) &
+            bind(C, name="lk_linop_dense_create_sharded") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx, A_rows
+            integer(c_int), value :: dtype
+            integer(c_int64_t), value :: n_global, lda
+            integer(c_int64_t), intent(in) :: row_starts(*)
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
+        function lk_linop_dense_wrap_sharded(ctx, dtype, n_global, row_starts, dev_ptr, lda, op) &
+            bind(C, name="lk_linop_dense_wrap_sharded") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx, dev_ptr
+            integer(c_int), value :: dtype
+            integer(c_int64_t), value :: n_global, lda
+            integer(c_int64_t), intent(in) :: row_starts(*)
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
+        !> row-sharded CSR operator: this rank's rows with GLOBAL 0-based column indices
+        function lk_linop_csr_create_sharded(ctx, dtype, n_global, row_starts, rowptr, colind, vals, op) &
+            bind(C, name="lk_linop_csr_create_sharded") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx, rowptr, colind, vals
+            integer(c_int), value :: dtype
+            integer(c_int64_t), value :: n_global
+            integer(c_int64_t), intent(in) :: row_starts(*)
+            type(c_ptr), intent(out) :: op
+            integer(c_int) :: rc
+        end function
         function lk_linop_lap5_create(ctx, N, op) bind(C, name="lk_linop_lap5_create") result(rc)
             import :: c_int, c_ptr, c_int64_t
             type(c_ptr), value :: ctx

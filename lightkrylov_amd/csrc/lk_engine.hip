@@ -89,7 +89,7 @@ struct lk_context_s {
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
     double *red = nullptr;      // device results: 3 sections of (KMAX_FUSED+1)*2 doubles
     double *red_host = nullptr; // pinned mirror
-    double *coef = nullptr;     // device coefficients for lincomb (KMAX_FUSED*2 doubles)
+    double *coef = nullptr;     // device coefficients of the lazy path's pending updates (KMAX_WIDE*2 doubles)
     double *scratch = nullptr;  // scratch vector (grown on demand), scratch_n doubles
     int64_t scratch_n = 0;
     double *lz_red = nullptr, *lz_red_host = nullptr;   // lk_lanczos: per step 4 sections (two local passes x {dot, update})
@@ -983,7 +983,7 @@ int fused_sub_with_dots(lk_context_t c) {
     c->sub.active = false;
     LKCHK(stage_coef(c, q.coef, q.cnt, ED, c->sub.s[0], c->sub.s[1]));
     LKCHK((sweepm<2>(q.Bx, q.j0, q.cnt, y, c->coef, nullptr, 1, c->red)));
-    LKCHK(fetch(c, 0, 1));
+    LKCHK(fetch(c, 0, 1, red_stride(q.cnt)));
     auto &mm = c->memo;
     mm.vals.assign(c->red_host, c->red_host + (size_t)q.cnt * ED);
     mm.valid = true; mm.xbase = q.Bx->data; mm.y = y; mm.j0 = q.j0; mm.cnt = q.cnt;
@@ -1052,8 +1052,8 @@ int lk_init(int device, void *stream, lk_context_t *ctx) {
         HIPCHK(hipMalloc((void **)&c->red, (size_t)RED_TOTAL * RED_SECTION_WIDE * sizeof(double)));
         HIPCHK(hipMemsetAsync(c->red, 0, (size_t)RED_TOTAL * RED_SECTION_WIDE * sizeof(double), c->stream));
         HIPCHK(hipHostMalloc((void **)&c->red_host, (size_t)RED_TOTAL * RED_SECTION_WIDE * sizeof(double), hipHostMallocDefault));
-        HIPCHK(hipMalloc((void **)&c->coef, (size_t)KMAX_FUSED * 2 * sizeof(double)));
-        HIPCHK(hipHostMalloc((void **)&c->coef_host, (size_t)KMAX_FUSED * 2 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&c->coef, (size_t)KMAX_WIDE * 2 * sizeof(double)));
+        HIPCHK(hipHostMalloc((void **)&c->coef_host, (size_t)KMAX_WIDE * 2 * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipMalloc((void **)&c->stop_dev, sizeof(int)));
         HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
         HIPCHK(hipHostMalloc((void **)&c->stop_host, sizeof(int), hipHostMallocDefault));
@@ -1584,7 +1584,7 @@ int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta,
         if (unit_beta && Bx->ncols > 1 && xp != yp && xp != T) {
             LKCHK(apply_sub(c));                                 // an earlier y update used the queue as it was
             const bool same_target = q.active && q.By && q.By->col(q.jy) == yp;
-            const bool extends = same_target && q.cnt < KMAX_FUSED &&
+            const bool extends = same_target && q.cnt < KMAX_WIDE &&
                                  (q.cnt == 0 || (q.Bx == Bx && jx == q.j0 + q.cnt));
             if (!extends) {
                 const VecRef w{By, jy}, r{Bx, jx};
@@ -1688,13 +1688,13 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
         // unused columns: sweeping them would cost up to 128/k times the eager traffic)
         int jend = (By->data == Bx->data && jy > jx) ? jy : (Bx->hwm < Bx->ncols ? Bx->hwm : Bx->ncols);
         int cnt = jend - jx;
-        if (cnt > KMAX_FUSED) cnt = KMAX_FUSED;
+        if (cnt > KMAX_WIDE) cnt = KMAX_WIDE;               // one (lane-split) sweep holds up to 512 columns
         if (c->queue.active && c->queue.By && c->queue.By->data == Bx->data && c->queue.jy > jx && c->queue.jy < jx + cnt)
             cnt = c->queue.jy - jx;                              // never sweep a column whose contents are still virtual
         const bool y_inside = (By->data == Bx->data) && jy >= jx && jy < jx + cnt;
         if (cnt >= 2 && !y_inside) {
             LKCHK((sweepm<1>(Bx, jx, cnt, By->col(jy), nullptr, nullptr, 0, c->red)));
-            LKCHK(fetch(c, 0, 1));
+            LKCHK(fetch(c, 0, 1, red_stride(cnt)));
             mm.vals.assign(c->red_host, c->red_host + (size_t)cnt * ED);
             mm.valid = true; mm.xbase = Bx->data; mm.y = yp; mm.j0 = jx; mm.cnt = cnt;
             c->lazy_stats[1] += 1;

@@ -385,3 +385,33 @@ def test_block_dgs_three_pass_schedule_on_the_matrix_cores(dtype, fused, n, k, p
     assert np.abs(Q.conj().T @ Yg).max() <= 1e-13 * np.linalg.norm(Y, axis=0).max()
     del B, Z
     c.close()
+
+
+def test_per_object_arnoldi_in_lazy_mode_beyond_128_columns(ctx):
+    """The per-object (type-bound-procedure) schedule an unchanged LightKrylov drives, lazy mode, kdim = 200: the batched dot
+    sweeps and the fused update + dot sweeps cover up to 512 columns each (one sweep per Gram-Schmidt pass at every step, not
+    one per 128 columns); H equals the fused lk_arnoldi factorisation to 1e-12 per column."""
+    n, m = 20_011, 200
+    d = 1.0 + np.arange(n) / n
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", 1)
+    A = lk.diag_linop_gpu(d, c)
+
+    class pyop(lk.abstract_linop):                            # python operator => the python (reference) step loop
+        def matvec(self, vi, vo): A.matvec(vi, vo)
+    B = lk.krylov_basis_gpu(n, m + 1, np.float64, c)
+    B[0].rand(True, seed=7)
+    X = [B[j] for j in range(m + 1)]
+    H = np.zeros((m + 1, m), order="F")
+    assert lk.arnoldi(pyop(), X, H) == 0
+    fs, ls = c.lazy_fusion_stats(), c.lazy_stats()
+    assert fs[0] == 2 * m and fs[1] == 0 and fs[3] == 0       # two fused update + dot sweeps per step, nothing materialised
+    assert ls[1] == m                                         # one batched dot sweep per step (the first pass), whatever the width
+    X1 = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
+    X1[0].rand(True, seed=7)
+    H1 = np.zeros((m + 1, m), order="F")
+    assert lk.arnoldi(lk.diag_linop_gpu(d, ctx), X1, H1) == 0
+    for j in range(m):
+        assert np.abs(H[:, j] - H1[:, j]).max() <= 1e-12 * np.abs(H1[:, j]).max()
+    del B
+    c.close()

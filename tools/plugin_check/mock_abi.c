@@ -211,6 +211,11 @@ int lk_linop_dense_create(mock_ctx *c, int dtype, int64_t n, const void *A, int6
     return LK_OK;
 }
 int lk_vec_device_ptr(mock_basis *b, int j, int access, void **p) { (void)access; *p = col(b, j); return LK_OK; }
+int lk_linop_dense_create_sharded(mock_ctx *c, int dtype, int64_t n, const int64_t *rs, const void *A, int64_t lda, mock_op **op) {
+    if (rs[0] != 0 || rs[1] != n) return fail("the mock is one rank");
+    return lk_linop_dense_create(c, dtype, n, A, lda, op);
+}
+int lk_linop_csr_create_sharded(mock_ctx *c, int dtype, int64_t n, const int64_t *rs, const int64_t *rp, const int32_t *ci, const void *v, mock_op **op) { (void)c; (void)dtype; (void)n; (void)rs; (void)rp; (void)ci; (void)v; (void)op; return fail("not in the mock"); }
 int lk_linop_csr_create(mock_ctx *c, int dtype, int64_t n, const int64_t *rp, const int32_t *ci, const void *v, mock_op **op) { (void)c; (void)dtype; (void)n; (void)rp; (void)ci; (void)v; (void)op; return fail("not in the mock"); }
 int lk_linop_diag_linspace_create(mock_ctx *c, int64_t n, int64_t r0, double d0, double ds, mock_op **op) { (void)c; (void)n; (void)r0; (void)d0; (void)ds; (void)op; return fail("not in the mock"); }
 int lk_linop_lap5_create(mock_ctx *c, int64_t N, mock_op **op) { (void)c; (void)N; (void)op; return fail("not in the mock"); }
