@@ -20,4 +20,12 @@ python3 "$R/tools/bench_configs.py" > "$D/configs.log" 2>&1
 python3 "$R/tools/bench_blas1.py" 1e8 2 > "$D/blas1.log" 2>&1
 python3 "$R/tools/bench_per_object_arnoldi.py" 1e7 64 > "$D/per_object_arnoldi.log" 2>&1
 python3 "$R/tools/bench_block.py" 1e7 > "$D/block.log" 2>&1
+python3 "$R/tools/bench_wide.py" 1e7 f64 > "$D/wide_f64.log" 2>&1
+python3 "$R/tools/bench_wide.py" 5e6 c128 > "$D/wide_c128.log" 2>&1
+LK_LINCOMB_SCAN=1 python3 "$R/tools/bench_lincomb.py" gemm_mfma_min=100 > "$D/lincomb_scan_valu.log" 2>&1
+LK_LINCOMB_SCAN=1 python3 "$R/tools/bench_lincomb.py" gemm_mfma_min=1 > "$D/lincomb_scan_mfma.log" 2>&1
+for op in dense lap5 csr; do python3 "$R/bench.py" --operator $op --steps 3 --warmup 1 > "$D/bench_$op.log" 2> "$D/bench_$op.err"; done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$D/dense" -o dense -- python3 "$R/bench.py" --operator dense --steps 1 --warmup 1 --no-cpu-baseline > "$D/dense_traced.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_wide_fetch" -o wide -- python3 "$R/tools/bench_wide.py" 4e6 f64 > "$D/pmc_wide_fetch.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_block_fetch" -o block -- python3 "$R/tools/bench_block_dgs.py" 32 1 > "$D/pmc_block_fetch.log" 2>&1
 tail -c 600 "$D/bench_default.log"
