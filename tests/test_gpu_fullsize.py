@@ -231,6 +231,33 @@ def test_config4_on_its_own_operator_against_live_oracle(ctx, capsys):
               f"{wall:.2e}, 8 leading {w8:.2e}")
 
 
+@pytest.mark.parametrize("dtype,n,k", [(np.float64, 2_000_003, 256), (np.float64, 1_000_001, 512), (np.complex128, 1_000_001, 384)])
+def test_wide_dgs_at_a_streaming_size_against_live_oracle(ctx, dtype, n, k):
+    """double_gram_schmidt_step against 256 / 384 / 512 basis columns (the lane-split fused sweeps) on panels of 4-8 GB -- every
+    block walks many tiles, ragged last tile -- against a live multi-threaded oracle run: coefficients and vector normwise 1e-12."""
+    B = lk.krylov_basis_gpu(n, k + 1, dtype, ctx)
+    for j in range(k + 1):
+        B[j].rand(False, seed=300 + j)
+    R = np.zeros((k, k), dtype=dtype, order="F")
+    lk.qr(B[:k], R)                                                     # an orthonormal basis made on the device
+    Q = B.download(0, k)
+    y = B.download(k, 1)[:, 0].copy()
+    beta = np.zeros(k, dtype=dtype)
+    assert lk.double_gram_schmidt_step(B[k], B[:k], if_chk_orthonormal=False, beta=beta) == 0
+    yg = B.download(k, 1)[:, 0]
+    del B
+    ora.set_threads(min(64, ora.max_threads()))
+    try:
+        yo = y.copy()
+        ho, info_o = ora.double_gram_schmidt_step(yo, np.asfortranarray(Q), fast=True)
+    finally:
+        ora.set_threads(1)
+    ynorm = np.linalg.norm(y)
+    assert info_o == 0
+    assert np.abs(beta - ho).max() <= TOL * ynorm
+    assert np.abs(yg - yo).max() <= TOL * ynorm
+
+
 @pytest.mark.parametrize("dtype,ncol", [(np.float64, 5), (np.complex128, 3)])
 def test_maximum_vector_size(ctx, dtype, ncol):
     """The largest vector the contract allows: get_size() returns a default integer (AbstractVectors.fypp:375-381), so
