@@ -148,6 +148,12 @@ int lk_lazy_stats(lk_context_t ctx, int64_t *out4);
  * written only if something reads it.  out4 = {fused update+dot sweeps, pending updates applied as plain panel updates,
  * virtual temporaries dropped unwritten, virtual temporaries written after all}. */
 int lk_lazy_fusion_stats(lk_context_t ctx, int64_t *out4);
+/* The first pass of a Gram-Schmidt step opens with y%norm() and then asks X(1..k)%dot(y) (gram_schmidt.fypp:126, 141): a norm
+ * kernel and the batched dot sweep, two host synchronisations -- although the sweep computes ||y||^2 on the side.  Once that pair
+ * has been seen for y = column j of a panel, the norm of column j + 1 (the next Arnoldi / Lanczos step) runs the sweep at once and
+ * serves the norm and the k dots from it (tuning key "lazy_speculate", default 1).  A prediction nobody uses disarms it.
+ * out2 = {anticipated sweeps, of which unused}. */
+int lk_lazy_speculation_stats(lk_context_t ctx, int64_t *out2);
 
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg).
  * tags: "dgs_sweep1|2|3" (the three panel sweeps; "dgs_sweep*" sums them -- a trailing '*' is a

@@ -235,6 +235,12 @@ class Context:
         _capi.check(self._lib.lk_lazy_fusion_stats(self._h, out))
         return tuple(out)
 
+    def lazy_speculation_stats(self):
+        """(anticipated first-pass sweeps, of which unused) -- see lk_lazy_speculation_stats in the header."""
+        out = (C.c_int64 * 2)()
+        _capi.check(self._lib.lk_lazy_speculation_stats(self._h, out))
+        return tuple(out)
+
     def sync(self) -> None:
         _capi.check(self._lib.lk_sync(self._h))
 

@@ -161,7 +161,21 @@ struct lk_context_s {
         double s[2] = {0.0, 0.0};
     } sub;
     struct { bool valid = false; const double *y = nullptr; double nrm2 = 0.0; } nmemo;   // ||y||^2 from the last fused sweep
+    // first pass of a Gram-Schmidt step, anticipated.  orthogonalize_against_basis opens with y%norm() (gram_schmidt.fypp:126) and
+    // then asks X(1..k)%dot(y): a norm kernel + a host synchronisation, then the batched dot sweep + another one -- although the
+    // sweep computes ||y||^2 on the side.  Once that pair has been SEEN for y = column j of a panel (norm of column j, then the
+    // dots of columns [0, j) against it), the norm of column j + 1 of the same panel -- the next Arnoldi / Lanczos step -- runs
+    // the sweep over [0, j + 1) at once and serves norm and dots from it: one kernel and one synchronisation less per step.
+    // A prediction nobody used (no dot of the batch was asked for before the next one) disarms it: at most one wasted sweep.
+    struct {
+        const double *xbase = nullptr;   // panel the pattern was seen on
+        int jy = -1, j0 = 0;             // ... for this column, against the columns [j0, jy)
+        bool armed = false, unused = false;
+        const double *last_norm_y = nullptr;   // the vector whose norm was the previous lazy-mode call (plain kernel)
+    } spec;
+    int lazy_speculate = 1;              // tuning key: 0 switches the anticipation off
     int64_t fusion_stats[4] = {0, 0, 0, 0};  // fused update+dot sweeps, plain deferred updates, virtual temporaries dropped, materialised
+    int64_t spec_stats[2] = {0, 0};          // anticipated first-pass sweeps, of which unused
     double *coef_host = nullptr;         // pinned staging for queued coefficients
     hipEvent_t coef_ev = nullptr;        // completion of the last staging copy
     int64_t lazy_stats[4] = {0, 0, 0, 0};  // dot memo hits, batched dot sweeps, queued axpbys, queue flushes
@@ -1182,6 +1196,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         c->lazy = value != 0;
         return LK_OK;
     }
+    if (!strcmp(key, "lazy_speculate")) { c->lazy_speculate = value != 0; c->spec.armed = false; return LK_OK; }
     if (!strcmp(key, "stream_two")) { c->stream_two = value != 0; return LK_OK; }
     if (!strcmp(key, "recompute_update")) { c->recompute_update = value != 0; return LK_OK; }
     if (!strcmp(key, "store_policy")) {
@@ -1256,6 +1271,13 @@ int lk_profile_get(lk_context_t c, const char *tag, int64_t *count, double *tota
 int lk_lazy_fusion_stats(lk_context_t c, int64_t *out4) {
     if (!c || !out4) return fail(LK_ERR_INVALID, "lk_lazy_fusion_stats: null argument");
     for (int i = 0; i < 4; ++i) out4[i] = c->fusion_stats[i];
+    return LK_OK;
+}
+
+int lk_lazy_speculation_stats(lk_context_t c, int64_t *out2) {
+    if (!c || !out2) return fail(LK_ERR_INVALID, "lk_lazy_speculation_stats: null argument");
+    out2[0] = c->spec_stats[0];
+    out2[1] = c->spec_stats[1];
     return LK_OK;
 }
 
@@ -1615,6 +1637,29 @@ int lk_vec_axpby(const double *alpha, lk_basis_t Bx, int jx, const double *beta,
     return LK_OK;
 }
 
+// see lk_context_s::spec.  Returns 1 when the norm of column j was served by an anticipated first-pass sweep (memos filled).
+static int speculative_first_pass(lk_context_t c, lk_basis_t B, int j, int *done) {
+    *done = 0;
+    auto &sp = c->spec;
+    if (!c->lazy || !c->lazy_speculate || !sp.armed || sp.xbase != B->data || j != sp.jy + 1) return LK_OK;
+    if (sp.unused) { sp.armed = false; c->spec_stats[1] += 1; return LK_OK; }      // the last prediction was wasted: stop predicting
+    const int cnt = j - sp.j0;
+    if (cnt < 2 || cnt > KMAX_WIDE || j >= B->ncols || B->hwm <= j || c->queue.active || c->sub.active) return LK_OK;
+    const int ED = B->ed();
+    double *y = B->col(j);
+    LKCHK((sweepm<1>(B, sp.j0, cnt, y, nullptr, nullptr, 0, c->red)));
+    LKCHK(fetch(c, 0, 1, red_stride(cnt)));
+    auto &mm = c->memo;
+    mm.vals.assign(c->red_host, c->red_host + (size_t)cnt * ED);
+    mm.valid = true; mm.xbase = B->data; mm.y = y; mm.j0 = sp.j0; mm.cnt = cnt;
+    c->nmemo.valid = true; c->nmemo.y = y; c->nmemo.nrm2 = c->red_host[(size_t)cnt * ED];
+    sp.jy = j; sp.unused = true;
+    c->spec_stats[0] += 1;
+    c->lazy_stats[1] += 1;
+    *done = 1;
+    return LK_OK;
+}
+
 int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
     LKCHK(check_vec(Bx, jx, "lk_vec_dot(self)"));
     LKCHK(check_vec(By, jy, "lk_vec_dot(vec)"));
@@ -1631,11 +1676,19 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
         const VecRef r1{Bx, jx}, r2{By, jy};
         LKCHK(lazy_enter_vec(c, nullptr, false, &r1, &r2));
     }
+    if (c->lazy && self_dot && !(c->nmemo.valid && c->nmemo.y == By->col(jy))) {
+        int done = 0;
+        LKCHK(speculative_first_pass(c, By, jy, &done));       // the norm that opens a Gram-Schmidt pass: the whole first pass at once
+    }
     if (c->lazy && self_dot && c->nmemo.valid && c->nmemo.y == By->col(jy)) {
         out[0] = c->nmemo.nrm2;
         if (Bx->dtype == LK_C128) out[1] = 0.0;
         c->lazy_stats[0] += 1;
         return LK_OK;
+    }
+    if (c->lazy) {
+        if (self_dot) c->spec.last_norm_y = By->col(jy);       // a plain norm: remember it (the dots that follow may complete the pattern)
+        else if (c->spec.last_norm_y != By->col(jy)) c->spec.last_norm_y = nullptr;
     }
     if (c->lazy && c->xhy_mfma && Bx->data == By->data && Bx->ncols > 1) {
         // gram_matrix's loop: see gmemo
@@ -1682,6 +1735,7 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
         if (mm.valid && mm.xbase == Bx->data && mm.y == yp && jx >= mm.j0 && jx < mm.j0 + mm.cnt) {
             for (int e = 0; e < ED; ++e) out[e] = mm.vals[(size_t)(jx - mm.j0) * ED + e];
             c->lazy_stats[0] += 1;
+            if (c->spec.armed && c->spec.xbase == Bx->data && c->spec.jy == jy) c->spec.unused = false;   // the anticipated sweep was wanted
             return LK_OK;
         }
         // X(:k) vs y = X(k+1) in the same panel; otherwise the run of columns ever written (slab panels are mostly
@@ -1698,6 +1752,11 @@ int lk_vec_dot(lk_basis_t Bx, int jx, lk_basis_t By, int jy, double *out) {
             mm.vals.assign(c->red_host, c->red_host + (size_t)cnt * ED);
             mm.valid = true; mm.xbase = Bx->data; mm.y = yp; mm.j0 = jx; mm.cnt = cnt;
             c->lazy_stats[1] += 1;
+            // norm of column jy, then the dots of ALL columns before it against it: the opening of a Gram-Schmidt pass against
+            // X(:jy) with y = X(jy + 1) of the same panel.  The next step's norm may run this sweep at once (spec).
+            if (By->data == Bx->data && jx < jy && cnt == jy - jx && c->spec.last_norm_y == yp) {
+                c->spec.armed = true; c->spec.xbase = Bx->data; c->spec.jy = jy; c->spec.j0 = jx; c->spec.unused = false;
+            }
             for (int e = 0; e < ED; ++e) out[e] = mm.vals[e];
             return LK_OK;
         }
@@ -1722,11 +1781,16 @@ int lk_vec_norm(lk_basis_t B, int j, double *out) {
         const VecRef r{B, j};
         LKCHK(lazy_enter_vec(c, nullptr, false, &r, nullptr));
     }
+    if (c->lazy && !(c->nmemo.valid && c->nmemo.y == B->col(j))) {
+        int done = 0;
+        LKCHK(speculative_first_pass(c, B, j, &done));
+    }
     if (c->lazy && c->nmemo.valid && c->nmemo.y == B->col(j)) {
         *out = std::sqrt(std::fabs(c->nmemo.nrm2));
         c->lazy_stats[0] += 1;
         return LK_OK;
     }
+    if (c->lazy) c->spec.last_norm_y = B->col(j);
     LKCHK(dot_device(B, j, B, j, c->red));
     LKCHK(fetch(c, 0, 1));
     // alpha = abs(self%dot(self)); alpha = sqrt(alpha)   AbstractVectors.fypp:431

@@ -407,6 +407,8 @@ def test_per_object_arnoldi_in_lazy_mode_beyond_128_columns(ctx):
     fs, ls = c.lazy_fusion_stats(), c.lazy_stats()
     assert fs[0] == 2 * m and fs[1] == 0 and fs[3] == 0       # two fused update + dot sweeps per step, nothing materialised
     assert ls[1] == m - 1                                     # one batched dot sweep per step from the second on (one column is a plain dot)
+    # from the third step on the norm that opens the first pass runs that sweep itself (one kernel + one synchronisation less)
+    assert c.lazy_speculation_stats() == (m - 2, 0)
     X1 = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
     X1[0].rand(True, seed=7)
     H1 = np.zeros((m + 1, m), order="F")
@@ -415,3 +417,42 @@ def test_per_object_arnoldi_in_lazy_mode_beyond_128_columns(ctx):
         assert np.abs(H[:, j] - H1[:, j]).max() <= 1e-12 * np.abs(H1[:, j]).max()
     del B
     c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_anticipated_first_pass_is_result_neutral_and_disarms_when_unused(dtype):
+    """Lazy mode anticipates the first Gram-Schmidt pass of the next Arnoldi step (the norm of column j + 1 runs the dot sweep over
+    the columns before it, once `norm(column j)` followed by those dots has been seen): same H as without the anticipation to 1e-12
+    (the norm comes out of another kernel), and a prediction nobody uses costs one sweep and switches it off."""
+    n, m = 50_003, 24
+    g = np.arange(n) / n
+    d = (1.0 + g).astype(dtype) if np.dtype(dtype).kind == "f" else ((1.0 + g) * np.exp(1j * g)).astype(dtype)
+    out = {}
+    for spec in (1, 0):
+        c = lk.Context(device=0)
+        c.set_tuning("lazy", 1); c.set_tuning("lazy_speculate", spec)
+        A = lk.diag_linop_gpu(d, c)
+
+        class pyop(lk.abstract_linop):
+            def matvec(self, vi, vo): A.matvec(vi, vo)
+        B = lk.krylov_basis_gpu(n, m + 3, dtype, c)
+        B[0].rand(True, seed=7)
+        X = [B[j] for j in range(m + 1)]
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        assert lk.arnoldi(pyop(), X, H) == 0
+        st = c.lazy_speculation_stats()
+        assert st == ((m - 2, 0) if spec else (0, 0))
+        if spec:
+            # break the pattern: the norm of the next column is asked for, its dots are not; the one after that is not anticipated
+            B[m + 1].rand(False, seed=90); B[m + 2].rand(False, seed=91)
+            n1 = B[m + 1].norm()                                   # anticipated (column m + 1 follows column m): m - 1 sweeps so far
+            assert c.lazy_speculation_stats() == (m - 1, 0)
+            n2 = B[m + 2].norm()                                   # the previous prediction went unused: disarmed, plain norm
+            assert c.lazy_speculation_stats() == (m - 1, 1)
+            ref1, ref2 = np.linalg.norm(B.download(m + 1, 1)), np.linalg.norm(B.download(m + 2, 1))
+            assert abs(n1 - ref1) <= 1e-13 * ref1 and abs(n2 - ref2) <= 1e-13 * ref2
+        out[spec] = H
+        del B
+        c.close()
+    for j in range(m):
+        assert np.abs(out[1][:, j] - out[0][:, j]).max() <= 1e-12 * np.abs(out[0][:, j]).max()
