@@ -1644,7 +1644,10 @@ static int speculative_first_pass(lk_context_t c, lk_basis_t B, int j, int *done
     if (!c->lazy || !c->lazy_speculate || !sp.armed || sp.xbase != B->data || j != sp.jy + 1) return LK_OK;
     if (sp.unused) { sp.armed = false; c->spec_stats[1] += 1; return LK_OK; }      // the last prediction was wasted: stop predicting
     const int cnt = j - sp.j0;
-    if (cnt < 2 || cnt > KMAX_WIDE || j >= B->ncols || B->hwm <= j || c->queue.active || c->sub.active) return LK_OK;
+    if (cnt < 2 || cnt > KMAX_WIDE || j >= B->ncols || B->hwm <= j || c->sub.active) return LK_OK;
+    // (a virtual temporary elsewhere -- the previous step's last projection, never asked for -- does not matter; one INSIDE the
+    //  swept columns does: its contents are not in memory)
+    if (c->queue.active && c->queue.By && c->queue.By->data == B->data && c->queue.jy >= sp.j0 && c->queue.jy <= j) return LK_OK;
     const int ED = B->ed();
     double *y = B->col(j);
     LKCHK((sweepm<1>(B, sp.j0, cnt, y, nullptr, nullptr, 0, c->red)));
