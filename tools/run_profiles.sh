@@ -20,6 +20,7 @@ python3 "$R/tools/bench_configs.py" > "$D/configs.log" 2>&1
 python3 "$R/tools/bench_blas1.py" 1e8 2 > "$D/blas1.log" 2>&1
 python3 "$R/tools/bench_per_object_arnoldi.py" 1e7 64 > "$D/per_object_arnoldi.log" 2>&1
 python3 "$R/tools/bench_block.py" 1e7 > "$D/block.log" 2>&1
+gcc -O2 -o /tmp/bench_per_object "$R/tools/bench_per_object.c" -I"$R/include" -L"$R/lightkrylov_amd" -llightkrylov_hip -lm -Wl,-rpath,"$R/lightkrylov_amd" && (/tmp/bench_per_object 10000000 64; /tmp/bench_per_object 1000000 128; /tmp/bench_per_object 100000000 32) > "$D/per_object_c.log" 2>&1
 python3 "$R/tools/bench_wide.py" 1e7 f64 > "$D/wide_f64.log" 2>&1
 python3 "$R/tools/bench_wide.py" 5e6 c128 > "$D/wide_c128.log" 2>&1
 LK_LINCOMB_SCAN=1 python3 "$R/tools/bench_lincomb.py" gemm_mfma_min=100 > "$D/lincomb_scan_valu.log" 2>&1
