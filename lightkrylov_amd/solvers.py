@@ -428,7 +428,7 @@ def eighs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | N
         return np.count_nonzero(res[:k] < tolerance) >= nev                        # :96, :101
 
     can_pipeline = (isinstance(Xwrk, krylov_basis_gpu) and isinstance(A, _engine_linop) and not write_intermediate
-                    and kdim_ <= 128)
+                    and kdim_ <= 512)
     pipelined = can_pipeline and (_hostlapack.threaded() if pipelined is None else bool(pipelined))
     nthreads = max(1, min(32, os.cpu_count() or 1))
     k, k_from, stopped = 0, 1, False
@@ -505,7 +505,7 @@ def svds(A: abstract_linop, U, V, u0: abstract_vector | None = None, kdim: int |
         return np.count_nonzero(res[:k] < tolerance) >= nsv
 
     can_pipeline = (isinstance(Uwrk, krylov_basis_gpu) and isinstance(Vwrk, krylov_basis_gpu) and isinstance(A, _engine_linop)
-                    and not write_intermediate and kdim_ <= 128 and tolerance >= atol_dp)
+                    and not write_intermediate and kdim_ <= 512 and tolerance >= atol_dp)
     pipelined = can_pipeline and (_hostlapack.threaded() if pipelined is None else bool(pipelined))
     nthreads = max(1, min(32, os.cpu_count() or 1))
     k, k_from, stopped = 0, 1, False

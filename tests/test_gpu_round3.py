@@ -456,3 +456,22 @@ def test_anticipated_first_pass_is_result_neutral_and_disarms_when_unused(dtype)
         c.close()
     for j in range(m):
         assert np.abs(out[1][:, j] - out[0][:, j]).max() <= 1e-12 * np.abs(out[0][:, j]).max()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_pipelined_eighs_beyond_128_lanczos_steps(ctx, dtype):
+    """eighs with kdim = 160: the Lanczos steps beyond 128 basis columns run in the asynchronous device segments too (lk_lanczos
+    takes up to 512 columns now), bit-identical to the reference's alternation of one step and one eigh."""
+    n, nev, kdim = 12_007, 3, 160
+    d = np.linspace(1.0, 2.0, n).astype(dtype)                      # a dense spectrum: no Ritz pair converges to 1e-14 in 160 steps
+    x0 = seeded(n, dtype, 9)
+    out = []
+    for pipe in (False, True):
+        X = lk.krylov_basis_gpu(n, nev, dtype, ctx)
+        vals, res, info = lk.eighs(lk.diag_linop_gpu(d, ctx), X, x0=lk.dense_vector_gpu.from_array(x0, ctx), kdim=kdim,
+                                   tolerance=1e-14, pipelined=pipe)
+        out.append((vals, res, info, X.download()))
+    (v0, r0, i0, X0), (v1, r1, i1, X1) = out
+    assert i0 == i1 == kdim
+    assert np.array_equal(v0, v1) and np.array_equal(r0, r1) and np.array_equal(X0, X1)
+    assert (np.diff(v0) <= 0).all() and 1.99 < v0[0] <= 2.0 + 1e-12
