@@ -31,7 +31,7 @@ def _run(cmd, **extra_env):
         # a multi-process rendezvous on a freshly leased box has (once in ~20 runs) stalled before the first collective; the runs
         # themselves take seconds, so a stalled launch is cut off early and repeated once instead of eating the suite's time
         try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600 if attempt == 2 else 240, cwd=ROOT, env=env)
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600 if attempt == 2 else 150, cwd=ROOT, env=env)
             break
         except subprocess.TimeoutExpired as exc:
             if attempt == 2:
