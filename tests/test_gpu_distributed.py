@@ -92,13 +92,14 @@ def test_two_processes_on_the_row_sharded_dense_and_csr_operators(operator, rows
     assert one["roofline"]["matvec"]["launches"] == 12
 
 
-def test_four_processes_sharing_one_gpu_shard_the_metric_workload():
-    """BASELINE configs[4]'s partitioning (row blocks of n / P contiguous rows, reductions all-reduced) with P = 4 real processes
-    on one GPU (gloo standing in for RCCL) at a reduced n: same H as the single process to rounding.  (The full-size 8-process run
-    of the same command is recorded in profiles/r03_cfg5_8rank_one_gpu.jsonl.)"""
-    args = ["--rows", "4000002", "--kdim", "32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+def test_three_processes_sharing_one_gpu_shard_the_metric_workload():
+    """BASELINE configs[4]'s partitioning (row blocks of n / P contiguous rows, the last one ragged, reductions all-reduced) with
+    P = 3 real processes on one GPU (gloo standing in for RCCL) at a reduced n: same H as the single process to rounding.  (The
+    full-size 8-process run of the same command is recorded in profiles/r03_cfg5_8rank_one_gpu.jsonl; more than three ranks beside
+    the test process itself on ONE GPU have stalled at launch inside a long pytest session, never from a shell.)"""
+    args = ["--rows", "3000001", "--kdim", "32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py", "--gpus", "1"] + args)
-    four = _run([sys.executable, "bench.py", "--gpus", "4"] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
-    assert four["n_gpus"] == 4 and four["config"]["n_local"] == 1000000 and four["config"]["info"] == 0
-    assert abs(four["config"]["H_fro"] - one["config"]["H_fro"]) <= 1e-13 * one["config"]["H_fro"]
-    assert abs(four["config"]["H_last_subdiag"] - one["config"]["H_last_subdiag"]) <= 1e-12 * one["config"]["H_last_subdiag"]
+    three = _run([sys.executable, "bench.py", "--gpus", "3"] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
+    assert three["n_gpus"] == 3 and three["config"]["n_local"] == 1000000 and three["config"]["info"] == 0
+    assert abs(three["config"]["H_fro"] - one["config"]["H_fro"]) <= 1e-13 * one["config"]["H_fro"]
+    assert abs(three["config"]["H_last_subdiag"] - one["config"]["H_last_subdiag"]) <= 1e-12 * one["config"]["H_last_subdiag"]
