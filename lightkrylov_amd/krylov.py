@@ -315,17 +315,29 @@ def _ordschur(T: np.ndarray, Q: np.ndarray, selected: np.ndarray):
     return out[0], out[1]
 
 
-@_hostlapack.small_problems
-def krylov_schur(X, H: np.ndarray, select_eigs) -> int:
-    """Krylov-Schur restart: re-order the Schur form of H and compress the basis.
-    src/Krylov/BaseKrylov.fypp:782-834.  Returns n, the number of selected eigenvalues."""
-    kdim = len(X) - 1
+def krylov_schur_host_part(H: np.ndarray, kdim: int, select_eigs):
+    """The small-matrix half of krylov_schur (gees, the selector, trsen: BaseKrylov.fypp:807-813) as a pure function of H:
+    returns (T, Tk, Z, n).  eigs runs it on a spare host thread as soon as the device has delivered the last column of H, beside
+    the per-step Ritz tests still in flight, and hands the result to krylov_schur -- same LAPACK calls on the same data."""
     m = H.shape[1]
     T, Z, eigvals = _schur(H[:m, :])                                                # :807
-    H[:m, :] = T
+    Hc = np.array(H, order="F", copy=True)                                          # what H holds after `H(:m, :) = T`
+    Hc[:m, :] = T
     selected = np.asarray(select_eigs(eigvals), dtype=bool)                         # :810
     n = int(np.count_nonzero(selected))
-    Tk, Z = _ordschur(H[:kdim, :], Z, selected)                                     # :813
+    Tk, Z = _ordschur(Hc[:kdim, :], Z, selected)                                    # :813
+    return T, Tk, Z, n
+
+
+@_hostlapack.small_problems
+def krylov_schur(X, H: np.ndarray, select_eigs, _host_part=None) -> int:
+    """Krylov-Schur restart: re-order the Schur form of H and compress the basis.
+    src/Krylov/BaseKrylov.fypp:782-834.  Returns n, the number of selected eigenvalues.
+    (`_host_part`: the result of krylov_schur_host_part on THIS H, computed ahead by the caller.)"""
+    kdim = len(X) - 1
+    m = H.shape[1]
+    T, Tk, Z, n = _host_part if _host_part is not None else krylov_schur_host_part(H, kdim, select_eigs)
+    H[:m, :] = T
     H[:kdim, :] = Tk
     # basis update (:816-824): Xwrk = X(:m) Z(:, :n); X(:n) = Xwrk; X(n+1) = X(kdim+1); X(n+2:) = 0
     if n > 0:

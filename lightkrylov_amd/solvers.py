@@ -17,6 +17,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 from . import _hostlapack
 from .constants import atol_dp, rtol_dp
+from .krylov import krylov_schur_host_part  # noqa: E402,F401  (re-exported for the pipelined eigs cycle)
 from .krylov import _engine_linop, arnoldi, bidiagonalization, double_gram_schmidt_step, krylov_schur, lanczos
 from .linops import abstract_linop
 from .outputs import eigs_output, write_results
@@ -277,6 +278,7 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
             break
         restarts += 1
         k_from, stopped = kstart, False
+        schur_ahead = None
         if pipelined and kstart <= kdim_:
             # segments of _EIGS_SEGMENT steps: while the device runs segment s + 1 (one asynchronous lk_arnoldi call on a helper thread;
             # ctypes drops the interpreter lock for its duration) the host tests the steps of segment s
@@ -292,6 +294,11 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                     kdone = klast
                     if ainfo == 0 and si + 1 < len(bounds):
                         fut = device.submit(arnoldi, A, Xwrk, H, bounds[si + 1][0], bounds[si + 1][1], atol_dp, transpose)
+                    elif ainfo == 0 and klast == kdim_:
+                        # H is complete: unless one of the Ritz tests still to come stops the cycle early, the restart below factors
+                        # exactly this H -- start its small-matrix half (gees, selector, trsen) now, on a spare host thread, beside
+                        # the last segment's tests (same LAPACK calls on the same data; discarded on an early stop)
+                        schur_ahead = pool.submit(krylov_schur_host_part, H.copy(order="F"), kdim_, median_selector)
                     for c0 in range(a, klast + 1, nthreads):
                         ks = range(c0, min(c0 + nthreads, klast + 1))
                         for k, (_vals, r) in zip(ks, pool.map(ritz_test, ks)):
@@ -308,6 +315,8 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                 if fut is not None:                                                # a segment still in flight when the loop stopped
                     ainfo = fut.result()
                     kdone = ainfo if ainfo > 0 else bounds[si + 1][1]
+                if schur_ahead is not None:                                        # (collected while the BLAS libraries' own threading is still off)
+                    schur_ahead = schur_ahead.result()
             if stopped and k < kdone:
                 # put the work arrays into the state the reference is in when it leaves the loop at step k (:1093):
                 # krylov_schur below acts on ALL of H and Xwrk
@@ -325,7 +334,8 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                     write_results(eigs_output, vals[:k], res[:k], tolerance)       # :1091 (sorts res(:k) in place)
                 if conv >= nev:
                     break
-        kstart = krylov_schur(Xwrk, H, median_selector) + 1                        # :1100
+        host_part = schur_ahead if (schur_ahead is not None and not stopped) else None   # (an early stop changed H: factor that one)
+        kstart = krylov_schur(Xwrk, H, median_selector, _host_part=host_part) + 1  # :1100
     k = min(k, kdim_)
     vecs, vals = eig(H[:k, :k])                                                    # :1115
     vals_f = np.zeros(kdim_, dtype=np.complex128)
