@@ -155,6 +155,47 @@ def geev(Hk: np.ndarray):
     return vr, vals
 
 
+def gees(Hm: np.ndarray):
+    """(T, Z, w) = Schur form, Schur vectors and eigenvalues of Hm by LAPACK gees without sorting (jobvs = 'V', sort = 'N') --
+    what stdlib's `schur` (BaseKrylov.fypp:807) calls -- with scipy's default workspace size (lwork = 3 n: same code path, same
+    rounding as scipy.linalg.lapack.{d,z}gees, tests/test_host_logic.py), through ctypes so that the interpreter lock is released
+    for the duration of the call: eigs runs the restart's Schur factorisation beside the last Ritz tests of a cycle."""
+    lib = _load()
+    k = Hm.shape[0]
+    if lib is None or k == 0 or not (hasattr(lib, "scipy_dgees_") and hasattr(lib, "scipy_zgees_")):
+        if Hm.dtype == np.float64:
+            T, _sdim, wr, wi, Z, _work, info = _lapack.dgees(lambda *a: False, np.asfortranarray(Hm), sort_t=0)
+            w = wr + 1j * wi
+        else:
+            T, _sdim, w, Z, _work, info = _lapack.zgees(lambda *a: False, np.asfortranarray(Hm), sort_t=0)
+        if info != 0:
+            raise RuntimeError(f"GEES failed, info={info}")
+        return T, Z, w
+    cplx = Hm.dtype == np.complex128
+    a = np.array(Hm, dtype=Hm.dtype, order="F", copy=True)          # overwritten by T
+    vs = np.empty((k, k), dtype=Hm.dtype, order="F")
+    n, lda, ldvs, sdim, info = C.c_int(k), C.c_int(k), C.c_int(k), C.c_int(0), C.c_int(0)
+    jobvs, sort = C.c_char(b"V"), C.c_char(b"N")
+    one = C.c_size_t(1)
+    lw = C.c_int(max(3 * k, 1))
+    work = np.empty(lw.value, dtype=Hm.dtype)
+    bwork = np.empty(max(k, 1), dtype=np.int32)
+    nosel = C.c_void_p(None)                                        # SELECT is not referenced when SORT = 'N'
+    if cplx:
+        w = np.empty(k, dtype=np.complex128)
+        rwork = np.empty(max(k, 1), dtype=np.float64)
+        lib.scipy_zgees_(C.byref(jobvs), C.byref(sort), nosel, C.byref(n), _p(a), C.byref(lda), C.byref(sdim), _p(w), _p(vs), C.byref(ldvs),
+                         _p(work), C.byref(lw), _p(rwork), _p(bwork), C.byref(info), one, one)
+    else:
+        wr, wi = np.empty(k), np.empty(k)
+        lib.scipy_dgees_(C.byref(jobvs), C.byref(sort), nosel, C.byref(n), _p(a), C.byref(lda), C.byref(sdim), _p(wr), _p(wi), _p(vs),
+                         C.byref(ldvs), _p(work), C.byref(lw), _p(bwork), C.byref(info), one, one)
+        w = wr + 1j * wi
+    if info.value != 0:
+        raise RuntimeError(f"GEES failed, info={info.value}")
+    return a, vs, w
+
+
 def syev(Tk: np.ndarray):
     """(w, v) = eigenvalues (ascending) and orthonormal eigenvectors of the symmetric / Hermitian matrix whose UPPER triangle is
     Tk's -- LAPACK syev / heev with a workspace query, i.e. what stdlib's `eigh(a, lambda, vectors)` (the routine `eighs` calls,

@@ -295,7 +295,10 @@ def bidiagonalization(A: abstract_linop, U, V, B: np.ndarray, kstart: int = 1, k
 
 # ------------------------------------------------------------------------------------------
 def _schur(Hm: np.ndarray):
-    """stdlib `schur` = LAPACK gees without sorting (BaseKrylov.fypp:807)."""
+    """stdlib `schur` = LAPACK gees without sorting (BaseKrylov.fypp:807).  Through ctypes when the library is reachable
+    (bit-identical to scipy's wrapper, and the interpreter lock is free meanwhile: _hostlapack.gees)."""
+    if _hostlapack.threaded():
+        return _hostlapack.gees(Hm)
     if Hm.dtype == np.float64:
         T, _sdim, wr, wi, Z, _work, info = _lapack.dgees(lambda *a: False, np.asfortranarray(Hm), sort_t=0)
         w = wr + 1j * wi

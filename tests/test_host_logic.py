@@ -348,6 +348,31 @@ def test_threadable_geev_is_bit_identical_to_scipys_wrapper():
         assert all(pool.map(check, list(range(1, 41)) * 3))
 
 
+def test_threadable_gees_is_bit_identical_to_scipys_wrapper():
+    """_hostlapack.gees = LAPACK gees (jobvs 'V', sort 'N', scipy's default lwork = 3 n) through ctypes: the bits of
+    scipy.linalg.lapack.{d,z}gees -- T, Z and the eigenvalues -- from one thread or from eight at once.  eigs starts the restart's Schur
+    factorisation with it beside the last Ritz tests of a cycle (the scipy wrapper takes a python callback and holds the interpreter
+    lock for the whole call)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from scipy.linalg import lapack
+    from lightkrylov_amd import _hostlapack as hl
+    rng = np.random.default_rng(6)
+    Hr = np.asfortranarray(np.triu(rng.standard_normal((40, 40)), -1))
+    Hz = np.asfortranarray(np.triu(rng.standard_normal((40, 40)) + 1j * rng.standard_normal((40, 40)), -1))
+
+    def check(k):
+        T, Z, w = hl.gees(Hz[:k, :k])
+        T0, _s, w0, Z0, _wk, info = lapack.zgees(lambda *a: False, np.asfortranarray(Hz[:k, :k]), sort_t=0)
+        ok = info == 0 and np.array_equal(T, T0) and np.array_equal(Z, Z0) and np.array_equal(w, w0)
+        T, Z, w = hl.gees(Hr[:k, :k])
+        T0, _s, wr, wi, Z0, _wk, info = lapack.dgees(lambda *a: False, np.asfortranarray(Hr[:k, :k]), sort_t=0)
+        return ok and info == 0 and np.array_equal(T, T0) and np.array_equal(Z, Z0) and np.array_equal(w, wr + 1j * wi)
+
+    assert all(check(k) for k in range(1, 41))
+    with hl.blas_threads(1), ThreadPoolExecutor(8) as pool:
+        assert all(pool.map(check, list(range(1, 41)) * 2))
+
+
 def test_oracle_cg_eighs_svds_known_answers():
     """The oracle's restatements of the three thin solver loops against numpy: cg solves an SPD system, eighs finds the
     leading eigenvalues, svds the leading singular values (the reference's own tests check the same invariants:
