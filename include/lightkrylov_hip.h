@@ -278,8 +278,11 @@ int lk_orthogonalize(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, int
 int lk_dgs(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, double *norms, int flags,
            int *info);
 /* basis-against-basis variant (gram_schmidt.fypp:59-105): Y(jy0:jy0+p) against X(:k),
- * h is k x p column-major.  Panel x panel schedule for k <= 128: per group of up to 4 columns of Y, one multi-right-hand-
- * side dot sweep + one MFMA update, twice (4 passes over X per group). */
+ * h is k x p column-major.  Panel x panel schedules for k <= 128 -- p <= 4: the fused sweeps with several right-hand sides
+ * (three passes over X per group of <= 2 columns, or of 4 columns of the real kind for k <= 64; else four);  p >= 5: the
+ * coefficients and updates on the FP64 matrix cores, per group of <= 32 columns H1 = X^H Y | Y' = Y - X H1 with H2 = X^H Y' in the
+ * same pass | Y'' = Y' - X H2: THREE passes over X (real kind; the complex kind keeps four: H1 | update | H2 | update).
+ * Wider bases: column by column through lk_dgs. */
 int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h, int *info);
 
 /* ---- operators (stand where a user's abstract_linop matvec/rmatvec stands,
