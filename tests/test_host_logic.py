@@ -2,6 +2,8 @@
 double_gram_schmidt_step / qr / arnoldi / lanczos / gmres / eigs / krylov_schur, driven with the
 test-only oracle-backed vector type, must reproduce the oracle's own restatement of the reference
 drivers (same arithmetic underneath, so agreement is to rounding of the host LAPACK calls)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -396,3 +398,38 @@ def test_oracle_cg_eighs_svds_known_answers():
     S, r, U, V, k = ora.svds(ora.DenseOp(G), ora.DenseOp(np.asfortranarray(G.T)), b.copy(), 3, kdim=40, tolerance=1e-10)
     assert np.abs(S - np.linalg.svd(G, compute_uv=False)[:3]).max() <= 1e-9
     assert np.abs(G @ V - U * S).max() <= 1e-8
+
+
+def test_bench_helpers_csr_rows_self_launch_and_traffic_record(monkeypatch):
+    """bench.py's host-side pieces: the rows of the 5-point Laplacian it hands to the row-sharded CSR operator equal scipy's
+    matrix; `--gpus N` without a launcher's environment composes a torch.distributed.run child (loopback rendezvous, NCCL_ALGO
+    pinned); and the committed PMC traffic record describes THIS build's kernel sources (bench.py refuses any other)."""
+    import json
+    import subprocess
+    import sys
+    import scipy.sparse as sp
+    import bench
+    N = 9
+    T = sp.diags([-1.0, 4.0, -1.0], [-1, 0, 1], shape=(N, N))
+    L = ((sp.kron(sp.identity(N), T) + sp.kron(sp.diags([-1.0, -1.0], [-1, 1], shape=(N, N)), sp.identity(N))) * float((N + 1) ** 2)).tocsr()
+    for row0, nl in ((0, N * N), (18, 27), (72, 9)):
+        rp, ci, v = bench._laplacian_csr_rows(N, row0, nl)
+        assert rp[0] == 0 and ci.dtype == np.int32 and (np.diff(ci[rp[0]:rp[1]]) > 0).all()
+        assert abs(sp.csr_matrix((v, ci, rp), shape=(nl, N * N)) - L[row0:row0 + nl]).max() == 0.0
+    seen = {}
+
+    def fake_run(cmd, env=None, cwd=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return subprocess.CompletedProcess(cmd, 7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    monkeypatch.delenv("NCCL_ALGO", raising=False)
+    assert bench._self_launch(4) == 7                                   # the child's exit code is relayed
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert seen["env"]["NCCL_ALGO"] == "Ring" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")))
+    assert rec["kernel_source_sha256"] == bench.kernel_source_hash(), (
+        "profiles/pmc_traffic.json was measured on other kernel sources: re-run tools/run_profiles.sh + tools/make_profiles.py")
+    assert 0.98 <= rec["traffic_over_algorithmic"] <= 1.02
