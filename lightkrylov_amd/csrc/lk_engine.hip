@@ -5,6 +5,8 @@
 #include <hip/hip_ext.h>
 #include <type_traits>
 
+#include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -238,6 +240,14 @@ struct lk_linop_s {
     double *xfull = nullptr;              // the gathered input vector / the full-length adjoint product (ncols_g elements)
     double *gpart = nullptr;              // k_gemv_n's per-chunk partial sums
     int gchunks = 1;
+    // row-sharded CSR, COMPRESSED exchange: only the entries of x that some other rank's rows reference travel.  cx_send_idx =
+    // local indices of this rank's entries anybody needs (sorted); every rank's packed entries are all-gathered into cx_xrem
+    // (rank r's at cx_displs[r]); the column indices of csr[0] address [own rows | cx_xrem].
+    bool cx = false;
+    int32_t *cx_send_idx = nullptr;
+    int64_t cx_nsend = 0, cx_total = 0;
+    double *cx_sendbuf = nullptr, *cx_xrem = nullptr;
+    std::vector<int64_t> cx_counts, cx_displs;   // in DOUBLES, per rank
     int64_t row0 = 0;
     double d0 = 0, dstep = 0;
     int64_t N = 0;
@@ -2391,6 +2401,102 @@ static int csr_upload(lk_linop_t o, int which, int64_t n, const int64_t *rowptr,
     return LK_OK;
 }
 
+// creation-time metadata exchange through the data-path hook: every rank contributes `mine` (counts[rank] doubles), all receive all
+static int host_allgatherv(lk_context_t c, const std::vector<double> &mine, const std::vector<int64_t> &counts, std::vector<double> &all) {
+    std::vector<int64_t> displs(c->nranks, 0);
+    int64_t total = 0;
+    for (int r = 0; r < c->nranks; ++r) { displs[r] = total; total += counts[r]; }
+    all.assign((size_t)total, 0.0);
+    if (total == 0) return LK_OK;
+    if (!c->allgather) return fail(LK_ERR_COMM, "row-sharded CSR operator but no all-gather installed (lk_comm_init_rank / lk_set_allgather)");
+    double *ds = nullptr, *dr = nullptr;
+    HIPCHK(hipMalloc((void **)&ds, (size_t)(mine.size() > 0 ? mine.size() : 1) * sizeof(double)));
+    hipError_t e = hipMalloc((void **)&dr, (size_t)total * sizeof(double));
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)hipFree(ds); return fail(LK_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e)); }
+    int rc = LK_OK;
+    if (!mine.empty() && hipMemcpyAsync(ds, mine.data(), mine.size() * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = fail(LK_ERR_HIP, "metadata upload failed");
+    if (rc == LK_OK && c->allgather(c->allgather_user, ds, dr, counts.data(), displs.data(), c->nranks, (void *)c->stream) != 0)
+        rc = fail(LK_ERR_COMM, "all-gather callback failed (metadata)");
+    if (rc == LK_OK && hipMemcpyAsync(all.data(), dr, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(LK_ERR_HIP, "metadata download failed");
+    if (rc == LK_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(LK_ERR_HIP, "stream synchronisation failed");
+    (void)hipFree(ds); (void)hipFree(dr);
+    return rc;
+}
+
+// Decide and set up the compressed exchange of a row-sharded CSR operator (COLLECTIVE: every rank calls it at creation).  On
+// return `cols` holds the column indices csr[0] is uploaded with: remapped to [own rows | packed remote entries] when o->cx, the
+// global ones otherwise.  The exchange is compressed when what travels is less than half of x (stencils, banded matrices: a few
+// boundary entries per neighbour); matrices whose rows reach everywhere keep the plain all-gather of x.
+static int csr_compress_setup(lk_linop_t o, lk_context_t c, const int64_t *row_starts, int64_t n, const int64_t *rowptr, const int32_t *colind,
+                              std::vector<int32_t> &cols) {
+    const int P = c->nranks, me = c->rank;
+    const int ED = o->dtype == LK_C128 ? 2 : 1;
+    const int64_t nnz = rowptr[n], row0 = row_starts[me], n_global = row_starts[P];
+    cols.assign(colind, colind + nnz);
+    if (P == 1) return LK_OK;
+    auto owner = [&](int64_t j) {                        // rank whose block holds global row j
+        int lo = 0, hi = P - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (row_starts[mid] <= j) lo = mid; else hi = mid - 1; }
+        while (lo + 1 < P && row_starts[lo + 1] <= j) ++lo;      // empty blocks share a start
+        return lo;
+    };
+    // what I need from whom
+    std::vector<std::vector<int64_t>> need(P);
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t j = colind[p];
+        if (j < row0 || j >= row0 + n) need[owner(j)].push_back(j);
+    }
+    for (auto &v : need) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+    // everybody learns everybody's requests: first the P x P table of list lengths, then the lists
+    std::vector<double> mycnt(P), allcnt;
+    for (int r = 0; r < P; ++r) mycnt[r] = (double)need[r].size();
+    LKCHK(host_allgatherv(c, mycnt, std::vector<int64_t>(P, P), allcnt));
+    std::vector<int64_t> listlen(P, 0);
+    for (int q = 0; q < P; ++q) for (int r = 0; r < P; ++r) listlen[q] += (int64_t)allcnt[(size_t)q * P + r];
+    std::vector<double> mylist, alllist;
+    for (int r = 0; r < P; ++r) for (int64_t j : need[r]) mylist.push_back((double)j);
+    LKCHK(host_allgatherv(c, mylist, listlen, alllist));
+    // S_r = what anybody needs of rank r's block (sorted, unique): the packed buffer rank r contributes per matvec
+    std::vector<std::vector<int64_t>> S(P);
+    {
+        size_t pos = 0;
+        for (int q = 0; q < P; ++q)
+            for (int r = 0; r < P; ++r) {
+                const int64_t cnt = (int64_t)allcnt[(size_t)q * P + r];
+                for (int64_t i = 0; i < cnt; ++i) S[r].push_back((int64_t)alllist[pos + (size_t)i]);
+                pos += (size_t)cnt;
+            }
+        for (auto &v : S) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+    }
+    int64_t total = 0;
+    for (int r = 0; r < P; ++r) total += (int64_t)S[r].size();
+    int64_t maxn = 0;
+    for (int r = 0; r < P; ++r) maxn = std::max(maxn, row_starts[r + 1] - row_starts[r]);
+    // nearly all of x travels anyway, or the remapped indices would not fit: plain all-gather.  Decided from quantities every rank
+    // holds identically (a rank that chose differently would issue a different collective)
+    if (2 * total >= n_global || maxn + total > 2147483647LL) return LK_OK;
+    o->cx = true;
+    o->cx_total = total;
+    o->cx_counts.resize(P); o->cx_displs.resize(P);
+    std::vector<int64_t> off(P, 0);
+    { int64_t a = 0; for (int r = 0; r < P; ++r) { off[r] = a; o->cx_counts[r] = (int64_t)S[r].size() * ED; o->cx_displs[r] = a * ED; a += (int64_t)S[r].size(); } }
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t j = colind[p];
+        if (j >= row0 && j < row0 + n) { cols[(size_t)p] = (int32_t)(j - row0); continue; }
+        const int r = owner(j);
+        const int64_t k = std::lower_bound(S[r].begin(), S[r].end(), j) - S[r].begin();
+        cols[(size_t)p] = (int32_t)(n + off[r] + k);
+    }
+    o->cx_nsend = (int64_t)S[me].size();
+    std::vector<int32_t> sidx((size_t)(o->cx_nsend > 0 ? o->cx_nsend : 1), 0);
+    for (int64_t i = 0; i < o->cx_nsend; ++i) sidx[(size_t)i] = (int32_t)(S[me][(size_t)i] - row0);
+    HIPCHK(hipMalloc((void **)&o->cx_send_idx, sidx.size() * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(o->cx_send_idx, sidx.data(), sidx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&o->cx_sendbuf, (size_t)(o->cx_nsend > 0 ? o->cx_nsend : 1) * ED * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&o->cx_xrem, (size_t)(total > 0 ? total : 1) * ED * sizeof(double)));
+    return LK_OK;
+}
+
 int lk_linop_csr_create_sharded(lk_context_t c, int dtype, int64_t n_global, const int64_t *row_starts, const int64_t *rowptr,
                                 const int32_t *colind, const void *vals, lk_linop_t *op) {
     if (!c || !rowptr || !op || !row_starts) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null argument");
@@ -2427,7 +2533,9 @@ int lk_linop_csr_create_sharded(lk_context_t c, int dtype, int64_t n_global, con
     lk_linop_t o = new lk_linop_s();
     o->ctx = c; o->kind = OP_CSR; o->dtype = dtype;
     int rc = shard_setup(o, c, n_global, row_starts, "lk_linop_csr_create");
-    if (rc == LK_OK) rc = csr_upload(o, 0, n, rowptr, colind, v, ED);
+    std::vector<int32_t> cols0;
+    if (rc == LK_OK) rc = csr_compress_setup(o, c, row_starts, n, rowptr, colind, cols0);
+    if (rc == LK_OK) rc = csr_upload(o, 0, n, rowptr, cols0.data(), v, ED);
     if (rc == LK_OK) rc = csr_upload(o, 1, n_global, tp.data(), tc.data(), tv.data(), ED);
     if (rc != LK_OK) { (void)lk_linop_destroy(o); return rc; }
     *op = o;
@@ -2453,6 +2561,9 @@ int lk_linop_destroy(lk_linop_t op) {
     if (op->kind == OP_LAP5 && op->halo) (void)hipFree(op->halo);
     if (op->wk) (void)hipFree(op->wk);
     if (op->xfull) (void)hipFree(op->xfull);
+    if (op->cx_send_idx) (void)hipFree(op->cx_send_idx);
+    if (op->cx_sendbuf) (void)hipFree(op->cx_sendbuf);
+    if (op->cx_xrem) (void)hipFree(op->cx_xrem);
     if (op->gpart) (void)hipFree(op->gpart);
     if (op->dev && op->own_dev) (void)hipFree(op->dev);  // synchronises; the context may already be finalized
     delete op;
@@ -2531,7 +2642,23 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
         const int64_t nr = trans == LK_OP_N ? n : op->ncols_g;          // rows of the product computed here
         const double *xin = x;
         double *yout = y;
-        if (shard && trans == LK_OP_N) LKCHK(gather_x(op, x, &xin));
+        const double *xrem = nullptr;
+        int64_t nloc = INT64_MAX;                                        // column indices below nloc address `xin`, the others `xrem`
+        if (shard && trans == LK_OP_N && op->cx) {
+            // compressed exchange: pack what other ranks' rows reference, all-gather the packed pieces, multiply [own rows | pieces]
+            if (!c->allgather) return fail(LK_ERR_COMM, "row-sharded CSR operator but no all-gather installed (lk_comm_init_rank / lk_set_allgather)");
+            if (op->cx_nsend > 0) {
+                if (cp) hipLaunchKernelGGL(k_pack<true>, dim3(blas1_grid(c, op->cx_nsend)), dim3(256), 0, c->stream, x, op->cx_send_idx, op->cx_nsend, op->cx_sendbuf, c->guard());
+                else hipLaunchKernelGGL(k_pack<false>, dim3(blas1_grid(c, op->cx_nsend)), dim3(256), 0, c->stream, x, op->cx_send_idx, op->cx_nsend, op->cx_sendbuf, c->guard());
+                HIPCHK(hipGetLastError());
+            }
+            if (c->allgather(c->allgather_user, op->cx_sendbuf, op->cx_xrem, op->cx_counts.data(), op->cx_displs.data(), c->nranks, (void *)c->stream) != 0)
+                return fail(LK_ERR_COMM, "all-gather callback failed");
+            xrem = op->cx_xrem;
+            nloc = n;
+        } else if (shard && trans == LK_OP_N) {
+            LKCHK(gather_x(op, x, &xin));
+        }
         if (shard && trans != LK_OP_N) yout = op->xfull;
         bool launched = false;
         if (c->csr_stream && nr > 0 && (double)m.nnz_hint / (double)nr <= 32.0 && !c->csr_lanes) {
@@ -2540,8 +2667,8 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
             const int64_t cap = (int64_t)c->num_cu * 16;
             if (g > cap) g = cap;
             if (g < 1) g = 1;
-            if (cp) hipLaunchKernelGGL(k_csr_stream<true>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, xin, yout, m.nblocks, c->guard());
-            else hipLaunchKernelGGL(k_csr_stream<false>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, xin, yout, m.nblocks, c->guard());
+            if (cp) hipLaunchKernelGGL(k_csr_stream<true>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, xin, yout, m.nblocks, c->guard(), xrem, nloc);
+            else hipLaunchKernelGGL(k_csr_stream<false>, dim3((unsigned)g), dim3(256), 0, c->stream, m.rowblocks, m.rowptr, m.colind, m.vals, xin, yout, m.nblocks, c->guard(), xrem, nloc);
             launched = true;
         }
         if (!launched) {
@@ -2553,8 +2680,8 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
             if (g < 1) g = 1;
 #define LK_CSR_LAUNCH(WW)                                                                                                  \
     case WW:                                                                                                               \
-        if (cp) hipLaunchKernelGGL((k_csr<true, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, xin, yout, nr, c->guard()); \
-        else hipLaunchKernelGGL((k_csr<false, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, xin, yout, nr, c->guard());   \
+        if (cp) hipLaunchKernelGGL((k_csr<true, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, xin, yout, nr, c->guard(), xrem, nloc); \
+        else hipLaunchKernelGGL((k_csr<false, WW>), dim3((unsigned)g), dim3(256), 0, c->stream, m.rowptr, m.colind, m.vals, xin, yout, nr, c->guard(), xrem, nloc);   \
         break;
             switch (m.W) {
                 LK_CSR_LAUNCH(1) LK_CSR_LAUNCH(2) LK_CSR_LAUNCH(4) LK_CSR_LAUNCH(8) LK_CSR_LAUNCH(16) LK_CSR_LAUNCH(32) LK_CSR_LAUNCH(64)

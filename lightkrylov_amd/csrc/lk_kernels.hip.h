@@ -1743,10 +1743,19 @@ __global__ __launch_bounds__(256) void k_diag_linspace(double d0, double dstep, 
 // y = A x, A in CSR (0-based, int64 row pointers, int32 column indices).  W lanes per row (W = the power of two next to
 // the mean row length, 2..64): lane l of a row's group sums entries l, l + W, ... in index order, the W partial sums meet
 // in a fixed xor tree (deterministic).  Consecutive groups read consecutive rows, so short rows still coalesce.
+// x in two pieces (row-sharded operator with a COMPRESSED exchange): column indices below `nloc` address this rank's own rows in
+// `x`, the others the packed entries received from the other ranks in `xrem`; a whole x is (x, anything, nloc = INT64_MAX).
+template <bool CPLX>
+__device__ __forceinline__ const double *csr_x(const double *__restrict__ x, const double *__restrict__ xrem, int64_t nloc, int64_t j) {
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    return j < nloc ? x + j * ED : xrem + (j - nloc) * ED;
+}
+
 template <bool CPLX, int W>
 __global__ __launch_bounds__(256) void k_csr(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
                                              const double *__restrict__ vals, const double *__restrict__ x,
-                                             double *__restrict__ y, int64_t n, Guard guard) {
+                                             double *__restrict__ y, int64_t n, Guard guard,
+                                             const double *__restrict__ xrem, int64_t nloc) {
     if (stopped(guard)) return;
     const int sub = threadIdx.x % W;
     const int64_t groups = (int64_t)gridDim.x * (256 / W);
@@ -1755,13 +1764,14 @@ __global__ __launch_bounds__(256) void k_csr(const int64_t *__restrict__ rowptr,
         const int64_t p1 = rowptr[r + 1];
         for (int64_t p = rowptr[r] + sub; p < p1; p += W) {
             const int64_t j = colind[p];
+            const double *xp = csr_x<CPLX>(x, xrem, nloc, j);
             if constexpr (CPLX) {
                 const v2d a = *reinterpret_cast<const v2d *>(vals + 2 * p);
-                const v2d b = *reinterpret_cast<const v2d *>(x + 2 * j);
+                const v2d b = *reinterpret_cast<const v2d *>(xp);
                 sr += a.x * b.x - a.y * b.y;
                 si += a.x * b.y + a.y * b.x;
             } else {
-                sr += vals[p] * x[j];
+                sr += vals[p] * xp[0];
             }
         }
 #pragma unroll
@@ -1784,7 +1794,8 @@ constexpr int CSR_NNZ = 2048;
 template <bool CPLX>
 __global__ __launch_bounds__(256) void k_csr_stream(const int64_t *__restrict__ rowblocks, const int64_t *__restrict__ rowptr,
                                                     const int32_t *__restrict__ colind, const double *__restrict__ vals,
-                                                    const double *__restrict__ x, double *__restrict__ y, int64_t nblocks, Guard guard) {
+                                                    const double *__restrict__ x, double *__restrict__ y, int64_t nblocks, Guard guard,
+                                                    const double *__restrict__ xrem, int64_t nloc) {
     if (stopped(guard)) return;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     __shared__ double prod[CSR_NNZ * ED];
@@ -1797,12 +1808,13 @@ __global__ __launch_bounds__(256) void k_csr_stream(const int64_t *__restrict__ 
             double sr = 0.0, si = 0.0;
             for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
                 const int64_t j = colind[p];
+                const double *xp = csr_x<CPLX>(x, xrem, nloc, j);
                 if constexpr (CPLX) {
-                    const v2d a = *reinterpret_cast<const v2d *>(vals + 2 * p), c = *reinterpret_cast<const v2d *>(x + 2 * j);
+                    const v2d a = *reinterpret_cast<const v2d *>(vals + 2 * p), c = *reinterpret_cast<const v2d *>(xp);
                     sr += a.x * c.x - a.y * c.y;
                     si += a.x * c.y + a.y * c.x;
                 } else {
-                    sr += vals[p] * x[j];
+                    sr += vals[p] * xp[0];
                 }
             }
             sr = wave_sum(sr);
@@ -1820,12 +1832,13 @@ __global__ __launch_bounds__(256) void k_csr_stream(const int64_t *__restrict__ 
         __syncthreads();                                        // the previous block's segments have been read
         for (int64_t i = threadIdx.x; i < nnzb; i += 256) {
             const int64_t p = p0 + i, j = colind[p];
+            const double *xp = csr_x<CPLX>(x, xrem, nloc, j);
             if constexpr (CPLX) {
-                const v2d a = *reinterpret_cast<const v2d *>(vals + 2 * p), c = *reinterpret_cast<const v2d *>(x + 2 * j);
+                const v2d a = *reinterpret_cast<const v2d *>(vals + 2 * p), c = *reinterpret_cast<const v2d *>(xp);
                 prod[2 * i] = a.x * c.x - a.y * c.y;
                 prod[2 * i + 1] = a.x * c.y + a.y * c.x;
             } else {
-                prod[i] = vals[p] * x[j];
+                prod[i] = vals[p] * xp[0];
             }
         }
         __syncthreads();
@@ -1949,6 +1962,18 @@ __global__ __launch_bounds__(256) void k_gemv_h(const double *__restrict__ A, in
 __global__ __launch_bounds__(256) void k_copy_guarded(const double *__restrict__ z, double *__restrict__ y, int64_t nd, Guard guard) {
     if (stopped(guard)) return;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += (int64_t)gridDim.x * blockDim.x) y[i] = z[i];
+}
+
+// out[i] = x[idx[i]] (ED doubles each): the entries of this rank's block that other ranks' rows reference, packed for the
+// compressed exchange of the row-sharded CSR operator
+template <bool CPLX>
+__global__ __launch_bounds__(256) void k_pack(const double *__restrict__ x, const int32_t *__restrict__ idx, int64_t cnt,
+                                              double *__restrict__ out, Guard guard) {
+    if (stopped(guard)) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += (int64_t)gridDim.x * blockDim.x) {
+        if constexpr (CPLX) reinterpret_cast<v2d *>(out)[i] = reinterpret_cast<const v2d *>(x)[idx[i]];
+        else out[i] = x[idx[i]];
+    }
 }
 
 // 5-point Laplacian, N x N grid, Dirichlet, scale s = (N+1)^2.  One thread per 2 grid points
