@@ -317,8 +317,12 @@ int lk_linop_dense_wrap_sharded(lk_context_t ctx, int dtype, int64_t n_global, c
 int lk_linop_csr_create(lk_context_t ctx, int dtype, int64_t n, const int64_t *rowptr, const int32_t *colind,
                         const void *vals, lk_linop_t *op);
 /* row-sharded CSR operator: rank r owns rows [row_starts[r], row_starts[r+1]); rowptr (n_local + 1 entries, 0-based) / colind /
- * vals describe those rows with GLOBAL column indices.  matvec all-gathers x, rmatvec sums the ranks' full-length products of
- * their blocks' conjugate transposes and keeps the local rows -- as lk_linop_dense_create_sharded. */
+ * vals describe those rows with GLOBAL column indices.  COLLECTIVE: every rank calls it at the same point (the ranks exchange
+ * which entries of x their rows reference, through the all-gather hook).  matvec then moves only THOSE entries -- each rank packs
+ * what others need of its block, the packed pieces are all-gathered, the local rows multiply [own rows | pieces]: a stencil or
+ * banded matrix exchanges a few boundary entries per neighbour, not x -- unless half of x or more would travel anyway, in which
+ * case x is all-gathered whole as for the dense operator.  Either way a row's entries are summed in the same order as on one rank.
+ * rmatvec sums the ranks' full-length products of their blocks' conjugate transposes (all-reduce hook) and keeps the local rows. */
 int lk_linop_csr_create_sharded(lk_context_t ctx, int dtype, int64_t n_global, const int64_t *row_starts, const int64_t *rowptr,
                                 const int32_t *colind, const void *vals, lk_linop_t *op);
 /* 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (BASELINE config 3).
