@@ -1,0 +1,44 @@
+#!/usr/bin/env bash
+# Runs in the build container after `gpurun -- 'bash tools/run_profiles.sh <dir> <commit>'`: turns gpurun_out/<dir>/ into the
+# tracked files profiles/<tag>_*  (tools/make_profiles.py for the bench / kernel-stats / PMC records, the rest here).
+#   bash tools/collect_profiles.sh r03r r03
+set -euo pipefail
+cd "$(dirname "$0")/.."
+D=gpurun_out/$1; TAG=$2
+C=$(cat "$D/commit.txt")
+python tools/make_profiles.py "$D" "$TAG"
+hdr="{\"commit\": \"$C\", \"box\": \"1 x MI355X (gpurun), tools/run_profiles.sh $1\"}"
+j() { grep -h '^{' "$@" 2>/dev/null || true; }
+(echo "$hdr"; j "$D/wide_f64.log" "$D/wide_c128.log") > "profiles/${TAG}_wide_dgs.jsonl"
+(echo "$hdr"; j "$D/block.log") > "profiles/${TAG}_block_mfma.jsonl"
+(echo "$hdr"; for op in dense lap5 csr; do j "$D/bench_$op.log"; done) > "profiles/${TAG}_operators.jsonl"
+(echo "$hdr"; j "$D/blas1.log") > "profiles/${TAG}_blas1_n1e8.jsonl"
+(echo "$hdr"; j "$D/per_object_arnoldi.log") > "profiles/${TAG}_per_object_arnoldi.jsonl"
+(echo "$hdr"; j "$D/per_object_c.log") > "profiles/${TAG}_per_object_c.jsonl"
+(echo "$hdr"; j "$D/bench_default.log") > "profiles/${TAG}_bench_default_stdout.jsonl"
+(echo "$hdr"; j "$D/cfg2.log") > "profiles/${TAG}_cfg2_f64_n1e7_m64.jsonl"
+(echo "$hdr"; j "$D/configs.log") > "profiles/${TAG}_configs.jsonl"
+(echo "# VALU (gemm_mfma_min=100) vs MFMA (gemm_mfma_min=1) for narrow tall-skinny products; commit $C"; python - "$D" <<'PY'
+import json, sys
+D = sys.argv[1]
+def load(f):
+    out = {}
+    for l in open(f):
+        if l.startswith('{'):
+            d = json.loads(l); out[(d['dtype'], d['k'], d['q'])] = (d['kernel_ms_per_call'], d['GBps_algorithmic(k+q cols)'], d['TFLOPs_fp64'])
+    return out
+v, m = load(D + '/lincomb_scan_valu.log'), load(D + '/lincomb_scan_mfma.log')
+print("dtype k q | VALU ms GB/s | MFMA ms GB/s TFLOP/s | faster   (n = 1e7 real / 5e6 complex)")
+for key in sorted(v):
+    a, b = v[key], m.get(key, (0, 0, 0))
+    print(key[0], key[1], key[2], '| %.3f %5.0f | %.3f %5.0f %5.1f |' % (a[0], a[1], b[0], b[1], b[2]), 'VALU' if a[0] < b[0] else 'MFMA')
+PY
+) > "profiles/${TAG}_lincomb_scan.txt"
+(echo "# rocprofv3 --pmc FETCH_SIZE (KB, x2 on gfx950) per kernel; commit $C"
+ echo "## tools/bench_block_dgs.py 32 1  (n = 1e7 real, p = 32 against k = 64 and k = 128, 6 calls each: X 5.12 / 10.24 GB + Y 2.56 GB per pass => 122.88 GB per kernel = ONE pass each: three passes per block DGS)"
+ python tools/pmc_sum.py "$D/pmc_block_fetch" FETCH_SIZE
+ echo "## tools/bench_wide.py 4e6 f64  (k = 64..640, 5 calls each; lane-split sweeps <.., 2> / <.., 4>: (k + 1) columns of 32 MB per launch = one pass)"
+ python tools/pmc_sum.py "$D/pmc_wide_fetch" FETCH_SIZE
+ if [ -f profiles/${TAG}_pmc_lds_note.txt ]; then cat profiles/${TAG}_pmc_lds_note.txt; fi) > "profiles/${TAG}_pmc_wide_and_block.txt"
+find "$D/dense" -name "*kernel_stats.csv" -exec cp {} "profiles/${TAG}_dense_n65536_kernel_stats.csv" \;
+echo "profiles/${TAG}_* written from $D (commit $C)"
