@@ -47,25 +47,69 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 NCCL_PIN = {"NCCL_ALGO": "Ring"}
 
 
-def _free_port() -> int:
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
-
-
 def _self_launch(ngpus: int) -> int:
     """--gpus N > 1 without a launcher: run this script under torch.distributed.run in a FRESH child process (decided before
-    anything in this process touches the GPU; never an exec), relay its output, return its exit code."""
+    anything in this process touches the GPU; never an exec), relay its output, return its exit code.  `--standalone` lets the
+    launcher's own store pick and HOLD a free port (a port probed here and released could be taken before the launcher binds
+    it); `--local-addr 127.0.0.1` keeps the rendezvous on loopback (the box's hostname may not resolve)."""
     import subprocess
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k, v in NCCL_PIN.items():
         env.setdefault(k, v)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.run(cmd, env=env, cwd=ROOT)
     return proc.returncode
+
+
+class Progress:
+    """Where is this rank, and is it still moving?  Every phase of a run writes ONE marker line to stderr
+    (`bench.py[rank r/N pid P] +12.3s phase: ...`) and re-arms a watchdog: `seconds` without the next marker (or `tick`) and
+    the interpreter's fault handler -- a C thread that needs neither the interpreter lock nor a responsive main thread --
+    dumps the Python stack of EVERY thread to stderr and ends the process with a fresh `_exit(1)` (never a re-exec of a
+    process that has touched the GPU).  Under torch.distributed.run one rank exiting non-zero makes the launcher terminate
+    the others, whose SIGTERM handler dumps their stacks too: a hang becomes rc != 0 plus the place every rank was stuck at,
+    within `seconds`.  SIGUSR1 dumps the stacks without ending the process."""
+
+    def __init__(self, seconds: float, rank: int = 0, world: int = 1):
+        import faulthandler
+        import signal
+        self.fh, self.seconds, self.rank, self.world, self.t0 = faulthandler, float(seconds), rank, world, time.perf_counter()
+        self.last = "start"
+        faulthandler.enable(all_threads=True)
+        try:
+            faulthandler.register(signal.SIGUSR1, all_threads=True, chain=False)
+            faulthandler.register(signal.SIGTERM, all_threads=True, chain=True)
+        except (AttributeError, ValueError, RuntimeError):      # not the main thread / no such signal: markers still work
+            pass
+
+    def _arm(self) -> None:
+        if self.seconds > 0:
+            self.fh.dump_traceback_later(self.seconds, repeat=False, file=sys.stderr, exit=True)
+
+    def phase(self, name: str) -> None:
+        self.last = name
+        print(f"bench.py[rank {self.rank}/{self.world} pid {os.getpid()}] +{time.perf_counter() - self.t0:.1f}s phase: {name}"
+              + (f" (watchdog {self.seconds:.0f}s)" if self.seconds > 0 else ""), file=sys.stderr, flush=True)
+        self._arm()
+
+    def tick(self) -> None:
+        """progress inside a phase (one factorisation done): re-arm without a marker line"""
+        self._arm()
+
+    def done(self) -> None:
+        self.fh.cancel_dump_traceback_later()
+
+
+def _die(progress: "Progress", msg: str, code: int = 3) -> None:
+    """A failure the other ranks cannot be told about (they may be inside a collective this rank never entered): say so and
+    leave with a non-zero status at once -- the launcher then terminates the whole job.  `os._exit`: no destructor of this
+    process may wait for a peer on the way out."""
+    print(f"bench.py[rank {progress.rank}/{progress.world} pid {os.getpid()}] FATAL after phase '{progress.last}': {msg}",
+          file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os._exit(code)
 
 
 def kernel_source_hash() -> str:
@@ -96,7 +140,7 @@ def _oracle_sample(n: int, m: int, threads: int, fused: bool, repeat: int = 1):
     return dt, int(info)
 
 
-def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int) -> dict:
+def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int, progress=None) -> dict:
     """Two legs, both on this host, both on a BOUNDED sample scaled to the metric's unit by a byte model:
       reference_schedule_1thread -- the oracle's Arnoldi in the reference's own schedule (per-primitive BLAS-1,
         sequential dots, scal-then-axpy axpby, fresh projection vector per pass; ONE thread: the reference has no
@@ -111,12 +155,20 @@ def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int) -> dict
     # -- leg 1: reference schedule, 1 thread.  Three DRAM-resident samples: two fit t = n (a m + b m(m+1)/2)
     #    (a: per-step cost independent of k -- matvec, norms, allocations; b: cost per basis column), the
     #    third validates the fit; the byte model alone (one sample) is reported beside it.
+    #    The second sample carries m >= 44, so the fit is extrapolated by < 3x in m to the metric's m = 128 (and linearly in n,
+    #    which a DRAM-bound stream is).
     n1, m1 = budget_n, max(budget_m // 2, 4)
-    n2, m2 = max(budget_n // 2, 1000), min(budget_m + budget_m // 2, 64)
-    n3, m3 = max(3 * budget_n // 4, 1000), budget_m
+    n2, m2 = max(budget_n // 4, 1000), max(min(2 * budget_m + 4, m_full), 4)
+    n3, m3 = max(budget_n // 2, 1000), max(budget_m + budget_m // 5, 4)
     dt1, info1 = _oracle_sample(n1, m1, 1, fused=False)
+    if progress is not None:
+        progress.tick()
     dt2, _ = _oracle_sample(n2, m2, 1, fused=False)
+    if progress is not None:
+        progress.tick()
     dt3, _ = _oracle_sample(n3, m3, 1, fused=False)
+    if progress is not None:
+        progress.tick()
     tri = lambda mm: mm * (mm + 1) / 2.0                                                      # noqa: E731
     Afit = np.array([[n1 * m1, n1 * tri(m1)], [n2 * m2, n2 * tri(m2)]], dtype=float)
     a, b = np.linalg.solve(Afit, np.array([dt1, dt2]))
@@ -132,6 +184,7 @@ def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int) -> dict
                     {"n": n3, "m": m3, "seconds": dt3, "predicted_seconds_by_fit": pred3,
                      "model_error": abs(pred3 - dt3) / dt3, "within_10_percent": bool(abs(pred3 - dt3) / dt3 <= 0.10)}],
         "fit_seconds_per_row": {"per_step": a, "per_step_per_column": b, "used": bool(fit_ok)},
+        "extrapolation": {"in_m": m_full / max(m1, m2), "in_n": n_full / max(n1, n2)},
         "value_by_byte_model_only": m_full / t_full_bytes,
         "effective_GBps_on_reference_schedule": bw3 / 1e9,
         "sample": (f"samples (n, m) = ({n1}, {m1}), ({n2}, {m2}) fit t = n(a m + b m(m+1)/2); validated on ({n3}, {m3}): "
@@ -142,9 +195,14 @@ def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int) -> dict
     #    OMP_NUM_THREADS would do; the scan is reported.
     tmax = ora.max_threads()
     scan = {}
+    ns, ms = budget_n, max(budget_m + budget_m // 2, 4) + 2           # the scan's own sample is DRAM-resident: >= 2 GB of basis
+    if progress is not None:
+        progress.phase(f"cpu_baseline: thread scan of the fused schedule on a {8e-9 * ns * (ms + 1):.1f} GB basis")
     for T in sorted({t for t in (8, 16, 32, 64, 128, tmax) if t <= tmax}):
-        dts, _ = _oracle_sample(max(budget_n // 2, 1000), max(budget_m // 2, 4), T, fused=True, repeat=2)
+        dts, _ = _oracle_sample(ns, ms, T, fused=True, repeat=2)
         scan[T] = dts
+        if progress is not None:
+            progress.tick()
     T = min(scan, key=scan.get)
     n4, m4 = min(4 * budget_n, n_full), min(2 * budget_m, m_full)
     dt4, _ = _oracle_sample(n4, m4, T, fused=True, repeat=2)   # 2nd run timed: pages already first-touched in parallel
@@ -153,6 +211,7 @@ def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int) -> dict
         "value": m_full / (fus_model(n_full, m_full) / bw4), "unit": "Arnoldi iterations/s", "cores": T,
         "sample_seconds": dt4, "sample_iters_per_s": m4 / dt4, "effective_GBps_on_fused_schedule": bw4 / 1e9,
         "thread_scan_seconds": {str(k): v for k, v in scan.items()}, "host_threads_available": tmax,
+        "thread_scan_sample": {"n": ns, "m": ms, "basis_GB": 8e-9 * ns * (ms + 1)},
         "sample": f"three-sweep fused CGS2 (the engine's schedule) with OpenMP on {T} threads (best of the scan), n={n4}, m={m4} "
                   f"({dt4:.2f} s) scaled by sum_k 8n(3k+10) bytes",
     }
@@ -230,6 +289,9 @@ def main() -> None:
     ap.add_argument("--cpu-m", type=int, default=20)
     ap.add_argument("--grid-mult", type=int, default=0)
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=INT", help="lk_set_tuning knob (repeatable)")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("LK_BENCH_WATCHDOG", "600")),
+                    help="seconds without progress after which every thread's stack is dumped to stderr and the process exits 1 "
+                         "(0 = off; env LK_BENCH_WATCHDOG)")
     ap.add_argument("--no-profile", action="store_true",
                     help="diagnostic: leave the library's per-kernel HIP events off (value only; roofline fields are then zero)")
     args = ap.parse_args()
@@ -238,48 +300,74 @@ def main() -> None:
         sys.exit(_self_launch(args.gpus))
     for k, v in NCCL_PIN.items():
         os.environ.setdefault(k, v)
-
-    import torch
-    import lightkrylov_amd as lk
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL between processes needs on this driver
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    progress = Progress(args.watchdog, rank, world)
+    if world != args.gpus:
+        # a launcher's environment that disagrees with --gpus (a stale WORLD_SIZE export, a scheduler's variables): running on
+        # the launcher's size would hand the caller a number for a job it did not ask for -- refuse, on every rank
+        print(f"bench.py[rank {rank}/{world}]: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run", file=sys.stderr, flush=True)
+        sys.exit(2)
+    progress.phase("importing torch and the engine")
+
+    import torch
+    import lightkrylov_amd as lk
+
     # test hooks (tests/test_gpu_distributed.py): several ranks on ONE device with the gloo backend, which
     # all-reduces CUDA tensors through the host -- exercises the multi-process sharded path where RCCL cannot
     # (RCCL refuses two ranks on one GPU).  Never set by the driver.
     backend = os.environ.get("LK_DIST_BACKEND", "nccl")
     if "LK_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["LK_FORCE_DEVICE"])
-    if world != args.gpus and rank == 0:       # under a launcher its world size wins
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running on {world} rank(s)", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:      # under torch.distributed.run: RCCL path even for one rank
         import torch.distributed as dist  # noqa: PLW0621
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        progress.phase(f"rendezvous: init_process_group({backend}) on device {local_rank}, store {os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend)
+        progress.phase("rendezvous done; first collective (barrier)")
+        dist.barrier()
 
+    progress.phase("creating the engine context")
+    if os.environ.get("LK_TEST_HANG_RANK") == str(rank):                  # test hook: this rank stops making progress
+        time.sleep(1e6)
     ctx = lk.Context(device=local_rank)
     reduce_path = "none (single rank)"
     if dist is not None:
         # data-path collective: ncclAllReduce issued by the library itself on its own stream (lk_comm_init_rank);
         # torch.distributed only ships the 128 bootstrap bytes and provides barrier / max-over-ranks for timing.
-        # LK_NATIVE_RCCL=0 selects the older route (torch.distributed.all_reduce through a ctypes callback).
-        native = backend == "nccl" and os.environ.get("LK_NATIVE_RCCL", "1") != "0"
+        # LK_NATIVE_RCCL=0 selects the older route (torch.distributed.all_reduce through a ctypes callback), `force` tries the
+        # native one whatever the torch backend (test hook).  The route is AGREED ON by all ranks -- the wish (an environment
+        # variable, which a launcher may not hand to every rank alike) by a MIN all-reduce here, the availability of librccl
+        # and the outcome of ncclCommInitRank inside init_native_comm_from_process_group -- never decided per rank.
+        wish = os.environ.get("LK_NATIVE_RCCL", "1")
+        want = torch.tensor([1 if (wish == "force" or (backend == "nccl" and wish != "0")) else 0], dtype=torch.int32,
+                            device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        dist.all_reduce(want, op=dist.ReduceOp.MIN)
+        native = bool(int(want.item()))
         if native:
+            progress.phase("native RCCL communicator: agreeing on librccl, unique id, ncclCommInitRank")
+            if os.environ.get("LK_TEST_FAIL_COMM_RANK") == str(rank):     # test hook: this rank alone cannot enter the collective
+                _die(progress, "LK_TEST_FAIL_COMM_RANK: simulated failure of lk_comm_init_rank on this rank only")
             try:
-                ctx.init_native_comm_from_process_group(dist.group.WORLD)
+                native = ctx.init_native_comm_from_process_group(dist.group.WORLD)
+            except Exception as exc:  # noqa: BLE001 - agreed on by all ranks inside; every rank leaves
+                _die(progress, f"native RCCL communicator failed: {exc!r}")
+            if native:
                 reduce_path = "RCCL native (ncclAllReduce issued by liblightkrylov_hip on its own stream)"
-            except Exception as exc:  # noqa: BLE001
-                print(f"bench.py: native RCCL communicator failed ({exc!r}); using torch.distributed", file=sys.stderr)
-                native = False
+            elif rank == 0:
+                print("bench.py: librccl is not available on every rank; all ranks use torch.distributed", file=sys.stderr, flush=True)
         if not native:
             ctx.set_process_group(dist.group.WORLD)
             reduce_path = ("RCCL" if backend == "nccl" else backend) + " via torch.distributed callback"
+        progress.phase(f"communicator up: {reduce_path}")
     if args.grid_mult:
         ctx.set_tuning("grid_mult", args.grid_mult)
     for kv in args.tune:
@@ -306,6 +394,7 @@ def main() -> None:
     ctx.set_partition(row0, n)
 
     # ---- inputs resident in HBM before the timed region
+    progress.phase(f"generating the inputs in HBM ({args.operator} operator, n_local = {n_local}, m = {m})")
     X = lk.krylov_basis_gpu(n_local, m + 1, dtype, ctx)
     keep = None
     if args.operator == "diag":
@@ -345,19 +434,24 @@ def main() -> None:
         torch.cuda.synchronize()
         ctx.sync()
 
+    progress.phase(f"warm-up: {args.warmup} factorisation(s)")
     for _ in range(args.warmup):
         one_factorisation()
+        progress.tick()
     fence()
     ctx.profile_reset()
     ctx.profile_enable(not args.no_profile)
     fence()
+    progress.phase(f"timed region: {args.steps} factorisation(s)")
     t0 = time.perf_counter()
     info = 0
     for _ in range(args.steps):
         info = one_factorisation()
+        progress.tick()
     fence()
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
+    progress.phase(f"timed region done ({elapsed:.2f} s on this rank); max over ranks")
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -401,6 +495,7 @@ def main() -> None:
             "value": iters / elapsed,
             "unit": "Arnoldi iterations/s",
             "n_gpus": world,
+            "gpus_requested": args.gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -422,6 +517,7 @@ def main() -> None:
                 "bound": "hbm", "kernel": "the three DGS sweeps: lk::panel_dot_cw (DOT, one column at a time) | lk::panel_sweep (UPDATE+DOT, y' kept in registers) | lk::panel_sweep (UPDATE with two coefficient sets)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_measured_in_this_run": False,      # a stored record of separate --pmc passes (profiles/pmc_traffic.json)
                 "traffic_source": traffic_src if traffic_src is not None else
                                   "rocprofv3 --pmc passes cannot run inside bench.py; see profiles/ (no record for this workload)",
                 "bytes_priced": "ALGORITHMIC three-sweep schedule, s*n_local*(k+1 | k+2 | k+2) = s*n*(3k+5) per DGS (SURVEY 8d); "
@@ -454,6 +550,8 @@ def main() -> None:
             r["algorithmic_bytes_per_launch"] = mv_bytes_model
             r["bytes_priced"] = "ALGORITHMIC bytes of one operator application: s*n_local*n (the matrix) + s*(n + n_local) (x read, y written)"
             r["traffic"], r["traffic_source"] = None, "no PMC record for this workload"
+        if world == 1 and not args.no_cpu_baseline:
+            progress.phase("cpu_baseline: the oracle on this host's cores (bounded samples)")
         if world == 1 and not args.no_cpu_baseline and args.operator != "diag":
             try:
                 out["cpu_baseline"] = cpu_baseline_operator(args.operator, n, m)
@@ -461,18 +559,20 @@ def main() -> None:
                 out["cpu_baseline"] = {"value": None, "unit": "Arnoldi iterations/s", "cores": 1, "kind": "port", "sample": f"failed: {exc!r}"}
         elif world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(n, m, args.cpu_n, args.cpu_m)
+                out["cpu_baseline"] = cpu_baseline(n, m, args.cpu_n, args.cpu_m, progress)
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "Arnoldi iterations/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {exc!r}"}
         print(json.dumps(out))
     # orderly teardown: device objects, then the library's own communicator (lk_finalize), then torch's group
+    progress.phase("teardown")
     del X, A, keep
     if dist is not None:
         dist.barrier()
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    progress.done()
 
 
 if __name__ == "__main__":

@@ -220,7 +220,12 @@ module lightkrylov_hip_c
             integer(c_int) :: rc
         end function
         !> native RCCL all-reduce: rank 0 fills id(128) and ships it (e.g. MPI_Bcast); every rank then calls
-        !> lk_comm_init_rank (collective).
+        !> lk_comm_init_rank (collective).  lk_comm_available: local check that librccl resolves (agree on it over MPI
+        !> before anyone enters the collective).
+        function lk_comm_available() bind(C, name="lk_comm_available") result(rc)
+            import :: c_int
+            integer(c_int) :: rc
+        end function
         function lk_comm_get_unique_id(id) bind(C, name="lk_comm_get_unique_id") result(rc)
             import :: c_int, c_char
             character(kind=c_char), intent(out) :: id(128)

@@ -88,8 +88,13 @@ int lk_context_info(lk_context_t ctx, int *device, void **stream);
  * device), which installs ncclAllReduce(ncclDouble, ncclSum) on the context's stream as the engine's
  * reduction hook -- the <= 129 (258 complex) scalars of each sweep are reduced in place in device memory.
  * The reference itself has no collective (paper/paper.md:35,97,101: "the user's job inside dot").
- * librccl is dlopen'ed on first use.  lk_comm_destroy (or lk_finalize) releases the communicator. */
+ * librccl is dlopen'ed on first use.  lk_comm_destroy (or lk_finalize) releases the communicator.
+ * lk_comm_available is the LOCAL half of that (no collective, no GPU work): LK_OK when librccl and every entry point the
+ * communicator needs resolve in this process -- so that the ranks of a job can agree on the route (native, or a host-provided
+ * lk_set_allreduce) BEFORE anyone enters the collective lk_comm_init_rank, where a rank that fails alone leaves the others
+ * waiting in the bootstrap (bench.py: the flag is all-reduced over the launcher's process group). */
 #define LK_COMM_ID_BYTES 128
+int lk_comm_available(void);
 int lk_comm_get_unique_id(void *id_out);
 int lk_comm_init_rank(lk_context_t ctx, int nranks, int rank, const void *id);
 int lk_comm_destroy(lk_context_t ctx);

@@ -172,17 +172,56 @@ class Context:
         self.nranks, self.rank = int(nranks), int(rank)
         self._cb = None
 
-    def init_native_comm_from_process_group(self, pg=None) -> None:
-        """Bootstrap the native communicator through an existing torch.distributed group: rank 0's unique id
-        is broadcast over `pg` (torch only carries the 128 bootstrap bytes; the data path is the library's)."""
+    @staticmethod
+    def native_comm_available() -> bool:
+        """LOCAL check (no collective, no GPU work): librccl and every entry point the communicator needs resolve in this
+        process (lk_comm_available)."""
+        return _capi.load().lk_comm_available() == 0
+
+    def init_native_comm_from_process_group(self, pg=None) -> bool:
+        """Bootstrap the native communicator through an existing torch.distributed group -- COLLECTIVELY DECIDED, so that the
+        ranks can never disagree on the reduction route (a rank on the callback route and a rank on the native one would each
+        wait for the other in the first sweep):
+          1. every rank checks locally that librccl resolves and the group takes the MINIMUM of the flags: when it is missing
+             anywhere, nothing is installed anywhere and every rank returns False (the caller picks another route, the same on
+             all ranks);
+          2. rank 0's unique id is broadcast over `pg` (torch only carries the 128 bootstrap bytes; the data path is the
+             library's) and every rank enters ncclCommInitRank;
+          3. the group takes the minimum of the outcomes: when ncclCommInitRank failed on any rank, every rank destroys what it
+             built and raises -- the same error everywhere.
+        A rank that cannot even enter step 2 must leave the job (a non-zero exit: the launcher tears the others down); it cannot
+        be waited for, the others are inside the communicator's bootstrap."""
         import torch
         import torch.distributed as dist
         nranks, rank = dist.get_world_size(pg), dist.get_rank(pg)
+        on_device = dist.get_backend(pg) == "nccl"
+        dev = torch.device(f"cuda:{self.device}") if on_device else torch.device("cpu")
+
+        def agree(ok: bool) -> bool:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
+            return bool(int(flag.item()))
+
+        have = self.native_comm_available()
+        if not agree(have):
+            if not have:
+                import sys
+                print(f"[lightkrylov_amd] rank {rank}: librccl unavailable ({_capi.load().lk_last_error().decode()})", file=sys.stderr)
+            return False
         payload = [self.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(payload, src=dist.get_global_rank(pg, 0) if pg is not None else 0, group=pg,
-                                   device=torch.device(f"cuda:{self.device}") if dist.get_backend(pg) == "nccl" else None)
-        self.init_native_comm(nranks, rank, payload[0])
+                                   device=dev if on_device else None)
+        err = None
+        try:
+            self.init_native_comm(nranks, rank, payload[0])
+        except Exception as exc:  # noqa: BLE001 - the outcome is agreed on below, then raised on every rank
+            err = exc
+        if not agree(err is None):
+            if err is None:
+                self.destroy_native_comm()
+            raise RuntimeError(f"native RCCL communicator failed on at least one rank (rank {rank}: {err!r})")
         self._pg = pg
+        return True
 
     def destroy_native_comm(self) -> None:
         _capi.check(self._lib.lk_comm_destroy(self._h))

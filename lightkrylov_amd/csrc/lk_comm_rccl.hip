@@ -116,6 +116,11 @@ int rccl_allgatherv(void *user, const void *send, void *recv, const int64_t *cou
 
 extern "C" {
 
+int lk_comm_available(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    return load_rccl();
+}
+
 int lk_comm_get_unique_id(void *id_out) {
     if (!id_out) return lk_fail_(LK_ERR_INVALID, "lk_comm_get_unique_id: null id");
     std::lock_guard<std::mutex> lock(g_mu);

@@ -22,22 +22,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(cmd, **extra_env):
+def _launch(cmd, timeout=420, **extra_env):
+    """One attempt, no retry: bench.py's own watchdog (LK_BENCH_WATCHDOG) turns a stalled rank into a non-zero exit with every
+    rank's phase markers and stacks on stderr, which a failure here prints."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    env.setdefault("LK_BENCH_WATCHDOG", "150")
     if extra_env.get("LK_DIST_BACKEND") == "gloo":
         env.setdefault("GLOO_SOCKET_IFNAME", "lo")          # the box's hostname does not resolve: keep gloo's full mesh on loopback
-    out = None
-    for attempt in (1, 2):
-        # a multi-process rendezvous on a freshly leased box has (once in ~20 runs) stalled before the first collective; the runs
-        # themselves take seconds, so a stalled launch is cut off early and repeated once instead of eating the suite's time
-        try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600 if attempt == 2 else 150, cwd=ROOT, env=env)
-            break
-        except subprocess.TimeoutExpired as exc:
-            if attempt == 2:
-                raise
-            print(f"launch stalled, retrying once: {cmd}\n{(exc.stderr or b'')[-2000:]}")
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+def _run(cmd, **extra_env):
+    out = _launch(cmd, **extra_env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-8000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     return json.loads(line)
 
@@ -92,14 +89,40 @@ def test_two_processes_on_the_row_sharded_dense_and_csr_operators(operator, rows
     assert one["roofline"]["matvec"]["launches"] == 12
 
 
-def test_three_processes_sharing_one_gpu_shard_the_metric_workload():
+@pytest.mark.parametrize("P", [3, 4, 8])
+def test_processes_sharing_one_gpu_shard_the_metric_workload(P):
     """BASELINE configs[4]'s partitioning (row blocks of n / P contiguous rows, the last one ragged, reductions all-reduced) with
-    P = 3 real processes on one GPU (gloo standing in for RCCL) at a reduced n: same H as the single process to rounding.  (The
-    full-size 8-process run of the same command is recorded in profiles/r03_cfg5_8rank_one_gpu.jsonl; more than three ranks beside
-    the test process itself on ONE GPU have stalled at launch inside a long pytest session, never from a shell.)"""
-    args = ["--rows", "3000001", "--kdim", "32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    P = 3, 4, 8 real processes on one GPU (gloo standing in for RCCL) at a reduced n, through the plain `--gpus P` entry: same H as
+    the single process to rounding.  (The full-size 8-process run of the same command is recorded under profiles/.)"""
+    args = ["--rows", str(1000000 * P + 2), "--kdim", "32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py", "--gpus", "1"] + args)
-    three = _run([sys.executable, "bench.py", "--gpus", "3"] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
-    assert three["n_gpus"] == 3 and three["config"]["n_local"] == 1000000 and three["config"]["info"] == 0
-    assert abs(three["config"]["H_fro"] - one["config"]["H_fro"]) <= 1e-13 * one["config"]["H_fro"]
-    assert abs(three["config"]["H_last_subdiag"] - one["config"]["H_last_subdiag"]) <= 1e-12 * one["config"]["H_last_subdiag"]
+    many = _run([sys.executable, "bench.py", "--gpus", str(P)] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
+    assert many["n_gpus"] == many["gpus_requested"] == P and many["config"]["n_local"] == 1000000 and many["config"]["info"] == 0
+    assert abs(many["config"]["H_fro"] - one["config"]["H_fro"]) <= 1e-13 * one["config"]["H_fro"]
+    assert abs(many["config"]["H_last_subdiag"] - one["config"]["H_last_subdiag"]) <= 1e-12 * one["config"]["H_last_subdiag"]
+
+
+def test_a_rank_that_cannot_enter_the_native_communicator_ends_the_whole_job():
+    """ncclCommInitRank is a collective: a rank that fails BEFORE entering it cannot be waited for (the others sit in the
+    bootstrap).  bench.py's answer: that rank says so and exits non-zero at once, the launcher terminates the rest -- rc != 0
+    within seconds on every rank, never a deadlock with the ranks on different reduction routes."""
+    import time
+    args = ["--gpus", "2", "--rows", "200001", "--kdim", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    t0 = time.time()
+    out = _launch([sys.executable, "bench.py"] + args, timeout=300, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0",
+                  LK_NATIVE_RCCL="force", LK_TEST_FAIL_COMM_RANK="1")
+    took = time.time() - t0
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stdout[-2000:] + out.stderr[-6000:]
+    assert "FATAL after phase 'native RCCL communicator" in out.stderr and "simulated failure of lk_comm_init_rank on this rank only" in out.stderr
+    assert took < 120, f"{took:.0f} s"            # interpreter start-up + torch import of three processes; the failure itself is immediate
+
+
+def test_a_rank_that_stops_moving_is_reported_with_its_stack_and_ends_the_job():
+    """The watchdog of bench.py: one rank hangs before its first engine call; after LK_BENCH_WATCHDOG seconds every thread's stack of
+    that rank is on stderr with the phase it was in, the process leaves with status 1 and the launcher ends the job."""
+    args = ["--gpus", "2", "--rows", "200001", "--kdim", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    out = _launch([sys.executable, "bench.py"] + args, timeout=300, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0",
+                  LK_TEST_HANG_RANK="0", LK_BENCH_WATCHDOG="20")
+    assert out.returncode != 0, out.stdout[-2000:] + out.stderr[-6000:]
+    assert "Timeout (0:00:20)!" in out.stderr and "phase: creating the engine context" in out.stderr
+    assert 'bench.py", line' in out.stderr                   # the dumped stack names the line the rank sat on

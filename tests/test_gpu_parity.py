@@ -11,7 +11,7 @@ import pytest
 
 import lightkrylov_amd as lk
 from oracle import oracle as ora
-from tests._tol import assert_columns_close, assert_ritz_close
+from tests._tol import assert_close, assert_columns_close, assert_ritz_close, gmres_condition
 
 pytestmark = pytest.mark.gpu
 
@@ -324,7 +324,9 @@ def test_lanczos_spd_toeplitz_known_answer(ctx):
     k = info if info > 0 else n
     lam = np.sort(np.linalg.eigvalsh((T[:k, :k] + T[:k, :k].T) / 2))[::-1]
     true = np.array([a + 2 * abs(b) * np.cos(i * np.pi / (n + 1)) for i in range(1, n + 1)])
-    assert np.abs(lam - true[:k]).max() / np.abs(true).max() < lk.rtol_dp
+    # the reference asserts rtol_dp; symmetric T: every eigenvalue has condition number 1 -> north_star's 1e-12, elementwise
+    assert k == n
+    assert_close(lam / true, np.ones(n), "HIP lanczos SPD Toeplitz KAT (elementwise relative)")
 
 
 # ----------------------------------------------------------------------------- solvers on the path
@@ -341,9 +343,10 @@ def test_eigs_complex_known_answer(ctx):
     x0 = lk.dense_vector_gpu.from_array(seeded(n, np.complex128, 3), ctx)
     vals, res, info = lk.eigs(lk.dense_linop_gpu(A, ctx), X, x0=x0, tolerance=lk.atol_dp)
     true = np.array([2 * (n - i + 1) - 1 for i in range(1, n + 1)], dtype=float)
-    assert np.abs(vals - true).max() / np.abs(true).max() < lk.rtol_dp
+    # the reference asserts rtol_dp; A is Hermitian (normal): 1e-12, elementwise relative as in tests/test_oracle_kat.py
+    assert_close(vals / true, np.ones(n), "HIP eigs complex KAT 255, 253, ..., 1 (elementwise relative)")
     V = X.download()
-    assert np.abs(A @ V - V * vals[None, :]).max() < 1e-8 * np.abs(true).max()
+    assert_close(A @ V, V * vals[None, :], "HIP eigs complex KAT: A V = V diag(w)", scale=np.abs(true).max())
 
 
 def test_eigs_leading_pairs_against_oracle(ctx):
@@ -381,8 +384,8 @@ def test_gmres_poisson_against_oracle(ctx):
     info_o, res_o = ora.gmres(ora.Lap5Op(N), b, xo, rtol=1e-8, kdim=30, maxiter=2)
     assert info == info_o
     assert len(meta.res) == len(res_o)
-    assert np.abs(np.array(meta.res) - res_o).max() <= 1e-10 * res_o[0]
-    assert np.abs(x.to_array() - xo).max() <= 1e-10 * np.abs(xo).max()
+    assert_close(np.array(meta.res), res_o, "gmres Poisson N=96: residual history vs oracle", scale=res_o[0])
+    assert_close(x.to_array(), xo, "gmres Poisson N=96: solution vs oracle", kappa=gmres_condition(lk.laplacian2d_linop_gpu(N, ctx), b, 30, ctx))
 
 
 # ----------------------------------------------------------------------------- size-independent properties
@@ -535,9 +538,9 @@ def test_bidiagonalization_against_oracle(ctx, dtype):
     Vo = np.zeros((n, kdim + 1), dtype=dtype, order="F")
     Bo = np.zeros((kdim + 1, kdim), dtype=dtype, order="F")
     assert ora.bidiagonalization(ora.DenseOp(A), ora.DenseOp(np.asfortranarray(A.conj().T)), Uo, Vo, Bo) == 0
-    assert np.abs(B - Bo).max() <= 1e-11 * np.abs(Bo).max()
+    assert_columns_close(B, Bo, f"bidiagonalization dense 300 x 300 {np.dtype(dtype)}")
     Ug, Vg = U.download(), V.download(0, kdim)
-    assert np.abs(A @ Vg - Ug @ B).max() <= 1e-11 * np.abs(B).max()
+    assert_close(A @ Vg, Ug @ B, f"bidiagonalization relation A V = U B {np.dtype(dtype)}", scale=np.abs(B).max())
     assert np.abs(Ug.conj().T @ Ug - np.eye(kdim + 1)).max() <= 1e-12
     assert np.abs(Vg.conj().T @ Vg - np.eye(kdim)).max() <= 1e-12
 

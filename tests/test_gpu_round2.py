@@ -10,7 +10,7 @@ import pytest
 import lightkrylov_amd as lk
 from lightkrylov_amd import _capi
 from oracle import oracle as ora
-from tests._tol import assert_columns_close
+from tests._tol import assert_close, assert_columns_close, gmres_condition
 
 pytestmark = pytest.mark.gpu
 KINDS = [np.float64, np.complex128]
@@ -582,8 +582,8 @@ def test_csr_laplacian_reproduces_the_stencil_operator_in_gmres_and_arnoldi(ctx)
                         meta=meta)
         out.append((info, np.array(meta.res), xs.to_array()))
     assert out[0][0] == out[1][0] and len(out[0][1]) == len(out[1][1])
-    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-10 * out[1][1][0]
-    assert np.abs(out[0][2] - out[1][2]).max() <= 1e-10 * np.abs(out[1][2]).max()
+    assert_close(out[0][1], out[1][1], "gmres on the Laplacian as CSR vs stencil: residual history", scale=out[1][1][0])
+    assert_close(out[0][2], out[1][2], "gmres on the Laplacian as CSR vs stencil: solution", kappa=gmres_condition(As, bh, 30, ctx))
     m = 20
     X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
     X[0].rand(True, seed=5)
@@ -712,8 +712,11 @@ def test_cg_against_oracle(lazy):
     xo = np.zeros(n)
     info_o, res_o = ora.cg(ora.DenseOp(A), bh, xo, rtol=1e-10, atol=1e-14, maxiter=200)
     assert info == info_o > 0 and len(meta.res) == len(res_o)
-    assert np.abs(np.array(meta.res) - res_o).max() <= 1e-9 * res_o[0]
-    assert np.abs(x.to_array() - xo).max() <= 1e-9 * np.abs(xo).max()
+    # cg is a three-term recurrence without re-orthogonalisation: rounding differences between two runs are amplified along the
+    # iteration by up to the condition number of A (computed here), not a property of the projected matrix
+    kap = float(np.linalg.cond(A))
+    assert_close(np.array(meta.res), res_o, f"cg residual history vs oracle (lazy={lazy})", scale=res_o[0], kappa=kap)
+    assert_close(x.to_array(), xo, f"cg solution vs oracle (lazy={lazy})", kappa=kap)
     assert np.abs(A @ x.to_array() - bh).max() <= 1e-8 * np.abs(bh).max()
     c.close()
 
@@ -727,8 +730,8 @@ def test_eighs_against_oracle_and_known_spectrum(ctx):
     vals, res, info = lk.eighs(lk.dense_linop_gpu(A, ctx), X, x0=lk.dense_vector_gpu.from_array(x0, ctx), kdim=40, tolerance=1e-10)
     vo, ro, Xo, info_o = ora.eighs(ora.DenseOp(A), x0.copy(), nev, kdim=40, tolerance=1e-10)
     assert info == info_o
-    assert np.abs(vals - vo).max() <= 1e-11 * np.abs(vo).max()
-    assert np.abs(vals - np.sort(np.linalg.eigvalsh(A))[::-1][:nev]).max() <= 1e-9
+    assert_close(vals, vo, "eighs values vs oracle (symmetric T: kappa = 1)")
+    assert np.abs(vals - np.sort(np.linalg.eigvalsh(A))[::-1][:nev]).max() <= 1e-9        # the solver's own tolerance, not parity
     V = X.download()
     for i in range(nev):
         assert np.linalg.norm(A @ V[:, i] - vals[i] * V[:, i]) <= 1e-8 * abs(vals[i])
@@ -754,7 +757,7 @@ def test_pipelined_eighs_equals_the_step_by_step_one(ctx, dtype):
     assert np.array_equal(v0, v1) and np.array_equal(r0, r1) and np.array_equal(X0, X1)
     vo, ro, Xo, info_o = ora.eighs(ora.DiagOp(d), x0.copy(), nev, kdim=kdim, tolerance=1e-10)
     assert info_o == i0
-    assert np.abs(v0 - vo).max() <= 1e-11 * np.abs(vo).max()
+    assert_close(v0, vo, f"pipelined eighs values vs oracle {np.dtype(dtype)}")
     assert np.abs(v0 - (3.0 + 0.5 * np.arange(nev))[::-1]).max() <= 1e-9
 
 
@@ -771,7 +774,7 @@ def test_svds_against_oracle_and_known_singular_values(ctx):
     S, res, info = lk.svds(lk.dense_linop_gpu(G, ctx), U, V, u0=lk.dense_vector_gpu.from_array(u0, ctx), kdim=40, tolerance=1e-10)
     So, ro, Uo, Vo, info_o = ora.svds(ora.DenseOp(G), ora.DenseOp(np.asfortranarray(G.T)), u0.copy(), nsv, kdim=40, tolerance=1e-10)
     assert info == info_o
-    assert np.abs(S - So).max() <= 1e-11 * So[0]
+    assert_close(S, So, "svds singular values vs oracle", scale=So[0])
     assert np.abs(S - np.linalg.svd(G, compute_uv=False)[:nsv]).max() <= 1e-9
     Uh, Vh = U.download(), V.download()
     for i in range(nsv):
@@ -801,10 +804,10 @@ def test_fused_bidiagonalization_against_the_oracle_breakdown_and_ranges(ctx, dt
     Vo = np.zeros((n, m + 1), dtype=dtype, order="F")
     Bo = np.zeros((m + 1, m), dtype=dtype, order="F")
     assert ora.bidiagonalization(ora.DenseOp(G), ora.DenseOp(np.asfortranarray(G.conj().T)), Uo, Vo, Bo) == 0
-    assert np.abs(B - Bo).max() <= 1e-11 * np.abs(Bo).max()                 # dense gemv order differs too
+    assert_columns_close(B, Bo, f"fused bidiagonalization in ranges {np.dtype(dtype)}")
     Ud, Vd = U.download(), V.download()
     assert np.abs(Ud.conj().T @ Ud - np.eye(m + 1)).max() < 1e-12 and np.abs(Vd[:, :m].conj().T @ Vd[:, :m] - np.eye(m)).max() < 1e-12
-    assert np.abs(G @ Vd[:, :m] - Ud @ B).max() <= 1e-11                    # A V = U B
+    assert_close(G @ Vd[:, :m], Ud @ B, f"fused bidiagonalization relation {np.dtype(dtype)}", scale=np.abs(B).max())   # A V = U B
     # rank 2: the Krylov space of A A^H on u0 has dimension 2
     a, b, c_, e = (seeded(n, dtype, s_) for s_ in (31, 32, 33, 34))
     R = np.asfortranarray((np.outer(a, b.conj()) + np.outer(c_, e.conj())).astype(dtype) / n)
@@ -814,7 +817,8 @@ def test_fused_bidiagonalization_against_the_oracle_breakdown_and_ranges(ctx, dt
     info_o = ora.bidiagonalization(ora.DenseOp(R), ora.DenseOp(np.asfortranarray(R.conj().T)), Uo, Vo, Bo, tol=1e-10)
     # v1, v2 span range(A^H) = span(b, e); u2, u3 use up what span(a, c) adds to u0: V(3) = A^H U(3) has nothing left
     assert info == info_o == 3
-    assert np.abs(B[:3, :2] - Bo[:3, :2]).max() <= 1e-11 * np.abs(Bo).max() and abs(B[2, 2]) < 1e-10
+    assert_close(B[:3, :2], Bo[:3, :2], f"rank-2 bidiagonalization {np.dtype(dtype)}", scale=np.abs(Bo).max())
+    assert abs(B[2, 2]) < 1e-10
     assert not B[3:, :].any() and not B[:, 3:].any()
     assert not U.download(3, m - 2).any() and not V.download(3, m - 2).any()          # nothing beyond the breakdown was touched
     # u0 in the kernel of A^H: alpha = 0 at step 1
@@ -855,6 +859,7 @@ def test_pipelined_svds_equals_the_step_by_step_one(ctx, dtype):
     assert a[2] == b[2] and 3 < a[2] < kdim
     assert all(np.array_equal(x, y) for x, y in zip(a, b) if isinstance(x, np.ndarray))
     So, ro, Uo, Vo, info_o = ora.svds(ora.DenseOp(G), ora.DenseOp(np.asfortranarray(G.conj().T)), u0.copy(), nsv, kdim=kdim, tolerance=1e-10)
-    assert info_o == a[2] and np.abs(a[0] - So).max() <= 1e-11 * So[0]
+    assert info_o == a[2]
+    assert_close(a[0], So, f"pipelined svds singular values vs oracle {np.dtype(dtype)}", scale=So[0])
     assert np.abs(a[0] - np.linalg.svd(G, compute_uv=False)[:nsv]).max() <= 1e-9
 

@@ -426,10 +426,47 @@ def test_bench_helpers_csr_rows_self_launch_and_traffic_record(monkeypatch):
     monkeypatch.delenv("NCCL_ALGO", raising=False)
     assert bench._self_launch(4) == 7                                   # the child's exit code is relayed
     cmd = seen["cmd"]
-    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
-    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    # the launcher's own store picks and holds the port (--standalone); the rendezvous stays on loopback
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
     assert seen["env"]["NCCL_ALGO"] == "Ring" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")))
     assert rec["kernel_source_sha256"] == bench.kernel_source_hash(), (
         "profiles/pmc_traffic.json was measured on other kernel sources: re-run tools/run_profiles.sh + tools/make_profiles.py")
     assert 0.98 <= rec["traffic_over_algorithmic"] <= 1.02
+
+
+def test_bench_watchdog_dumps_every_stack_and_exits_nonzero():
+    """bench.py's progress markers + watchdog (N > 1 robustness): a rank that stops moving writes where it was (its last phase
+    marker), the Python stack of every thread, and leaves with status 1 -- a fresh exit -- within the watchdog's period."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import bench, threading, time\n"
+            "threading.Thread(target=time.sleep, args=(60,), daemon=True).start()\n"
+            "p = bench.Progress(1.0, 3, 8)\n"
+            "p.phase('rendezvous')\n"
+            "p.tick()\n"
+            "p.phase('stuck here')\n"
+            "time.sleep(60)\n")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=50)
+    assert out.returncode == 1 and time.time() - t0 < 30
+    assert "bench.py[rank 3/8" in out.stderr and "phase: stuck here" in out.stderr
+    assert "Timeout (0:00:01)!" in out.stderr and out.stderr.count("Thread 0x") >= 2 and 'File "<string>", line 7' in out.stderr
+    # ... and a run that finishes cancels it
+    ok = subprocess.run([sys.executable, "-c", "import bench, time\np = bench.Progress(1.0)\np.phase('a')\np.done()\ntime.sleep(2.5)\n"],
+                        cwd=root, capture_output=True, text=True, timeout=50)
+    assert ok.returncode == 0 and "Timeout" not in ok.stderr
+
+
+def test_bench_refuses_a_launcher_environment_that_disagrees_with_gpus():
+    """--gpus N under a launcher whose WORLD_SIZE differs (a stale export, a scheduler's variables) is refused with status 2 on
+    every rank -- never a line for a job the caller did not ask for."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="1", LOCAL_RANK="1")
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and "--gpus 8 but WORLD_SIZE=4" in out.stderr and not out.stdout.strip()

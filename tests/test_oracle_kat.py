@@ -17,13 +17,20 @@ def seeded(n, dtype, seed):
     return x
 
 
+# The reference's own analytic known answers are the oracle's pin.  The reference asserts them at rtol_dp = 3.2e-8; every matrix
+# here is NORMAL (condition number 1 for every eigenvalue), so the pin is made at north_star's tolerance instead.
+KAT_RTOL = 1e-12
+
+
 def test_constants():
     assert ora.ATOL_DP == 1e-15 and abs(ora.RTOL_DP - 3.1622776601683794e-08) < 1e-22   # src/Constants.f90:33-37
 
 
 def test_eigs_complex_known_answer():
     """test/TestIterativeSolvers.fypp:176-185, 201-203: A(i,i)=n, A(i,i+1)=i*sqrt(i(n-i)), A(i+1,i)=-A(i,i+1)
-    => eigenvalues 2(n-i+1)-1 = 255, 253, ..., 1; asserted at rtol_dp."""
+    => eigenvalues 2(n-i+1)-1 = 255, 253, ..., 1.  The reference asserts rtol_dp; the pin is made at north_star's 1e-12, ELEMENTWISE
+    relative (A = n I + i B with B real antisymmetric is Hermitian, hence normal: every eigenvalue has condition number 1;
+    measured 1.0e-13 on the eigenvalue 1 of a matrix of norm 255)."""
     A = np.zeros((N, N), dtype=np.complex128)
     for i in range(1, N + 1):
         A[i - 1, i - 1] = N
@@ -32,14 +39,14 @@ def test_eigs_complex_known_answer():
             A[i, i - 1] = -A[i - 1, i]
     w, res, V, niter = ora.eigs(ora.DenseOp(A), seeded(N, np.complex128, 3), nev=N, tolerance=ora.ATOL_DP)
     true = np.array([2 * (N - i + 1) - 1 for i in range(1, N + 1)], dtype=float)
-    assert np.max(np.abs(w - true) / np.abs(true)) < ora.RTOL_DP
-    # eigenvector check of the same test (:205-216): ||A V - V diag(w)|| < rtol_dp
-    assert np.linalg.norm(A @ V - V * w[None, :]) < ora.RTOL_DP * np.abs(true).max()
+    assert np.max(np.abs(w - true) / np.abs(true)) < KAT_RTOL
+    # eigenvector check of the same test (:205-216): ||A V - V diag(w)|| (rtol_dp there; 1e-12 ||A|| here, measured 2.6e-14)
+    assert np.linalg.norm(A @ V - V * w[None, :]) < KAT_RTOL * np.abs(true).max()
 
 
 def test_eigs_real_toeplitz_known_answer():
     """test/TestIterativeSolvers.fypp:164-174, 193-199: a on the diagonal, +b / -b off-diagonals
-    => eigenvalues a +- 2 b cos(k pi/(n+1)) i."""
+    => eigenvalues a +- 2 b cos(k pi/(n+1)) i (a I + antisymmetric: normal; pinned at 1e-12 elementwise, measured 4.8e-15)."""
     a_, b_ = 0.37, 0.61
     A = a_ * np.eye(N) + b_ * np.eye(N, k=1) - b_ * np.eye(N, k=-1)
     w, res, V, niter = ora.eigs(ora.DenseOp(A), seeded(N, np.float64, 4), nev=N, tolerance=ora.ATOL_DP)
@@ -49,11 +56,12 @@ def test_eigs_real_toeplitz_known_answer():
         true[i] = a_ + 2j * b_ * np.cos(k * np.pi / (N + 1))
         true[i + 1] = a_ - 2j * b_ * np.cos(k * np.pi / (N + 1))
         k += 1
-    assert np.max(np.abs(w - true) / np.abs(true)) < ora.RTOL_DP
+    assert np.max(np.abs(w - true) / np.abs(true)) < KAT_RTOL
 
 
 def test_lanczos_spd_toeplitz_known_answer():
-    """test/TestIterativeSolvers.fypp:254-280 (eighs): SPD Toeplitz => a + 2|b| cos(i pi/(n+1))."""
+    """test/TestIterativeSolvers.fypp:254-280 (eighs): SPD Toeplitz => a + 2|b| cos(i pi/(n+1)); pinned at 1e-12 elementwise
+    (measured 1.5e-15)."""
     a, b = 2.5, 0.8
     A = a * np.eye(N) + b * (np.eye(N, k=1) + np.eye(N, k=-1))
     X = np.zeros((N, N + 1), order="F")
@@ -64,7 +72,7 @@ def test_lanczos_spd_toeplitz_known_answer():
     k = info if info > 0 else N
     lam = np.sort(np.linalg.eigvalsh((T[:k, :k] + T[:k, :k].T) / 2))[::-1]
     true = np.array([a + 2 * abs(b) * np.cos(i * np.pi / (N + 1)) for i in range(1, N + 1)])
-    assert k == N and np.abs(lam - true).max() / np.abs(true).max() < ora.RTOL_DP
+    assert k == N and np.max(np.abs(lam - true) / np.abs(true)) < KAT_RTOL
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
