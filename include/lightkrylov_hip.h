@@ -327,7 +327,12 @@ int lk_linop_csr_create(lk_context_t ctx, int dtype, int64_t n, const int64_t *r
  * what others need of its block, the packed pieces are all-gathered, the local rows multiply [own rows | pieces]: a stencil or
  * banded matrix exchanges a few boundary entries per neighbour, not x -- unless half of x or more would travel anyway, in which
  * case x is all-gathered whole as for the dense operator.  Either way a row's entries are summed in the same order as on one rank.
- * rmatvec sums the ranks' full-length products of their blocks' conjugate transposes (all-reduce hook) and keeps the local rows. */
+ * rmatvec sums the ranks' full-length products of their blocks' conjugate transposes (all-reduce hook) and keeps the local rows.
+ * Errors are collective too: the validation of a rank's row block (column index out of range, decreasing rowptr, null arrays),
+ * its buffer allocations and its uploads are each AGREED ON through the same hook before the next exchange, so when any rank fails
+ * every rank returns an error and no operator (the failing rank its own message, the others "rank r failed") -- nobody is left
+ * waiting in an exchange.  The one exception: a rank that cannot allocate the staging buffers of the metadata exchange itself
+ * (P-length tables, the request lists) returns alone; that is fatal for the job. */
 int lk_linop_csr_create_sharded(lk_context_t ctx, int dtype, int64_t n_global, const int64_t *row_starts, const int64_t *rowptr,
                                 const int32_t *colind, const void *vals, lk_linop_t *op);
 /* 5-point Laplacian on an N x N grid, Dirichlet, scaled by (N+1)^2 (BASELINE config 3).

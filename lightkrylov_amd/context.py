@@ -73,9 +73,20 @@ class Context:
         self.rank = dist.get_rank(pg)
         ext_stream_cache = {}
         view_cache = {}
+        # LK_TRACE_COLLECTIVES=1: one stderr line when a data-path collective is entered and one when it returns (sequence number,
+        # kind, count) -- with every rank's last lines side by side a stalled job shows whether the ranks sit in the SAME call
+        trace = os.environ.get("LK_TRACE_COLLECTIVES", "0") not in ("", "0")
+        seq = [0]
+
+        def _trace(what, count, phase):
+            import sys
+            print(f"[lightkrylov_amd] rank {self.rank}/{self.nranks} collective #{seq[0]} {what} count={int(count)} {phase}", file=sys.stderr, flush=True)
 
         def _allreduce(_user, dev_ptr, count, stream_ptr):
             try:
+                if trace:
+                    seq[0] += 1
+                    _trace("all_reduce", count, "enter")
                 key = (int(dev_ptr), int(count))
                 t = view_cache.get(key)
                 if t is None:
@@ -91,6 +102,8 @@ class Context:
                         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
                 else:
                     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
+                if trace:
+                    _trace("all_reduce", count, "done")
                 return 0
             except Exception as exc:  # noqa: BLE001 - must not propagate through C
                 import sys

@@ -86,6 +86,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
+    int wide_regs = 1;         // 129..256 real / 129..192 complex basis columns on wide REGISTER tiles (8 waves x 32 / 24 columns) instead of the lane split
     int cplx_wide = 32;        // complex sweeps with 8 waves x 16 columns per block when k exceeds this (0: never) instead of 16 x 8
     // reduction workspace
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
@@ -414,7 +415,7 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
                  const double *hin2, int store, double *out) {
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr bool UPDATE = MODE != 1, DOT = MODE <= 2;
-    static_assert(KC * NW * SC == KMAX_FUSED * SC && KMAX_FUSED * SC <= KMAX_WIDE, "fused capacity");
+    static_assert(KC * NW * SC >= KMAX_FUSED && KC * NW * SC <= KMAX_WIDE, "fused capacity");
     if (k > KC * NW * SC) return fail(LK_ERR_INVALID, "internal: sweep of %d columns on a block that holds %d", k, KC * NW * SC);
     SweepCfg s = sweep_cfg<CPLX, KC, NW, SC>(c, k, n, MODE == 2 ? c->grid_mult_s2 : (MODE == 4 ? c->grid_mult_s3 : 0));
     // ALGORITHMIC bytes of the three-sweep schedule: k+1 | k+2 | k+2 columns
@@ -493,15 +494,25 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
     lk_context_t c = Bx->ctx;
     const double *X = Bx->col(c0);
     if (k > KMAX_FUSED) {
-        // wide basis (129..512 columns): 8 waves x 16 columns with the lanes of every wave split 2 / 4 ways over column
-        // groups, so that the block still holds ALL k columns of its (shorter) tile: one pass over X per sweep.  The split
-        // depends on k only, so the three sweeps of one DGS share it (sweep 3 re-forms y' in sweep 2's order).
-        const bool two = k <= 2 * KMAX_FUSED;
-        if (Bx->dtype == LK_C128)
-            return two ? launch_sweep<true, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
-                       : launch_sweep<true, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
-        return two ? launch_sweep<false, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
-                   : launch_sweep<false, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        // wide basis (129..512 columns): the block still holds ALL k columns of its tile, so every sweep is one pass over X.
+        // Just beyond 128 columns the REGISTER tile grows instead of the lanes splitting (round 4; "wide_regs", 0 = the round-3
+        // lane split everywhere): 8 waves x 32 columns of a full-height 128-row tile for 129..256 real columns, 8 x 24 for
+        // 129..192 complex ones -- with the lane split a basis of 129 columns left 7 of a lane group's 16 register columns empty
+        // and ran tiles half as tall (5.9 / 4.8 TB/s against 6.7 at k = 128).  Beyond that the 64 lanes of every wave split 2 / 4
+        // ways over column groups (8 x 16 columns per group, tiles 1/2 / 1/4 as tall).  The shape depends on k only, so the three
+        // sweeps of one DGS share it (sweep 3 re-forms y' in sweep 2's order).
+        // (the dot-only sweep, when it runs as a panel_sweep at all -- "dot_colwise" = 0 --, keeps the lane split: its 32-column
+        // register tile would spill, and no other sweep has to share its summation order)
+        const bool regs = c->wide_regs && MODE != 1;
+        if (Bx->dtype == LK_C128) {
+            if (regs && k <= 192) return launch_sweep<true, MODE, 24, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            return k <= 2 * KMAX_FUSED ? launch_sweep<true, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
+                                       : launch_sweep<true, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        }
+        if (k <= 2 * KMAX_FUSED)
+            return regs ? launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
+                                : launch_sweep<false, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        return launch_sweep<false, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
     }
     if (Bx->dtype == LK_C128) {
         // complex block shape: 16 waves x 8 columns for narrow bases, 8 waves x 16 columns beyond 32 columns (half the
@@ -1215,6 +1226,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
+    if (!strcmp(key, "wide_regs")) { c->wide_regs = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value < 0 ? 0 : value; return LK_OK; }
     if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }
     if (!strcmp(key, "pool_slab_cols")) {
@@ -2423,6 +2435,22 @@ static int host_allgatherv(lk_context_t c, const std::vector<double> &mine, cons
     return rc;
 }
 
+// A COLLECTIVE creation routine must not leave a rank behind: a rank that returned early (a bad column index, a failed
+// allocation) would let the others wait for it in the next exchange for ever.  Every rank contributes its local status; when any
+// rank failed, EVERY rank returns an error -- its own where it has one, otherwise one naming the first rank that failed.  One
+// tiny all-gather through the data-path hook + a stream synchronisation: creation time only.
+static int agree_status(lk_context_t c, int rc_local, const char *what) {
+    if (c->nranks <= 1) return rc_local;
+    std::vector<double> mine(1, (double)rc_local), all;
+    const int xrc = host_allgatherv(c, mine, std::vector<int64_t>((size_t)c->nranks, 1), all);
+    if (xrc != LK_OK) return rc_local != LK_OK ? rc_local : xrc;
+    if (rc_local != LK_OK) return rc_local;                   // lk_last_error already says why
+    for (int r = 0; r < c->nranks; ++r)
+        if (all[(size_t)r] != 0.0)
+            return fail(LK_ERR_COMM, "%s: rank %d failed (status %d); every rank returns without the operator", what, r, (int)all[(size_t)r]);
+    return LK_OK;
+}
+
 // Decide and set up the compressed exchange of a row-sharded CSR operator (COLLECTIVE: every rank calls it at creation).  On
 // return `cols` holds the column indices csr[0] is uploaded with: remapped to [own rows | packed remote entries] when o->cx, the
 // global ones otherwise.  The exchange is compressed when what travels is less than half of x (stencils, banded matrices: a few
@@ -2440,17 +2468,36 @@ static int csr_compress_setup(lk_linop_t o, lk_context_t c, const int64_t *row_s
         while (lo + 1 < P && row_starts[lo + 1] <= j) ++lo;      // empty blocks share a start
         return lo;
     };
-    // what I need from whom
-    std::vector<std::vector<int64_t>> need(P);
+    // what I need from whom: the out-of-block column indices, sorted and unique -- owners hold contiguous row ranges, so the
+    // sorted list falls apart into one run per owner (4 bytes per remote entry of transient memory, no per-owner vectors)
+    std::vector<int32_t> rem;
     for (int64_t p = 0; p < nnz; ++p) {
         const int64_t j = colind[p];
-        if (j < row0 || j >= row0 + n) need[owner(j)].push_back(j);
+        if (j < row0 || j >= row0 + n) rem.push_back((int32_t)j);
     }
-    for (auto &v : need) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
-    // everybody learns everybody's requests: first the P x P table of list lengths, then the lists
+    std::sort(rem.begin(), rem.end());
+    rem.erase(std::unique(rem.begin(), rem.end()), rem.end());
+    std::vector<std::vector<int64_t>> need(P);
+    for (int32_t j : rem) need[owner(j)].push_back(j);
+    std::vector<int32_t>().swap(rem);
+    // everybody learns everybody's request COUNTS (a P x P table); the lists themselves travel only when the compressed exchange
+    // can still pay off: what anybody needs of rank r's block is at least the longest single request for it, so
+    // 2 * sum_r max_q count[q][r] >= n_global already means "half of x or more travels anyway" -- decided from the table every
+    // rank holds identically, before the O(P * requests) exchange of the lists (matrices whose rows reach widely)
     std::vector<double> mycnt(P), allcnt;
     for (int r = 0; r < P; ++r) mycnt[r] = (double)need[r].size();
     LKCHK(host_allgatherv(c, mycnt, std::vector<int64_t>(P, P), allcnt));
+    int64_t maxn = 0;
+    for (int r = 0; r < P; ++r) maxn = std::max(maxn, row_starts[r + 1] - row_starts[r]);
+    {
+        int64_t lower = 0;
+        for (int r = 0; r < P; ++r) {
+            int64_t mx = 0;
+            for (int q = 0; q < P; ++q) mx = std::max(mx, (int64_t)allcnt[(size_t)q * P + r]);
+            lower += mx;
+        }
+        if (2 * lower >= n_global) return LK_OK;
+    }
     std::vector<int64_t> listlen(P, 0);
     for (int q = 0; q < P; ++q) for (int r = 0; r < P; ++r) listlen[q] += (int64_t)allcnt[(size_t)q * P + r];
     std::vector<double> mylist, alllist;
@@ -2470,8 +2517,6 @@ static int csr_compress_setup(lk_linop_t o, lk_context_t c, const int64_t *row_s
     }
     int64_t total = 0;
     for (int r = 0; r < P; ++r) total += (int64_t)S[r].size();
-    int64_t maxn = 0;
-    for (int r = 0; r < P; ++r) maxn = std::max(maxn, row_starts[r + 1] - row_starts[r]);
     // nearly all of x travels anyway, or the remapped indices would not fit: plain all-gather.  Decided from quantities every rank
     // holds identically (a rank that chose differently would issue a different collective)
     if (2 * total >= n_global || maxn + total > 2147483647LL) return LK_OK;
@@ -2497,21 +2542,36 @@ static int csr_compress_setup(lk_linop_t o, lk_context_t c, const int64_t *row_s
     return LK_OK;
 }
 
-int lk_linop_csr_create_sharded(lk_context_t c, int dtype, int64_t n_global, const int64_t *row_starts, const int64_t *rowptr,
-                                const int32_t *colind, const void *vals, lk_linop_t *op) {
-    if (!c || !rowptr || !op || !row_starts) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null argument");
-    DevGuard dev_guard(c);
+// local (rank-private) validation of a row block: nothing here talks to another rank
+static int csr_validate_rows(lk_context_t c, int dtype, int64_t n_global, const int64_t *row_starts, const int64_t *rowptr, const int32_t *colind,
+                             const void *vals) {
+    if (!rowptr) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null rowptr (this rank's row block was rejected by the caller)");
     if (dtype != LK_F64 && dtype != LK_C128) return fail(LK_ERR_INVALID, "lk_linop_csr_create: bad dtype %d", dtype);
     if (n_global < 0 || n_global > 2147483647LL) return fail(LK_ERR_INVALID, "lk_linop_csr_create: bad size %lld", (long long)n_global);
     const int64_t n = row_starts[c->rank + 1] - row_starts[c->rank];      // rows held here; column indices are GLOBAL
     if (n < 0) return fail(LK_ERR_INVALID, "lk_linop_csr_create: row_starts decreases");
     if (rowptr[0] != 0) return fail(LK_ERR_INVALID, "lk_linop_csr_create: rowptr must be 0-based");
-    const int64_t nnz = rowptr[n];
-    if (nnz > 0 && (!colind || !vals)) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null colind / vals");
     for (int64_t i = 0; i < n; ++i)
         if (rowptr[i + 1] < rowptr[i]) return fail(LK_ERR_INVALID, "lk_linop_csr_create: rowptr decreases at row %lld", (long long)i);
+    const int64_t nnz = rowptr[n];
+    if (nnz > 0 && (!colind || !vals)) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null colind / vals");
     for (int64_t p = 0; p < nnz; ++p)
         if (colind[p] < 0 || colind[p] >= n_global) return fail(LK_ERR_INVALID, "lk_linop_csr_create: column index %d out of range at entry %lld", colind[p], (long long)p);
+    return LK_OK;
+}
+
+int lk_linop_csr_create_sharded(lk_context_t c, int dtype, int64_t n_global, const int64_t *row_starts, const int64_t *rowptr,
+                                const int32_t *colind, const void *vals, lk_linop_t *op) {
+    // a null context / result / partition is a programming error of the call site, identical on every rank: plain early return.
+    // A null rowptr is NOT: it is how a host-side wrapper that found this rank's input unusable (wrong number of rows, wrong
+    // value type) still joins the agreement below, so that every rank fails together (lightkrylov_amd/linops.py).
+    if (!c || !op || !row_starts) return fail(LK_ERR_INVALID, "lk_linop_csr_create: null argument");
+    DevGuard dev_guard(c);
+    // COLLECTIVE from here on.  Everything that can fail on ONE rank only (this rank's rows, this rank's allocations) is agreed
+    // on before the next exchange is entered: first the validation of the row block ...
+    LKCHK(agree_status(c, csr_validate_rows(c, dtype, n_global, row_starts, rowptr, colind, vals), "lk_linop_csr_create_sharded (validation)"));
+    const int64_t n = row_starts[c->rank + 1] - row_starts[c->rank];
+    const int64_t nnz = rowptr[n];
     const int ED = dtype == LK_C128 ? 2 : 1;
     const double *v = (const double *)vals;
     // conjugate transpose of the row block (n_global rows, LOCAL column indices) by counting sort over the column indices
@@ -2532,11 +2592,18 @@ int lk_linop_csr_create_sharded(lk_context_t c, int dtype, int64_t n_global, con
     }
     lk_linop_t o = new lk_linop_s();
     o->ctx = c; o->kind = OP_CSR; o->dtype = dtype;
-    int rc = shard_setup(o, c, n_global, row_starts, "lk_linop_csr_create");
+    // ... then this rank's share of the set-up that precedes the metadata exchange (the gathered-x buffer) ...
+    int rc = agree_status(c, shard_setup(o, c, n_global, row_starts, "lk_linop_csr_create"), "lk_linop_csr_create_sharded (buffers)");
     std::vector<int32_t> cols0;
-    if (rc == LK_OK) rc = csr_compress_setup(o, c, row_starts, n, rowptr, colind, cols0);
-    if (rc == LK_OK) rc = csr_upload(o, 0, n, rowptr, cols0.data(), v, ED);
-    if (rc == LK_OK) rc = csr_upload(o, 1, n_global, tp.data(), tc.data(), tv.data(), ED);
+    if (rc == LK_OK) {
+        // ... the metadata exchange itself (its decisions come from quantities every rank holds identically; its staging buffers
+        // are a few P-length tables and the request lists -- a rank that cannot allocate THOSE is fatal for the job, see header) ...
+        rc = csr_compress_setup(o, c, row_starts, n, rowptr, colind, cols0);
+        if (rc == LK_OK) rc = csr_upload(o, 0, n, rowptr, cols0.data(), v, ED);
+        if (rc == LK_OK) rc = csr_upload(o, 1, n_global, tp.data(), tc.data(), tv.data(), ED);
+        // ... and finally the uploads: an operator exists on every rank or on none
+        rc = agree_status(c, rc, "lk_linop_csr_create_sharded (upload)");
+    }
     if (rc != LK_OK) { (void)lk_linop_destroy(o); return rc; }
     *op = o;
     return LK_OK;

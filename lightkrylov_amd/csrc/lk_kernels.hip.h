@@ -168,6 +168,22 @@ __device__ __forceinline__ void load_cols(const double *__restrict__ Xw, int64_t
     }
 }
 
+// Wide register tiles (KC > 16, SC = 1): the lane's rows of columns [0, nc) of a tile whose first row `Xt` points at (a
+// wave-uniform pointer: scalar registers) -- each column's address is a scalar base plus ONE 32-bit lane offset
+// (`global_load_dwordx4 v, v_off, s[base:base+1]`), where the generic path keeps a 64-bit VGPR address per column: 2 * KC
+// vector registers that a 24- / 32-column tile does not have to spare.  `full` tiles only (the ragged tile takes load_cols).
+template <int KC>
+__device__ __forceinline__ void load_cols_sbase(const double *__restrict__ Xt, int64_t colstride, uint32_t lane_bytes, int nc,
+                                                v2d (&xv)[KC]) {
+#pragma unroll
+    for (int jj = 0; jj < KC; ++jj) {
+        if (jj < nc) {
+            const char *cb = reinterpret_cast<const char *>(Xt + jj * colstride);
+            xv[jj] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(cb + lane_bytes));
+        } else xv[jj] = v2d{0.0, 0.0};
+    }
+}
+
 template <bool CPLX, int KC, bool UNIFORM = true>
 __device__ __forceinline__ void load_tile(const double *__restrict__ Xw, int64_t colstride, const double *__restrict__ y,
                                           int64_t r, int64_t n, bool full, int nc, v2d (&xv)[KC], v2d &yv) {
@@ -285,9 +301,16 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
         }
     };
 
-    v2d acc[KC];  // real: (sum over even rows, sum over odd rows) ; complex: (re, im)
+    // real: (sum over even rows, sum over odd rows) ; complex: (re, im).  The wide register tiles of the real kind (KC > 16)
+    // keep ONE accumulator per column (both rows of the lane through the same chain): 2 * KC registers less.
+    constexpr bool BIG = KC > 16;               // wide register tile: scalar-base addressing (SC = 1), slim accumulators
+    constexpr bool ACC1 = BIG && !CPLX;
+    v2d acc[ACC1 ? 1 : KC];
+    double acc1[ACC1 ? KC : 1];
 #pragma unroll
-    for (int jj = 0; jj < KC; ++jj) acc[jj] = v2d{0.0, 0.0};
+    for (int jj = 0; jj < (ACC1 ? 1 : KC); ++jj) acc[jj] = v2d{0.0, 0.0};
+#pragma unroll
+    for (int jj = 0; jj < (ACC1 ? KC : 1); ++jj) acc1[jj] = 0.0;
     double nrm = 0.0;
 
     const int64_t tile_rows = (int64_t)WR * WROWS;
@@ -310,7 +333,16 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
         const bool full = (t + 1) * tile_rows <= n;   // block-uniform
         v2d xv[KC];
         v2d yv;
-        load_tile<CPLX, KC, SC == 1>(Xw, colstride, y, r, n, full, nc, xv, yv);
+        if constexpr (BIG && SC == 1) {
+            if (full) {
+                yv = load_y<CPLX>(y, r, n, true);
+                load_cols_sbase<KC>(Xw + (t * tile_rows + (int64_t)wr * WROWS) * ED, colstride, (uint32_t)(rl * ROWS * ED * 8), nc, xv);
+            } else {
+                load_tile<CPLX, KC, false>(Xw, colstride, y, r, n, false, nc, xv, yv);
+            }
+        } else {
+            load_tile<CPLX, KC, SC == 1>(Xw, colstride, y, r, n, full, nc, xv, yv);
+        }
 
         if constexpr (UPDATE) {
             v2d u = v2d{0.0, 0.0}, u2 = v2d{0.0, 0.0};
@@ -368,6 +400,7 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
 #pragma unroll
             for (int jj = 0; jj < KC; ++jj) {
                 if constexpr (CPLX) acc[jj] += cmulconj(xv[jj], yv);
+                else if constexpr (ACC1) acc1[jj] = fma(xv[jj].y, yv.y, fma(xv[jj].x, yv.x, acc1[jj]));
                 else acc[jj] += xv[jj] * yv;
             }
         }
@@ -384,7 +417,9 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
                     double re = wave_sum(acc[jj].x), im = wave_sum(acc[jj].y);
                     if (lane == 0) { red_lds[wave * SLOTS + 2 * jj] = re; red_lds[wave * SLOTS + 2 * jj + 1] = im; }
                 } else {
-                    double s = wave_sum(acc[jj].x + acc[jj].y);
+                    double s;
+                    if constexpr (ACC1) s = wave_sum(acc1[jj]);
+                    else s = wave_sum(acc[jj].x + acc[jj].y);
                     if (lane == 0) red_lds[wave * SLOTS + jj] = s;
                 }
             } else {
@@ -392,6 +427,8 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
                 if constexpr (CPLX) {
                     group_sums<SC>(acc[jj].x, a);
                     group_sums<SC>(acc[jj].y, b);
+                } else if constexpr (ACC1) {
+                    group_sums<SC>(acc1[jj], a);
                 } else {
                     group_sums<SC>(acc[jj].x + acc[jj].y, a);
                 }

@@ -225,32 +225,46 @@ class csr_linop_gpu(_engine_linop):
 
     def __init__(self, A, ctx: Context | None = None, n_global: int | None = None, row_starts=None):
         super().__init__(ctx)
-        if isinstance(A, tuple):
-            rowptr, colind, vals = A
-            n = len(rowptr) - 1
-            ncols = n if n_global is None else int(n_global)
-        else:
-            if getattr(A, "format", "csr") != "csr":
-                A = A.tocsr()
-            rowptr, colind, vals, n, ncols = A.indptr, A.indices, A.data, A.shape[0], A.shape[1]
-            if n_global is not None and ncols != n_global:
-                raise TypeError("csr_linop_gpu: the block's column count must be n_global")
-        vals = np.ascontiguousarray(vals)
-        if vals.dtype not in _DT:
-            raise TypeError("csr_linop_gpu needs float64 / complex128 values")
-        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
-        colind = np.ascontiguousarray(colind, dtype=np.int32)
-        self.dtype, self.n, self.nnz = vals.dtype, int(n), int(rowptr[-1])
-        if n_global is None and self.ctx.nranks == 1:
-            if n != ncols:
-                raise TypeError("csr_linop_gpu needs a square matrix")
-            _capi.check(self._lib.lk_linop_csr_create(self.ctx._h, _DT[vals.dtype], self.n, rowptr.ctypes.data_as(C.c_void_p),
-                                                      colind.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
-                                                      C.byref(self._h)))
-            return
-        rs = _row_starts(self.ctx, int(ncols), row_starts)
-        if int(rs[self.ctx.rank + 1] - rs[self.ctx.rank]) != self.n:
-            raise TypeError("csr_linop_gpu: the number of rows passed is not this rank's block")
+        sharded = not (n_global is None and self.ctx.nranks == 1)
+        try:
+            if isinstance(A, tuple):
+                rowptr, colind, vals = A
+                n = len(rowptr) - 1
+                ncols = n if n_global is None else int(n_global)
+            else:
+                if getattr(A, "format", "csr") != "csr":
+                    A = A.tocsr()
+                rowptr, colind, vals, n, ncols = A.indptr, A.indices, A.data, A.shape[0], A.shape[1]
+                if n_global is not None and ncols != n_global:
+                    raise TypeError("csr_linop_gpu: the block's column count must be n_global")
+            vals = np.ascontiguousarray(vals)
+            if vals.dtype not in _DT:
+                raise TypeError("csr_linop_gpu needs float64 / complex128 values")
+            rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+            colind = np.ascontiguousarray(colind, dtype=np.int32)
+            self.dtype, self.n, self.nnz = vals.dtype, int(n), int(rowptr[-1])
+            if not sharded:
+                if n != ncols:
+                    raise TypeError("csr_linop_gpu needs a square matrix")
+                _capi.check(self._lib.lk_linop_csr_create(self.ctx._h, _DT[vals.dtype], self.n, rowptr.ctypes.data_as(C.c_void_p),
+                                                          colind.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p),
+                                                          C.byref(self._h)))
+                return
+            rs = _row_starts(self.ctx, int(ncols), row_starts)
+            if int(rs[self.ctx.rank + 1] - rs[self.ctx.rank]) != self.n:
+                raise TypeError("csr_linop_gpu: the number of rows passed is not this rank's block")
+        except (TypeError, ValueError):
+            # the sharded creation is COLLECTIVE: a rank whose input is unusable must not leave the others waiting in the
+            # metadata exchange -- it joins the library's status agreement with a null row block (every rank then fails) and
+            # raises its own error afterwards
+            if sharded and self.ctx.nranks > 1:
+                try:
+                    rs = _row_starts(self.ctx, int(n_global) if n_global is not None else 0, row_starts)
+                    self._lib.lk_linop_csr_create_sharded(self.ctx._h, _capi.LK_F64, int(rs[-1]), rs.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                          None, None, None, C.byref(self._h))
+                except (TypeError, ValueError):
+                    pass                    # the partition itself is unusable: the same arguments fail on every rank alike
+            raise
         _capi.check(self._lib.lk_linop_csr_create_sharded(self.ctx._h, _DT[vals.dtype], int(ncols), rs.ctypes.data_as(C.POINTER(C.c_int64)),
                                                           rowptr.ctypes.data_as(C.c_void_p), colind.ctypes.data_as(C.c_void_p),
                                                           vals.ctypes.data_as(C.c_void_p), C.byref(self._h)))

@@ -505,8 +505,28 @@ def gmres(A: _OpBase, b: np.ndarray, x: np.ndarray, rtol: float = RTOL_DP, atol:
     return info, np.array(res)
 
 
-def krylov_schur(X: np.ndarray, H: np.ndarray, select):
-    """src/Krylov/BaseKrylov.fypp:782-834.  Returns n (number of selected eigenvalues)."""
+def _lincomb_columns(X: np.ndarray, Zc: np.ndarray, threads: int = 1) -> np.ndarray:
+    """Xw(:, j) = linear_combination(X, Zc(:, j)) for every column j -- each column is its own chain of axpbys in the reference's
+    order (AbstractVectors.fypp:605-643 loops over the columns), so running the COLUMNS on several host threads is bit-identical
+    to the sequential loop (ctypes releases the interpreter lock for the duration of a call)."""
+    q = Zc.shape[1]
+    Xw = np.zeros((X.shape[0], q), dtype=X.dtype, order="F")
+
+    def one(j):
+        Xw[:, j] = linear_combination(X, np.ascontiguousarray(Zc[:, j]))
+    if threads > 1 and q > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(min(threads, q)) as ex:
+            list(ex.map(one, range(q)))
+    else:
+        for j in range(q):
+            one(j)
+    return Xw
+
+
+def krylov_schur(X: np.ndarray, H: np.ndarray, select, threads: int = 1):
+    """src/Krylov/BaseKrylov.fypp:782-834.  Returns n (number of selected eigenvalues).  `threads` > 1: the columns of the basis
+    update on several host threads (bit-identical, see _lincomb_columns)."""
     kdim = X.shape[1] - 1
     m = H.shape[1]
     if H.dtype == np.float64:
@@ -527,9 +547,7 @@ def krylov_schur(X: np.ndarray, H: np.ndarray, select):
     H[:kdim, :] = out[0]
     Z = out[1]
     # basis update: Xwrk = X(:m) Z(:, :n) by n*m axpby;  X(:n) = Xwrk ; X(n+1) = X(kdim+1) ; rest zero
-    Xw = np.zeros((X.shape[0], n), dtype=X.dtype, order="F")
-    for j in range(n):
-        Xw[:, j] = linear_combination(X[:, :m], np.ascontiguousarray(Z[:, j]))
+    Xw = _lincomb_columns(X[:, :m], np.asarray(Z)[:, :n], threads)
     X[:, :n] = Xw
     X[:, n] = X[:, kdim]
     X[:, n + 1:] = 0
@@ -541,9 +559,13 @@ def krylov_schur(X: np.ndarray, H: np.ndarray, select):
 
 
 def eigs(A: _OpBase, x0: np.ndarray, nev: int, kdim: int | None = None, tolerance: float = RTOL_DP,
-         max_restarts: int = 1000):
+         max_restarts: int = 1000, fast: bool = False, stop_after_cycles: int | None = None):
     """Krylov-Schur eigensolver.  src/IterativeSolvers/IterativeSolvers.fypp:972-1143.
-    Returns (eigvals[nev], residuals[nev], eigvecs (n, nev), info=niter)."""
+    Returns (eigvals[nev], residuals[nev], eigvecs (n, nev), info=niter).
+    fast=True: the Arnoldi steps and the columns of the restart's basis update run through the multi-threaded, bit-identical
+    evaluation (set_threads).  stop_after_cycles = c: leave the loop after c Arnoldi cycles (each followed by its restart) whether
+    or not `nev` pairs have converged -- the reference loops for ever; the engine mirror's `max_restarts` = c - 1 is the same cut, so
+    that a fixed amount of RESTARTED work can be compared at sizes where convergence is out of reach."""
     n, dt = x0.size, x0.dtype
     kdim = 4 * nev if kdim is None else kdim
     X = np.zeros((n, kdim + 1), dtype=dt, order="F")
@@ -553,9 +575,12 @@ def eigs(A: _OpBase, x0: np.ndarray, nev: int, kdim: int | None = None, toleranc
     res = np.zeros(kdim)
     kstart, conv, niter, k = 1, 0, 0, 0
     restarts = 0
+    nthr = int(lib().ora_get_threads()) if fast else 1
     while conv < nev:
+        if stop_after_cycles is not None and restarts >= stop_after_cycles:
+            break
         for k in range(kstart, kdim + 1):
-            info = arnoldi(A, X, H, kstart=k, kend=k)                    # :1059
+            info = arnoldi(A, X, H, kstart=k, kend=k, fast=fast)         # :1059
             w, vr = eig(np.asfortranarray(H[:k, :k]))                    # :1065
             beta = H[k, k - 1]
             if dt == np.complex128:
@@ -577,7 +602,7 @@ def eigs(A: _OpBase, x0: np.ndarray, nev: int, kdim: int | None = None, toleranc
         if restarts > max_restarts:
             raise RuntimeError("oracle eigs: too many restarts")
         # NB the reference restarts unconditionally, also after convergence (:1100)
-        nsel = krylov_schur(X, H, lambda lam: np.abs(lam) > np.median(np.abs(lam)))
+        nsel = krylov_schur(X, H, lambda lam: np.abs(lam) > np.median(np.abs(lam)), threads=nthr)
         kstart = nsel + 1
     k = min(k, kdim)
     w, vr = eig(np.asfortranarray(H[:k, :k]))                            # :1115
@@ -587,9 +612,7 @@ def eigs(A: _OpBase, x0: np.ndarray, nev: int, kdim: int | None = None, toleranc
     vfull = np.zeros((kdim, kdim), dtype=vr.dtype)
     vfull[:k, :k] = vr
     wsorted, vsorted, rsorted = wfull[idx], vfull[:, idx], res[idx]
-    vecs = np.zeros((n, nev), dtype=dt, order="F")
-    for i in range(nev):                                                 # :1127-1132
-        vecs[:, i] = linear_combination(X[:, :k], np.ascontiguousarray(vsorted[:k, i].astype(dt)))
+    vecs = _lincomb_columns(X[:, :k], np.asfortranarray(vsorted[:k, :nev].astype(dt)), nthr)   # :1127-1132
     return wsorted[:nev], rsorted[:nev], vecs, niter
 
 

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as ora
-from tests._tol import assert_close, assert_columns_close, assert_ritz_close, gmres_condition
+from tests._tol import assert_close, assert_columns_close, assert_ritz_close
 from tests.golden.make_golden import GL_REF, arnoldi_diag, cfg1_matrix, diag_values, gl_reference_size, seeded
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -127,6 +127,5 @@ def test_engine_reproduces_gmres_fixture(ctx):
     assert info == int(z["info"]) and len(meta.res) == len(z["res"])
     assert_close(np.array(meta.res), z["res"], "gmres Poisson 64 fixture: residual history", scale=z["res"][0])
     xa = x.to_array()
-    kap = gmres_condition(lk.laplacian2d_linop_gpu(N, ctx), b, 30, ctx)
-    assert_close(np.linalg.norm(xa), float(z["x_norm"]), "gmres Poisson 64 fixture: |x|", kappa=kap)
-    assert_close(xa[:64], z["x_head"], "gmres Poisson 64 fixture: head of x", scale=np.abs(xa).max(), kappa=kap)
+    assert_close(np.linalg.norm(xa), float(z["x_norm"]), "gmres Poisson 64 fixture: |x|")
+    assert_close(xa[:64], z["x_head"], "gmres Poisson 64 fixture: head of x", scale=np.abs(xa).max())

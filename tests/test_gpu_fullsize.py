@@ -18,7 +18,7 @@ import pytest
 import lightkrylov_amd as lk
 from lightkrylov_amd import _capi
 from oracle import oracle as ora
-from tests._tol import assert_close, gmres_condition, assert_columns_close, assert_ritz_close, ritz_condition
+from tests._tol import assert_close, assert_columns_close, assert_ritz_close, ritz_condition
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -154,8 +154,7 @@ def test_config3_full_size_gmres_against_live_oracle(ctx):
         ora.set_threads(1)
     assert info == info_o and len(meta.res) == len(res_o)
     assert_close(np.array(meta.res), res_o, "configs[2] full size gmres: residual history vs live oracle", scale=res_o[0])
-    assert_close(x.to_array(), xo, "configs[2] full size gmres: solution vs live oracle",
-                 kappa=gmres_condition(lk.laplacian2d_linop_gpu(N, ctx), b, 30, ctx))
+    assert_close(x.to_array(), xo, "configs[2] full size gmres: solution vs live oracle")
 
 
 def test_config4_size_complex_arnoldi_against_live_oracle(ctx):
@@ -230,6 +229,45 @@ def test_config4_on_its_own_operator_against_live_oracle(ctx, capsys):
         print(f"\n  GL n = 1e6, kdim = 128: max normwise |dH| per column {worst:.2e}; step amplification ||H(:,j)||/|H(j+1,j)| max "
               f"{amp.max():.2f}; Ritz condition numbers: max {kap.max():.2e} (8 leading: {k8:.2e}); Ritz differences / ||H||: all "
               f"{wall:.2e}, 8 leading {w8:.2e}")
+
+
+def test_config4_restarted_eigs_against_live_oracle(ctx, capsys):
+    """BASELINE configs[3], the RESTART loop at full size (IterativeSolvers.fypp:1059-1100): eigs(nev = 8, kdim = 128) on the
+    Ginzburg-Landau stepper, complex(dp), n = 10^6, cut after three Arnoldi cycles = three Krylov-Schur restarts (on a domain this
+    long the spectrum is too clustered to converge in a test's time; the reference would loop on) -- engine (`max_restarts` = 2)
+    against a LIVE oracle run of the same cut (`stop_after_cycles` = 3; Arnoldi steps and the columns of X <- X Z on the host
+    threads, bit-identical to its one-thread restatement: tests/test_oracle_fast.py).  Same number of Arnoldi steps; the returned
+    eigenvalues within 1e-12 * kappa_i * ||H|| with kappa_i the condition number of the Ritz value COMPUTED from the first cycle's
+    Hessenberg matrix (the matrix both runs restart from), the residual estimates within the same bound relative to |beta|."""
+    n, nev, kdim = 1_000_000, 8, 128
+    A = lk.ginzburg_landau_linop_gpu(n, ctx, tau=0.01, nsub=1)
+    p = A.params
+    Ao = ora.GLOp(n, p["dx"], 0.01, 1, p["nu"], p["gamma"], p["mu_c"], p["mu2"])
+    x0 = np.empty(n, dtype=np.complex128)
+    ora.fill_counter(x0, 13)
+    X = lk.krylov_basis_gpu(n, nev, np.complex128, ctx)
+    vals, res, info = lk.eigs(A, X, x0=lk.dense_vector_gpu.from_array(x0, ctx), kdim=kdim, tolerance=1e-30, max_restarts=2)
+    # the first cycle's Hessenberg matrix, for the condition numbers (the engine's own: same operator, same start)
+    Xc = lk.krylov_basis_gpu(n, kdim + 1, np.complex128, ctx)
+    Xc.upload((x0 / np.linalg.norm(x0)).reshape(-1, 1), 0)
+    H1 = np.zeros((kdim + 1, kdim), dtype=np.complex128, order="F")
+    assert lk.arnoldi(A, Xc, H1) == 0
+    del Xc
+    ora.set_threads(min(64, ora.max_threads()))
+    try:
+        vo, ro, Vo, info_o = ora.eigs(Ao, x0.copy(), nev, kdim, 1e-30, fast=True, stop_after_cycles=3)
+    finally:
+        ora.set_threads(1)
+    assert info == info_o and info > kdim + 2                            # >= 2 restarts really happened
+    worst, kmax = assert_ritz_close(vals, vo, H1[:kdim, :kdim], "configs[3] restarted eigs (3 cycles), n = 1e6: returned eigenvalues")
+    hn = np.linalg.norm(H1[:kdim, :kdim], 2)
+    rerr = assert_close(res, ro, "configs[3] restarted eigs (3 cycles), n = 1e6: residual estimates", scale=hn, kappa=kmax)
+    V = X.download()
+    vdiff = max(min(np.linalg.norm(V[:, i] - ph * Vo[:, i]) for ph in (np.vdot(Vo[:, i], V[:, i]) / abs(np.vdot(Vo[:, i], V[:, i])),))
+                for i in range(nev))
+    with capsys.disabled():
+        print(f"\n  restarted eigs n = 1e6, kdim = 128, 3 cycles ({info} Arnoldi steps): eigenvalue differences / ||H|| {worst:.2e} (max kappa "
+              f"{kmax:.2e}), residual estimates {rerr:.2e}, eigenvectors (phase-aligned) {vdiff:.2e}")
 
 
 @pytest.mark.parametrize("dtype,n,k", [(np.float64, 2_000_003, 256), (np.float64, 1_000_001, 512), (np.complex128, 1_000_001, 384)])

@@ -11,7 +11,7 @@ import pytest
 
 import lightkrylov_amd as lk
 from oracle import oracle as ora
-from tests._tol import assert_close, assert_columns_close, assert_ritz_close, gmres_condition
+from tests._tol import assert_close, assert_columns_close, assert_ritz_close
 
 pytestmark = pytest.mark.gpu
 
@@ -385,7 +385,7 @@ def test_gmres_poisson_against_oracle(ctx):
     assert info == info_o
     assert len(meta.res) == len(res_o)
     assert_close(np.array(meta.res), res_o, "gmres Poisson N=96: residual history vs oracle", scale=res_o[0])
-    assert_close(x.to_array(), xo, "gmres Poisson N=96: solution vs oracle", kappa=gmres_condition(lk.laplacian2d_linop_gpu(N, ctx), b, 30, ctx))
+    assert_close(x.to_array(), xo, "gmres Poisson N=96: solution vs oracle")
 
 
 # ----------------------------------------------------------------------------- size-independent properties

@@ -13,7 +13,7 @@ import pytest
 import lightkrylov_amd as lk
 from lightkrylov_amd import _capi
 from lightkrylov_amd.context import _DevMem
-from tests._tol import assert_close, gmres_condition
+from tests._tol import assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -277,7 +277,7 @@ def test_sharded_laplacian_matvec_and_gmres(ctx, nranks):
     xs = np.concatenate([r[1] for r in res])
     assert all(r[2] == info1 for r in res)
     assert np.abs(res[0][3] - np.array(m1.res)).max() <= 1e-12 * m1.res[0]
-    assert_close(xs, x1.to_array(), "sharded stencil gmres: solution vs single rank", kappa=gmres_condition(A1, b_full, 20, ctx))
+    assert_close(xs, x1.to_array(), "sharded stencil gmres: solution vs single rank")
     assert halo.calls >= 20
 
 
@@ -533,7 +533,7 @@ def test_sharded_csr_linop_matvec_rmatvec_and_gmres(ctx, dtype, nranks):
     xs = np.concatenate([r[0] for r in res2])
     assert all(r[1] == info1 for r in res2)
     assert_close(res2[0][2], np.array(m1.res), "sharded CSR gmres: residual history vs single rank", scale=m1.res[0])
-    assert_close(xs, x1.to_array(), "sharded CSR gmres: solution vs single rank", kappa=gmres_condition(A1, b_full, 20, ctx))
+    assert_close(xs, x1.to_array(), "sharded CSR gmres: solution vs single rank")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
@@ -613,3 +613,45 @@ def test_sharded_csr_compressed_exchange_on_a_banded_matrix(ctx, dtype, nranks):
     assert volumes["banded"][-1] == volumes["banded"][-2] <= 2 * bw * (nranks - 1) * 2 * ED
     # one dense row: (nearly) everything would travel -> the whole x is gathered
     assert volumes["one dense row"][-1] == n * ED
+
+
+@pytest.mark.parametrize("fault", ["column index", "rows", "value type"])
+def test_sharded_csr_creation_fails_on_every_rank_together(ctx, fault):
+    """lk_linop_csr_create_sharded is COLLECTIVE in its errors too: ONE rank's row block is unusable (a column index out of range:
+    caught by the library's validation; the wrong number of rows / values of the wrong type: caught by the python wrapper) and
+    EVERY rank comes back with an error -- the faulty rank with its own message, the others naming the rank that failed -- instead of
+    waiting for it in the metadata exchange.  The ranks then create the operator properly: nothing was left half-built."""
+    import scipy.sparse as sp
+    from oracle import oracle as ora
+    nn, nranks, bad = 600, 3, 1
+    L = sp.diags([1.0, -2.0, 1.0], [-1, 0, 1], shape=(nn, nn)).tocsr()
+    x_full = np.empty(nn); ora.fill_counter(x_full, 5)
+
+    def body(rank, c, row0, nl):
+        blk = L[row0:row0 + nl, :].copy()
+        if rank == bad and fault == "column index":
+            blk = (blk.indptr.copy(), np.where(np.arange(blk.nnz) == 7, nn + 3, blk.indices).astype(np.int32), blk.data.copy())
+        elif rank == bad and fault == "rows":
+            blk = L[row0:row0 + nl - 1, :].copy()
+        elif rank == bad and fault == "value type":
+            blk = blk.astype(np.float32)
+        try:
+            lk.csr_linop_gpu(blk, c, n_global=nn)
+            msg = None
+        except Exception as exc:  # noqa: BLE001
+            msg = f"{type(exc).__name__}: {exc}"
+        A = lk.csr_linop_gpu(L[row0:row0 + nl, :], c, n_global=nn)          # the communicator is still usable, on every rank
+        v = lk.dense_vector_gpu.from_array(x_full[row0:row0 + nl], c)
+        w = v.zeros_like()
+        A.apply_matvec(v, w)
+        return msg, w.to_array()
+
+    res, _ = _sharded_with_allgather(nn, nranks, body)
+    msgs = [r[0] for r in res]
+    assert all(m is not None for m in msgs), msgs
+    want = {"column index": "out of range", "rows": "not this rank's block", "value type": "float64 / complex128"}[fault]
+    assert want in msgs[bad], msgs
+    for r in range(nranks):
+        if r != bad:
+            assert f"rank {bad} failed" in msgs[r], msgs
+    assert np.abs(np.concatenate([r[1] for r in res]) - L @ x_full).max() <= 1e-13 * np.abs(x_full).max() * 4

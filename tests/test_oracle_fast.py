@@ -122,3 +122,29 @@ def test_compensated_arnoldi_close_to_sequential(dtype):
     ora.arnoldi(ora.DiagOp(d), X2, H2, mode=ora.COMPENSATED)
     err = max(np.abs(H1[:, j] - H2[:, j]).max() / np.abs(H1[:, j]).max() for j in range(m))
     assert err < 1e-13
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_restarted_eigs_on_several_threads_is_bit_identical(dtype):
+    """oracle eigs(fast=True): Arnoldi steps through the multi-threaded evaluation, the columns of the restart's basis update
+    X <- X Z(:, :n) (BaseKrylov.fypp:816-824) and of the eigenvector reconstruction on a thread pool -- the checker of the
+    restarted-eigs test at n = 10^6 -- must reproduce the one-thread restatement bit for bit; `stop_after_cycles` cuts the loop
+    after a fixed number of cycles (the reference loops until convergence)."""
+    n, nev, kdim = 1500, 3, 12
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((n, n)) / np.sqrt(n)
+    x0 = rng.standard_normal(n)
+    if np.dtype(dtype).kind == "c":
+        A = A + 1j * rng.standard_normal((n, n)) / np.sqrt(n)
+        x0 = x0 + 1j * rng.standard_normal(n)
+    A = np.asfortranarray(A.astype(dtype))
+    ref = ora.eigs(ora.DenseOp(A), x0.astype(dtype), nev, kdim, 1e-30, stop_after_cycles=3)
+    assert kdim + 2 <= ref[3] < 3 * kdim                                # one full cycle, then two from where the restarts left off
+    ora.set_threads(3)
+    try:
+        got = ora.eigs(ora.DenseOp(A), x0.astype(dtype), nev, kdim, 1e-30, stop_after_cycles=3, fast=True)
+    finally:
+        ora.set_threads(1)
+    assert got[3] == ref[3]
+    for a, b in zip(got[:3], ref[:3]):
+        assert np.array_equal(a, b)
