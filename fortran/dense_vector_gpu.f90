@@ -61,6 +61,7 @@ module lightkrylov_gpu
 
     type(c_ptr), save :: ctx = c_null_ptr
     integer(c_int64_t), save :: part_row0 = 0          ! first global row of this rank's block (lk_gpu_set_partition)
+    integer, save :: comm_nranks = 1                   ! ranks of the communicator installed by lk_gpu_comm_init (1: none)
     integer, save :: last_n = -1                       ! size of the vector bound most recently (resolve_size)
 
     !> Device storage of one vector: a column of a pool slab.  Defined assignment = deep copy.
@@ -182,6 +183,7 @@ contains
     subroutine lk_gpu_finalize()
         integer(c_int) :: rc
         rc = lk_finalize(ctx); ctx = c_null_ptr
+        comm_nranks = 1
     end subroutine
 
     !> out4 = slabs, columns ever carved, columns currently registered, acquisitions served by re-use
@@ -208,6 +210,19 @@ contains
         integer, intent(in) :: nranks, rank
         character(kind=c_char), intent(in) :: id(128)
         call chk(lk_comm_init_rank(ctx, int(nranks, c_int), int(rank, c_int), id), 'lk_gpu_comm_init')
+        comm_nranks = nranks
+    end subroutine
+
+    !> the offsets of a row-sharded operator: exactly nranks + 1 of them, from 0 to the global size (the library reads
+    !> row_starts(rank + 1) and row_starts(nranks): a shorter array would be read out of bounds)
+    subroutine check_row_starts(row_starts, n_global, procedure)
+        integer(c_int64_t), intent(in) :: row_starts(0:)
+        integer, intent(in) :: n_global
+        character(len=*), intent(in) :: procedure
+        if (size(row_starts) /= comm_nranks + 1) call stop_error( &
+            'row_starts needs nranks + 1 entries (0-based offsets of every rank''s row block; lk_gpu_comm_init first)', this_module, procedure)
+        if (row_starts(0) /= 0 .or. row_starts(comm_nranks) /= int(n_global, c_int64_t)) call stop_error( &
+            'row_starts must run from 0 to the number of columns of the row block', this_module, procedure)
     end subroutine
 
     subroutine chk(rc, procedure)
@@ -656,6 +671,7 @@ contains
         real(dp), intent(in), target :: A_rows(:, :)
         integer(c_int64_t), intent(in) :: row_starts(0:)
         type(dense_linop_gpu_rdp) :: L
+        call check_row_starts(row_starts, size(A_rows, 2), 'dense_linop_gpu (row block)')
         call chk(lk_linop_dense_create_sharded(ctx, LK_F64, int(size(A_rows, 2), c_int64_t), row_starts, c_loc(A_rows), &
                                                int(max(size(A_rows, 1), 1), c_int64_t), L%op), 'dense_linop_gpu (row block)')
     end function
@@ -663,6 +679,7 @@ contains
         complex(dp), intent(in), target :: A_rows(:, :)
         integer(c_int64_t), intent(in) :: row_starts(0:)
         type(dense_linop_gpu_cdp) :: L
+        call check_row_starts(row_starts, size(A_rows, 2), 'dense_linop_gpu (row block)')
         call chk(lk_linop_dense_create_sharded(ctx, LK_C128, int(size(A_rows, 2), c_int64_t), row_starts, c_loc(A_rows), &
                                                int(max(size(A_rows, 1), 1), c_int64_t), L%op), 'dense_linop_gpu (row block)')
     end function

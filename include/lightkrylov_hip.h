@@ -212,8 +212,9 @@ int lk_basis_download(lk_basis_t B, int col0, int ncols, void *host, int64_t ldh
  *                    of one panel and the lazy per-object path (lk_lazy_stats) can batch it;
  *   lk_pool_owner    tag a column is registered to (0: free or not a pool column; `slab` is validated
  *                    against the pool before it is dereferenced, so stale handles are safe to ask about);
- *   lk_pool_column_info  the same plus the column's GENERATION, which lk_pool_acquire increments every time it hands the
- *                    column out (first use, re-use by tag, re-use after a release).  A plugin stores the generation in its
+ *   lk_pool_column_info  the same plus the column's GENERATION: a fresh value of ONE per-context counter that only grows (never
+ *                    per slab, never reset by lk_pool_release_all: no value is ever handed out twice), assigned every time
+ *                    lk_pool_acquire hands the column out (first use, re-use by tag, re-use after a release).  A plugin stores the generation in its
  *                    handle: a bit copy of a handle whose source object has since died and been replaced at the same address
  *                    (`allocate(b, source=dense_vector_gpu(x))` followed by another temporary) carries an old generation and
  *                    is refused instead of silently reading the new occupant's data;

@@ -20,11 +20,6 @@ class _DevMem:
             "shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
 
 
-def _null_ctx():
-    import contextlib
-    return contextlib.nullcontext()
-
-
 def row_partition(n_global: int, nranks: int, rank: int):
     """Contiguous row block of `rank`: (row0, n_local).  Every block but the last has an even
     number of rows (n_global // nranks rounded down to even); the last takes the remainder."""
@@ -65,14 +60,25 @@ class Context:
 
     # -- multi-GPU: sum all-reduce of the (<= 258) reduction scalars over RCCL ------------
     def set_process_group(self, pg) -> None:
+        """Route the engine's collectives (sum all-reduce of the sweep scalars, all-gather of row blocks, neighbour exchange)
+        through a torch.distributed group.  backend "nccl" (= RCCL): on the device tensors themselves, on the engine's stream.
+        Any other backend (gloo, mpi without device support): STAGED THROUGH PINNED HOST MEMORY by this hook -- device -> host copy
+        on the engine's stream, stream synchronisation, the collective on CPU tensors, host -> device copy on the engine's stream.
+        (torch's gloo backend does accept device tensors and stages them itself, on streams and events of its own; four ranks
+        sharing one GPU stalled inside exactly that path -- every rank in the SAME all-reduce, same sequence number and count,
+        tests/test_gpu_distributed.py, round-4 record in DESIGN.md section 6 -- so the hook does the staging where it can be seen,
+        with nothing but one stream and one synchronisation.)"""
         import torch
         import torch.distributed as dist
         self._torch = torch
         self._pg = pg
         self.nranks = dist.get_world_size(pg)
         self.rank = dist.get_rank(pg)
+        on_device = dist.get_backend(pg) == "nccl"
+        dev = f"cuda:{self.device}"
         ext_stream_cache = {}
         view_cache = {}
+        host_cache = {}
         # LK_TRACE_COLLECTIVES=1: one stderr line when a data-path collective is entered and one when it returns (sequence number,
         # kind, count) -- with every rank's last lines side by side a stalled job shows whether the ranks sit in the SAME call
         trace = os.environ.get("LK_TRACE_COLLECTIVES", "0") not in ("", "0")
@@ -82,26 +88,48 @@ class Context:
             import sys
             print(f"[lightkrylov_amd] rank {self.rank}/{self.nranks} collective #{seq[0]} {what} count={int(count)} {phase}", file=sys.stderr, flush=True)
 
+        def _stream(stream_ptr):
+            sp = int(stream_ptr or 0)
+            if sp not in ext_stream_cache:
+                ext_stream_cache[sp] = torch.cuda.ExternalStream(sp, device=self.device) if sp else torch.cuda.current_stream(self.device)
+            return ext_stream_cache[sp]
+
+        def _view(ptr, count):
+            key = (int(ptr), int(count))
+            t = view_cache.get(key)
+            if t is None:
+                t = torch.as_tensor(_DevMem(*key), device=dev)
+                if len(view_cache) < 4096:
+                    view_cache[key] = t
+            return t
+
+        def _host(tag, count):
+            """pinned staging buffer (one per use and length; re-used: the engine's stream orders the copies in and out of it)"""
+            key = (tag, int(count))
+            h = host_cache.get(key)
+            if h is None:
+                h = torch.empty(int(count), dtype=torch.float64).pin_memory()
+                host_cache[key] = h
+            return h
+
+        def _src(r):
+            return dist.get_global_rank(pg, r) if pg is not None and pg is not dist.group.WORLD else r
+
         def _allreduce(_user, dev_ptr, count, stream_ptr):
             try:
                 if trace:
                     seq[0] += 1
                     _trace("all_reduce", count, "enter")
-                key = (int(dev_ptr), int(count))
-                t = view_cache.get(key)
-                if t is None:
-                    t = torch.as_tensor(_DevMem(*key), device=f"cuda:{self.device}")
-                    if len(view_cache) < 4096:
-                        view_cache[key] = t
-                sp = int(stream_ptr or 0)
-                if sp not in ext_stream_cache:
-                    ext_stream_cache[sp] = torch.cuda.ExternalStream(sp, device=self.device) if sp else None
-                st = ext_stream_cache[sp]
-                if st is not None:
-                    with torch.cuda.stream(st):
+                t, st = _view(dev_ptr, count), _stream(stream_ptr)
+                with torch.cuda.stream(st):
+                    if on_device:
                         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
-                else:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
+                    else:
+                        h = _host("ar", count)
+                        h.copy_(t, non_blocking=True)
+                        st.synchronize()
+                        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=pg)
+                        t.copy_(h, non_blocking=True)
                 if trace:
                     _trace("all_reduce", count, "done")
                 return 0
@@ -117,17 +145,34 @@ class Context:
             # every rank's row block of a vector to every rank (row-sharded dense / CSR matvec): one broadcast per block, which
             # every backend supports for unequal blocks
             try:
-                sp = int(stream_ptr or 0)
-                st = torch.cuda.ExternalStream(sp, device=self.device) if sp else None
-                with (torch.cuda.stream(st) if st is not None else _null_ctx()):
-                    mine = int(counts[self.rank])
-                    if mine:
-                        src = torch.as_tensor(_DevMem(int(send_ptr), mine), device=f"cuda:{self.device}")
-                        torch.as_tensor(_DevMem(int(recv_ptr) + 8 * int(displs[self.rank]), mine), device=f"cuda:{self.device}").copy_(src)
-                    for r in range(int(nranks)):
-                        if int(counts[r]):
-                            blk = torch.as_tensor(_DevMem(int(recv_ptr) + 8 * int(displs[r]), int(counts[r])), device=f"cuda:{self.device}")
-                            dist.broadcast(blk, src=dist.get_global_rank(pg, r) if pg is not None and pg is not dist.group.WORLD else r, group=pg)
+                cnts = [int(counts[r]) for r in range(int(nranks))]
+                offs = [int(displs[r]) for r in range(int(nranks))]
+                total = max(o + c for o, c in zip(offs, cnts)) if cnts else 0
+                if trace:
+                    seq[0] += 1
+                    _trace("all_gather", total, "enter")
+                st = _stream(stream_ptr)
+                mine = cnts[self.rank]
+                with torch.cuda.stream(st):
+                    if on_device:
+                        if mine:
+                            _view(int(recv_ptr) + 8 * offs[self.rank], mine).copy_(_view(send_ptr, mine))
+                        for r in range(int(nranks)):
+                            if cnts[r]:
+                                dist.broadcast(_view(int(recv_ptr) + 8 * offs[r], cnts[r]), src=_src(r), group=pg)
+                    elif total:
+                        h = _host("ag", total)
+                        if mine:
+                            h[offs[self.rank]:offs[self.rank] + mine].copy_(_view(send_ptr, mine), non_blocking=True)
+                        st.synchronize()
+                        for r in range(int(nranks)):
+                            if cnts[r]:
+                                dist.broadcast(h[offs[r]:offs[r] + cnts[r]], src=_src(r), group=pg)
+                        for r in range(int(nranks)):          # (the blocks may leave gaps in recv: copy block by block)
+                            if cnts[r]:
+                                _view(int(recv_ptr) + 8 * offs[r], cnts[r]).copy_(h[offs[r]:offs[r] + cnts[r]], non_blocking=True)
+                if trace:
+                    _trace("all_gather", total, "done")
                 return 0
             except Exception as exc:  # noqa: BLE001 - must not propagate through C
                 import sys
@@ -141,22 +186,29 @@ class Context:
             # nearest-neighbour exchange of the stencil operators through collectives every backend has: all ranks gather
             # every rank's two edge blocks and keep their neighbours' (the native communicator uses ncclSend / ncclRecv)
             try:
-                sp = int(stream_ptr or 0)
-                st = torch.cuda.ExternalStream(sp, device=self.device) if sp else None
-                with (torch.cuda.stream(st) if st is not None else _null_ctx()):
-                    cnt = int(count)
-                    dev = f"cuda:{self.device}"
-                    mine = torch.zeros(2 * cnt, dtype=torch.float64, device=dev)
+                cnt = int(count)
+                if trace:
+                    seq[0] += 1
+                    _trace("halo", cnt, "enter")
+                st = _stream(stream_ptr)
+                with torch.cuda.stream(st):
+                    mine = torch.zeros(2 * cnt, dtype=torch.float64, device=dev) if on_device else _host("halo", 2 * cnt)
+                    if not on_device:
+                        mine.zero_()
                     if send_lo:
-                        mine[:cnt].copy_(torch.as_tensor(_DevMem(int(send_lo), cnt), device=dev))
+                        mine[:cnt].copy_(_view(send_lo, cnt), non_blocking=True)
                     if send_hi:
-                        mine[cnt:].copy_(torch.as_tensor(_DevMem(int(send_hi), cnt), device=dev))
+                        mine[cnt:].copy_(_view(send_hi, cnt), non_blocking=True)
+                    if not on_device:
+                        st.synchronize()
                     every = [torch.empty_like(mine) for _ in range(self.nranks)]
                     dist.all_gather(every, mine, group=pg)
                     if recv_lo and self.rank > 0:
-                        torch.as_tensor(_DevMem(int(recv_lo), cnt), device=dev).copy_(every[self.rank - 1][cnt:])
+                        _view(recv_lo, cnt).copy_(every[self.rank - 1][cnt:])
                     if recv_hi and self.rank + 1 < self.nranks:
-                        torch.as_tensor(_DevMem(int(recv_hi), cnt), device=dev).copy_(every[self.rank + 1][:cnt])
+                        _view(recv_hi, cnt).copy_(every[self.rank + 1][:cnt])
+                if trace:
+                    _trace("halo", cnt, "done")
                 return 0
             except Exception as exc:  # noqa: BLE001 - must not propagate through C
                 import sys

@@ -86,6 +86,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
+    int gemm_u = 4;            // k-steps of X in flight per wave of the MFMA tall-skinny product (<= 32 real / 16 complex outputs): 4 or 8
     int wide_regs = 1;         // 129..256 real / 129..192 complex basis columns on wide REGISTER tiles (8 waves x 32 / 24 columns) instead of the lane split
     int cplx_wide = 32;        // complex sweeps with 8 waves x 16 columns per block when k exceeds this (0: never) instead of 16 x 8
     // reduction workspace
@@ -197,8 +198,13 @@ struct lk_context_s {
         lk_basis_t B = nullptr;
         int used = 0;                          // columns carved so far
         std::vector<uint64_t> owner;           // owner tag per column (0 = free)
-        std::vector<uint64_t> gen;             // generation per column: +1 every time lk_pool_acquire hands the column out
+        std::vector<uint64_t> gen;             // generation per column: a fresh value of pool_epoch every time lk_pool_acquire hands the column out
     };
+    // Generations are drawn from ONE counter per context that only ever grows -- never per slab, never reset by
+    // lk_pool_release_all: a slab allocated later can land on a freed slab's heap address, and with per-slab counters its column
+    // j would be handed out with generation 1 again; a stale handle from before the release (same address, column, generation)
+    // would then pass as the new occupant's.
+    uint64_t pool_epoch = 0;
     std::vector<PoolSlab> pool;
     std::map<uint64_t, std::pair<int, int>> pool_by_tag;   // owner tag -> (slab index, column)
     std::set<std::pair<int, int>> pool_free;                // released columns, lowest first
@@ -790,6 +796,16 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     const int64_t cap = (int64_t)c->num_cu * (NG >= 8 ? 1 : (NG >= 4 && CPLX ? 2 : c->gemm_grid_mult));
     if (g > cap) g = cap;
     if (g < 1) g = 1;
+    if constexpr (NG <= 2) {
+        if (c->gemm_u == 8) {                    // A/B knob "gemm_u": 8 k-steps (16 loads of 16 B per lane) in flight instead of 4
+            if (lds > 48 * 1024)
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, 8>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                               c->gemm_store_policy);
+            HIPCHK(hipGetLastError());
+            return LK_OK;
+        }
+    }
     hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
                        c->gemm_store_policy);
     HIPCHK(hipGetLastError());
@@ -1226,6 +1242,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
+    if (!strcmp(key, "gemm_u")) { c->gemm_u = value == 8 ? 8 : 4; return LK_OK; }
     if (!strcmp(key, "wide_regs")) { c->wide_regs = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value < 0 ? 0 : value; return LK_OK; }
     if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }
@@ -1447,7 +1464,7 @@ int lk_pool_acquire(lk_context_t c, int dtype, int64_t n_local, uint64_t tag, lk
         const int si = it->second.first, cj = it->second.second;
         if (matches(si)) {                                   // the object that lived at this address is gone: re-use
             *slab = c->pool[si].B; *col = cj;
-            c->pool[si].gen[cj] += 1;                        // bit copies of the previous occupant's handle are stale from here on
+            c->pool[si].gen[cj] = ++c->pool_epoch;           // bit copies of the previous occupant's handle are stale from here on
             c->pool_stats[1] += 1;
             return LK_OK;
         }
@@ -1460,7 +1477,7 @@ int lk_pool_acquire(lk_context_t c, int dtype, int64_t n_local, uint64_t tag, lk
         const int si = f->first, cj = f->second;
         c->pool_free.erase(f);
         c->pool[si].owner[cj] = tag;
-        c->pool[si].gen[cj] += 1;
+        c->pool[si].gen[cj] = ++c->pool_epoch;
         c->pool_by_tag[tag] = {si, cj};
         *slab = c->pool[si].B; *col = cj;
         c->pool_stats[1] += 1;
@@ -1501,7 +1518,7 @@ int lk_pool_acquire(lk_context_t c, int dtype, int64_t n_local, uint64_t tag, lk
     auto &ps = c->pool[si];
     const int cj = ps.used++;
     ps.owner[cj] = tag;
-    ps.gen[cj] += 1;
+    ps.gen[cj] = ++c->pool_epoch;
     c->pool_by_tag[tag] = {si, cj};
     c->pool_stats[0] += 1;
     *slab = ps.B; *col = cj;

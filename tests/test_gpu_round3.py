@@ -268,14 +268,23 @@ def test_pool_generation_counter_exposes_stale_bit_copies():
     lib, acquire, info = _pool_fns(c)
     c.set_tuning("pool_slab_cols", 8)
     a = acquire(_capi.LK_F64, 1000, 0x1000)
-    assert info(*a) == (0x1000, 1)
+    ga = info(*a)[1]
+    assert info(*a) == (0x1000, ga) and ga >= 1
     b = acquire(_capi.LK_F64, 1000, 0x2000)
-    assert info(*b) == (0x2000, 1)
-    assert acquire(_capi.LK_F64, 1000, 0x1000) == a and info(*a) == (0x1000, 2)      # same address again: same column, next generation
+    gb = info(*b)[1]
+    assert info(*b)[0] == 0x2000 and gb > ga                                          # ONE counter per context: never the same value twice
+    assert acquire(_capi.LK_F64, 1000, 0x1000) == a and info(*a)[1] > gb             # same address again: same column, a later generation
     _capi.check(lib.lk_pool_release(c._h, C.c_void_p(b[0]), b[1]))
-    assert info(*b) == (0, 1)
-    assert acquire(_capi.LK_F64, 1000, 0x3000) == b and info(*b) == (0x3000, 2)      # released column handed to another owner
+    assert info(*b) == (0, gb)
+    g3 = info(*a)[1]
+    assert acquire(_capi.LK_F64, 1000, 0x3000) == b and info(*b)[0] == 0x3000 and info(*b)[1] > g3   # released column handed to another owner
     assert info(a[0], 7) == (0, 0) and info(0xdead0, 0) == (0, 0)                     # never carved / not a slab: safe to ask
+    # a stale handle from before lk_pool_release_all must not match whatever a NEW slab hands out, even when that slab lands on
+    # the freed one's heap address and the column index is the same: generations do not restart
+    seen = {info(*a)[1], info(*b)[1]}
+    _capi.check(lib.lk_pool_release_all(c._h))
+    a2 = acquire(_capi.LK_F64, 1000, 0x1000)
+    assert info(*a2)[1] not in seen and info(*a2)[1] > max(seen)
     _capi.check(lib.lk_pool_release_all(c._h))
     c.close()
 
