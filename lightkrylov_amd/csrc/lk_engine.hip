@@ -512,12 +512,14 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
         const bool regs = c->wide_regs && MODE != 1;
         if (Bx->dtype == LK_C128) {
             if (regs && k <= 192) return launch_sweep<true, MODE, 24, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            if (regs && c->wide_regs >= 2 && k <= 384) return launch_sweep<true, MODE, 24, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
             return k <= 2 * KMAX_FUSED ? launch_sweep<true, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
                                        : launch_sweep<true, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
         }
         if (k <= 2 * KMAX_FUSED)
             return regs ? launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
-                                : launch_sweep<false, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+                        : launch_sweep<false, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        if (regs && c->wide_regs >= 2 && k <= 384) return launch_sweep<false, MODE, 24, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
         return launch_sweep<false, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
     }
     if (Bx->dtype == LK_C128) {
@@ -1243,7 +1245,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_u")) { c->gemm_u = value == 8 ? 8 : 4; return LK_OK; }
-    if (!strcmp(key, "wide_regs")) { c->wide_regs = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "wide_regs")) { c->wide_regs = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value < 0 ? 0 : value; return LK_OK; }
     if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }
     if (!strcmp(key, "pool_slab_cols")) {

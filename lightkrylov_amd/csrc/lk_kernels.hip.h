@@ -241,6 +241,7 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     constexpr int LG = 64 / SC;          // lanes per group
     constexpr int WROWS = LG * ROWS;     // rows one wave covers per tile
     constexpr int NU = TWO ? 2 : 1;
+    constexpr bool BIG = KC > 16;        // wide register tile: scalar-base addressing (SC = 1), slim accumulators
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -293,6 +294,10 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
         if constexpr (HLDS) {
             int idx = c0 + jj;
             idx = idx < CAP ? idx : CAP - 1;
+            // wide register tiles: keep the read INSIDE the tile loop (the index is laundered through an empty asm, so the
+            // compiler cannot prove it loop invariant) -- hoisted, the NU * KC coefficients cost 2-4 VGPRs each on top of a tile
+            // that already fills the register file (the real two-coefficient sweep at KC = 24 spilled 140 bytes per lane)
+            if constexpr (BIG) asm volatile("" : "+v"(idx));
             if constexpr (CPLX) return *reinterpret_cast<const v2d *>(&hc_lds[(set * CAP + idx) * 2]);
             else return v2d{hc_lds[set * CAP + idx], 0.0};
         } else {
@@ -303,7 +308,6 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
 
     // real: (sum over even rows, sum over odd rows) ; complex: (re, im).  The wide register tiles of the real kind (KC > 16)
     // keep ONE accumulator per column (both rows of the lane through the same chain): 2 * KC registers less.
-    constexpr bool BIG = KC > 16;               // wide register tile: scalar-base addressing (SC = 1), slim accumulators
     constexpr bool ACC1 = BIG && !CPLX;
     v2d acc[ACC1 ? 1 : KC];
     double acc1[ACC1 ? KC : 1];

@@ -1,5 +1,5 @@
 """Many right-hand sides: Gram / innerprod_matrix / block DGS with the X^H Y pass on the matrix cores (xhy_mfma = 1) against
-the VALU schedule (panel_dot_p, <= 4 right-hand sides per pass over X).   python tools/bench_block.py [rows]"""
+the VALU schedule (panel_dot_p, <= 4 right-hand sides per pass over X).   python tools/bench_block.py [rows] [KEY=INT ...]"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,6 +7,9 @@ import lightkrylov_amd as lk
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 ctx = lk.Context(device=0)
+for kv in sys.argv[2:]:
+    key, val = kv.split("=")
+    ctx.set_tuning(key, int(val))
 for dtype in (np.float64, np.complex128):
     nn = n if dtype == np.float64 else n // 2
     s = np.dtype(dtype).itemsize
