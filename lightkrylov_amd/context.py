@@ -62,12 +62,12 @@ class Context:
     def set_process_group(self, pg) -> None:
         """Route the engine's collectives (sum all-reduce of the sweep scalars, all-gather of row blocks, neighbour exchange)
         through a torch.distributed group.  backend "nccl" (= RCCL): on the device tensors themselves, on the engine's stream.
-        Any other backend (gloo, mpi without device support): STAGED THROUGH PINNED HOST MEMORY by this hook -- device -> host copy
-        on the engine's stream, stream synchronisation, the collective on CPU tensors, host -> device copy on the engine's stream.
+        Any other backend (gloo, mpi without device support): STAGED THROUGH HOST MEMORY by this hook -- a blocking device -> host
+        copy on the engine's stream, the collective on CPU tensors, a blocking host -> device copy on the engine's stream.
         (torch's gloo backend does accept device tensors and stages them itself, on streams and events of its own; four ranks
         sharing one GPU stalled inside exactly that path -- every rank in the SAME all-reduce, same sequence number and count,
         tests/test_gpu_distributed.py, round-4 record in DESIGN.md section 6 -- so the hook does the staging where it can be seen,
-        with nothing but one stream and one synchronisation.)"""
+        with nothing but one stream and blocking copies.)"""
         import torch
         import torch.distributed as dist
         self._torch = torch
@@ -104,11 +104,14 @@ class Context:
             return t
 
         def _host(tag, count):
-            """pinned staging buffer (one per use and length; re-used: the engine's stream orders the copies in and out of it)"""
+            """host staging buffer (one per use and length, re-used).  Plain pageable memory and BLOCKING copies on the engine's
+            stream: nothing here outlives the call -- no pinned blocks whose release the caching allocator would tie to the
+            engine's stream by events (a first version with pinned buffers and asynchronous copies crashed in the interpreter's
+            garbage collection at teardown)."""
             key = (tag, int(count))
             h = host_cache.get(key)
             if h is None:
-                h = torch.empty(int(count), dtype=torch.float64).pin_memory()
+                h = torch.empty(int(count), dtype=torch.float64)
                 host_cache[key] = h
             return h
 
@@ -126,10 +129,9 @@ class Context:
                         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=pg)
                     else:
                         h = _host("ar", count)
-                        h.copy_(t, non_blocking=True)
-                        st.synchronize()
+                        h.copy_(t)                                   # device -> host on the engine's stream, returns when done
                         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=pg)
-                        t.copy_(h, non_blocking=True)
+                        t.copy_(h)
                 if trace:
                     _trace("all_reduce", count, "done")
                 return 0
@@ -163,14 +165,13 @@ class Context:
                     elif total:
                         h = _host("ag", total)
                         if mine:
-                            h[offs[self.rank]:offs[self.rank] + mine].copy_(_view(send_ptr, mine), non_blocking=True)
-                        st.synchronize()
+                            h[offs[self.rank]:offs[self.rank] + mine].copy_(_view(send_ptr, mine))
                         for r in range(int(nranks)):
                             if cnts[r]:
                                 dist.broadcast(h[offs[r]:offs[r] + cnts[r]], src=_src(r), group=pg)
                         for r in range(int(nranks)):          # (the blocks may leave gaps in recv: copy block by block)
                             if cnts[r]:
-                                _view(int(recv_ptr) + 8 * offs[r], cnts[r]).copy_(h[offs[r]:offs[r] + cnts[r]], non_blocking=True)
+                                _view(int(recv_ptr) + 8 * offs[r], cnts[r]).copy_(h[offs[r]:offs[r] + cnts[r]])
                 if trace:
                     _trace("all_gather", total, "done")
                 return 0
@@ -196,11 +197,9 @@ class Context:
                     if not on_device:
                         mine.zero_()
                     if send_lo:
-                        mine[:cnt].copy_(_view(send_lo, cnt), non_blocking=True)
+                        mine[:cnt].copy_(_view(send_lo, cnt))
                     if send_hi:
-                        mine[cnt:].copy_(_view(send_hi, cnt), non_blocking=True)
-                    if not on_device:
-                        st.synchronize()
+                        mine[cnt:].copy_(_view(send_hi, cnt))
                     every = [torch.empty_like(mine) for _ in range(self.nranks)]
                     dist.all_gather(every, mine, group=pg)
                     if recv_lo and self.rank > 0:

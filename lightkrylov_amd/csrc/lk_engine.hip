@@ -86,8 +86,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
-    int gemm_u = 4;            // k-steps of X in flight per wave of the MFMA tall-skinny product (<= 32 real / 16 complex outputs): 4 or 8
-    int wide_regs = 1;         // 129..256 real / 129..192 complex basis columns on wide REGISTER tiles (8 waves x 32 / 24 columns) instead of the lane split
+    int wide_regs = 2;         // wide REGISTER tiles: 1 = 8 waves x 32 / 24 columns for 129..256 real / 129..192 complex basis columns instead of the lane split; 2 = also the lane split on 24-column groups for 257..384 columns; 0 = round 3's shapes
     int cplx_wide = 32;        // complex sweeps with 8 waves x 16 columns per block when k exceeds this (0: never) instead of 16 x 8
     // reduction workspace
     double *partial = nullptr;  // [(KMAX_FUSED+1)*2][MAX_GRID]
@@ -512,7 +511,7 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
         const bool regs = c->wide_regs && MODE != 1;
         if (Bx->dtype == LK_C128) {
             if (regs && k <= 192) return launch_sweep<true, MODE, 24, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
-            if (regs && c->wide_regs >= 2 && k <= 384) return launch_sweep<true, MODE, 24, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            if (regs && c->wide_regs >= 2 && k > 2 * KMAX_FUSED && k <= 384) return launch_sweep<true, MODE, 24, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
             return k <= 2 * KMAX_FUSED ? launch_sweep<true, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
                                        : launch_sweep<true, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
         }
@@ -798,16 +797,6 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     const int64_t cap = (int64_t)c->num_cu * (NG >= 8 ? 1 : (NG >= 4 && CPLX ? 2 : c->gemm_grid_mult));
     if (g > cap) g = cap;
     if (g < 1) g = 1;
-    if constexpr (NG <= 2) {
-        if (c->gemm_u == 8) {                    // A/B knob "gemm_u": 8 k-steps (16 loads of 16 B per lane) in flight instead of 4
-            if (lds > 48 * 1024)
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, 8>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                               c->gemm_store_policy);
-            HIPCHK(hipGetLastError());
-            return LK_OK;
-        }
-    }
     hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
                        c->gemm_store_policy);
     HIPCHK(hipGetLastError());
@@ -1244,7 +1233,6 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
-    if (!strcmp(key, "gemm_u")) { c->gemm_u = value == 8 ? 8 : 4; return LK_OK; }
     if (!strcmp(key, "wide_regs")) { c->wide_regs = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value < 0 ? 0 : value; return LK_OK; }
     if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }

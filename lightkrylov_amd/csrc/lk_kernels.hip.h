@@ -953,7 +953,7 @@ __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, 
 // Cp: coefficient tiles packed per lane by pack_coef_mfma: [group][k-step t][64 lanes].
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <bool CPLX, int NG, int U = 4>        // U: k-steps of X in flight per wave (2 U loads of 16 B per lane)
+template <bool CPLX, int NG>
 __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                        double *__restrict__ Y, int64_t ldy, int qn,
                                                        const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
@@ -961,6 +961,7 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
     constexpr int RG = CPLX ? 16 : 32;           // rows per row group (one MFMA N extent; x2 rows per lane for real)
     constexpr int NACC = CPLX ? 1 : 2;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int U = 4;                         // k-steps of X in flight per wave: 2 U loads of 16 B per lane (8 k-steps: null, DESIGN.md tuning log 19)
     extern __shared__ double tiles[];            // [NG][nt][64]
     const int nt = (k + 3) >> 2;
     for (int i = threadIdx.x; i < NG * nt * 64; i += blockDim.x) tiles[i] = Cp[i];
