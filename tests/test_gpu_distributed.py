@@ -90,15 +90,20 @@ def test_two_processes_on_the_row_sharded_dense_and_csr_operators(operator, rows
     assert one["roofline"]["matvec"]["launches"] == 12
 
 
-@pytest.mark.parametrize("P", [3, 4, 8])
+@pytest.mark.parametrize("P", [2, 3, 4, 8])
 def test_processes_sharing_one_gpu_shard_the_metric_workload(P):
     """BASELINE configs[4]'s partitioning (row blocks of n / P contiguous rows, the last one ragged, reductions all-reduced) with
-    P = 3, 4, 8 real processes on one GPU (gloo standing in for RCCL) at a reduced n, through the plain `--gpus P` entry: same H as
+    P = 2, 3, 4, 8 real processes on one GPU (gloo standing in for RCCL) at a reduced n, through the plain `--gpus P` entry: same H as
     the single process to rounding.  (The full-size 8-process run of the same command is recorded under profiles/.)"""
     args = ["--rows", str(1000000 * P + 2), "--kdim", "32", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py", "--gpus", "1"] + args)
-    for _ in range(int(os.environ.get("LK_TEST_REPEAT", "1"))):            # (the stress run of a round: LK_TEST_REPEAT=20)
+    import time
+    for rep in range(int(os.environ.get("LK_TEST_REPEAT", "1"))):          # (the stress run of a round: LK_TEST_REPEAT=20)
+        t0 = time.time()
         many = _run([sys.executable, "bench.py", "--gpus", str(P)] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
+        if os.environ.get("LK_STRESS_REPORT"):
+            with open(os.environ["LK_STRESS_REPORT"], "a") as f:
+                f.write(json.dumps({"P": P, "rep": rep, "seconds": round(time.time() - t0, 1), "rc": 0, "H_fro": many["config"]["H_fro"]}) + "\n")
         assert many["n_gpus"] == many["gpus_requested"] == P and many["config"]["n_local"] == 1000000 and many["config"]["info"] == 0
         assert abs(many["config"]["H_fro"] - one["config"]["H_fro"]) <= 1e-13 * one["config"]["H_fro"]
         assert abs(many["config"]["H_last_subdiag"] - one["config"]["H_last_subdiag"]) <= 1e-12 * one["config"]["H_last_subdiag"]
