@@ -86,6 +86,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
+    int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
     int wide_regs = 2;         // wide REGISTER tiles: 1 = 8 waves x 32 / 24 columns for 129..256 real / 129..192 complex basis columns instead of the lane split; 2 = also the lane split on 24-column groups for 257..384 columns; 0 = round 3's shapes
     int cplx_wide = 32;        // complex sweeps with 8 waves x 16 columns per block when k exceeds this (0: never) instead of 16 x 8
     // reduction workspace
@@ -415,14 +416,27 @@ SweepCfg sweep_cfg(lk_context_t c, int k, int64_t n, int mult = 0) {
 //   MODE 4: y'' = (y - X hin) - X hin2      (UPDATE, two coefficient sets; pairs with MODE 2, store = 0)
 // out == nullptr (update-only modes): the norm of the result is not wanted -- no finish kernel, and above all NO
 // all-reduce (the lazy flush runs at rank-dependent times; a collective there could mismatch across ranks).
-template <bool CPLX, int MODE, int KC = (CPLX ? 8 : 16), int NW = (CPLX ? 16 : 8), int SC = 1>
+// G > 1 (MODE 4 only): the two-coefficient sweep with G column groups per wave and no lane split -- the partner of a sweep 2 run
+// as launch_sweep<CPLX, 2, KC / G, NW, G>: same WC and kcw (taken from THAT configuration), so y' is re-formed bit for bit, on
+// tiles G times as tall (panel_sweep's G).
+template <bool CPLX, int MODE, int KC = (CPLX ? 8 : 16), int NW = (CPLX ? 16 : 8), int SC = 1, int G = 1>
 int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y, int64_t n, const double *hin,
                  const double *hin2, int store, double *out) {
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr bool UPDATE = MODE != 1, DOT = MODE <= 2;
     static_assert(KC * NW * SC >= KMAX_FUSED && KC * NW * SC <= KMAX_WIDE, "fused capacity");
+    static_assert(G == 1 || (MODE == 4 && SC == 1), "column groups per wave: the two-coefficient sweep only");
     if (k > KC * NW * SC) return fail(LK_ERR_INVALID, "internal: sweep of %d columns on a block that holds %d", k, KC * NW * SC);
-    SweepCfg s = sweep_cfg<CPLX, KC, NW, SC>(c, k, n, MODE == 2 ? c->grid_mult_s2 : (MODE == 4 ? c->grid_mult_s3 : 0));
+    SweepCfg s = sweep_cfg<CPLX, KC / G, NW, SC * G>(c, k, n, MODE == 2 ? c->grid_mult_s2 : (MODE == 4 ? c->grid_mult_s3 : 0));
+    if (G > 1) {                             // WC and kcw are the lane-split configuration's; the tiles are G times as tall
+        const int64_t tile_rows = (int64_t)(NW / s.WC) * 64 * K<CPLX>::ROWS;
+        s.ntiles = (n + tile_rows - 1) / tile_rows;
+        int64_t g = (int64_t)c->num_cu * (c->grid_mult_s3 > 0 ? c->grid_mult_s3 : c->grid_mult);
+        if (g > s.ntiles) g = s.ntiles;
+        if (g > MAX_GRID) g = MAX_GRID;
+        if (g < 1) g = 1;
+        s.grid = (int)g;
+    }
     // ALGORITHMIC bytes of the three-sweep schedule: k+1 | k+2 | k+2 columns
     const double bytes = (double)n * ED * 8.0 * (k + 1 + (UPDATE ? 1 : 0));
     int nblocks = s.grid;
@@ -460,7 +474,7 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
         // the sweep's two HIP events ride on the kernel's own dispatch (start / stop timestamps of the launch itself), not on
         // separate stream markers: six markers per Arnoldi step cost 3-4 % of a launch-bound factorisation (n = 10^6 complex)
         ProfScope ps(c, MODE == 1 ? "dgs_sweep1" : (MODE == 2 ? "dgs_sweep2" : "dgs_sweep3"), bytes, c->prof_ext);
-        if ((MODE == 3 && c->stream_update) || (MODE == 4 && c->stream_two)) {
+        if ((MODE == 3 && c->stream_update) || (MODE == 4 && c->stream_two && G == 1)) {
             ps.ext = false;
             if (ps.on) (void)hipEventRecord(ps.rec.e0, c->stream);
             const int64_t tile_rows = (int64_t)NW * 64 * K<CPLX>::ROWS;
@@ -475,11 +489,11 @@ int launch_sweep(lk_context_t c, const double *X, int64_t ldx, int k, double *y,
         } else {
             const int st = (store ? (1 | (c->store_policy << 1) | (c->store_split ? 8 : 0)) : 0) | (c->xcd_map ? 16 : 0);
             if (ps.on && ps.ext)
-                hipExtLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4, SC>), dim3(s.grid), dim3(NW * 64), 0, c->stream,
+                hipExtLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4, SC, G>), dim3(s.grid), dim3(NW * 64), 0, c->stream,
                                       ps.rec.e0, ps.rec.e1, 0, X, ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st,
                                       c->guard());
             else
-                hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4, SC>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
+                hipLaunchKernelGGL((panel_sweep<CPLX, KC, NW, UPDATE, DOT, MODE == 4, SC, G>), dim3(s.grid), dim3(NW * 64), 0, c->stream, X,
                                    ldx, k, y, n, hin, hin2, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, st, c->guard());
         }
     }
@@ -509,16 +523,34 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
         // (the dot-only sweep, when it runs as a panel_sweep at all -- "dot_colwise" = 0 --, keeps the lane split: its 32-column
         // register tile would spill, and no other sweep has to share its summation order)
         const bool regs = c->wide_regs && MODE != 1;
+        // "wide_s3" (round 4): where sweep 2 runs lane-split (SC = 2), the two-coefficient sweep 3 -- no accumulators to keep -- holds
+        // BOTH column groups of a wave-column in one wave's registers instead (panel_sweep's G = 2): same WC, kcw and summation
+        // order, so y' is re-formed bit for bit, on tiles twice as tall with twice the loads in flight per lane.
         if (Bx->dtype == LK_C128) {
             if (regs && k <= 192) return launch_sweep<true, MODE, 24, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
-            if (regs && c->wide_regs >= 2 && k > 2 * KMAX_FUSED && k <= 384) return launch_sweep<true, MODE, 24, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
-            return k <= 2 * KMAX_FUSED ? launch_sweep<true, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
-                                       : launch_sweep<true, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            if (regs && c->wide_regs >= 2 && k > 2 * KMAX_FUSED && k <= 384) {
+                if constexpr (MODE == 4)
+                    if (c->wide_s3) return launch_sweep<true, 4, 48, 8, 1, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+                return launch_sweep<true, MODE, 24, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            }
+            if (k <= 2 * KMAX_FUSED) {
+                if constexpr (MODE == 4)
+                    if (c->wide_s3) return launch_sweep<true, 4, 32, 8, 1, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+                return launch_sweep<true, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            }
+            return launch_sweep<true, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
         }
-        if (k <= 2 * KMAX_FUSED)
-            return regs ? launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out)
-                        : launch_sweep<false, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
-        if (regs && c->wide_regs >= 2 && k <= 384) return launch_sweep<false, MODE, 24, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        if (k <= 2 * KMAX_FUSED) {
+            if (regs) return launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            if constexpr (MODE == 4)
+                if (c->wide_s3) return launch_sweep<false, 4, 32, 8, 1, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            return launch_sweep<false, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        }
+        if (regs && c->wide_regs >= 2 && k <= 384) {
+            if constexpr (MODE == 4)
+                if (c->wide_s3) return launch_sweep<false, 4, 48, 8, 1, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            return launch_sweep<false, MODE, 24, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        }
         return launch_sweep<false, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
     }
     if (Bx->dtype == LK_C128) {
@@ -1233,6 +1265,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
+    if (!strcmp(key, "wide_s3")) { c->wide_s3 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "wide_regs")) { c->wide_regs = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value < 0 ? 0 : value; return LK_OK; }
     if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }

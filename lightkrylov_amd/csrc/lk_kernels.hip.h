@@ -226,7 +226,13 @@ __device__ __forceinline__ void store_rows(double *__restrict__ y, int64_t r, in
 // the update and the dot phase for up to 512 basis columns: ONE pass over X per sweep, 3k+4 columns per DGS, where column
 // panels of 128 cost 4k - |last panel|.  The groups' partial products meet by two cross-lane adds before the LDS exchange,
 // dots reduce per group.  SC = 1 is the narrow kernel, instruction for instruction.
-template <bool CPLX, int KC, int NW, bool UPDATE, bool DOT, bool TWO, int SC = 1>
+// G (round 4; the two-coefficient sweep 3 of a lane-split DGS): a wave holds G COLUMN GROUPS of KC / G register slots each, all
+// 64 lanes along rows (SC = 1) -- the column groups 'G wc .. G wc + G - 1' that the G lane groups of wave-column wc hold in the
+// lane-split sweep 2 with the same (WC, kcw).  Every group's share of X h1 is summed over its own columns in slot order and the
+// groups' shares are then added exactly as `across_groups` adds them, so y' = y - X h1 comes out BIT FOR BIT as sweep 2 formed it
+// (the condition for dropping the y' store), while the tile is G times as tall and every lane has G times as many loads in
+// flight: the update-only sweep has no accumulators to keep, so the registers the lane split spends on them hold columns instead.
+template <bool CPLX, int KC, int NW, bool UPDATE, bool DOT, bool TWO, int SC = 1, int G = 1>
 __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict__ X, int64_t ldx, int k,
                                                         double *__restrict__ y, int64_t n,
                                                         const double *__restrict__ hin,
@@ -235,6 +241,8 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
                                                         int WC, int kcw, int store, Guard guard) {
     static_assert(!TWO || (UPDATE && !DOT), "TWO is the update-only sweep with two coefficient sets");
     static_assert(SC == 1 || SC == 2 || SC == 4, "lane split");
+    static_assert(G == 1 || G == 2 || G == 4, "column groups per wave");
+    static_assert(G == 1 || (SC == 1 && UPDATE && !DOT && KC % G == 0), "column groups per wave: update-only sweeps without a lane split");
     if (stopped(guard)) return;
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
@@ -250,9 +258,10 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     const int WR = NW / WC;
     const int lg = SC > 1 ? lane / LG : 0;            // lane group (per lane)
     const int rl = SC > 1 ? lane % LG : lane;         // lane within its group = row pair / row index
-    const int c0 = (wc * SC + lg) * kcw;
+    constexpr int KCG = KC / G;          // register slots per column group
+    const int c0 = (wc * SC + lg) * kcw * G;
     int nc = k - c0;
-    nc = nc > kcw ? kcw : nc;
+    nc = nc > kcw * G ? kcw * G : nc;
     nc = nc < 0 ? 0 : nc;
 
     __shared__ v2d u_lds[UPDATE ? 2 * NU * NW * 64 : 1];
@@ -275,12 +284,14 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     } else if constexpr (UPDATE) {
 #pragma unroll
         for (int jj = 0; jj < KC; ++jj) {
-            if (jj < nc) {
-                if constexpr (CPLX) hc[jj] = v2d{hin[2 * (c0 + jj)], hin[2 * (c0 + jj) + 1]};
-                else hc[jj] = v2d{hin[c0 + jj], 0.0};
+            // slot jj holds column cj (G > 1: slot jj % KCG of column group jj / KCG, when that group has so many columns)
+            const int cj = G > 1 ? c0 + (jj / KCG) * kcw + (jj % KCG) : c0 + jj;
+            if (G > 1 ? ((jj % KCG) < kcw && cj < k) : (jj < nc)) {
+                if constexpr (CPLX) hc[jj] = v2d{hin[2 * cj], hin[2 * cj + 1]};
+                else hc[jj] = v2d{hin[cj], 0.0};
                 if constexpr (TWO) {
-                    if constexpr (CPLX) hc2[jj] = v2d{hin2[2 * (c0 + jj)], hin2[2 * (c0 + jj) + 1]};
-                    else hc2[jj] = v2d{hin2[c0 + jj], 0.0};
+                    if constexpr (CPLX) hc2[jj] = v2d{hin2[2 * cj], hin2[2 * cj + 1]};
+                    else hc2[jj] = v2d{hin2[cj], 0.0};
                 }
             } else {
                 hc[jj] = v2d{0.0, 0.0};
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
     // holds for the groups that own columns, and the others are clamped onto the padding's last entry)
     auto hcoef = [&](int set, int jj) -> v2d {
         if constexpr (HLDS) {
-            int idx = c0 + jj;
+            int idx = G > 1 ? c0 + (jj / KCG) * kcw + (jj % KCG) : c0 + jj;      // slot jj of group jj / KCG
             idx = idx < CAP ? idx : CAP - 1;
             // wide register tiles: keep the read INSIDE the tile loop (the index is laundered through an empty asm, so the
             // compiler cannot prove it loop invariant) -- hoisted, the NU * KC coefficients cost 2-4 VGPRs each on top of a tile
@@ -337,7 +348,27 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
         const bool full = (t + 1) * tile_rows <= n;   // block-uniform
         v2d xv[KC];
         v2d yv;
-        if constexpr (BIG && SC == 1) {
+        if constexpr (G > 1) {
+            // slot g * KCG + j <- column c0 + g * kcw + j (j < kcw, column < k); the other slots hold zeros
+            yv = load_y<CPLX>(y, r, n, full);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                int ng = nc - g * kcw;
+                ng = ng > kcw ? kcw : ng;
+                if (full) {
+                    v2d xg[KCG];
+                    load_cols_sbase<KCG>(Xw + (int64_t)g * kcw * colstride + (t * tile_rows + (int64_t)wr * WROWS) * ED, colstride,
+                                         (uint32_t)(rl * ROWS * ED * 8), ng, xg);
+#pragma unroll
+                    for (int j = 0; j < KCG; ++j) xv[g * KCG + j] = xg[j];
+                } else {
+                    v2d xg[KCG];
+                    load_cols<CPLX, KCG, false>(Xw + (int64_t)g * kcw * colstride, colstride, r, n, false, ng < 0 ? 0 : ng, xg);
+#pragma unroll
+                    for (int j = 0; j < KCG; ++j) xv[g * KCG + j] = xg[j];
+                }
+            }
+        } else if constexpr (BIG && SC == 1) {
             if (full) {
                 yv = load_y<CPLX>(y, r, n, true);
                 load_cols_sbase<KC>(Xw + (t * tile_rows + (int64_t)wr * WROWS) * ED, colstride, (uint32_t)(rl * ROWS * ED * 8), nc, xv);
@@ -350,6 +381,32 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
 
         if constexpr (UPDATE) {
             v2d u = v2d{0.0, 0.0}, u2 = v2d{0.0, 0.0};
+            if constexpr (G > 1) {
+                // per column group in slot order, then the groups' shares in the order across_groups adds them:
+                // (g0 + g1) for two groups, ((g0 + g1) + (g2 + g3)) for four
+                v2d ug[G], ug2[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    ug[g] = v2d{0.0, 0.0};
+                    ug2[g] = v2d{0.0, 0.0};
+#pragma unroll
+                    for (int j = 0; j < KCG; ++j) {
+                        const int jj = g * KCG + j;
+                        if constexpr (CPLX) ug[g] += cmul(xv[jj], hcoef(0, jj));
+                        else ug[g] += xv[jj] * hcoef(0, jj).x;
+                    }
+                    if constexpr (TWO) {
+#pragma unroll
+                        for (int j = 0; j < KCG; ++j) {
+                            const int jj = g * KCG + j;
+                            if constexpr (CPLX) ug2[g] += cmul(xv[jj], hcoef(1, jj));
+                            else ug2[g] += xv[jj] * hcoef(1, jj).x;
+                        }
+                    }
+                }
+                if constexpr (G == 2) { u = ug[0] + ug[1]; u2 = ug2[0] + ug2[1]; }
+                else { u = (ug[0] + ug[1]) + (ug[2] + ug[3]); u2 = (ug2[0] + ug2[1]) + (ug2[2] + ug2[3]); }
+            } else {
 #pragma unroll
             for (int jj = 0; jj < KC; ++jj) {
                 if constexpr (CPLX) u += cmul(xv[jj], hcoef(0, jj));
@@ -361,6 +418,7 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep(const double *__restrict_
                     if constexpr (CPLX) u2 += cmul(xv[jj], hcoef(1, jj));
                     else u2 += xv[jj] * hcoef(1, jj).x;
                 }
+            }
             }
             if constexpr (SC > 1) {                    // the lane groups of this wave hold the same rows: add their shares
                 u.x = across_groups<SC>(u.x);

@@ -114,6 +114,35 @@ def test_wide_sweep_knobs_are_result_invariant(dtype):
 
 
 @pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("k,wide_regs", [(140, 0), (200, 0), (200, 2), (256, 2), (257, 2), (300, 2), (384, 2), (300, 1)])
+def test_sweep3_with_two_column_groups_per_wave_reforms_the_same_bits(dtype, k, wide_regs):
+    """Round 4, "wide_s3": where sweep 2 of a DGS runs lane-split (two lane groups per wave), sweep 3 holds both column groups of a
+    wave-column in ONE wave's registers on tiles twice as tall.  It must re-form y' = y - X h1 exactly as sweep 2 summed it (or the
+    rounding of y' would escape the second projection), and it applies the second set in the same grouping too: the vector that
+    comes out is bit-identical to the lane-split sweep 3's, the coefficients are untouched (sweeps 1 and 2 do not change)."""
+    n = 5003
+    Q = orthonormal_basis(n, k, dtype, 11)
+    y = seeded(n, dtype, 12)
+    out = []
+    for s3 in (0, 1):
+        c = lk.Context(device=0)
+        c.set_tuning("wide_regs", wide_regs)
+        c.set_tuning("wide_s3", s3)
+        B = lk.krylov_basis_gpu(n, k + 1, dtype, c)
+        B.upload(Q, 0); B.upload(y.reshape(-1, 1), k)
+        beta = np.zeros(k, dtype=dtype)
+        assert lk.double_gram_schmidt_step(B[k], B[:k], if_chk_orthonormal=False, beta=beta) == 0
+        out.append((beta.copy(), B.download(k, 1)[:, 0].copy()))
+        del B
+        c.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1]), f"max difference {np.abs(out[0][1] - out[1][1]).max():.2e}"
+    yo = y.copy()
+    ho, _ = ora.double_gram_schmidt_step(yo, Q)
+    assert np.abs(out[1][0] - ho).max() <= 1e-12 * np.linalg.norm(y) and np.abs(out[1][1] - yo).max() <= 1e-12 * np.linalg.norm(y)
+
+
+@pytest.mark.parametrize("dtype", KINDS)
 def test_arnoldi_with_256_basis_columns_is_one_asynchronous_batch(dtype):
     """kdim = 256: every step runs as three fused sweeps inside ONE asynchronous batch (one host synchronisation per call);
     H against the oracle column by column, orthonormality, and bit-identity with the one-round-trip-per-step schedule."""
