@@ -134,7 +134,13 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * more right-hand sides -- Gram, innerprod_matrix, block DGS -- in one pass over X on the FP64 matrix cores; 0: four
  * right-hand sides per pass on the vector units) and "xhy_small"; "gemm_mfma" likewise for the tall-skinny product, from "gemm_mfma_min" output columns on (default 5; narrower
  * products stream X through the vector units with 1 / 2 / 4 accumulators per lane); "gemm_store_policy" (cache policy of its
- * output stores, as "store_policy"). */
+ * output stores, as "store_policy");
+ * "wide_regs" (shape of the update sweeps against 129..384 basis columns: 2 [default] = 8 waves x 32 / 24 register columns for
+ * 129..256 real / 129..192 complex columns and the lane split on 24-column groups up to 384; 1 = the first only; 0 = round 3's lane
+ * split on 16-column groups everywhere) and "kc32" (the 32-column register tile for the real update sweeps of k <= 128 columns too:
+ * -1 [default] = for k > 32 on panels of >= 2^25 rows, 0 = never, v = for k > v).
+ * "wide_s3" (default 1: sweep 3 of a lane-split DGS holds both column groups of a wave-column in one wave's registers on tiles twice as
+ * tall; 0: lane-split like sweep 2) changes NO result bit: it reproduces the lane split's summation order (tests/test_gpu_round3.py). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
 
 /* Lazy batching of the per-object path (tuning key "lazy", off by default).  When on, k consecutive

@@ -86,7 +86,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
-    int kc32 = 0;              // real update sweeps of k > kc32 (<= 128) columns on 32-column register tiles (0: never)
+    int kc32 = -1;             // real update sweeps of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 on panels of >= 2^25 rows)
     int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
     int wide_regs = 2;         // wide REGISTER tiles: 1 = 8 waves x 32 / 24 columns for 129..256 real / 129..192 complex basis columns instead of the lane split; 2 = also the lane split on 24-column groups for 257..384 columns; 0 = round 3's shapes
     int cplx_wide = 32;        // complex sweeps with 8 waves x 16 columns per block when k exceeds this (0: never) instead of 16 x 8
@@ -562,10 +562,15 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
         if (c->cplx_wide && k > (MODE == 1 ? c->cplx_wide + 24 : c->cplx_wide)) return launch_sweep<true, MODE, 16, 8>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
         return launch_sweep<true, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
     }
-    // "kc32" (round 4, A/B): the real kind's update sweeps on 32-column register tiles (the 129..256-column shape) for narrow
-    // bases too: k > kc32 columns run 8 waves x 32 columns (WC = 1 / 2 / 4 wave-columns, tiles 2-8 times as tall) -- sweeps 2 and 3
-    // together, they share the summation order.  0 = off.
-    if (c->kc32 && k > c->kc32 && MODE != 1) return launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+    // "kc32" (round 4): the real kind's update sweeps on 32-column register tiles (the 129..256-column shape) for narrow bases too:
+    // k > kc32 columns run 8 waves x 32 columns (WC = 2 / 4 wave-columns, tiles 2-4 times as tall) -- sweeps 2 and 3 together, they
+    // share the summation order.  Measured (profiles/r04_ab_kc32.txt): sweep 2 +2 % and sweep 3 -0.5 % at n = 10^8 (+0.6 % on the three
+    // sweeps), null at n = 10^7, -0.6 % at n = 2 10^6 -- so the default (-1) turns it on for k > 32 on LONG panels only, a column
+    // beyond the 256 MB memory-side cache (n >= 2^25 rows); 0 = never, v > 0 = for k > v at every size.
+    {
+        const int kc32 = c->kc32 >= 0 ? c->kc32 : (Bx->n >= ((int64_t)1 << 25) ? 32 : 0);
+        if (kc32 && k > kc32 && MODE != 1) return launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+    }
     return launch_sweep<false, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
 }
 
@@ -1270,7 +1275,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
-    if (!strcmp(key, "kc32")) { c->kc32 = value < 0 ? 0 : value; return LK_OK; }
+    if (!strcmp(key, "kc32")) { c->kc32 = value < 0 ? -1 : value; return LK_OK; }
     if (!strcmp(key, "wide_s3")) { c->wide_s3 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "wide_regs")) { c->wide_regs = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value < 0 ? 0 : value; return LK_OK; }

@@ -41,4 +41,8 @@ PY
  python tools/pmc_sum.py "$D/pmc_wide_fetch" FETCH_SIZE
  if [ -f profiles/${TAG}_pmc_lds_note.txt ]; then cat profiles/${TAG}_pmc_lds_note.txt; fi) > "profiles/${TAG}_pmc_wide_and_block.txt"
 find "$D/dense" -name "*kernel_stats.csv" -exec cp {} "profiles/${TAG}_dense_n65536_kernel_stats.csv" \;
+if [ -d "$D/block_stats" ]; then find "$D/block_stats" -name "*kernel_stats.csv" -exec cp {} "profiles/${TAG}_block_dgs_kernel_stats.csv" \;; fi
+if [ -f "$D/eigs_profile.log" ]; then (echo "# tools/profile_eigs_cycle.py 5 (configs[3] eigs cycle, cProfile of the calling thread); commit $C"; grep -v amdgpu.ids "$D/eigs_profile.log") > "profiles/${TAG}_eigs_cycle_profile.txt"; fi
+if [ -f "$D/tol.txt" ]; then sort -u "$D/tol.txt" > "profiles/${TAG}_parity_margins.txt"; fi
+(echo "$hdr"; j "$D/cfg4_untraced.log") > "profiles/${TAG}_cfg4_untraced.jsonl"
 echo "profiles/${TAG}_* written from $D (commit $C)"

@@ -29,4 +29,8 @@ for op in dense lap5 csr; do python3 "$R/bench.py" --operator $op --steps 3 --wa
 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/dense" -o dense -- python3 "$R/bench.py" --operator dense --steps 1 --warmup 1 --no-cpu-baseline > "$D/dense_traced.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_wide_fetch" -o wide -- python3 "$R/tools/bench_wide.py" 4e6 f64 > "$D/pmc_wide_fetch.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_block_fetch" -o block -- python3 "$R/tools/bench_block_dgs.py" 32 1 > "$D/pmc_block_fetch.log" 2>&1
-tail -c 600 "$D/bench_default.log"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$D/block_stats" -o block -- python3 "$R/tools/bench_block_dgs.py" 32 1 > "$D/block_stats.log" 2>&1
+python3 "$R/tools/profile_eigs_cycle.py" 5 > "$D/eigs_profile.log" 2>&1
+python3 "$R/bench.py" --dtype c128 --rows 1000000 --steps 5 --warmup 2 --no-cpu-baseline > "$D/cfg4_untraced.log" 2>&1
+(cd "$R" && LK_TOL_REPORT="$D/tol.txt" timeout 1500 python3 -m pytest tests -m gpu -q -p no:cacheprovider > "$D/pytest.log" 2>&1; echo "pytest rc $?" >> "$D/pytest.log")
+tail -c 600 "$D/bench_default.log"; tail -3 "$D/pytest.log"
