@@ -86,6 +86,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
+    int gemm_3m = 1;           // complex MFMA tall-skinny product with three real products per complex one (0: four, the doubled real problem)
     int kc32 = -1;             // real update sweeps of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 on panels of >= 2^25 rows)
     int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
     int wide_regs = 2;         // wide REGISTER tiles: 1 = 8 waves x 32 / 24 columns for 129..256 real / 129..192 complex basis columns instead of the lane split; 2 = also the lane split on 24-column groups for 257..384 columns; 0 = round 3's shapes
@@ -845,11 +846,61 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     return LK_OK;
 }
 
+// complex kind, three real products per complex one (panel_gemm_mfma3m): groups of 16 complex outputs, up to 4 per launch
+template <int NG, int NR = (NG >= 4 ? 1 : 2)>
+int gemm_mfma3m_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *Y, int64_t ldy, int qn, const double *Cp, int64_t n,
+                    int accumulate) {
+    const int nt = (kk + 3) / 4;
+    const size_t lds = (size_t)NG * nt * 128 * sizeof(double);
+    if (lds > 48 * 1024)
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma3m<NG, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    constexpr int tile_rows = 8 * NR * 16;
+    int64_t g = (n + tile_rows - 1) / tile_rows;
+    const int64_t cap = (int64_t)c->num_cu * (NG >= 4 ? 2 : (NG >= 2 ? 2 : c->gemm_grid_mult));
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL((panel_gemm_mfma3m<NG, NR>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                       c->gemm_store_policy);
+    HIPCHK(hipGetLastError());
+    return LK_OK;
+}
+
+int gemm_launch_mfma3m(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, const double *Cdev, int64_t ldc, double sign,
+                       int accumulate, double *pack) {
+    lk_context_t c = Bx->ctx;
+    constexpr int QB = 16, NGMAX = 4;
+    for (int kc = 0; kc < k; kc += KMAX_FUSED) {
+        const int kk = (k - kc) < KMAX_FUSED ? (k - kc) : KMAX_FUSED;
+        const int nt = (kk + 3) / 4;
+        const int ngroups = (q + QB - 1) / QB;
+        const int total = ngroups * nt * 128;
+        hipLaunchKernelGGL(pack_coef_mfma3m, dim3((total + 255) / 256 > 64 ? 64 : (total + 255) / 256), dim3(256), 0, c->stream,
+                           Cdev + (int64_t)kc * 2, ldc, kk, q, sign, pack);
+        HIPCHK(hipGetLastError());
+        const int acc = (accumulate || kc > 0) ? 1 : 0;
+        for (int g0 = 0; g0 < ngroups; g0 += NGMAX) {
+            const int groups = (ngroups - g0) < NGMAX ? (ngroups - g0) : NGMAX;
+            const int qn = (q - g0 * QB) < groups * QB ? (q - g0 * QB) : groups * QB;
+            const double *Cp = pack + (int64_t)g0 * nt * 128;
+            const double *Xp = Bx->col(c0 + kc);
+            double *Yp = By->col(jy0 + g0 * QB);
+            ProfScope ps(c, "lincomb", (double)Bx->n * 16.0 * (kk + qn * (acc ? 2 : 1)));
+            int rc;
+            if (groups <= 1) rc = gemm_mfma3m_one<1>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+            else if (groups == 2) rc = gemm_mfma3m_one<2>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+            else rc = gemm_mfma3m_one<4>(c, Xp, Bx->ld, kk, Yp, By->ld, qn, Cp, Bx->n, acc);
+            LKCHK(rc);
+        }
+    }
+    return LK_OK;
+}
+
 int gemm_launch_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q, const double *Cdev, int64_t ldc, double sign,
                      int accumulate, double *pack) {
     lk_context_t c = Bx->ctx;
     const bool cp = Bx->dtype == LK_C128;
     const int ED = Bx->ed();
+    if (cp && c->gemm_3m) return gemm_launch_mfma3m(Bx, c0, k, By, jy0, q, Cdev, ldc, sign, accumulate, pack);
     const int QB = cp ? 8 : 16, NGMAX = cp ? 8 : 4;
     for (int kc = 0; kc < k; kc += KMAX_FUSED) {
         const int kk = (k - kc) < KMAX_FUSED ? (k - kc) : KMAX_FUSED;
@@ -1275,6 +1326,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
+    if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "kc32")) { c->kc32 = value < 0 ? -1 : value; return LK_OK; }
     if (!strcmp(key, "wide_s3")) { c->wide_s3 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "wide_regs")) { c->wide_regs = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }

@@ -1128,6 +1128,118 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
     }
 }
 
+// Complex tall-skinny product with THREE real products per complex one (round 4).  panel_gemm_mfma<true> computes a complex
+// product as a real one of doubled size -- four real multiplications per complex multiplication, 8 flop -- and runs AT the
+// matrix pipe's sustained FP64 rate (49-50 TFLOP/s, tools/mfma_f64_peak.hip), so the only way down is fewer flops:
+//     P1 = Xr Cr,   P2 = Xi Ci,   P3 = (Xr + Xi)(Cr + Ci)      =>      Re(X C) = P1 - P2,   Im(X C) = P3 - P1 - P2
+// (Karatsuba / "3M": 6 flop per complex multiplication).  A group is 16 COMPLEX outputs (all 16 rows of the A operand); per
+// k-step of four basis columns and row group three MFMAs -- A = Cr | Ci | Cr + Ci, B = xr | xi | xr + xi of the lane's row -- into
+// three accumulators, combined when the tile is stored.  Only Cr and Ci are staged in LDS (the sum is one add per k-step and group).
+// Rounding: Im(X C) carries the cancellation of P3 - P1 - P2, i.e. an error of order eps (|Xr| + |Xi|)(|Cr| + |Ci|) per term --
+// bounded NORMWISE like the 4-multiplication form (the comparisons of this suite are normwise), not componentwise.
+// Cp: [group][k-step][Cr | Ci][64 lanes] from pack_coef_mfma3m.
+template <int NG, int NR>                     // NR: row groups of 16 rows per wave (2; 1 for 64 outputs, whose 12 accumulators of 8 registers leave no room for 24)
+__global__ __launch_bounds__(512) void panel_gemm_mfma3m(const double *__restrict__ X, int64_t ldx, int k,
+                                                         double *__restrict__ Y, int64_t ldy, int qn,
+                                                         const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
+    constexpr int QB = 16;                       // complex output columns per group
+    constexpr int RG = 16;                       // rows per row group (the MFMA's N extent)
+    constexpr int U = 8 / NR;                    // k-steps of X in flight per wave: NR U = 8 loads of 16 B per lane
+    extern __shared__ double tiles3[];           // [NG][nt][2][64]
+    const int nt = (k + 3) >> 2;
+    for (int i = threadIdx.x; i < NG * nt * 128; i += blockDim.x) tiles3[i] = Cp[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kk = lane >> 4, j = lane & 15;
+    const int64_t xstride = ldx * 2, ystride = ldy * 2;
+    constexpr int tile_rows = 8 * NR * RG;       // 8 waves x NR row groups
+    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
+    const double *__restrict__ Xl = X + (int64_t)kk * xstride;      // this lane's column within a k-step
+    const bool kfast = (k & 3) == 0;
+
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * tile_rows + (int64_t)wave * (NR * RG) + j;
+        const bool fast = kfast && (tile + 1) * tile_rows <= n;
+        v4d acc[NG][NR][3];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int g2 = 0; g2 < NR; ++g2)
+#pragma unroll
+                for (int e = 0; e < 3; ++e) acc[g][g2][e] = v4d{0.0, 0.0, 0.0, 0.0};
+
+        for (int t0 = 0; t0 < nt; t0 += U) {
+            v2d x[U][NR];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u;
+#pragma unroll
+                for (int g2 = 0; g2 < NR; ++g2) {
+                    x[u][g2] = v2d{0.0, 0.0};
+                    if (t < nt) {
+                        const double *__restrict__ xc = Xl + (int64_t)(4 * t) * xstride;
+                        if (fast) x[u][g2] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xc + (r0 + g2 * RG) * 2));
+                        else if ((4 * t + kk) < k) x[u][g2] = load_y<true>(xc, r0 + g2 * RG, n, false);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u;
+                if (t < nt) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const double ar = tiles3[((g * nt + t) * 2 + 0) * 64 + lane];
+                        const double ai = tiles3[((g * nt + t) * 2 + 1) * 64 + lane];
+                        const double as = ar + ai;
+#pragma unroll
+                        for (int g2 = 0; g2 < NR; ++g2) {
+                            acc[g][g2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, x[u][g2].x, acc[g][g2][0], 0, 0, 0);
+                            acc[g][g2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, x[u][g2].y, acc[g][g2][1], 0, 0, 0);
+                            acc[g][g2][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, x[u][g2].x + x[u][g2].y, acc[g][g2][2], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // D[output i = kk + 4 reg][row j] of group g: (Re, Im) = (P1 - P2, P3 - P1 - P2)
+        const bool full = (tile + 1) * tile_rows <= n;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int g2 = 0; g2 < NR; ++g2) {
+                const int64_t r = r0 + g2 * RG;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int qq = g * QB + kk + 4 * reg;
+                    if (qq < qn) {
+                        double *yc = Y + (int64_t)qq * ystride;
+                        const double p1 = acc[g][g2][0][reg], p2 = acc[g][g2][1][reg], p3 = acc[g][g2][2][reg];
+                        v2d out = v2d{p1 - p2, (p3 - p1) - p2};
+                        if (accumulate) out += load_y<true>(yc, r, n, full);
+                        store_rows<true>(yc, r, n, full, out, policy);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// coefficient tiles of panel_gemm_mfma3m from device coefficients laid out [q][ldc][2] (column-major k x q, complex):
+// Cp[((g * nt + t) * 2 + part) * 64 + lane] = sign * (part ? Im : Re) C(col = 4 t + (lane >> 4), q = 16 g + (lane & 15)).
+__global__ __launch_bounds__(256) void pack_coef_mfma3m(const double *__restrict__ C, int64_t ldc, int k, int q, double sign,
+                                                        double *__restrict__ Cp) {
+    const int ngroups = (q + 15) / 16, nt = (k + 3) >> 2;
+    const int total = ngroups * nt * 128;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, part = (idx >> 6) & 1, t = (idx >> 7) % nt, g = idx / (128 * nt);
+        const int col = 4 * t + (lane >> 4), qq = g * 16 + (lane & 15);
+        Cp[idx] = (col < k && qq < q) ? sign * C[((int64_t)qq * ldc + col) * 2 + part] : 0.0;
+    }
+}
+
 // M = X(:, :k)^H Y(:, :p) on the FP64 matrix cores: ONE pass over X (and Y) for up to 128 x 128 results -- Gram matrices,
 // innerprod_matrix and the coefficient passes of the block Gram-Schmidt with many right-hand sides, where panel_dot_p
 // (VALU, <= 4 right-hand sides per pass) would read X p/4 times.

@@ -256,6 +256,33 @@ def test_narrow_linear_combinations_on_every_kernel_choice(dtype, mfma_min, n, k
     c.close()
 
 
+@pytest.mark.parametrize("n,k,q", [(4099, 5, 9), (20_003, 64, 16), (20_003, 128, 17), (9001, 128, 32), (9001, 100, 33), (7001, 128, 48),
+                                   (12_289, 128, 64), (5003, 200, 70), (255, 130, 64)])
+def test_complex_product_with_three_real_products_per_complex_one(n, k, q):
+    """Round 4, "gemm_3m": the complex tall-skinny product on the matrix cores as P1 = Xr Cr, P2 = Xi Ci, P3 = (Xr + Xi)(Cr + Ci),
+    Re = P1 - P2, Im = P3 - P1 - P2 (6 flop per complex multiplication instead of 8; the four-product kernel already runs at the
+    matrix pipe's sustained rate).  Every output column against the oracle's loop of axpbys (AbstractVectors.fypp:605-643) and against
+    the four-product kernel, normwise -- the imaginary part carries the cancellation of P3 - P1 - P2, bounded by eps * sum (|xr| +
+    |xi|)(|cr| + |ci|), which is what the bound below is scaled with; groups of 16 outputs, ragged rows and columns, k in chunks."""
+    dtype = np.complex128
+    X = basis(n, k, dtype, 31)
+    Cm = basis(k, q, dtype, 700)
+    scale = (np.abs(X.real) + np.abs(X.imag)).max(axis=0) @ (np.abs(Cm.real) + np.abs(Cm.imag))      # per output column
+    out = []
+    for three in (1, 0):
+        c = lk.Context(device=0)
+        c.set_tuning("gemm_3m", three)
+        Bx = lk.krylov_basis_gpu(n, k, dtype, c); Bx.upload(X)
+        Yg = lk.linear_combination(Bx, Cm)
+        out.append(Yg.download())
+        del Bx, Yg
+        c.close()
+    for j in range(q):
+        ref = ora.linear_combination(X, np.ascontiguousarray(Cm[:, j]))
+        assert np.abs(out[0][:, j] - ref).max() <= 1e-14 * scale[j]
+        assert np.abs(out[0][:, j] - out[1][:, j]).max() <= 1e-14 * scale[j]
+
+
 def test_gmres_update_uses_the_streaming_kernel(ctx):
     """The GMRES solution update dx = V(:, :k) y (gmres.fypp:200-201) is a q = 1 product: priced at k + 1 columns and run by
     the one-accumulator kernel (same profile tag, one launch)."""
