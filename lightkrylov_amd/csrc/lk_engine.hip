@@ -86,7 +86,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
-    int gemm_3m = 1;           // complex MFMA tall-skinny product with three real products per complex one (0: four, the doubled real problem)
+    int gemm_3m = 1;           // complex MFMA kernels (tall-skinny product; X^H Y with <= 32 right-hand sides) with three real products per complex one (0: four, the doubled real problem)
     int kc32 = -1;             // real update sweeps of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 on panels of >= 2^25 rows)
     int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
     int wide_regs = 2;         // wide REGISTER tiles: 1 = 8 waves x 32 / 24 columns for 129..256 real / 129..192 complex basis columns instead of the lane split; 2 = also the lane split on 24-column groups for 257..384 columns; 0 = round 3's shapes
@@ -703,7 +703,10 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         c->xhy_n = need;
     }
     double *out = c->xhy + (int64_t)sec * sect, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
-    const size_t lds = (size_t)(KP + ((flags & 1) ? 0 : PJ)) * 16 * (TR + 2) * sizeof(double);
+    // complex kind, <= 32 right-hand sides: three real products per complex one on separate real / imaginary planes ("gemm_3m")
+    const bool three = cp && small && c->gemm_3m && !(flags & 1);
+    const size_t lds = three ? (size_t)(KP + PJ) * 16 * 18 * 2 * sizeof(double)
+                             : (size_t)(KP + ((flags & 1) ? 0 : PJ)) * 16 * (TR + 2) * sizeof(double);
     {
         ProfScope ps(c, "xhy_mfma", (double)Bx->n * ED * 8.0 * (k + ((flags & 1) ? 0 : p)));
         auto go = [&](auto kern) -> int {
@@ -713,7 +716,8 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
                                p, Bx->n, flags, NI, part, npart);
             return LK_OK;
         };
-        if (cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32>) : go(&panel_xhy_mfma<true, 8, 64>));
+        if (three) LKCHK(go(&panel_xhy_mfma3m));
+        else if (cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32>) : go(&panel_xhy_mfma<true, 8, 64>));
         else LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32>) : go(&panel_xhy_mfma<false, 8, 64>));
     }
     HIPCHK(hipGetLastError());

@@ -1403,6 +1403,138 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     }
 }
 
+// X^H Y for the complex kind with THREE real products per complex one (round 4; <= 32 right-hand sides, the shape of the block
+// Gram-Schmidt's coefficient passes and of innerprod_matrix).  panel_xhy_mfma<true> reads the panel as a real one of 2n rows and spends
+// two MFMAs per k-step of two complex rows (4 real multiplications per complex one); here a k-step is FOUR complex rows and
+//     P1 = Xr^T Yr,   P2 = Xi^T Yi,   P3 = (Xr + Xi)^T (Yi - Yr)      =>      Re M = P1 + P2,   Im M = P3 + P1 - P2      (conj on X)
+// -- three MFMAs.  The real and imaginary parts are staged as SEPARATE planes (two 8-byte LDS writes per 16-byte load; an operand read
+// with stride 2 in an interleaved tile cannot be made bank-conflict free), each [columns][S = 18]: 16 complex rows per tile, column
+// stride 18 words (18 c mod 32 runs through the even residues: conflict-free operand reads).  46 KB of LDS at k = 128, p = 32: three
+// blocks per CU.  Same grid, wave roles, partial layout and norms as panel_xhy_mfma<true, 2, 32>; no aliasing (Gram keeps the 4-product form).
+__global__ __launch_bounds__(512) void panel_xhy_mfma3m(const double *__restrict__ X, int64_t ldx, int k,
+                                                        const double *__restrict__ Y, int64_t ldy, int p, int64_t n, int flags,
+                                                        int NI, double *__restrict__ partial, double *__restrict__ npartial) {
+    constexpr int PJM = 2, TRC = 16, S = TRC + 2, CHS = 4, CPP = 512 / TRC;      // 32 columns staged per block-wide pass
+    constexpr int NXP = 128 / CPP, NYP = (16 * PJM + CPP - 1) / CPP;
+    extern __shared__ __attribute__((aligned(16))) double xh3_lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int KP = (k + 15) >> 4, PJ = (p + 15) >> 4;
+    const int KS = (k + CPP - 1) / CPP, PS = (p + CPP - 1) / CPP;
+    const bool upper = flags & 2;
+    double *Xr = xh3_lds, *Xi = Xr + KP * 16 * S, *Yr = Xi + KP * 16 * S, *Yi = Yr + PJ * 16 * S;
+    const int64_t ntiles = (n + TRC - 1) / TRC;
+    const int64_t xcs = ldx * 2, ycs = ldy * 2;
+    const int WR = 8 / NI;
+    const int wi = wave % NI, wr = wave / NI;
+    const bool active = wi < KP;
+    const int arow = lane >> 4, acol = lane & 15;
+
+    v4d p1[PJM], p2[PJM], p3[PJM];
+#pragma unroll
+    for (int J = 0; J < PJM; ++J) { p1[J] = v4d{0.0, 0.0, 0.0, 0.0}; p2[J] = v4d{0.0, 0.0, 0.0, 0.0}; p3[J] = v4d{0.0, 0.0, 0.0, 0.0}; }
+    double nacc[NYP];
+#pragma unroll
+    for (int s = 0; s < NYP; ++s) nacc[s] = 0.0;
+    v2d xs[NXP], ys[NYP];
+
+    auto gload = [&](int64_t T) {
+        const int64_t rbase = T * TRC;
+#pragma unroll
+        for (int s = 0; s < NXP; ++s) {
+            xs[s] = v2d{0.0, 0.0};
+            if (s < KS) {
+                const int c = t + 512 * s, col = c >> CHS;
+                const int64_t rr = rbase + (c & (TRC - 1));
+                if (col < k && rr < n) xs[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(X + (int64_t)col * xcs + 2 * rr));
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NYP; ++s) {
+            ys[s] = v2d{0.0, 0.0};
+            if (s < PS) {
+                const int c = t + 512 * s, col = c >> CHS;
+                const int64_t rr = rbase + (c & (TRC - 1));
+                if (col < p && rr < n) ys[s] = *reinterpret_cast<const v2d *>(Y + (int64_t)col * ycs + 2 * rr);
+            }
+        }
+    };
+
+    int64_t T = blockIdx.x;
+    if (T < ntiles) gload(T);
+    for (; T < ntiles; T += gridDim.x) {
+        __syncthreads();                                            // the previous tile's operands have been read
+#pragma unroll
+        for (int s = 0; s < NXP; ++s)
+            if (s < KS) {
+                const int c = t + 512 * s;
+                if ((c >> CHS) < KP * 16) {
+                    Xr[(c >> CHS) * S + (c & (TRC - 1))] = xs[s].x;
+                    Xi[(c >> CHS) * S + (c & (TRC - 1))] = xs[s].y;
+                }
+            }
+#pragma unroll
+        for (int s = 0; s < NYP; ++s)
+            if (s < PS) {
+                const int c = t + 512 * s;
+                if ((c >> CHS) < PJ * 16) {
+                    Yr[(c >> CHS) * S + (c & (TRC - 1))] = ys[s].x;
+                    Yi[(c >> CHS) * S + (c & (TRC - 1))] = ys[s].y;
+                }
+                nacc[s] += ys[s].x * ys[s].x + ys[s].y * ys[s].y;
+            }
+        __syncthreads();
+        if (T + gridDim.x < ntiles) gload(T + gridDim.x);           // in flight while this tile's MFMAs run
+        if (active) {
+            for (int step = wr; step < TRC / 4; step += WR) {
+                const int ro = 4 * step + arow;
+                const double ar = Xr[(16 * wi + acol) * S + ro], ai = Xi[(16 * wi + acol) * S + ro];
+                const double as = ar + ai;
+#pragma unroll
+                for (int J = 0; J < PJM; ++J) {
+                    if (J < PJ && (!upper || J >= wi)) {
+                        const double br = Yr[(16 * J + acol) * S + ro], bi = Yi[(16 * J + acol) * S + ro];
+                        p1[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, p1[J], 0, 0, 0);
+                        p2[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, p2[J], 0, 0, 0);
+                        p3[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, bi - br, p3[J], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    const int64_t nslots = (int64_t)p * (k + 1) * 2;
+    double *pb = partial + ((int64_t)blockIdx.x * WR + wr) * nslots;
+    if (active) {
+#pragma unroll
+        for (int J = 0; J < PJM; ++J) {
+            if (J < PJ && (!upper || J >= wi)) {
+                const int q = 16 * J + acol;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * wi + arow + 4 * r;
+                    if (i < k && q < p) {
+                        pb[((int64_t)q * (k + 1) + i) * 2] = p1[J][r] + p2[J][r];
+                        pb[((int64_t)q * (k + 1) + i) * 2 + 1] = (p3[J][r] + p1[J][r]) - p2[J][r];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NYP; ++s) {
+        if (s < PS) {
+            double v = nacc[s];
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            const int col = (t >> CHS) + CPP * s;
+            if ((t & (TRC - 1)) == 0 && col < p) npartial[(int64_t)blockIdx.x * p + col] = v;
+        }
+    }
+}
+
 // Pass B of the block Gram-Schmidt with many right-hand sides, FUSED on the matrix cores (gram_schmidt.fypp:59-105):
 //     Y' = Y - X H1   (stored)      M2 = X^H Y'      ||Y'_q||^2
 // in ONE pass over X(:, :k) (k <= 128) and Y(:, :p) (p <= 32) -- the update and the second coefficient pass of

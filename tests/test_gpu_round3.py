@@ -283,6 +283,42 @@ def test_complex_product_with_three_real_products_per_complex_one(n, k, q):
         assert np.abs(out[0][:, j] - out[1][:, j]).max() <= 1e-14 * scale[j]
 
 
+@pytest.mark.parametrize("n,k,p", [(4099, 7, 5), (20_003, 64, 16), (9001, 128, 32), (7001, 100, 17), (255, 128, 32), (12_289, 33, 31)])
+def test_complex_innerprod_with_three_real_products_per_complex_one(n, k, p):
+    """Round 4: X^H Y with <= 32 right-hand sides, complex kind, on separate real / imaginary planes with P1 = Xr^T Yr, P2 = Xi^T Yi,
+    P3 = (Xr + Xi)^T (Yi - Yr), Re = P1 + P2, Im = P3 + P1 - P2 (conj on X as in dotc, AbstractVectors.fypp:550) -- against numpy and
+    against the four-product kernel, normwise with the scale of the cancelling terms; the block Gram-Schmidt built on it against the oracle."""
+    dtype = np.complex128
+    X, Y = basis(n, k, dtype, 41), basis(n, p, dtype, 800)
+    ref = X.conj().T @ Y
+    scale = (np.abs(X.real) + np.abs(X.imag)).T @ (np.abs(Y.real) + np.abs(Y.imag))
+    out = []
+    for three in (1, 0):
+        c = lk.Context(device=0)
+        c.set_tuning("gemm_3m", three)
+        Bx = lk.krylov_basis_gpu(n, k, dtype, c); Bx.upload(X)
+        By = lk.krylov_basis_gpu(n, p, dtype, c); By.upload(Y)
+        out.append(np.array(lk.innerprod(Bx, By)))
+        if three:
+            Q = orthonormal_basis(n, k, dtype, 43) if n > k else None
+            if Q is not None:
+                Bx.upload(Q)
+                beta = np.zeros((k, p), dtype=dtype, order="F")
+                assert lk.double_gram_schmidt_step(By, Bx, if_chk_orthonormal=False, beta=beta) == 0
+                Yo = Y.copy(order="F")
+                ho = np.zeros((k, p), dtype=dtype, order="F")
+                for j in range(p):
+                    yj = np.ascontiguousarray(Yo[:, j])
+                    ho[:, j], _ = ora.double_gram_schmidt_step(yj, Q)
+                    Yo[:, j] = yj
+                ynorm = np.linalg.norm(Y, axis=0).max()
+                assert np.abs(beta - ho).max() <= 1e-12 * ynorm and np.abs(By.download() - Yo).max() <= 1e-12 * ynorm
+        del Bx, By
+        c.close()
+    assert (np.abs(out[0] - ref) <= 1e-14 * scale).all()
+    assert (np.abs(out[0] - out[1]) <= 1e-14 * scale).all()
+
+
 def test_gmres_update_uses_the_streaming_kernel(ctx):
     """The GMRES solution update dx = V(:, :k) y (gmres.fypp:200-201) is a q = 1 product: priced at k + 1 columns and run by
     the one-accumulator kernel (same profile tag, one launch)."""
