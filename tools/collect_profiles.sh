@@ -37,7 +37,7 @@ PY
 (echo "# rocprofv3 --pmc FETCH_SIZE (KB, x2 on gfx950) per kernel; commit $C"
  echo "## tools/bench_block_dgs.py 32 1  (n = 1e7 real, p = 32 against k = 64 and k = 128, 6 calls each: X 5.12 / 10.24 GB + Y 2.56 GB per pass => 122.88 GB per kernel = ONE pass each: three passes per block DGS)"
  python tools/pmc_sum.py "$D/pmc_block_fetch" FETCH_SIZE
- echo "## tools/bench_wide.py 4e6 f64  (k = 64..640, 5 calls each; lane-split sweeps <.., 2> / <.., 4>: (k + 1) columns of 32 MB per launch = one pass)"
+ echo "## tools/bench_wide.py 4e6 f64  (k = 64..640, 5 calls each; panel_sweep<f64, KC, 8, UPDATE, DOT, TWO, SC, G>: <32,..,1,1> = k 129..256 (sum of k+1 = 749 columns x 160 MB = 119.84 GB), <24,..,2,1> sweep 2 and <48,..,1,2> sweep 3 = k 257..384 (964 columns = 154.24 GB), <16,..,4,1> = k 512: (k + 1) columns of 32 MB per launch = ONE pass each)"
  python tools/pmc_sum.py "$D/pmc_wide_fetch" FETCH_SIZE
  if [ -f profiles/${TAG}_pmc_lds_note.txt ]; then cat profiles/${TAG}_pmc_lds_note.txt; fi) > "profiles/${TAG}_pmc_wide_and_block.txt"
 find "$D/dense" -name "*kernel_stats.csv" -exec cp {} "profiles/${TAG}_dense_n65536_kernel_stats.csv" \;
