@@ -292,6 +292,7 @@ def main() -> None:
     ap.add_argument("--watchdog", type=float, default=float(os.environ.get("LK_BENCH_WATCHDOG", "600")),
                     help="seconds without progress after which every thread's stack is dumped to stderr and the process exits 1 "
                          "(0 = off; env LK_BENCH_WATCHDOG)")
+    ap.add_argument("--dump-h", default=None, metavar="PATH", help="rank 0 saves the Hessenberg matrix of the last factorisation (.npy): parity checks of sharded runs")
     ap.add_argument("--no-profile", action="store_true",
                     help="diagnostic: leave the library's per-kernel HIP events off (value only; roofline fields are then zero)")
     args = ap.parse_args()
@@ -468,6 +469,8 @@ def main() -> None:
                                       "algorithmic_bytes_per_launch": by / cnt,
                                       "GBps": by / ms / 1e6, "frac": by / ms / 1e6 / HBM_PEAK_GBS}
 
+    if rank == 0 and args.dump_h:
+        np.save(args.dump_h, H)
     if rank == 0:
         iters = args.steps * m
         achieved = (sweep_bytes / 1e9) / (sweep_ms / 1e3) if sweep_ms > 0 else 0.0

@@ -135,3 +135,22 @@ def test_a_rank_that_stops_moving_is_reported_with_its_stack_and_ends_the_job():
     # (the dumped stacks name bench.py's lines; both ranks' watchdogs fire within the same second here and their dumps can interleave
     # character by character on the shared stderr, so only the file name is looked for)
     assert "bench.py" in out.stderr.split("Timeout (0:00:20)!", 1)[1]
+
+
+def test_config5_at_full_size_as_eight_processes_against_the_oracle_fixture(tmp_path):
+    """BASELINE configs[4] -- arnoldi, n = 10^8 real(dp), m = 128, row-sharded 8 ways, reductions all-reduced -- at FULL size as eight
+    real processes (12.5 million rows each; all on this one GPU, gloo standing in for RCCL) through the plain `--gpus 8` entry: EVERY
+    column of H against the committed fixture of the reference's arithmetic (tests/golden/arnoldi_diaglin_n100000000_m128_rdp.npz, the
+    same fixture the single-GPU test uses) normwise within 1e-12, and against the twice-working-precision fixture within 1e-13.  (The
+    timing of this run means nothing: eight processes time-share one GPU.)"""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "arnoldi_diaglin_n100000000_m128_rdp.npz"))
+    hpath = str(tmp_path / "H8.npy")
+    out = _run([sys.executable, "bench.py", "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--dump-h", hpath],
+               LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
+    assert out["n_gpus"] == 8 and out["config"]["n_local"] == 12_500_000 and out["config"]["m"] == 128 and out["config"]["info"] == 0
+    H = np.load(hpath)
+    colerr = lambda A, B: max(np.abs(A[:, j] - B[:, j]).max() / np.abs(B[:, j]).max() for j in range(B.shape[1]))   # noqa: E731
+    e_seq, e_comp = colerr(H, z["H_seq"]), colerr(H, z["H_comp"])
+    print(f"n = 1e8, m = 128 on 8 ranks: |dH| vs the reference's arithmetic {e_seq:.2e}, vs compensated dots {e_comp:.2e}")
+    assert e_seq <= 1e-12 and e_comp <= 1e-13
