@@ -703,6 +703,36 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         c->xhy_n = need;
     }
     double *out = c->xhy + (int64_t)sec * sect, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
+    // complex Gram matrix beyond 32 columns: upper tiles dealt to the waves, three real products per complex one (panel_gram_mfma3m)
+    if (cp && !small && c->gemm_3m && flags == 3) {
+        const int64_t nt32 = (Bx->n + 31) / 32;
+        int64_t gg = (int64_t)c->num_cu;
+        if (gg > nt32) gg = nt32;
+        if (gg < 1) gg = 1;
+        int64_t need3 = 2 * sect + npart_n + gg * nslots;
+        if (c->xhy_n < need3) {
+            const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
+            if (need3 < fused) need3 = fused;
+            if (c->xhy) HIPCHK(hipFree(c->xhy));
+            c->xhy = nullptr;
+            c->xhy_n = 0;
+            HIPCHK(hipMalloc((void **)&c->xhy, (size_t)need3 * sizeof(double)));
+            c->xhy_n = need3;
+        }
+        double *out3 = c->xhy + (int64_t)sec * sect, *npart3 = c->xhy + 2 * sect, *part3 = npart3 + npart_n;
+        const size_t lds3 = (size_t)KP * 16 * 34 * 2 * sizeof(double);
+        {
+            ProfScope ps(c, "xhy_mfma", (double)Bx->n * ED * 8.0 * k);
+            if (lds3 > 48 * 1024)
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gram_mfma3m), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            hipLaunchKernelGGL(panel_gram_mfma3m, dim3((unsigned)gg), dim3(512), lds3, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, part3);
+        }
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, part3, (int)gg, npart3, (int)gg, k, p, ED, flags, out3);
+        HIPCHK(hipGetLastError());
+        if (out_dev) *out_dev = out3;
+        return allreduce(c, out3, nslots);
+    }
     // complex kind, <= 32 right-hand sides: three real products per complex one on separate real / imaginary planes ("gemm_3m")
     const bool three = cp && small && c->gemm_3m && !(flags & 1);
     const size_t lds = three ? (size_t)(KP + PJ) * 16 * 18 * 2 * sizeof(double)

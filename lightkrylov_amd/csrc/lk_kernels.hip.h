@@ -1535,6 +1535,104 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma3m(const double *__restrict
     }
 }
 
+// Gram matrix G = X^H X of a complex basis (k <= 128), upper tiles only, with three real products per complex one (round 4):
+//     P1 = Xr_I^T Xr_J,   P2 = Xi_I^T Xi_J,   P3 = (Xr + Xi)_I^T (Xi - Xr)_J      =>      Re G_IJ = P1 + P2,   Im G_IJ = P3 + P1 - P2.
+// panel_xhy_mfma<true, 8, 64> gives every wave one tile ROW (up to 8 tiles, two accumulators each: 128 registers); three accumulators
+// per tile do not fit that way, so here the KP (KP + 1) / 2 upper tiles (I <= J) are DEALT to the 8 waves round-robin -- 36 tiles at
+// k = 128: five for waves 0-3, four for waves 4-7, i.e. nine per SIMD (waves w and w + 4 share one) -- and a wave reads the A operand of
+// each of its tiles itself (four 8-byte LDS reads per three MFMAs: ~8 % of the LDS rate).  Real and imaginary parts are staged as separate
+// planes, 32 complex rows per tile, column stride 34 words (conflict-free operand reads); the next tile's loads are in flight while the
+// current tile's MFMAs run.  Results: partial[block][slot], slot = (j (k + 1) + i) * 2 (+1) for i in tile row I, j in tile column J >= I --
+// panel_xhy_mfma's layout with flags = 3 (Y is X, upper tiles only), summed by finish_xhy; no norm slots.
+__global__ __launch_bounds__(512) void panel_gram_mfma3m(const double *__restrict__ X, int64_t ldx, int k, int64_t n,
+                                                         double *__restrict__ partial) {
+    constexpr int TRC = 32, S = TRC + 2, CHS = 5, CPP = 512 / TRC, NXP = 128 / CPP;      // 16 columns staged per block-wide pass
+    constexpr int MAXT = 5;                                                             // ceil(36 / 8) tiles per wave
+    extern __shared__ __attribute__((aligned(16))) double gr3_lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int KP = (k + 15) >> 4, KS = (k + CPP - 1) / CPP;
+    double *Xr = gr3_lds, *Xi = Xr + KP * 16 * S;
+    const int64_t ntiles = (n + TRC - 1) / TRC;
+    const int64_t xcs = ldx * 2;
+    const int arow = lane >> 4, acol = lane & 15;
+
+    // this wave's tiles: upper tiles in the order (0,0), (0,1), ..., (0,KP-1), (1,1), ...; tile number == wave (mod 8)
+    int tI[MAXT], tJ[MAXT], nt = 0;
+    {
+        int idx = 0;
+        for (int I = 0; I < KP; ++I)
+            for (int J = I; J < KP; ++J, ++idx)
+                if ((idx & 7) == wave && nt < MAXT) { tI[nt] = I; tJ[nt] = J; ++nt; }
+        for (int q = nt; q < MAXT; ++q) { tI[q] = 0; tJ[q] = 0; }
+    }
+
+    v4d p1[MAXT], p2[MAXT], p3[MAXT];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) { p1[q] = v4d{0.0, 0.0, 0.0, 0.0}; p2[q] = v4d{0.0, 0.0, 0.0, 0.0}; p3[q] = v4d{0.0, 0.0, 0.0, 0.0}; }
+    v2d xs[NXP];
+
+    auto gload = [&](int64_t T) {
+        const int64_t rbase = T * TRC;
+#pragma unroll
+        for (int s = 0; s < NXP; ++s) {
+            xs[s] = v2d{0.0, 0.0};
+            if (s < KS) {
+                const int c = t + 512 * s, col = c >> CHS;
+                const int64_t rr = rbase + (c & (TRC - 1));
+                if (col < k && rr < n) xs[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(X + (int64_t)col * xcs + 2 * rr));
+            }
+        }
+    };
+
+    int64_t T = blockIdx.x;
+    if (T < ntiles) gload(T);
+    for (; T < ntiles; T += gridDim.x) {
+        __syncthreads();                                            // the previous tile's operands have been read
+#pragma unroll
+        for (int s = 0; s < NXP; ++s)
+            if (s < KS) {
+                const int c = t + 512 * s;
+                if ((c >> CHS) < KP * 16) {
+                    Xr[(c >> CHS) * S + (c & (TRC - 1))] = xs[s].x;
+                    Xi[(c >> CHS) * S + (c & (TRC - 1))] = xs[s].y;
+                }
+            }
+        __syncthreads();
+        if (T + gridDim.x < ntiles) gload(T + gridDim.x);           // in flight while this tile's MFMAs run
+        for (int step = 0; step < TRC / 4; ++step) {
+            const int ro = 4 * step + arow;
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q) {
+                if (q < nt) {
+                    const double ar = Xr[(16 * tI[q] + acol) * S + ro], ai = Xi[(16 * tI[q] + acol) * S + ro];
+                    const double br = Xr[(16 * tJ[q] + acol) * S + ro], bi = Xi[(16 * tJ[q] + acol) * S + ro];
+                    p1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, br, p1[q], 0, 0, 0);
+                    p2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, bi, p2[q], 0, 0, 0);
+                    p3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar + ai, bi - br, p3[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int64_t nslots = (int64_t)k * (k + 1) * 2;
+    double *pb = partial + (int64_t)blockIdx.x * nslots;
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        if (q < nt) {
+            const int j = 16 * tJ[q] + acol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tI[q] + arow + 4 * r;
+                if (i < k && j < k) {
+                    pb[((int64_t)j * (k + 1) + i) * 2] = p1[q][r] + p2[q][r];
+                    pb[((int64_t)j * (k + 1) + i) * 2 + 1] = (p3[q][r] + p1[q][r]) - p2[q][r];
+                }
+            }
+        }
+    }
+}
+
 // Pass B of the block Gram-Schmidt with many right-hand sides, FUSED on the matrix cores (gram_schmidt.fypp:59-105):
 //     Y' = Y - X H1   (stored)      M2 = X^H Y'      ||Y'_q||^2
 // in ONE pass over X(:, :k) (k <= 128) and Y(:, :p) (p <= 32) -- the update and the second coefficient pass of

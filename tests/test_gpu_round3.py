@@ -319,6 +319,29 @@ def test_complex_innerprod_with_three_real_products_per_complex_one(n, k, p):
     assert (np.abs(out[0] - out[1]) <= 1e-14 * scale).all()
 
 
+@pytest.mark.parametrize("n,k", [(4099, 33), (20_003, 64), (9001, 100), (12_289, 128), (255, 128), (31, 48)])
+def test_complex_gram_matrix_with_three_real_products_per_complex_one(n, k):
+    """Round 4: Gram (AbstractVectors.fypp:645-657) of a complex basis beyond 32 columns -- upper tiles dealt to the waves, P1 = Xr^T Xr,
+    P2 = Xi^T Xi, P3 = (Xr + Xi)^T (Xi - Xr), Re = P1 + P2, Im = P3 + P1 - P2 -- against numpy (upper triangle; the reference mirrors it
+    WITHOUT conjugation) and against the four-product kernel, with the scale of the cancelling terms."""
+    dtype = np.complex128
+    X = basis(n, k, dtype, 51)
+    ref = X.conj().T @ X
+    scale = (np.abs(X.real) + np.abs(X.imag)).T @ (np.abs(X.real) + np.abs(X.imag))
+    out = []
+    for three in (1, 0):
+        c = lk.Context(device=0)
+        c.set_tuning("gemm_3m", three)
+        Bx = lk.krylov_basis_gpu(n, k, dtype, c); Bx.upload(X)
+        out.append(np.array(lk.Gram(Bx)))
+        del Bx
+        c.close()
+    iu = np.triu_indices(k)
+    assert (np.abs(out[0][iu] - ref[iu]) <= 1e-14 * scale[iu]).all()
+    assert (np.abs(out[0] - out[1]) <= 1e-14 * scale).all()
+    assert np.array_equal(out[0], out[0].T)                              # mirrored without conjugation, like the reference
+
+
 def test_gmres_update_uses_the_streaming_kernel(ctx):
     """The GMRES solution update dx = V(:, :k) y (gmres.fypp:200-201) is a q = 1 product: priced at k + 1 columns and run by
     the one-accumulator kernel (same profile tag, one launch)."""
