@@ -139,7 +139,7 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * 129..256 real / 129..192 complex columns and the lane split on 24-column groups up to 384; 1 = the first only; 0 = round 3's lane
  * split on 16-column groups everywhere) and "kc32" (the 32-column register tile for the real update sweeps of k <= 128 columns too:
  * -1 [default] = for k > 32 on panels of >= 2^25 rows, 0 = never, v = for k > v).
- * "gemm_3m" (default 1: the complex MFMA kernels -- tall-skinny product, X^H Y with <= 32 right-hand sides -- use three real products per
+ * "gemm_3m" (default 1: the complex MFMA kernels -- tall-skinny product, X^H Y with <= 32 right-hand sides, Gram -- use three real products per
  * complex one, Re = P1 - P2, Im = P3 - P1 - P2; 0: four, the doubled real problem; same results normwise).
  * "wide_s3" (default 1: sweep 3 of a lane-split DGS holds both column groups of a wave-column in one wave's registers on tiles twice as
  * tall; 0: lane-split like sweep 2) changes NO result bit: it reproduces the lane split's summation order (tests/test_gpu_round3.py). */

@@ -86,7 +86,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
-    int gemm_3m = 1;           // complex MFMA kernels (tall-skinny product; X^H Y with <= 32 right-hand sides) with three real products per complex one (0: four, the doubled real problem)
+    int gemm_3m = 1;           // complex MFMA kernels (tall-skinny product; X^H Y with <= 32 right-hand sides; Gram) with three real products per complex one (0: four, the doubled real problem)
     int kc32 = -1;             // real update sweeps of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 on panels of >= 2^25 rows)
     int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
     int wide_regs = 2;         // wide REGISTER tiles: 1 = 8 waves x 32 / 24 columns for 129..256 real / 129..192 complex basis columns instead of the lane split; 2 = also the lane split on 24-column groups for 257..384 columns; 0 = round 3's shapes
