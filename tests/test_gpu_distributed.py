@@ -124,6 +124,21 @@ def test_a_rank_that_cannot_enter_the_native_communicator_ends_the_whole_job():
     assert took < 120, f"{took:.0f} s"            # interpreter start-up + torch import of three processes; the failure itself is immediate
 
 
+def test_a_communicator_that_fails_inside_the_collective_fails_on_every_rank_alike():
+    """ncclCommInitRank itself failing (here naturally: RCCL refuses two ranks on one GPU, on BOTH ranks): the outcome is MIN-reduced over
+    the launcher's group after the call, every rank raises the same error and leaves with status 3 -- nobody falls back alone onto
+    another reduction route."""
+    import time
+    args = ["--gpus", "2", "--rows", "200001", "--kdim", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    t0 = time.time()
+    out = _launch([sys.executable, "bench.py"] + args, timeout=300, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0", LK_NATIVE_RCCL="force",
+                  LK_BENCH_WATCHDOG="60")
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stdout[-2000:] + out.stderr[-6000:]
+    assert out.stderr.count("native RCCL communicator failed on at least one rank") >= 2            # both ranks, the same verdict
+    assert "exitcode: 3" in out.stderr or "exitcode  : 3" in out.stderr
+    assert time.time() - t0 < 120
+
+
 def test_a_rank_that_stops_moving_is_reported_with_its_stack_and_ends_the_job():
     """The watchdog of bench.py: one rank hangs before its first engine call; after LK_BENCH_WATCHDOG seconds every thread's stack of
     that rank is on stderr with the phase it was in, the process leaves with status 1 and the launcher ends the job."""
