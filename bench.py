@@ -18,6 +18,10 @@ reduction scalars after each sweep.  Inputs are generated in HBM before the time
 (dense, CSR: row block of A + all-gather of x; stencil: one grid line to each neighbour).  The headline line is the default
 (diagonal) operator.
 
+Every phase writes one marker line per rank to stderr and re-arms a watchdog (`--watchdog` seconds, 600): a rank that stops moving dumps
+every thread's stack and exits 1 (class Progress); the reduction route (native RCCL or a torch.distributed callback) is agreed on by all
+ranks; `--gpus N` under a launcher with another WORLD_SIZE is refused.  `--dump-h PATH`: rank 0 saves the last Hessenberg matrix.
+
 Prints ONE JSON line on rank 0; `value` = Arnoldi iterations per second, whole job.
   roofline   : the DGS sweep kernels (lk::panel_dot_cw for sweep 1, lk::panel_sweep for sweeps 2 and 3) -- algorithmic bytes s*n_local*(k+1|k+2)
                per launch (s*n*(3k+5) per DGS) / HIP-event duration on the kernel's

@@ -1,9 +1,14 @@
-"""The RCCL all-reduce plumbing on a real GPU: bench.py under torch.distributed.run with ONE rank goes
-through init_process_group("nccl") and the library's own communicator (lk_comm_init_rank: ncclAllReduce issued
-by liblightkrylov_hip on its stream), or -- LK_NATIVE_RCCL=0 -- through the ctypes callback, the zero-copy
-tensor view of the engine's reduction buffer and dist.all_reduce on the engine's stream.  With one rank the sum is the identity, so
-the factorisation must be bit-identical to the run without a process group.  (N > 1 GPUs are the
-driver's to launch; the N > 1 host logic is covered on CPU by tests/test_distributed_gloo.py.)"""
+"""The N > 1 entry on a real GPU (BASELINE configs[4]).
+* RCCL plumbing with ONE rank: bench.py under torch.distributed.run goes through init_process_group("nccl") and the library's own
+  communicator (lk_comm_init_rank: ncclAllReduce issued by liblightkrylov_hip on its stream), or -- LK_NATIVE_RCCL=0 -- through the
+  ctypes callback; with one rank the sum is the identity, so the factorisation must be bit-identical to the run without a group.
+* Row sharding with 2 / 3 / 4 / 8 REAL processes on this one GPU (gloo standing in for RCCL, which refuses two ranks on one device;
+  the engine's hook stages the scalars through host memory): every operator (diagonal, dense, CSR, stencil), the plain `--gpus P`
+  self-launch, and configs[4] itself at full size (n = 1e8, m = 128, 8 ranks) against the oracle fixture.
+* What must never happen on the first real 8-GPU lease: a silent hang.  A rank that cannot enter the native communicator, a communicator
+  that fails inside the collective, a rank that stops moving: each ends the whole job with a non-zero status, the phase every rank was
+  in and (watchdog) the stacks -- one attempt per launch, no retry branch.
+(The N > 1 host logic is also covered on CPU by tests/test_distributed_gloo.py.)"""
 import json
 import os
 import socket
