@@ -497,6 +497,20 @@ def main() -> None:
                         print("bench.py: " + traffic_src, file=sys.stderr)
             except Exception as exc:  # noqa: BLE001
                 traffic, traffic_src = None, f"profiles/pmc_traffic.json unreadable: {exc!r}"
+        # self-check of the line: where the repository holds a fixture of the reference's arithmetic for exactly this workload (the
+        # metric configuration and configs[1]), every column of the H just computed is compared with it -- whatever the number of
+        # ranks, so a scaling run whose reduction went wrong says so in its own line (the fixture is data, tests/golden/)
+        parity = None
+        fx = os.path.join(ROOT, "tests", "golden", f"arnoldi_diaglin_n{n}_m{m}_rdp.npz")
+        if args.operator == "diag" and args.dtype == "f64" and os.path.exists(fx):
+            try:
+                z = np.load(fx)
+                cerr = lambda Ha, Hb: float(max(np.abs(Ha[:, j] - Hb[:, j]).max() / np.abs(Hb[:, j]).max() for j in range(Hb.shape[1])))  # noqa: E731
+                e_seq, e_comp = cerr(H, z["H_seq"]), cerr(H, z["H_comp"])
+                parity = {"fixture": os.path.relpath(fx, ROOT), "max_normwise_column_error_vs_reference_arithmetic": e_seq,
+                          "vs_twice_working_precision_dots": e_comp, "bound": 1e-12, "ok": bool(e_seq <= 1e-12)}
+            except Exception as exc:  # noqa: BLE001
+                parity = {"fixture": os.path.relpath(fx, ROOT), "ok": None, "error": repr(exc)}
         out = {
             "metric": "Arnoldi iterations/s (+ DGS sweep HBM GB/s, % of 8 TB/s roofline)",
             "value": iters / elapsed,
@@ -517,6 +531,7 @@ def main() -> None:
                 "operator": args.operator,
                 "n_global": n, "n_local": n_local, "m": m, "parallelism": f"row-shard x{world} (RCCL all-reduce of <=129 scalars/sweep)",
                 "info": int(info), "H_fro": float(np.linalg.norm(H)), "H_last_subdiag": float(abs(H[m, m - 1])),
+                "parity": parity,
                 "all_reduce": reduce_path,
                 "nccl_algo": os.environ.get("NCCL_ALGO") if world > 1 or dist is not None else None,
             },

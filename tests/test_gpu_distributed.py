@@ -175,3 +175,6 @@ def test_config5_at_full_size_as_eight_processes_against_the_oracle_fixture(tmp_
     e_seq, e_comp = colerr(H, z["H_seq"]), colerr(H, z["H_comp"])
     print(f"n = 1e8, m = 128 on 8 ranks: |dH| vs the reference's arithmetic {e_seq:.2e}, vs compensated dots {e_comp:.2e}")
     assert e_seq <= 1e-12 and e_comp <= 1e-13
+    # ... and the bench line checks itself against the same fixture, at any number of ranks
+    par = out["config"]["parity"]
+    assert par["ok"] is True and par["max_normwise_column_error_vs_reference_arithmetic"] == pytest.approx(e_seq)
