@@ -141,6 +141,8 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * -1 [default] = for k > 32 on panels of >= 2^25 rows, 0 = never, v = for k > v).
  * "gemm_3m" (default 1: the complex MFMA kernels -- tall-skinny product, X^H Y with <= 32 right-hand sides, Gram -- use three real products per
  * complex one, Re = P1 - P2, Im = P3 - P1 - P2; 0: four, the doubled real problem; same results normwise).
+ * "gemm_prefetch_y" (default 1: the accumulating real MFMA product with <= 32 outputs -- the block Gram-Schmidt's updates -- loads the tile of Y
+ * ahead of its k-loop; 0: after it; no result bit changes).
  * "wide_s3" (default 1: sweep 3 of a lane-split DGS holds both column groups of a wave-column in one wave's registers on tiles twice as
  * tall; 0: lane-split like sweep 2) changes NO result bit: it reproduces the lane split's summation order (tests/test_gpu_round3.py). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);

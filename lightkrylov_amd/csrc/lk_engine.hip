@@ -86,6 +86,7 @@ struct lk_context_s {
     int recompute_update = 1;  // two-pass DGS: sweep 2 does not store y'; sweep 3 re-forms it (3k+4 instead of 3k+5 columns)
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
+    int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
     int gemm_3m = 1;           // complex MFMA kernels (tall-skinny product; X^H Y with <= 32 right-hand sides; Gram) with three real products per complex one (0: four, the doubled real problem)
     int kc32 = -1;             // real update sweeps of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 on panels of >= 2^25 rows)
     int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
@@ -874,6 +875,16 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     const int64_t cap = (int64_t)c->num_cu * (NG >= 8 ? 1 : (NG >= 4 && CPLX ? 2 : c->gemm_grid_mult));
     if (g > cap) g = cap;
     if (g < 1) g = 1;
+    if constexpr (!CPLX && NG <= 2) {
+        if (accumulate && c->gemm_prefetch_y) {          // the accumulating update of the block Gram-Schmidt: Y's tile loaded ahead of the k-loop
+            if (lds > 48 * 1024)
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                               c->gemm_store_policy);
+            HIPCHK(hipGetLastError());
+            return LK_OK;
+        }
+    }
     hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
                        c->gemm_store_policy);
     HIPCHK(hipGetLastError());
@@ -1360,6 +1371,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
+    if (!strcmp(key, "gemm_prefetch_y")) { c->gemm_prefetch_y = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "kc32")) { c->kc32 = value < 0 ? -1 : value; return LK_OK; }
     if (!strcmp(key, "wide_s3")) { c->wide_s3 = value ? 1 : 0; return LK_OK; }

@@ -1011,7 +1011,11 @@ __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, 
 // Cp: coefficient tiles packed per lane by pack_coef_mfma: [group][k-step t][64 lanes].
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-template <bool CPLX, int NG>
+// PF (round 4; real kind, <= 32 outputs, launched for accumulating calls only: the block Gram-Schmidt's updates Y -= X H): the tile of Y that
+// the result is added to is loaded BEFORE the k-loop, 16 more 16-byte loads in flight per lane under the MFMAs, instead of after it, where a
+// wave had nothing else to issue: block DGS k = 128, p = 32: 10.3 -> 9.8 ms, k = 32, p = 32: 4.9 -> 4.5 ms.  (Compiled into the plain
+// product as well it cost that one 13 %, so it is a template flag; for the complex three-product kernel it changed nothing and is not built.)
+template <bool CPLX, int NG, bool PFY = false>
 __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                        double *__restrict__ Y, int64_t ldy, int qn,
                                                        const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
@@ -1046,6 +1050,22 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
 #pragma unroll
                 for (int e = 0; e < NACC; ++e) acc[g][g2][e] = v4d{0.0, 0.0, 0.0, 0.0};
 
+        constexpr bool PF = PFY && !CPLX && NG <= 2;
+        v2d yin[PF ? NG : 1][2][4];
+        if constexpr (PF) {
+            if (accumulate) {
+                const bool fullp = (tile + 1) * tile_rows <= n;
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int qq = g * QB + kk + 4 * reg;
+                            yin[g][g2][reg] = qq < qn ? load_y<CPLX>(Y + (int64_t)qq * ystride, g2 ? r1 : r0, n, fullp) : v2d{0.0, 0.0};
+                        }
+            }
+        }
         // U k-steps per batch: 2 U loads of 16 B per lane in flight, then their MFMAs.  (A software-pipelined variant with
         // the next batch's loads issued ahead was measured 2-18 % SLOWER: it needs smaller batches to fit the register
         // file, and the two waves per SIMD already overlap each other's load latency.)
@@ -1118,7 +1138,8 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                         if (qq < qn) {
                             double *yc = Y + (int64_t)qq * ystride;
                             v2d out = v2d{acc[g][g2][0][reg], acc[g][g2][1][reg]};
-                            if (accumulate) out += load_y<CPLX>(yc, r, n, full);
+                            if constexpr (PF) { if (accumulate) out += yin[g][g2][reg]; }
+                            else if (accumulate) out += load_y<CPLX>(yc, r, n, full);
                             store_rows<CPLX>(yc, r, n, full, out, policy);
                         }
                     }
