@@ -116,6 +116,72 @@ def _die(progress: "Progress", msg: str, code: int = 3) -> None:
     os._exit(code)
 
 
+def _install_faulty_reduction(ctx, torch, factor: float) -> None:
+    """Test hook (LK_BENCH_TEST_HOOKS=1 + LK_TEST_SCALE_PARTIALS_RANK): wrap the all-reduce callback the context installed with one
+    that first scales this rank's partial sums in device memory -- through the public ABI (lk_set_allreduce), nothing inside the library."""
+    from lightkrylov_amd import _capi
+    from lightkrylov_amd.context import _DevMem
+    inner = ctx._cb
+
+    def faulty(user, dev_ptr, count, stream_ptr):
+        st = torch.cuda.ExternalStream(int(stream_ptr), device=ctx.device) if stream_ptr else torch.cuda.current_stream(ctx.device)
+        with torch.cuda.stream(st):
+            torch.as_tensor(_DevMem(int(dev_ptr), int(count)), device=f"cuda:{ctx.device}").mul_(factor)
+        return inner(user, dev_ptr, count, stream_ptr)
+
+    ctx._cb_faulty = _capi.ALLREDUCE_FN(faulty)
+    _capi.check(ctx._lib.lk_set_allreduce(ctx._h, ctx._cb_faulty, None, ctx.nranks, ctx.rank))
+
+
+def load_traffic_record(n_local: int, m: int, dtype: str):
+    """The stored PMC traffic record for a sweep workload (n_local rows per rank, m, dtype), or (None, why).  profiles/pmc_traffic.json
+    holds one record per n_local -- the sweep kernels of a rank see only their row block, so ONE GPU measures the record of every shard size
+    (bench.py --shard-of P under rocprofv3 --pmc).  A record names the SHA-256 of the kernel sources it was measured on; a record made on
+    other kernels is refused loudly instead of being quoted as if it described this build."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(pmc):
+        return None, "rocprofv3 --pmc passes cannot run inside bench.py; see profiles/ (no pmc_traffic.json)"
+    try:
+        doc = json.load(open(pmc))
+        recs = doc.get("records", [doc]) if isinstance(doc, dict) else list(doc)
+        rec = next((r for r in recs if r.get("n_local") == n_local and r.get("m") == m and r.get("dtype") == dtype), None)
+        if rec is None:
+            return None, (f"profiles/pmc_traffic.json has no record for n_local={n_local}, m={m}, {dtype} "
+                          f"(has n_local = {sorted(r.get('n_local') for r in recs)})")
+        have = kernel_source_hash()
+        if rec.get("kernel_source_sha256") != have:
+            why = (f"STALE: profiles/pmc_traffic.json (n_local={n_local}) was measured on kernel sources {str(rec.get('kernel_source_sha256'))[:12]}..., "
+                   f"this build is {have[:12]}...; re-run tools/run_profiles.sh")
+            print("bench.py: " + why, file=sys.stderr)
+            return None, why
+        return rec.get("hbm_bytes_per_launch"), {k: rec.get(k) for k in ("commit", "kernel_source_sha256", "source", "method", "traffic_over_algorithmic") if k in rec}
+    except Exception as exc:  # noqa: BLE001
+        return None, f"profiles/pmc_traffic.json unreadable: {exc!r}"
+
+
+def predicted_iters_per_s(n: int, m: int, world: int, operator: str, dtype: str):
+    """DESIGN.md section 6's scaling MODEL for the metric workload, printed next to the measured `value` so that a scaling run explains its
+    own gap: a factorisation costs T1 / N (the sweeps, the operator and the normalise are rank-local and bandwidth-bound; T1 = the measured
+    single-GPU factorisation, profiles/scaling_model.json) plus what does not shrink -- per Arnoldi step three all-reduces of <= 129 doubles
+    and three finish kernels.  Returns None when the repository holds no single-GPU record for this workload."""
+    path = os.path.join(ROOT, "profiles", "scaling_model.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        mod = json.load(open(path))
+        w = mod["workload"]
+        if (w["operator"], w["dtype"], w["n_global"], w["m"]) != (operator, dtype, n, m):
+            return None
+        t1 = mod["single_gpu_ms_per_factorisation"] * 1e-3
+        fixed = 0.0 if world == 1 else m * 3 * (mod["allreduce_us_assumed"] + mod["finish_partials_us"]) * 1e-6
+        t = t1 / world + fixed
+        return {"predicted_it_s": m / t, "predicted_ms_per_step": 1e3 * t,
+                "model": f"T1/N + m*3*(allreduce + finish) = {1e3 * t1:.1f} ms / {world} + {m}*3*({mod['allreduce_us_assumed']} + {mod['finish_partials_us']}) us",
+                "single_gpu_record": mod.get("source"), "note": "a model from single-GPU measurements (DESIGN.md section 6), not a measurement"}
+    except Exception as exc:  # noqa: BLE001
+        return {"predicted_it_s": None, "note": f"profiles/scaling_model.json unreadable: {exc!r}"}
+
+
 def kernel_source_hash() -> str:
     """SHA-256 over the device code and its launcher: what a PMC traffic record must have been measured on."""
     import hashlib
@@ -278,7 +344,13 @@ def _laplacian_csr_rows(N: int, row0: int, n_local: int):
 
 def main() -> None:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: the launcher's WORLD_SIZE when there is one, else 1); an EXPLICIT value that "
+                         "disagrees with a launcher's WORLD_SIZE is refused")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="P",
+                    help="diagnostic, single process: run ONE row block of a P-rank job (n_local = rows / P, partition announced as "
+                         "rows of the global problem, no communicator) -- what the sweep kernels of a rank see; used to take the "
+                         "per-shard PMC traffic records on one GPU (tools/run_profiles.sh).  Not a metric line.")
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--operator", default="diag", choices=["diag", "dense", "lap5", "csr"],
@@ -300,9 +372,18 @@ def main() -> None:
     ap.add_argument("--no-profile", action="store_true",
                     help="diagnostic: leave the library's per-kernel HIP events off (value only; roofline fields are then zero)")
     args = ap.parse_args()
+    parity_failed = False
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+    under_launcher = "WORLD_SIZE" in os.environ or "RANK" in os.environ
+    gpus_given = args.gpus is not None
+    if not gpus_given:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1     # the launcher's size wins when --gpus is silent
+    if args.gpus > 1 and not under_launcher:
         sys.exit(_self_launch(args.gpus))
+    # test hooks (tests/test_gpu_distributed.py) are honoured only with the explicit opt-in LK_BENCH_TEST_HOOKS=1: a leaked LK_TEST_*
+    # variable alone never changes a metric run
+    hooks = os.environ.get("LK_BENCH_TEST_HOOKS") == "1"
+    hook = lambda name: os.environ.get(name) if hooks else None                                 # noqa: E731
     for k, v in NCCL_PIN.items():
         os.environ.setdefault(k, v)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL between processes needs on this driver
@@ -311,9 +392,9 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     progress = Progress(args.watchdog, rank, world)
-    if world != args.gpus:
-        # a launcher's environment that disagrees with --gpus (a stale WORLD_SIZE export, a scheduler's variables): running on
-        # the launcher's size would hand the caller a number for a job it did not ask for -- refuse, on every rank
+    if gpus_given and world != args.gpus:
+        # a launcher's environment that disagrees with an EXPLICIT --gpus (a stale WORLD_SIZE export, a scheduler's variables):
+        # running on the launcher's size would hand the caller a number for a job it did not ask for -- refuse, on every rank
         print(f"bench.py[rank {rank}/{world}]: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run", file=sys.stderr, flush=True)
         sys.exit(2)
     progress.phase("importing torch and the engine")
@@ -341,7 +422,7 @@ def main() -> None:
         dist.barrier()
 
     progress.phase("creating the engine context")
-    if os.environ.get("LK_TEST_HANG_RANK") == str(rank):                  # test hook: this rank stops making progress
+    if hook("LK_TEST_HANG_RANK") == str(rank):                            # test hook: this rank stops making progress
         time.sleep(1e6)
     ctx = lk.Context(device=local_rank)
     reduce_path = "none (single rank)"
@@ -359,7 +440,7 @@ def main() -> None:
         native = bool(int(want.item()))
         if native:
             progress.phase("native RCCL communicator: agreeing on librccl, unique id, ncclCommInitRank")
-            if os.environ.get("LK_TEST_FAIL_COMM_RANK") == str(rank):     # test hook: this rank alone cannot enter the collective
+            if hook("LK_TEST_FAIL_COMM_RANK") == str(rank):               # test hook: this rank alone cannot enter the collective
                 _die(progress, "LK_TEST_FAIL_COMM_RANK: simulated failure of lk_comm_init_rank on this rank only")
             try:
                 native = ctx.init_native_comm_from_process_group(dist.group.WORLD)
@@ -373,6 +454,12 @@ def main() -> None:
             ctx.set_process_group(dist.group.WORLD)
             reduce_path = ("RCCL" if backend == "nccl" else backend) + " via torch.distributed callback"
         progress.phase(f"communicator up: {reduce_path}")
+        if hook("LK_TEST_SCALE_PARTIALS_RANK") == str(rank):
+            # test hook: THIS rank's contribution to every sweep reduction is scaled by 1 + 1e-6 before the sum (callback route only) --
+            # a wrong reduction; the line's parity check must catch it and the run must end non-zero
+            if native:
+                _die(progress, "LK_TEST_SCALE_PARTIALS_RANK needs the callback route (LK_NATIVE_RCCL=0)")
+            _install_faulty_reduction(ctx, torch, 1.0 + 1e-6)
     if args.grid_mult:
         ctx.set_tuning("grid_mult", args.grid_mult)
     for kv in args.tune:
@@ -396,6 +483,10 @@ def main() -> None:
     else:
         row0, n_local = lk.row_partition(n, world, rank)
         row_starts = [lk.row_partition(n, world, r)[0] for r in range(world)] + [n]
+    if args.shard_of:
+        if world != 1 or args.operator != "diag":
+            raise SystemExit("bench.py: --shard-of runs in one process on the diagonal operator")
+        row0, n_local = lk.row_partition(n, args.shard_of, 0)       # rank 0's block of the P-rank job, alone on this GPU
     ctx.set_partition(row0, n)
 
     # ---- inputs resident in HBM before the timed region
@@ -457,6 +548,7 @@ def main() -> None:
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     progress.phase(f"timed region done ({elapsed:.2f} s on this rank); max over ranks")
+    elapsed_local = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -465,6 +557,19 @@ def main() -> None:
     n_sweeps, sweep_ms, sweep_bytes = ctx.profile_get("dgs_sweep*")
     n_dgs, dgs_ms, dgs_bytes = ctx.profile_get("dgs")
     n_mv, mv_ms, mv_bytes = ctx.profile_get("matvec")
+    comm_tags = ("comm_allreduce", "comm_halo", "comm_allgather")
+    comm_local = {t: ctx.profile_get(t) for t in comm_tags}
+    # every rank's own numbers to rank 0: the line's roofline is the SLOWEST rank's, and the spread says whether a scaling gap is
+    # rank skew (one slow rank; the others wait for it inside the all-reduce) or a uniform slowdown
+    mine = [float(n_sweeps), sweep_ms, sweep_bytes, elapsed_local, float(n_mv), mv_ms, float(n_dgs), dgs_ms]
+    for t in comm_tags:
+        mine += [float(comm_local[t][0]), comm_local[t][1], comm_local[t][2]]
+    per_rank_rows = [mine]
+    if dist is not None and world > 1:
+        tt = torch.tensor(mine, dtype=torch.float64, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        every = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        per_rank_rows = [[float(v) for v in e.tolist()] for e in every]
     per_sweep = {}
     for i, what in ((1, "h1 = X^H y"), (2, "y' = y - X h1 (registers); h2 = X^H y'"), (3, "y'' = (y - X h1) - X h2, stored")):
         cnt, ms, by = ctx.profile_get(f"dgs_sweep{i}")
@@ -481,22 +586,44 @@ def main() -> None:
         # `traffic` comes from separate rocprofv3 --pmc passes (counters cannot be collected from inside this process); the
         # record names the SHA-256 of the kernel sources it was measured on.  A record made on other kernels is refused
         # loudly -- traffic = null and a line on stderr -- instead of being quoted as if it described this build.
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                rec = json.load(open(pmc))
-                if rec.get("n_local") == n_local and rec.get("m") == m and rec.get("dtype") == args.dtype:
-                    have = kernel_source_hash()
-                    if rec.get("kernel_source_sha256") == have:
-                        traffic = rec.get("hbm_bytes_per_launch")
-                        traffic_src = {k: rec.get(k) for k in ("commit", "kernel_source_sha256", "source", "method") if k in rec}
-                    else:
-                        traffic_src = (f"STALE: profiles/pmc_traffic.json was measured on kernel sources {str(rec.get('kernel_source_sha256'))[:12]}..., "
-                                       f"this build is {have[:12]}...; re-run tools/run_profiles.sh")
-                        print("bench.py: " + traffic_src, file=sys.stderr)
-            except Exception as exc:  # noqa: BLE001
-                traffic, traffic_src = None, f"profiles/pmc_traffic.json unreadable: {exc!r}"
+        traffic, traffic_src = load_traffic_record(n_local, m, args.dtype) if args.operator == "diag" else (None, "no PMC record for this workload")
+        # roofline of the SLOWEST rank (the one the others wait for); this rank's own figures sit beside it
+        R = per_rank_rows
+        rank_avg = [r[1] / max(r[0], 1.0) for r in R]                          # avg launch ms per rank
+        rank_gbs = [(r[2] / 1e9) / (r[1] / 1e3) if r[1] > 0 else 0.0 for r in R]
+        slow = int(np.argmax(rank_avg)) if R else 0
+        achieved_rank0 = achieved
+        if world > 1 and rank_gbs[slow] > 0:
+            achieved = rank_gbs[slow]
+        per_rank = {
+            "avg_launch_ms": {"min": min(rank_avg), "max": max(rank_avg), "mean": float(np.mean(rank_avg)), "by_rank": rank_avg},
+            "GBps": {"min": min(rank_gbs), "max": max(rank_gbs), "mean": float(np.mean(rank_gbs))},
+            "launches_by_rank": [int(r[0]) for r in R],
+            "timed_region_s_by_rank": [r[3] for r in R],
+            "slowest_rank": slow, "frac_is": "the slowest rank's",
+        }
+        # collectives on the engine's stream (HIP events either side of each one): what N > 1 adds to a step
+        comm = {"route": reduce_path, "ranks": world}
+        comm_ms_rank0 = 0.0
+        for ti, tag in enumerate(comm_tags):
+            cnt0, ms0, by0 = comm_local[tag]
+            comm_ms_rank0 += ms0
+            col = 8 + 3 * ti
+            ms_by_rank = [r[col + 1] for r in R]
+            comm[tag[len("comm_"):]] = {
+                "launches": int(cnt0), "avg_us": (1e3 * ms0 / cnt0) if cnt0 else None, "ms_total": ms0,
+                "bytes_per_launch": (by0 / cnt0) if cnt0 else None,
+                "frac_of_step_time": (ms0 / 1e3) / elapsed if elapsed > 0 else 0.0,
+                "ms_total_by_rank": {"min": min(ms_by_rank), "max": max(ms_by_rank), "mean": float(np.mean(ms_by_rank))},
+            }
+        comm["frac_of_step_time"] = (comm_ms_rank0 / 1e3) / elapsed if elapsed > 0 else 0.0
+        comm["measured"] = ("HIP events recorded on the engine's stream before and after every collective (native route: the time the RCCL kernel holds "
+                            "the stream = launch + ring latency + the wait for the slowest peer; host routes: the whole round trip); rank 0's totals, "
+                            "min / max / mean over ranks beside them") if world > 1 or dist is not None else "single rank: no collective is issued"
+        # where the step time of rank 0 went: sweeps + operator + collectives + the rest (finish kernels, normalise, launch gaps, host)
+        attribution = {"sweeps": (sweep_ms / 1e3) / elapsed, "matvec": (mv_ms / 1e3) / elapsed, "comm": comm["frac_of_step_time"]} if elapsed > 0 else {}
+        if attribution:
+            attribution["other (finish kernels, normalise, launch gaps, host)"] = max(0.0, 1.0 - sum(attribution.values()))
         # self-check of the line: where the repository holds a fixture of the reference's arithmetic for exactly this workload (the
         # metric configuration and configs[1]), every column of the H just computed is compared with it -- whatever the number of
         # ranks, so a scaling run whose reduction went wrong says so in its own line (the fixture is data, tests/golden/)
@@ -540,12 +667,14 @@ def main() -> None:
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_measured_in_this_run": False,      # a stored record of separate --pmc passes (profiles/pmc_traffic.json)
-                "traffic_source": traffic_src if traffic_src is not None else
-                                  "rocprofv3 --pmc passes cannot run inside bench.py; see profiles/ (no record for this workload)",
+                "traffic_source": traffic_src,
+                "traffic_over_algorithmic": (traffic / (sweep_bytes / max(n_sweeps, 1))) if traffic and n_sweeps else None,
                 "bytes_priced": "ALGORITHMIC three-sweep schedule, s*n_local*(k+1 | k+2 | k+2) = s*n*(3k+5) per DGS (SURVEY 8d); "
                                 "the shipped schedule moves 3k+4 columns (y' is never written), so HBM-level bandwidth is "
                                 "(3k+4)/(3k+5) of `achieved`",
-                "launches": int(n_sweeps), "avg_launch_ms": sweep_ms / max(n_sweeps, 1),
+                "launches": int(n_sweeps), "avg_launch_ms": rank_avg[slow] if world > 1 else sweep_ms / max(n_sweeps, 1),
+                "rank0": {"achieved": achieved_rank0, "avg_launch_ms": sweep_ms / max(n_sweeps, 1)},
+                "per_rank": per_rank,
                 "algorithmic_bytes_per_launch": sweep_bytes / max(n_sweeps, 1),
                 "per_sweep": per_sweep,
                 "dgs_call_GBps": (dgs_bytes / 1e9) / (dgs_ms / 1e3) if dgs_ms > 0 else 0.0,
@@ -559,6 +688,17 @@ def main() -> None:
                                         "markers around kernels + exchange otherwise) inside the asynchronous batch") if n_mv else "not measured"},
             },
         }
+        out["comm"] = comm
+        out["step_time_attribution_rank0"] = attribution
+        pred = predicted_iters_per_s(n, m, world, args.operator, args.dtype)
+        out["predicted_it_s"] = pred["predicted_it_s"] if pred else None
+        out["predicted"] = pred
+        if pred and pred.get("predicted_it_s"):
+            out["predicted"]["value_over_predicted"] = out["value"] / pred["predicted_it_s"]
+        if args.shard_of:
+            out["shard_emulation"] = {"of_ranks": args.shard_of, "note": "ONE row block of a P-rank job alone on this GPU (no communicator): "
+                                      "per-shard kernel measurements only -- `value` is NOT the metric"}
+            out["config"]["parity"] = None
         if mv_ms > sweep_ms and mv_ms > 0:
             # the operator, not the orthogonalisation, is the dominant kernel of this workload (dense GEMV): its roofline leads
             r = out["roofline"]
@@ -585,7 +725,14 @@ def main() -> None:
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "Arnoldi iterations/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {exc!r}"}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        parity_failed = bool(out["config"].get("parity")) and out["config"]["parity"].get("ok") is False
+    # a line whose own parity check failed (a reduction that went wrong in a sharded run) is printed -- and the run ends NON-ZERO on
+    # every rank: a throughput number for a wrong factorisation is not a result
+    if dist is not None and world > 1:
+        flag = torch.tensor([1 if (rank == 0 and parity_failed) else 0], dtype=torch.int32, device=f"cuda:{local_rank}" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        parity_failed = bool(int(flag.item()))
     # orderly teardown: device objects, then the library's own communicator (lk_finalize), then torch's group
     progress.phase("teardown")
     del X, A, keep
@@ -595,6 +742,9 @@ def main() -> None:
     if dist is not None:
         dist.destroy_process_group()
     progress.done()
+    if parity_failed:
+        print(f"bench.py[rank {rank}/{world}]: config.parity.ok is false -- the Hessenberg matrix of this run is not the reference's; exit 4", file=sys.stderr, flush=True)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -61,7 +61,6 @@ module lightkrylov_gpu
 
     type(c_ptr), save :: ctx = c_null_ptr
     integer(c_int64_t), save :: part_row0 = 0          ! first global row of this rank's block (lk_gpu_set_partition)
-    integer, save :: comm_nranks = 1                   ! ranks of the communicator installed by lk_gpu_comm_init (1: none)
     integer, save :: last_n = -1                       ! size of the vector bound most recently (resolve_size)
 
     !> Device storage of one vector: a column of a pool slab.  Defined assignment = deep copy.
@@ -183,7 +182,6 @@ contains
     subroutine lk_gpu_finalize()
         integer(c_int) :: rc
         rc = lk_finalize(ctx); ctx = c_null_ptr
-        comm_nranks = 1
     end subroutine
 
     !> out4 = slabs, columns ever carved, columns currently registered, acquisitions served by re-use
@@ -210,7 +208,6 @@ contains
         integer, intent(in) :: nranks, rank
         character(kind=c_char), intent(in) :: id(128)
         call chk(lk_comm_init_rank(ctx, int(nranks, c_int), int(rank, c_int), id), 'lk_gpu_comm_init')
-        comm_nranks = nranks
     end subroutine
 
     !> the offsets of a row-sharded operator: exactly nranks + 1 of them, from 0 to the global size (the library reads
@@ -219,9 +216,13 @@ contains
         integer(c_int64_t), intent(in) :: row_starts(0:)
         integer, intent(in) :: n_global
         character(len=*), intent(in) :: procedure
-        if (size(row_starts) /= comm_nranks + 1) call stop_error( &
-            'row_starts needs nranks + 1 entries (0-based offsets of every rank''s row block; lk_gpu_comm_init first)', this_module, procedure)
-        if (row_starts(0) /= 0 .or. row_starts(comm_nranks) /= int(n_global, c_int64_t)) call stop_error( &
+        integer(c_int) :: nranks, rank
+        ! the rank count comes from the LIBRARY (lk_comm_info), not from a shadow of this module: a context whose collectives were
+        ! installed through the iso_c bindings (lk_set_allreduce / lk_set_allgather) has ranks this module never saw
+        call chk(lk_comm_info(ctx, nranks, rank), procedure)
+        if (size(row_starts) /= nranks + 1) call stop_error( &
+            'row_starts needs nranks + 1 entries (0-based offsets of every rank''s row block; install the communicator first)', this_module, procedure)
+        if (row_starts(0) /= 0 .or. row_starts(nranks) /= int(n_global, c_int64_t)) call stop_error( &
             'row_starts must run from 0 to the number of columns of the row block', this_module, procedure)
     end subroutine
 

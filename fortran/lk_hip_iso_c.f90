@@ -219,6 +219,12 @@ module lightkrylov_hip_c
             type(c_ptr), intent(out) :: stream
             integer(c_int) :: rc
         end function
+        function lk_comm_info(ctx, nranks, rank) bind(C, name="lk_comm_info") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: ctx
+            integer(c_int), intent(out) :: nranks, rank
+            integer(c_int) :: rc
+        end function
         !> native RCCL all-reduce: rank 0 fills id(128) and ships it (e.g. MPI_Bcast); every rank then calls
         !> lk_comm_init_rank (collective).  lk_comm_available: local check that librccl resolves (agree on it over MPI
         !> before anyone enters the collective).

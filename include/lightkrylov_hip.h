@@ -80,6 +80,9 @@ int lk_sync(lk_context_t ctx);
 int lk_set_allreduce(lk_context_t ctx, lk_allreduce_fn fn, void *user, int nranks, int rank);
 /* device ordinal and hipStream_t the context runs on (either pointer may be NULL). */
 int lk_context_info(lk_context_t ctx, int *device, void **stream);
+/* ranks sharing the row-sharded basis and this context's rank, as installed by lk_set_allreduce or lk_comm_init_rank (1, 0 without
+ * either; either pointer may be NULL).  What a host-side check of a row partition must read -- not a shadow of its own. */
+int lk_comm_info(lk_context_t ctx, int *nranks, int *rank);
 
 /* Native RCCL all-reduce (one process per GPU; backend "nccl" of the reference-side launchers IS RCCL on
  * ROCm).  Rank 0 calls lk_comm_get_unique_id and ships the LK_COMM_ID_BYTES opaque bytes to every rank by

@@ -40,6 +40,7 @@ SIGNATURES = {
     "lk_set_halo_exchange": (_int, [_p, HALO_FN, _p]),
     "lk_set_allgather": (_int, [_p, ALLGATHER_FN, _p]),
     "lk_context_info": (_int, [_p, _ip, _pp]),
+    "lk_comm_info": (_int, [_p, _ip, _ip]),
     "lk_comm_available": (_int, []),
     "lk_comm_get_unique_id": (_int, [_p]),
     "lk_comm_init_rank": (_int, [_p, _int, _int, _p]),

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <mutex>
 #include <set>
@@ -88,7 +89,7 @@ struct lk_context_s {
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
     int gemm_3m = 1;           // complex MFMA kernels (tall-skinny product; X^H Y with <= 32 right-hand sides; Gram) with three real products per complex one (0: four, the doubled real problem)
-    int kc32 = -1;             // real update sweeps of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 on panels of >= 2^25 rows)
+    int kc32 = -1;             // real DGS update sweeps (2 and 3) of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 when the GLOBAL problem has >= 2^25 rows)
     int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
     int wide_regs = 2;         // wide REGISTER tiles: 1 = 8 waves x 32 / 24 columns for 129..256 real / 129..192 complex basis columns instead of the lane split; 2 = also the lane split on 24-column groups for 257..384 columns; 0 = round 3's shapes
     int cplx_wide = 32;        // complex sweeps with 8 waves x 16 columns per block when k exceeds this (0: never) instead of 16 x 8
@@ -297,7 +298,7 @@ struct ProfScope {
     ProfRec rec;
     bool ext = false;   // the launch itself carries the two events (hipExtLaunchKernelGGL): nothing is recorded on the stream
     ProfScope(lk_context_t ctx, const char *tag, double bytes, bool ext_launch = false) : c(ctx), on(ctx->prof), ext(ext_launch) {
-        if (on && c->prof_sweeps_only && strncmp(tag, "dgs_sweep", 9) != 0 && strcmp(tag, "matvec") != 0) on = false;
+        if (on && c->prof_sweeps_only && strncmp(tag, "dgs_sweep", 9) != 0 && strcmp(tag, "matvec") != 0 && strncmp(tag, "comm_", 5) != 0) on = false;
         if (!on) return;
         auto get = [&]() {
             hipEvent_t e;
@@ -380,6 +381,9 @@ int check_pair(lk_basis_t A, lk_basis_t B, const char *what) {
 int allreduce(lk_context_t c, double *dev, int64_t count) {
     if (c->nranks > 1 && !c->allreduce) return fail(LK_ERR_COMM, "nranks=%d but no all-reduce installed", c->nranks);
     if (c->allreduce) {
+        // "comm_allreduce": stream markers either side of the collective -- on the native route the time the ncclAllReduce kernel
+        // occupies the engine's stream (launch + ring latency + the wait for the slowest peer), on a host route the whole round trip
+        ProfScope ps(c, "comm_allreduce", (double)count * 8.0);
         int rc = c->allreduce(c->allreduce_user, dev, count, (void *)c->stream);
         if (rc != 0) return fail(LK_ERR_COMM, "all-reduce callback returned %d", rc);
     }
@@ -570,8 +574,13 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
     // sweeps), null at n = 10^7, -0.6 % at n = 2 10^6 -- so the default (-1) turns it on for k > 32 on LONG panels only, a column
     // beyond the 256 MB memory-side cache (n >= 2^25 rows); 0 = never, v > 0 = for k > v at every size.
     {
-        const int kc32 = c->kc32 >= 0 ? c->kc32 : (Bx->n >= ((int64_t)1 << 25) ? 32 : 0);
-        if (kc32 && k > kc32 && MODE != 1) return launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        // The size that decides is the GLOBAL row count where the host announced one (lk_set_partition): every rank of a sharded run then
+        // picks the same shape whatever its block -- the summation order inside a rank does not depend on the partition, and the 1 / 2 / 4 / 8-GPU
+        // points of a scaling run compare the same kernels (round-4 advisor).  Only the DGS pair (MODE 2 + 4) takes it: the single-set
+        // update (MODE 3: lazy path, one-pass orthogonalisation) keeps the 16-column tile its A/B was recorded on.
+        const int64_t nref = c->n_global > 0 ? c->n_global : Bx->n;
+        const int kc32 = c->kc32 >= 0 ? c->kc32 : (nref >= ((int64_t)1 << 25) ? 32 : 0);
+        if (kc32 && k > kc32 && (MODE == 2 || MODE == 4)) return launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
     }
     return launch_sweep<false, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
 }
@@ -1261,6 +1270,13 @@ int lk_context_info(lk_context_t c, int *device, void **stream) {
     if (!c) return fail(LK_ERR_INVALID, "lk_context_info: null context");
     if (device) *device = c->device;
     if (stream) *stream = (void *)c->stream;
+    return LK_OK;
+}
+
+int lk_comm_info(lk_context_t c, int *nranks, int *rank) {
+    if (!c) return fail(LK_ERR_INVALID, "lk_comm_info: null context");
+    if (nranks) *nranks = c->nranks;
+    if (rank) *rank = c->rank;
     return LK_OK;
 }
 
@@ -2043,6 +2059,10 @@ static int innerprod_impl(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, d
                 if (c->prof) prof_collect(c);
                 for (int q = 0; q < pn; ++q)
                     memcpy(M + ((size_t)(j + q) * k + c0) * ED, host.data() + (size_t)q * (kk + 1) * ED, (size_t)kk * ED * sizeof(double));
+                // diagonal of X^H X, complex kind: conj(x) . x has an imaginary part of exactly zero in the reference's dotc (every term
+                // is re*im - im*re); the three-product kernels form Im as P3 + P1 - P2 and would leave O(eps |x|^2) there
+                if (same && ED == 2)
+                    for (int q = 0; q < pn; ++q) M[((size_t)(j + q) * k + c0 + q) * 2 + 1] = 0.0;
             }
         }
         return LK_OK;
@@ -2432,6 +2452,7 @@ static int gather_x(lk_linop_t op, const double *x, const double **xg) {
     lk_context_t c = op->ctx;
     if (c->nranks == 1) { *xg = x; return LK_OK; }
     if (!c->allgather) return fail(LK_ERR_COMM, "row-sharded dense / CSR operator but no all-gather installed (lk_comm_init_rank / lk_set_allgather)");
+    ProfScope ps(c, "comm_allgather", (double)op->ncols_g * (op->dtype == LK_C128 ? 16.0 : 8.0));
     const int rc = c->allgather(c->allgather_user, x, op->xfull, op->gcounts.data(), op->gdispls.data(), c->nranks, (void *)c->stream);
     if (rc != 0) return fail(LK_ERR_COMM, "all-gather callback returned %d", rc);
     *xg = op->xfull;
@@ -2458,6 +2479,7 @@ int lk_set_allgather(lk_context_t c, lk_allgather_fn fn, void *user) {
 
 static int halo_exchange(lk_context_t c, const double *send_lo, const double *send_hi, double *recv_lo, double *recv_hi, int64_t count) {
     if (!c->halo) return fail(LK_ERR_COMM, "row-sharded stencil operator but no halo exchange installed (lk_comm_init_rank / lk_set_halo_exchange)");
+    ProfScope ps(c, "comm_halo", (double)count * 8.0 * ((send_lo ? 1 : 0) + (send_hi ? 1 : 0)));
     const int rc = c->halo(c->halo_user, send_lo, send_hi, recv_lo, recv_hi, count, (void *)c->stream);
     if (rc != 0) return fail(LK_ERR_COMM, "halo exchange callback returned %d", rc);
     return LK_OK;
@@ -2723,13 +2745,20 @@ int lk_linop_csr_create_sharded(lk_context_t c, int dtype, int64_t n_global, con
     const int64_t nnz = rowptr[n];
     const int ED = dtype == LK_C128 ? 2 : 1;
     const double *v = (const double *)vals;
-    // conjugate transpose of the row block (n_global rows, LOCAL column indices) by counting sort over the column indices
-    std::vector<int64_t> tp((size_t)n_global + 1, 0);
-    for (int64_t p = 0; p < nnz; ++p) tp[(size_t)colind[p] + 1] += 1;
-    for (int64_t j = 0; j < n_global; ++j) tp[(size_t)j + 1] += tp[(size_t)j];
-    std::vector<int32_t> tc((size_t)(nnz > 0 ? nnz : 1));
-    std::vector<double> tv((size_t)(nnz > 0 ? nnz : 1) * ED);
-    {
+    // conjugate transpose of the row block (n_global rows, LOCAL column indices) by counting sort over the column indices.  Host
+    // allocations of THIS rank (n_global + nnz entries): a bad_alloc must neither cross the C ABI nor leave the peers in the next
+    // exchange -- it becomes this rank's status in the "buffers" agreement below
+    std::vector<int64_t> tp;
+    std::vector<int32_t> tc;
+    std::vector<double> tv;
+    lk_linop_t o = nullptr;
+    int rc_host = LK_OK;
+    try {
+        tp.assign((size_t)n_global + 1, 0);
+        for (int64_t p = 0; p < nnz; ++p) tp[(size_t)colind[p] + 1] += 1;
+        for (int64_t j = 0; j < n_global; ++j) tp[(size_t)j + 1] += tp[(size_t)j];
+        tc.resize((size_t)(nnz > 0 ? nnz : 1));
+        tv.resize((size_t)(nnz > 0 ? nnz : 1) * ED);
         std::vector<int64_t> next(tp.begin(), tp.end() - 1);
         for (int64_t i = 0; i < n; ++i)
             for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p) {
@@ -2738,22 +2767,28 @@ int lk_linop_csr_create_sharded(lk_context_t c, int dtype, int64_t n_global, con
                 tv[(size_t)q * ED] = v[p * ED];
                 if (ED == 2) tv[(size_t)q * 2 + 1] = -v[p * 2 + 1];
             }
+        o = new lk_linop_s();
+        o->ctx = c; o->kind = OP_CSR; o->dtype = dtype;
+    } catch (const std::exception &e) {
+        rc_host = fail(LK_ERR_NOMEM, "lk_linop_csr_create_sharded: host allocation failed while transposing this rank's rows (%s)", e.what());
     }
-    lk_linop_t o = new lk_linop_s();
-    o->ctx = c; o->kind = OP_CSR; o->dtype = dtype;
-    // ... then this rank's share of the set-up that precedes the metadata exchange (the gathered-x buffer) ...
-    int rc = agree_status(c, shard_setup(o, c, n_global, row_starts, "lk_linop_csr_create"), "lk_linop_csr_create_sharded (buffers)");
-    std::vector<int32_t> cols0;
+    // ... then this rank's share of the set-up that precedes the metadata exchange (the transpose above, the gathered-x buffer) ...
+    int rc = agree_status(c, rc_host != LK_OK ? rc_host : shard_setup(o, c, n_global, row_starts, "lk_linop_csr_create"), "lk_linop_csr_create_sharded (buffers)");
     if (rc == LK_OK) {
         // ... the metadata exchange itself (its decisions come from quantities every rank holds identically; its staging buffers
         // are a few P-length tables and the request lists -- a rank that cannot allocate THOSE is fatal for the job, see header) ...
-        rc = csr_compress_setup(o, c, row_starts, n, rowptr, colind, cols0);
-        if (rc == LK_OK) rc = csr_upload(o, 0, n, rowptr, cols0.data(), v, ED);
-        if (rc == LK_OK) rc = csr_upload(o, 1, n_global, tp.data(), tc.data(), tv.data(), ED);
+        try {
+            std::vector<int32_t> cols0;
+            rc = csr_compress_setup(o, c, row_starts, n, rowptr, colind, cols0);
+            if (rc == LK_OK) rc = csr_upload(o, 0, n, rowptr, cols0.data(), v, ED);
+            if (rc == LK_OK) rc = csr_upload(o, 1, n_global, tp.data(), tc.data(), tv.data(), ED);
+        } catch (const std::exception &e) {
+            rc = fail(LK_ERR_NOMEM, "lk_linop_csr_create_sharded: host allocation failed (%s)", e.what());
+        }
         // ... and finally the uploads: an operator exists on every rank or on none
         rc = agree_status(c, rc, "lk_linop_csr_create_sharded (upload)");
     }
-    if (rc != LK_OK) { (void)lk_linop_destroy(o); return rc; }
+    if (rc != LK_OK) { if (o) (void)lk_linop_destroy(o); return rc; }
     *op = o;
     return LK_OK;
 }
@@ -2868,8 +2903,11 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
                 else hipLaunchKernelGGL(k_pack<false>, dim3(blas1_grid(c, op->cx_nsend)), dim3(256), 0, c->stream, x, op->cx_send_idx, op->cx_nsend, op->cx_sendbuf, c->guard());
                 HIPCHK(hipGetLastError());
             }
-            if (c->allgather(c->allgather_user, op->cx_sendbuf, op->cx_xrem, op->cx_counts.data(), op->cx_displs.data(), c->nranks, (void *)c->stream) != 0)
-                return fail(LK_ERR_COMM, "all-gather callback failed");
+            {
+                ProfScope ps(c, "comm_allgather", (double)op->cx_total * (cp ? 16.0 : 8.0));
+                if (c->allgather(c->allgather_user, op->cx_sendbuf, op->cx_xrem, op->cx_counts.data(), op->cx_displs.data(), c->nranks, (void *)c->stream) != 0)
+                    return fail(LK_ERR_COMM, "all-gather callback failed");
+            }
             xrem = op->cx_xrem;
             nloc = n;
         } else if (shard && trans == LK_OP_N) {

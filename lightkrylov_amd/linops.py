@@ -253,10 +253,11 @@ class csr_linop_gpu(_engine_linop):
             rs = _row_starts(self.ctx, int(ncols), row_starts)
             if int(rs[self.ctx.rank + 1] - rs[self.ctx.rank]) != self.n:
                 raise TypeError("csr_linop_gpu: the number of rows passed is not this rank's block")
-        except (TypeError, ValueError):
-            # the sharded creation is COLLECTIVE: a rank whose input is unusable must not leave the others waiting in the
-            # metadata exchange -- it joins the library's status agreement with a null row block (every rank then fails) and
-            # raises its own error afterwards
+        except Exception:  # noqa: BLE001 - ANY local failure, then re-raised
+            # the sharded creation is COLLECTIVE: a rank whose input is unusable -- for whatever reason: a wrong type or shape, an
+            # object without tocsr / indptr (AttributeError), an index that does not fit int32 (OverflowError), a failed allocation in
+            # ascontiguousarray (MemoryError) -- must not leave the others waiting in the metadata exchange: it joins the library's
+            # status agreement with a null row block (every rank then fails) and raises its own error afterwards
             if sharded and self.ctx.nranks > 1:
                 try:
                     rs = _row_starts(self.ctx, int(n_global) if n_global is not None else 0, row_starts)

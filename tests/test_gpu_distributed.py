@@ -122,7 +122,7 @@ def test_a_rank_that_cannot_enter_the_native_communicator_ends_the_whole_job():
     args = ["--gpus", "2", "--rows", "200001", "--kdim", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     t0 = time.time()
     out = _launch([sys.executable, "bench.py"] + args, timeout=300, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0",
-                  LK_NATIVE_RCCL="force", LK_TEST_FAIL_COMM_RANK="1")
+                  LK_NATIVE_RCCL="force", LK_BENCH_TEST_HOOKS="1", LK_TEST_FAIL_COMM_RANK="1")
     took = time.time() - t0
     assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")], out.stdout[-2000:] + out.stderr[-6000:]
     assert "FATAL after phase 'native RCCL communicator" in out.stderr and "simulated failure of lk_comm_init_rank on this rank only" in out.stderr
@@ -150,7 +150,7 @@ def test_a_rank_that_stops_moving_is_reported_with_its_stack_and_ends_the_job():
     that rank is on stderr with the phase it was in, the process leaves with status 1 and the launcher ends the job."""
     args = ["--gpus", "2", "--rows", "200001", "--kdim", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
     out = _launch([sys.executable, "bench.py"] + args, timeout=300, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0",
-                  LK_TEST_HANG_RANK="0", LK_BENCH_WATCHDOG="20")
+                  LK_BENCH_TEST_HOOKS="1", LK_TEST_HANG_RANK="0", LK_BENCH_WATCHDOG="20")
     assert out.returncode != 0, out.stdout[-2000:] + out.stderr[-6000:]
     assert "Timeout (0:00:20)!" in out.stderr and "phase: creating the engine context" in out.stderr
     # (the dumped stacks name bench.py's lines; both ranks' watchdogs fire within the same second here and their dumps can interleave
@@ -178,3 +178,38 @@ def test_config5_at_full_size_as_eight_processes_against_the_oracle_fixture(tmp_
     # ... and the bench line checks itself against the same fixture, at any number of ranks
     par = out["config"]["parity"]
     assert par["ok"] is True and par["max_normwise_column_error_vs_reference_arithmetic"] == pytest.approx(e_seq)
+    # ... and EXPLAINS itself (round 5): collectives timed on the engine's stream, every rank's sweep figures, the stored PMC traffic of
+    # this shard size, the scaling model's prediction, where rank 0's step time went
+    ar = out["comm"]["allreduce"]
+    assert 3 * 128 <= ar["launches"] <= 3 * 128 + 2 and ar["avg_us"] > 0 and 0 < out["comm"]["frac_of_step_time"] < 1     # three per Arnoldi step (+ x0's norm)
+    assert ar["bytes_per_launch"] <= 8 * 129 and ar["ms_total_by_rank"]["max"] >= ar["ms_total_by_rank"]["min"] > 0
+    assert out["comm"]["halo"]["launches"] == out["comm"]["allgather"]["launches"] == 0
+    pr = out["roofline"]["per_rank"]
+    assert len(pr["avg_launch_ms"]["by_rank"]) == 8 and pr["launches_by_rank"] == [3 * 128] * 8
+    assert pr["avg_launch_ms"]["min"] <= pr["avg_launch_ms"]["mean"] <= pr["avg_launch_ms"]["max"] == out["roofline"]["avg_launch_ms"]
+    assert out["roofline"]["frac"] == pytest.approx(pr["GBps"]["min"] / 8000.0)
+    assert out["roofline"]["traffic"] is not None and 0.98 <= out["roofline"]["traffic_over_algorithmic"] <= 1.02, out["roofline"]["traffic_source"]
+    assert out["predicted_it_s"] > 250 and out["predicted"]["value_over_predicted"] > 0
+    att = out["step_time_attribution_rank0"]
+    assert abs(sum(att.values()) - 1.0) < 1e-9 and att["comm"] == out["comm"]["frac_of_step_time"]
+
+
+def test_a_wrong_reduction_ends_the_run_nonzero_with_its_line_printed():
+    """The line polices itself: one rank's partial sums scaled by 1 + 1e-6 before every all-reduce (test hook, callback route) -- the
+    factorisation still runs to the end and the line is printed, with config.parity.ok = false against the committed fixture, and EVERY
+    rank leaves with a non-zero status.  The same command without the fault: ok = true, status 0."""
+    args = ["--gpus", "2", "--rows", "10000000", "--kdim", "64", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    good = _run([sys.executable, "bench.py"] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0")
+    assert good["config"]["parity"]["ok"] is True and 3 * 64 <= good["comm"]["allreduce"]["launches"] <= 3 * 64 + 2
+    # the hook variable alone (no opt-in) changes nothing
+    leaked = _run([sys.executable, "bench.py"] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0", LK_TEST_SCALE_PARTIALS_RANK="1")
+    assert leaked["config"]["parity"]["ok"] is True and leaked["config"]["H_fro"] == good["config"]["H_fro"]
+    out = _launch([sys.executable, "bench.py"] + args, LK_DIST_BACKEND="gloo", LK_FORCE_DEVICE="0", LK_BENCH_TEST_HOOKS="1",
+                  LK_TEST_SCALE_PARTIALS_RANK="1")
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode != 0 and lines, out.stdout[-2000:] + out.stderr[-6000:]
+    bad = json.loads(lines[-1])
+    assert bad["config"]["parity"]["ok"] is False and bad["config"]["parity"]["max_normwise_column_error_vs_reference_arithmetic"] > 1e-9
+    assert "config.parity.ok is false" in out.stderr
+    import re
+    assert len(re.findall(r"exitcode\s*: 4", out.stderr)) >= 1 or "exit 4" in out.stderr

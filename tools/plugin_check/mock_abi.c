@@ -255,3 +255,4 @@ int lk_arnoldi(void *A, void *X, double *H, int64_t ldh, int k0, int k1, double 
 }
 int lk_comm_get_unique_id(void *id) { memset(id, 0, 128); return LK_OK; }
 int lk_comm_init_rank(mock_ctx *c, int nranks, int rank, const void *id) { (void)c; (void)rank; (void)id; return nranks == 1 ? LK_OK : fail("no collective in the mock"); }
+int lk_comm_info(mock_ctx *c, int *nranks, int *rank) { (void)c; if (nranks) *nranks = 1; if (rank) *rank = 0; return LK_OK; }
