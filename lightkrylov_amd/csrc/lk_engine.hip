@@ -681,7 +681,14 @@ constexpr int XHY_GROUP = 32;       // right-hand sides per pass of the block DG
 
 // M = X(:, c0 : c0+k)^H Y(:, jy0 : jy0+p), k, p <= XHY_MAX, into result section `sec` (0 / 1) of c->xhy in panel_dot_p's
 // layout [q][k+1][ED] (slot k = ||Y_q||^2), all-reduced.  flags: see the kernel (1 = Y is X, 2 = upper tiles only).
-int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int flags, int sec, double **out_dev) {
+// `slot`: where in the result area the matrix lands, in units of XHY_SLOT doubles (= one group of XHY_GROUP right-hand sides against
+// XHY_MAX columns): 0 and XHY_SLOTS / 2 are the two classic sections; the block DGS of a basis wider than XHY_MAX columns keeps one
+// slot per column panel of X for H1 (0..3) and one for H2 (4..7).  `may_grow` = false: the workspace already holds coefficients of an
+// earlier pass and must not be re-allocated (the caller sized it with the first pass).
+constexpr int XHY_SLOTS = 8;
+constexpr int64_t XHY_SLOT = (int64_t)XHY_MAX * (XHY_MAX + 1) * 2 * 2 / XHY_SLOTS;   // = XHY_GROUP * (XHY_MAX + 1) * 2 doubles
+static_assert(XHY_SLOT == (int64_t)XHY_GROUP * (XHY_MAX + 1) * 2, "eight groups of 32 right-hand sides fill the two result sections");
+int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int flags, int slot, double **out_dev, bool may_grow = true) {
     lk_context_t c = Bx->ctx;
     const bool cp = Bx->dtype == LK_C128;
     const int ED = Bx->ed();
@@ -702,6 +709,8 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     if (g < 1) g = 1;
     const int grid = (int)g, nvb = grid * WR;
     int64_t need = 2 * sect + npart_n + (int64_t)nvb * nslots;
+    if (c->xhy_n < need && !may_grow)
+        return fail(LK_ERR_INVALID, "internal: xhy workspace too small for a later pass of the block Gram-Schmidt (%lld < %lld)", (long long)c->xhy_n, (long long)need);
     if (c->xhy_n < need) {
         // (also room for the fused block pass, one block per CU, so that it never has to grow the buffer between passes)
         const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
@@ -712,7 +721,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         HIPCHK(hipMalloc((void **)&c->xhy, (size_t)need * sizeof(double)));
         c->xhy_n = need;
     }
-    double *out = c->xhy + (int64_t)sec * sect, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
+    double *out = c->xhy + (int64_t)slot * XHY_SLOT, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
     // complex Gram matrix beyond 32 columns: upper tiles dealt to the waves, three real products per complex one (panel_gram_mfma3m)
     if (cp && !small && c->gemm_3m && flags == 3) {
         const int64_t nt32 = (Bx->n + 31) / 32;
@@ -729,7 +738,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
             HIPCHK(hipMalloc((void **)&c->xhy, (size_t)need3 * sizeof(double)));
             c->xhy_n = need3;
         }
-        double *out3 = c->xhy + (int64_t)sec * sect, *npart3 = c->xhy + 2 * sect, *part3 = npart3 + npart_n;
+        double *out3 = c->xhy + (int64_t)slot * XHY_SLOT, *npart3 = c->xhy + 2 * sect, *part3 = npart3 + npart_n;
         const size_t lds3 = (size_t)KP * 16 * 34 * 2 * sizeof(double);
         {
             ProfScope ps(c, "xhy_mfma", (double)Bx->n * ED * 8.0 * k);
@@ -769,7 +778,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
 
 // Pass B of the block DGS with many right-hand sides, fused (panel_xhy_upd_mfma): Y(:, jy0 : jy0+p) -= X(:, :k) H1, stored, and
 // M2 = X^H Y', ||Y'_q||^2 into result section `sec` of c->xhy (panel_dot_p's layout, all-reduced).  k <= 128, p <= 32.
-int upd_dots_mfma(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, const double *H1dev, int sec, double **out_dev) {
+int upd_dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, const double *H1dev, int slot, double **out_dev) {
     lk_context_t c = Bx->ctx;
     const bool cp = Bx->dtype == LK_C128;
     const int ED = Bx->ed();
@@ -787,13 +796,13 @@ int upd_dots_mfma(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, const dou
         // the coefficients of pass A live in this buffer: grow it BEFORE pass A ran (lk_dgs_block sizes it up front), never here
         return fail(LK_ERR_INVALID, "internal: xhy workspace too small for the fused block pass (%lld < %lld)", (long long)c->xhy_n, (long long)need);
     }
-    double *out = c->xhy + (int64_t)sec * sect, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
+    double *out = c->xhy + (int64_t)slot * XHY_SLOT, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
     const size_t lds = (size_t)(KG * 32 * 34 + 32 * 34 + KG * 32 * 34 * (cp ? 2 : 1)) * sizeof(double);
     {
         ProfScope ps(c, "xhy_upd_mfma", (double)Bx->n * ED * 8.0 * (k + 2 * p));
         auto go = [&](auto kern) -> int {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, (const double *)Bx->col(0), Bx->ld, k, By->col(jy0), By->ld, p, Bx->n,
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, (const double *)Bx->col(c0), Bx->ld, k, By->col(jy0), By->ld, p, Bx->n,
                                H1dev, part, npart, c->gemm_store_policy);
             return LK_OK;
         };
@@ -2246,10 +2255,10 @@ int lk_dgs(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, double *norms
 }
 
 // Y(:, jy0:jy0+qn) -= X(:, :k) * C, C = device coefficients laid out [q][ldc][ED] (what the multi-RHS dot sweep leaves in c->red)
-static int gemm_subtract(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int qn, const double *Cdev, int64_t ldc) {
+static int gemm_subtract(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int qn, const double *Cdev, int64_t ldc, int c0 = 0) {
     lk_context_t c = Bx->ctx;
     LKCHK(ensure_scratch(c, gemm_packed_doubles(k, qn, Bx->ed())));
-    return gemm_launch(Bx, 0, k, By, jy0, qn, Cdev, ldc, -1.0, 1, c->scratch);
+    return gemm_launch(Bx, c0, k, By, jy0, qn, Cdev, ldc, -1.0, 1, c->scratch);
 }
 
 int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h, int *info) {
@@ -2258,42 +2267,71 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
     if (p < 1 || jy0 < 0 || jy0 + p > By->ncols) return fail(LK_ERR_INVALID, "lk_dgs_block: bad column range");
     const int ED = Bx->ed();
     int inf = 0;
-    if (k >= 1 && k <= KMAX_FUSED && k <= Bx->ncols && p >= 2 && Bx->ctx == By->ctx && Bx->dtype == By->dtype &&
-        Bx->n == By->n && !(Bx->data == By->data && jy0 < k)) {
+    if (k >= 1 && k <= KMAX_WIDE && k <= Bx->ncols && p >= 2 && Bx->ctx == By->ctx && Bx->dtype == By->dtype &&
+        Bx->n == By->n && !(Bx->data == By->data && jy0 < k) && (k <= KMAX_FUSED || Bx->ctx->xhy_mfma)) {
         // panel x panel schedule, up to FOUR columns of Y per pass over X (4 passes per group instead of 4 per column):
         //   H1 = X^H Y | Y -= X H1 | H2 = X^H Y | Y -= X H2      (DGS_basis_against_basis, gram_schmidt.fypp:59-105)
         lk_context_t c = Bx->ctx;
         LKCHK(lazy_enter(c, true));
-        if (c->xhy_mfma && p >= XHY_MIN_P) {
+        if (c->xhy_mfma && (p >= XHY_MIN_P || k > KMAX_FUSED)) {
             // many right-hand sides: coefficients AND updates on the matrix cores, THREE passes over X per group of up to 32
             // columns of Y (H1 = X^H Y | Y' = Y - X H1 with H2 = X^H Y' in the same pass | Y'' = Y' - X H2); "block_fused" = 0
-            // keeps the four-pass schedule (H1 | update | H2 | update).  One copy + synchronisation per group
-            std::vector<double> host((size_t)2 * XHY_GROUP * (k + 1) * ED);
+            // keeps the four-pass schedule (H1 | update | H2 | update).  One copy + synchronisation per group.
+            // A basis WIDER than 128 columns (round 5; block Arnoldi with p = 4 is there after 32 steps, the reference routine is
+            // size-generic) runs the same schedule over column PANELS of X, <= 128 columns each, every panel's coefficients in a
+            // slot of its own on the device:
+            //   A: H1_c = X_c^H Y for every panel c                                            (k columns of X)
+            //   B: Y -= X_c H1_c, panel by panel; the LAST panel's update is the fused one -- it leaves the finished Y' and
+            //      brings H2_last = X_last^H Y' and ||Y'||^2 along                             (k columns)
+            //   C: H2_c = X_c^H Y' for the other panels                                        (k - |last panel| columns)
+            //   D: Y' -= X_c H2_c for every panel                                              (k columns)
+            // = 4k - |last| columns of X per group of up to 32 columns of Y (any p >= 2: below 5 right-hand sides too, where a basis
+            // of <= 128 columns takes the panel_dot_p route) instead of 3k per COLUMN on the single-vector path.
+            const int npan = (k + XHY_MAX - 1) / XHY_MAX, last = npan - 1;
+            auto pc0 = [&](int cp_) { return cp_ * XHY_MAX; };
+            auto pkk = [&](int cp_) { return (k - pc0(cp_)) < XHY_MAX ? (k - pc0(cp_)) : XHY_MAX; };
+            const bool fused = c->block_fused == 2 || (c->block_fused && Bx->dtype == LK_F64);   // complex: the 4-pass schedule is faster (2 = force)
+            std::vector<double> host((size_t)2 * npan * XHY_SLOT);
+            double *o1[XHY_SLOTS / 2] = {nullptr, nullptr, nullptr, nullptr}, *o2[XHY_SLOTS / 2] = {nullptr, nullptr, nullptr, nullptr};
             for (int j = 0; j < p; j += XHY_GROUP) {
                 const int pn = (p - j) < XHY_GROUP ? (p - j) : XHY_GROUP;
-                const size_t cnt = (size_t)pn * (k + 1) * ED;
-                double *o1 = nullptr, *o2 = nullptr;
-                LKCHK(dots_mfma(Bx, 0, k, By, jy0 + j, pn, 0, 0, &o1));                         // H1 = X^H Y
-                if (c->block_fused == 2 || (c->block_fused && Bx->dtype == LK_F64)) {   // complex: the 4-pass schedule is faster (2 = force)
-                    LKCHK(upd_dots_mfma(Bx, k, By, jy0 + j, pn, o1, 1, &o2));                   // Y' = Y - X H1 ; H2 = X^H Y'   (one pass)
+                for (int cp_ = 0; cp_ < npan; ++cp_)                                                // A: H1 = X^H Y
+                    LKCHK(dots_mfma(Bx, pc0(cp_), pkk(cp_), By, jy0 + j, pn, 0, cp_, &o1[cp_], cp_ == 0));
+                for (int cp_ = 0; cp_ < last; ++cp_)                                                // B: Y' = Y - X H1 ...
+                    LKCHK(gemm_subtract(Bx, pkk(cp_), By, jy0 + j, pn, o1[cp_], (int64_t)(pkk(cp_) + 1), pc0(cp_)));
+                if (fused) {
+                    LKCHK(upd_dots_mfma(Bx, pc0(last), pkk(last), By, jy0 + j, pn, o1[last], XHY_SLOTS / 2 + last, &o2[last]));   // ... ; H2_last = X_last^H Y'
                 } else {
-                    LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, o1, (int64_t)(k + 1)));
-                    LKCHK(dots_mfma(Bx, 0, k, By, jy0 + j, pn, 0, 1, &o2));
+                    LKCHK(gemm_subtract(Bx, pkk(last), By, jy0 + j, pn, o1[last], (int64_t)(pkk(last) + 1), pc0(last)));
+                    LKCHK(dots_mfma(Bx, pc0(last), pkk(last), By, jy0 + j, pn, 0, XHY_SLOTS / 2 + last, &o2[last], false));
                 }
-                LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, o2, (int64_t)(k + 1)));             // Y'' = Y' - X H2
-                HIPCHK(hipMemcpyAsync(host.data(), o1, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-                HIPCHK(hipMemcpyAsync(host.data() + cnt, o2, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                for (int cp_ = 0; cp_ < last; ++cp_)                                                // C: H2 = X^H Y' (the other panels)
+                    LKCHK(dots_mfma(Bx, pc0(cp_), pkk(cp_), By, jy0 + j, pn, 0, XHY_SLOTS / 2 + cp_, &o2[cp_], false));
+                for (int cp_ = 0; cp_ < npan; ++cp_)                                                // D: Y'' = Y' - X H2
+                    LKCHK(gemm_subtract(Bx, pkk(cp_), By, jy0 + j, pn, o2[cp_], (int64_t)(pkk(cp_) + 1), pc0(cp_)));
+                for (int cp_ = 0; cp_ < npan; ++cp_) {
+                    const size_t cnt = (size_t)pn * (pkk(cp_) + 1) * ED;
+                    HIPCHK(hipMemcpyAsync(host.data() + (size_t)cp_ * XHY_SLOT, o1[cp_], cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(hipMemcpyAsync(host.data() + (size_t)(npan + cp_) * XHY_SLOT, o2[cp_], cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+                }
                 HIPCHK(hipStreamSynchronize(c->stream));
                 if (c->prof) prof_collect(c);
-                const double *r1 = host.data(), *r2 = host.data() + cnt;
                 for (int q = 0; q < pn; ++q) {
-                    const double n1 = std::sqrt(std::fabs(r1[((size_t)q * (k + 1) + k) * ED]));
-                    const double n2 = std::sqrt(std::fabs(r2[((size_t)q * (k + 1) + k) * ED]));
+                    // ||Y_q||^2 rides in slot kk of every panel's column q: before pass 1 from panel 0, of the finished Y' from the
+                    // last panel (whose coefficients were formed last)
+                    const int k0 = pkk(0), kl = pkk(last);
+                    const double n1 = std::sqrt(std::fabs(host[((size_t)q * (k0 + 1) + k0) * ED]));
+                    const double n2 = std::sqrt(std::fabs(host[(size_t)(npan + last) * XHY_SLOT + ((size_t)q * (kl + 1) + kl) * ED]));
                     if (n2 < ATOL_DP) inf = j + q + 1;                              // gram_schmidt.fypp:171-173 (pass 2 overwrites)
                     if (n1 != n1 || n2 != n2) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
                     if (h)
-                        for (int i = 0; i < k * ED; ++i)
-                            h[((size_t)(j + q) * k) * ED + i] = r1[(size_t)q * (k + 1) * ED + i] + r2[(size_t)q * (k + 1) * ED + i];   // :97
+                        for (int cp_ = 0; cp_ < npan; ++cp_) {
+                            const int kk = pkk(cp_);
+                            const double *r1 = host.data() + (size_t)cp_ * XHY_SLOT + (size_t)q * (kk + 1) * ED;
+                            const double *r2 = host.data() + (size_t)(npan + cp_) * XHY_SLOT + (size_t)q * (kk + 1) * ED;
+                            double *hq = h + ((size_t)(j + q) * k + pc0(cp_)) * ED;
+                            for (int i = 0; i < kk * ED; ++i) hq[i] = r1[i] + r2[i];                                             // :97
+                        }
                 }
             }
             if (info) *info = inf;

@@ -343,6 +343,83 @@ def arnoldi(A: _OpBase, X: np.ndarray, H: np.ndarray, kstart: int = 1, kend: int
     return int(info)
 
 
+def orthogonalize_basis_against_basis(Y: np.ndarray, X: np.ndarray):
+    """One CGS pass of a BLOCK Y (n x p) against X (n x k); returns (coefficients k x p, info).  gram_schmidt.fypp:156-200:
+    zero-vector flag per column (:170-173), proj_coefficients = innerprod(X, Y) (:188), proj = linear_combination(X, coefficients)
+    column by column (AbstractVectors.fypp:605-643) and Y(j) <- -proj(j) + Y(j) (axpby_basis, :190-191)."""
+    info = 0
+    for i in range(Y.shape[1]):
+        if norm(Y[:, i]) < ATOL_DP:
+            info = i + 1
+    M = innerprod(X, Y).reshape(X.shape[1], Y.shape[1], order="F")
+    for j in range(Y.shape[1]):
+        proj = linear_combination(X, M[:, j])
+        axpby(-1.0, proj, 1.0, Y[:, j])
+    return M, info
+
+
+def double_gram_schmidt_step_block(Y: np.ndarray, X: np.ndarray):
+    """DGS_basis_against_basis: two passes of the above, beta = pass 1 + pass 2, info of the second.  gram_schmidt.fypp:59-105"""
+    M1, _ = orthogonalize_basis_against_basis(Y, X)
+    M2, info = orthogonalize_basis_against_basis(Y, X)
+    return M1 + M2, info
+
+
+def qr_no_pivoting(Q: np.ndarray, R: np.ndarray, tol: float = ATOL_DP, rand_seed: int = 12345) -> int:
+    """In-place double-Gram-Schmidt QR of the columns of Q, R upper triangular.  qr.fypp:116-167 (a colinear column is replaced by
+    counter-RNG numbers -- the reference draws from the unseeded intrinsic generator there, :146-162)."""
+    info, flag = 0, False
+    R[...] = 0
+    for j in range(Q.shape[1]):
+        if j > 0:
+            h, _ = double_gram_schmidt_step(Q[:, j], Q[:, :j])
+            R[:j, j] = h
+        beta = norm(Q[:, j])
+        if beta != beta:
+            raise FloatingPointError("|beta| = NaN detected! Abort")
+        if abs(beta) < tol:
+            if not flag:
+                flag, info = True, j + 1
+            R[j, j] = 0
+            if np.iscomplexobj(Q):
+                re, im = np.empty(Q.shape[0]), np.empty(Q.shape[0])
+                fill_counter(re, rand_seed + 2 * j); fill_counter(im, rand_seed + 2 * j + 1)
+                Q[:, j] = re + 1j * im
+            else:
+                fill_counter(Q[:, j], rand_seed + j)
+            if j > 0:
+                double_gram_schmidt_step(Q[:, j], Q[:, :j])
+            beta = norm(Q[:, j])
+        else:
+            R[j, j] = beta
+        scal(Q[:, j], 1.0 / beta)
+    return info
+
+
+def arnoldi_block(A: _OpBase, X: np.ndarray, H: np.ndarray, blksize: int, kstart: int = 1, kend: int | None = None,
+                  tol: float = ATOL_DP) -> int:
+    """arnoldi with blksize = p > 1.  src/Krylov/arnoldi.fypp:20-73: p matvecs (:39-47), the batch double Gram-Schmidt step with
+    beta = H(:kp, kpm+1:kp) (:50-51), qr of the new block into H(kp+1:kpp, kpm+1:kp) (:55), breakdown on the smallest |diagonal| of
+    that block (:58-71).  X: (n, (kdim+1) p) F-order, H: ((kdim+1) p, kdim p) F-order."""
+    p = blksize
+    kdim = (X.shape[1] - p) // p
+    kend = kdim if kend is None else kend
+    info = 0
+    for k in range(kstart, kend + 1):
+        kpm, kp, kpp = (k - 1) * p, k * p, (k + 1) * p
+        for i in range(p):
+            A.matvec(X[:, kpm + i], X[:, kp + i])
+        beta, _ = double_gram_schmidt_step_block(X[:, kp:kpp], X[:, :kp])
+        H[:kp, kpm:kp] = beta
+        R = np.zeros((p, p), dtype=X.dtype, order="F")
+        qr_no_pivoting(X[:, kp:kpp], R)
+        H[kp:kpp, kpm:kp] = R
+        if np.min(np.abs(np.diag(R))) < tol:
+            info = kp
+            break
+    return info
+
+
 def arnoldi_fused_allcores(A: _OpBase, X: np.ndarray, H: np.ndarray, tol: float = ATOL_DP) -> int:
     """NOT the reference's arithmetic and never a checker: the engine's three-sweep fused CGS2 schedule on
     the host cores (set_threads), timed by bench.py as the all-core leg of cpu_baseline."""

@@ -94,6 +94,31 @@ def test_arnoldi_factorisation_and_orthonormality(dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+def test_block_arnoldi_factorisation_and_orthonormality(dtype):
+    """test/TestKrylov.fypp:244-296, the reference's own sizes: p = 2, kdim = test_size / 2 (the basis then has p (kdim + 1) = 130
+    columns in a 128-dimensional space: the last block is colinear and re-drawn, qr.fypp:146-162) -- A X(:, :p kdim) = X H and the Gram
+    matrix of X(:, :p kdim) = I, asserted by the reference at rtol_dp (we hold 1e-12); H block upper Hessenberg."""
+    p, kdim = 2, N // 2
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((N, N)).astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        A = A + 1j * rng.standard_normal((N, N))
+    A = np.asfortranarray(A / np.sqrt(N))
+    X = np.zeros((N, p * (kdim + 1)), dtype=dtype, order="F")
+    for j in range(p):
+        X[:, j] = seeded(N, dtype, 40 + j)
+    R0 = np.zeros((p, p), dtype=dtype, order="F")
+    assert ora.qr_no_pivoting(X[:, :p], R0) == 0                       # initialize_krylov_subspace orthonormalises X0 (utilities.fypp)
+    H = np.zeros((p * (kdim + 1), p * kdim), dtype=dtype, order="F")
+    info = ora.arnoldi_block(ora.DenseOp(A), X, H, p)
+    assert info in (0, p * kdim)                                       # the 65th block has no room left: breakdown at the last step is legal
+    m = p * kdim
+    assert np.abs(A @ X[:, :m] - X @ H).max() < 1e-12
+    assert np.abs(X[:, :m].conj().T @ X[:, :m] - np.eye(m)).max() < 1e-12
+    assert np.abs(np.tril(H, -(p + 1))).max() == 0.0
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
 def test_vector_axioms_and_dense_vector_ops(dtype):
     """test/TestVectors.fypp:50-179: norm/add/sub/dot/scal against array formulas (rtol_dp there) and
     the axiom harness of AbstractVectors.fypp:733-927 (tolerance 1e-14)."""

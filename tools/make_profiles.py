@@ -67,10 +67,13 @@ for sub, name in (("lincomb", "lincomb"), ("cfg4", "cfg4_c128_n1e6_m128")):
         if lines:
             open(os.path.join(out, f"{tag}_{name}.jsonl"), "w").write(json.dumps({"commit": commit}) + "\n" + "".join(lines))
 
-ff, fw = find("pmc_fetch", "counter_collection.csv"), find("pmc_write", "counter_collection.csv")
-if ff and fw:
+def traffic_record(sub_fetch, sub_write, shard_of):
+    """One PMC traffic record (per n_local) from a FETCH_SIZE pass and a WRITE_SIZE pass of the same bench.py command."""
+    ff, fw = find(sub_fetch, "counter_collection.csv"), find(sub_write, "counter_collection.csv")
+    if not (ff and fw):
+        return None, None
     fetch, write = counter_sums(ff, "FETCH_SIZE"), counter_sums(fw, "WRITE_SIZE")
-    pb = bench_line(os.path.join(src, "pmc_fetch.log")) or {}
+    pb = bench_line(os.path.join(src, sub_fetch + ".log")) or {}
     n_local = pb.get("config", {}).get("n_local", 100_000_000)
     m = pb.get("config", {}).get("m", 128)
     is_sweep = lambda k: "panel_sweep" in k or "panel_dot_cw" in k          # sweep 1 is panel_dot_cw, sweeps 2 and 3 panel_sweep
@@ -86,10 +89,14 @@ if ff and fw:
     write_b = sum(write[k][1] for k in write if is_sweep(k)) * 1024.0 / max(launches, 1)
     alg = 8.0 * n_local * sum(3 * k + 5 for k in range(1, m + 1)) / (3.0 * m)
     must = 8.0 * n_local * sum(3 * k + 4 for k in range(1, m + 1)) / (3.0 * m)
+    flags = " --steps 1 --warmup 0 --no-cpu-baseline" + (f" --shard-of {shard_of}" if shard_of > 1 else "")
+    name = f"{tag}_pmc_n{n_local:.3g}_m{m}.json".replace("+0", "").replace("+", "")
     pm = {
         "commit": commit, "kernel_source_sha256": khash, "n_local": n_local, "m": m, "dtype": "f64",
-        "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
-        "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
+        "shard": (f"rank 0's row block of a {shard_of}-rank job (n_global = {pb.get('config', {}).get('n_global')}), alone on one GPU: bench.py --shard-of {shard_of}"
+                  if shard_of > 1 else "the single-GPU workload"),
+        "command_fetch": "rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py" + flags,
+        "command_write": "rocprofv3 --pmc WRITE_SIZE --output-format csv -- python3 bench.py" + flags,
         "method": "separate --pmc passes; KB units; FETCH_SIZE doubled (gfx950 reports 1/2 of a 16 B/lane streaming read, MI355X_MICROARCH.md); "
                   "WRITE_SIZE exact; per launch = sum over the three DGS sweep kernels (panel_dot_cw, panel_sweep x2) / their launch count",
         "fetch_calibration_on_k_scal(expected 2.0)": calib,
@@ -101,10 +108,23 @@ if ff and fw:
         "per_kernel": [{"kernel": k[:80], "counter": c, "launches": v[0], "sum_KB": v[1]}
                        for c, d in (("FETCH_SIZE", fetch), ("WRITE_SIZE", write)) for k, v in sorted(d.items())],
     }
-    json.dump(pm, open(os.path.join(out, f"{tag}_pmc_n1e8_m128.json"), "w"), indent=1)
-    json.dump({"n_local": n_local, "m": m, "dtype": "f64", "hbm_bytes_per_launch": fetch_b + write_b,
-               "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_b + write_b) / alg,
-               "commit": commit, "kernel_source_sha256": khash, "source": f"profiles/{tag}_pmc_n1e8_m128.json", "method": pm["method"]},
+    json.dump(pm, open(os.path.join(out, name), "w"), indent=1)
+    short = {"n_local": n_local, "m": m, "dtype": "f64", "hbm_bytes_per_launch": fetch_b + write_b,
+             "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch_b + write_b) / alg,
+             "commit": commit, "kernel_source_sha256": khash, "source": f"profiles/{name}", "method": pm["method"]}
+    return short, calib
+
+
+# one record per rows-per-rank: the single-GPU workload and rank 0's block of the 2 / 4 / 8-rank jobs (bench.py --shard-of P)
+records = []
+for shard_of, suffix in ((1, ""), (2, "_s2"), (4, "_s4"), (8, "_s8")):
+    short, calib = traffic_record("pmc_fetch" + suffix, "pmc_write" + suffix, shard_of)
+    if short:
+        records.append(short)
+        rec.setdefault("pmc", []).append({"n_local": short["n_local"], "traffic_over_algorithmic": short["traffic_over_algorithmic"], "calibration": calib})
+if records:
+    json.dump({"records": records,
+               "note": "one record per n_local (rows per rank): the sweep kernels of a rank see only their row block, so one GPU measures every shard "
+                       "size (bench.py --shard-of P under rocprofv3 --pmc, tools/run_profiles.sh); written by tools/make_profiles.py"},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
-    rec["pmc"] = {"traffic_over_algorithmic": pm["traffic_over_algorithmic"], "calibration": calib}
 print(json.dumps(rec))
