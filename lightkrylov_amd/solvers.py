@@ -13,6 +13,7 @@ import numpy as np
 from scipy.linalg import lapack as _lapack
 
 import os
+import threading
 from concurrent.futures import ThreadPoolExecutor
 
 from . import _hostlapack
@@ -205,6 +206,55 @@ def gmres(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float
 
 # ------------------------------------------------------------------------------------------
 _EIGS_SEGMENT = 16          # Arnoldi steps per asynchronous device batch of the pipelined eigs cycle
+_eigs_trace = None          # diagnostic (tools/profile_eigs_cycle.py): a list that receives (label, perf_counter()) marks of a cycle
+
+
+def _mark(label: str) -> None:
+    if _eigs_trace is not None:
+        import time
+        _eigs_trace.append((label, time.perf_counter()))
+
+
+def _tapered_segments(kstart: int, kdim: int, seg: int = 0):
+    """Step ranges [(a, b), ...] covering kstart..kdim: full segments of `seg` steps, the LAST `seg` steps split 8, 4, 2, 1, 1 (halves down
+    to single steps), so that the host work that can only start after a segment's last column shrinks towards the end of the cycle."""
+    seg = seg or _EIGS_SEGMENT
+    out, a = [], kstart
+    tail_from = max(kstart, kdim - seg + 1)
+    while a < tail_from:
+        b = min(a + seg - 1, tail_from - 1)
+        out.append((a, b))
+        a = b + 1
+    left = kdim - a + 1
+    while left > 0:
+        take = max(1, left // 2)
+        out.append((a, a + take - 1))
+        a += take
+        left -= take
+    return out
+
+
+def _schur_then_final_eig(Hc: np.ndarray, kdim: int, select_eigs, final_eig: bool):
+    """Host-thread job of the pipelined eigs cycle: the small-matrix half of krylov_schur on a copy of the complete H and -- when this is
+    the cycle after which eigs returns -- the `eig` of the RESTARTED H(1:kdim, 1:kdim) that eigs ends with (IterativeSolvers.fypp:1115),
+    formed exactly as krylov_schur leaves it (BaseKrylov.fypp:807-829).  Returns (host_part, None | (that matrix, eig's result)); the
+    caller uses the second only if the H it then holds equals that matrix bit for bit."""
+    host_part = krylov_schur_host_part(Hc, kdim, select_eigs)
+    _mark("schur host part done (worker)")
+    if not final_eig:
+        return host_part, None
+    T, Tk, Z, n = host_part
+    m = Hc.shape[1]
+    Hc[:m, :] = T
+    Hc[:kdim, :] = Tk
+    b = Hc[kdim, :] @ Z                                                             # :827
+    Hc[n, :] = b
+    Hc[n + 1:, :] = 0
+    Hc[:, n:] = 0
+    Hk = np.array(Hc[:kdim, :kdim], order="F", copy=True)
+    out = eig(Hk)
+    _mark("final eig ahead done (worker)")
+    return host_part, (Hk, out)
 _pools: dict = {}
 
 
@@ -279,44 +329,70 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
         restarts += 1
         k_from, stopped = kstart, False
         schur_ahead = None
+        eig_ahead = None
         if pipelined and kstart <= kdim_:
-            # segments of _EIGS_SEGMENT steps: while the device runs segment s + 1 (one asynchronous lk_arnoldi call on a helper thread;
-            # ctypes drops the interpreter lock for its duration) the host tests the steps of segment s
-            bounds = [(a, min(a + _EIGS_SEGMENT - 1, kdim_)) for a in range(kstart, kdim_ + 1, _EIGS_SEGMENT)]
-            kdone = kstart - 1                                                     # last step any segment has computed
+            # The cycle's steps run on the device in SEGMENTS (asynchronous lk_arnoldi calls queued on one helper thread; ctypes drops
+            # the interpreter lock for their duration); the moment a segment has delivered its columns of H, the Ritz test of every
+            # step in it is handed to the host pool, and this thread collects the tests IN STEP ORDER and stops where the reference
+            # would have stopped.  The tests of the last columns can only start when the device has finished, so the segments TAPER
+            # towards the end of the cycle (16, ..., 16, 8, 4, 2, 1, 1 steps): when the final column arrives one or two `geev`s are
+            # still to be started instead of sixteen (round 5; the tests no longer wait for each other segment by segment either).
+            bounds = _tapered_segments(kstart, kdim_)
             pool, device = _pool("geev", nthreads), _pool("device", 1)
+            tests: dict = {}
+            cancel = threading.Event()
+            last_cycle = max_restarts is not None and restarts > max_restarts        # the while loop ends after this cycle's restart
+            ahead: dict = {}
+
+            def run_segment(a, b):
+                if cancel.is_set():
+                    return None
+                ainfo = arnoldi(A, Xwrk, H, a, b, atol_dp, transpose)
+                _mark(f"device segment {a}..{b} done")
+                klast = ainfo if ainfo > 0 else b                                  # an exhausted Krylov space ends the cycle's batch early
+                if ainfo > 0:
+                    cancel.set()
+                for kk in range(a, klast + 1):
+                    tests[kk] = pool.submit(ritz_test, kk)
+                if ainfo == 0 and klast == kdim_:
+                    # H is complete: unless one of the Ritz tests still to come stops the cycle early, the restart below factors
+                    # exactly this H -- start its small-matrix half (gees, selector, trsen) now, on a spare host thread, beside
+                    # the last tests (same LAPACK calls on the same data; discarded on an early stop) ...
+                    ahead["schur"] = pool.submit(_schur_then_final_eig, H.copy(order="F"), kdim_, median_selector, last_cycle)
+                return a, klast, ainfo
+
             with _hostlapack.blas_threads(1):
-                fut = device.submit(arnoldi, A, Xwrk, H, bounds[0][0], bounds[0][1], atol_dp, transpose)
-                for si, (a, b) in enumerate(bounds):
-                    ainfo = fut.result()
-                    fut = None
-                    klast = ainfo if ainfo > 0 else b                              # an exhausted Krylov space ends the batch early
+                segs = [device.submit(run_segment, a, b) for a, b in bounds]
+                kdone = kstart - 1                                                 # last step any segment has computed
+                ainfo = 0
+                for sf in segs:
+                    seg = sf.result()
+                    if seg is None:
+                        break
+                    a, klast, ainfo = seg
                     kdone = klast
-                    if ainfo == 0 and si + 1 < len(bounds):
-                        fut = device.submit(arnoldi, A, Xwrk, H, bounds[si + 1][0], bounds[si + 1][1], atol_dp, transpose)
-                    elif ainfo == 0 and klast == kdim_:
-                        # H is complete: unless one of the Ritz tests still to come stops the cycle early, the restart below factors
-                        # exactly this H -- start its small-matrix half (gees, selector, trsen) now, on a spare host thread, beside
-                        # the last segment's tests (same LAPACK calls on the same data; discarded on an early stop)
-                        schur_ahead = pool.submit(krylov_schur_host_part, H.copy(order="F"), kdim_, median_selector)
-                    for c0 in range(a, klast + 1, nthreads):
-                        ks = range(c0, min(c0 + nthreads, klast + 1))
-                        for k, (_vals, r) in zip(ks, pool.map(ritz_test, ks)):
-                            res[:k] = r
-                            niter += 1
-                            conv = int(np.count_nonzero(res[:k] < tolerance))      # :1087
-                            if conv >= nev:
-                                stopped = True
-                                break
-                        if stopped:
+                    for k in range(a, klast + 1):
+                        _vals, r = tests[k].result()
+                        res[:k] = r
+                        niter += 1
+                        conv = int(np.count_nonzero(res[:k] < tolerance))          # :1087
+                        if conv >= nev:
+                            stopped = True
                             break
                     if stopped or ainfo > 0:
                         break
-                if fut is not None:                                                # a segment still in flight when the loop stopped
-                    ainfo = fut.result()
-                    kdone = ainfo if ainfo > 0 else bounds[si + 1][1]
-                if schur_ahead is not None:                                        # (collected while the BLAS libraries' own threading is still off)
-                    schur_ahead = schur_ahead.result()
+                cancel.set()                                                       # segments not started yet are skipped ...
+                for sf in segs:                                                    # ... one still in flight when the loop stopped is waited for
+                    seg = sf.result()
+                    if seg is not None:
+                        kdone = max(kdone, seg[1])
+                for kk, tf in tests.items():                                       # tests beyond the stop: never started, or left to finish unread
+                    if kk > k:
+                        tf.cancel()
+                _mark(f"tests collected up to step {k}")
+                if "schur" in ahead:                                               # (collected while the BLAS libraries' own threading is still off)
+                    schur_ahead, eig_ahead = ahead["schur"].result()
+                    _mark("schur (+ final eig) ahead collected")
             if stopped and k < kdone:
                 # put the work arrays into the state the reference is in when it leaves the loop at step k (:1093):
                 # krylov_schur below acts on ALL of H and Xwrk
@@ -336,8 +412,14 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                     break
         host_part = schur_ahead if (schur_ahead is not None and not stopped) else None   # (an early stop changed H: factor that one)
         kstart = krylov_schur(Xwrk, H, median_selector, _host_part=host_part) + 1  # :1100
+        _mark("krylov_schur done")
+        if host_part is None:
+            eig_ahead = None
     k = min(k, kdim_)
-    vecs, vals = eig(H[:k, :k])                                                    # :1115
+    if eig_ahead is not None and k == kdim_ and np.array_equal(eig_ahead[0], H[:k, :k]):
+        vecs, vals = eig_ahead[1]                                                  # :1115, computed ahead on exactly this matrix
+    else:
+        vecs, vals = eig(H[:k, :k])                                                # :1115
     vals_f = np.zeros(kdim_, dtype=np.complex128)
     vals_f[:k] = vals
     vecs_f = np.zeros((kdim_, kdim_), dtype=vecs.dtype)
@@ -346,8 +428,10 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
     vals_f, vecs_f, res_f = vals_f[idx], vecs_f[:, idx], res[idx]
     # eigenvectors X(i) = sum_j eigvecs(j, i) Xwrk(j)                                :1127-1132
     coef = np.asfortranarray(vecs_f[:k, :nev].astype(dt))
+    _mark("final eig done")
     Y = linear_combination(Xwrk[:k], coef)
     copy(X, Y)
+    _mark("eigenvectors done")
     return vals_f[:nev].copy(), res_f[:nev].copy(), niter
 
 

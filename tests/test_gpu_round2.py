@@ -505,18 +505,23 @@ def test_pipelined_eigs_cycle_equals_the_step_by_step_one(ctx, dtype):
         d = d * np.exp(0.2j * rng.random(n))
     A = lk.diag_linop_gpu(d.astype(dtype), ctx)
     out = {}
-    for kdim, tag in ((40, "early stop inside the first cycle"), (12, "several restarts")):
+    for kdim, maxr, tag in ((40, 60, "early stop inside the first cycle"), (12, 60, "several restarts"),
+                            (12, 1, "restarts exhausted: the final eig of the restarted H is computed ahead, beside the last tests"),
+                            (37, 0, "one cycle, tapered segments (16, 5 | 8, 4, 2, 1, 1)")):
         for pipe in (False, True):
             V = lk.krylov_basis_gpu(n, nev, dtype, ctx)
             x0 = lk.dense_vector_gpu(n, dtype, ctx); x0.rand(False, seed=3)
-            vals, res, info = lk.eigs(A, V, x0=x0, kdim=kdim, tolerance=1e-10, max_restarts=60, pipelined=pipe)
-            out[(kdim, pipe)] = (vals, res, info, V.download())
-        (v0, r0, i0, X0), (v1, r1, i1, X1) = out[(kdim, False)], out[(kdim, True)]
+            vals, res, info = lk.eigs(A, V, x0=x0, kdim=kdim, tolerance=1e-10 if maxr == 60 else 1e-15, max_restarts=maxr, pipelined=pipe)
+            out[(kdim, maxr, pipe)] = (vals, res, info, V.download())
+        (v0, r0, i0, X0), (v1, r1, i1, X1) = out[(kdim, maxr, False)], out[(kdim, maxr, True)]
         assert i0 == i1, tag
         assert np.array_equal(v0, v1) and np.array_equal(r0, r1), tag
         assert np.array_equal(X0, X1), tag
-        assert np.abs(np.sort(np.abs(v1))[::-1] - np.sort(np.abs(d))[::-1][:nev]).max() <= 1e-8, tag
-    assert out[(40, True)][2] < 40 and out[(12, True)][2] > 12
+        if maxr == 60:
+            assert np.abs(np.sort(np.abs(v1))[::-1] - np.sort(np.abs(d))[::-1][:nev]).max() <= 1e-8, tag
+    assert out[(40, 60, True)][2] < 40 and out[(12, 60, True)][2] > 12
+    assert 12 < out[(12, 1, True)][2] <= 24                                     # two cycles, tolerance out of reach: no early stop
+    assert out[(37, 0, True)][2] == 37
 
 
 # ----------------------------------------------------------------------------- CSR operator (a user's sparse abstract_linop)

@@ -498,3 +498,19 @@ def test_bench_refuses_a_launcher_environment_that_disagrees_with_gpus():
     env = dict(os.environ, WORLD_SIZE="4", RANK="1", LOCAL_RANK="1")
     out = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 2 and "--gpus 8 but WORLD_SIZE=4" in out.stderr and not out.stdout.strip()
+
+
+def test_eigs_segments_taper_towards_the_end_of_a_cycle():
+    """The device segments of the pipelined eigs cycle: full segments of 16 steps, the last 16 steps as 8, 4, 2, 1, 1 -- every step
+    exactly once, in order, whatever kstart / kdim (a restarted cycle starts mid-way; a short cycle is all taper)."""
+    from lightkrylov_amd.solvers import _tapered_segments
+    assert _tapered_segments(1, 128)[-5:] == [(113, 120), (121, 124), (125, 126), (127, 127), (128, 128)]
+    assert _tapered_segments(1, 128)[:7] == [(16 * i + 1, 16 * i + 16) for i in range(7)]
+    for kstart in (1, 2, 7, 65, 120, 128):
+        for kdim in (1, 2, 5, 16, 17, 31, 33, 128, 200):
+            if kstart > kdim:
+                continue
+            segs = _tapered_segments(kstart, kdim)
+            steps = [k for a, b in segs for k in range(a, b + 1)]
+            assert steps == list(range(kstart, kdim + 1)), (kstart, kdim, segs)
+            assert segs[-1][0] == segs[-1][1] == kdim and all(b - a + 1 <= 16 for a, b in segs)

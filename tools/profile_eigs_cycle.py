@@ -25,6 +25,18 @@ for _ in range(reps):
     pr.disable()
     ts.append(time.perf_counter() - t0)
 print("ms per eigs call:", [round(1e3 * t, 1) for t in ts])
+# timeline of one more call: the marks lightkrylov_amd.solvers leaves when asked (ms since the call began)
+from lightkrylov_amd import solvers as _sv
+_sv._eigs_trace = []
+t0 = time.perf_counter()
+lk.eigs(A, V, x0=x0, kdim=kdim, tolerance=1e-10, max_restarts=0)
+ctx.sync()
+t1 = time.perf_counter()
+print("timeline of one cycle (ms since the call):")
+for label, tm in _sv._eigs_trace:
+    print(f"  {1e3 * (tm - t0):8.2f}  {label}")
+print(f"  {1e3 * (t1 - t0):8.2f}  eigs returned")
+_sv._eigs_trace = None
 out = io.StringIO()
 pstats.Stats(pr, stream=out).sort_stats("cumulative").print_stats(30)
 print(out.getvalue())
