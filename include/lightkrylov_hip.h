@@ -128,7 +128,7 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * 16-byte y store: 0 plain, 1 nt, 2 sc1 = write-through [default], 3 sc0 sc1) and "store_split"; "async_arnoldi"
  * (default 1: lk_arnoldi enqueues all steps with a device-side breakdown flag, one host synchronisation per call; 0:
  * one host round trip per step); "cplx_wide" (complex sweeps on 8 waves x 16 columns when k exceeds this threshold, default 32, 0 = never); "pool_slab_cols" (columns per
- * pool slab); "lazy" (see lk_lazy_stats).  None of those changes a result bit (tests/test_gpu_round2.py).
+ * pool slab); "lazy" (see lk_lazy_stats).  None of those changes a result bit (tests/test_gpu_tuning_knobs.py).
  * Shapes and kernel selectors -- same results to rounding (different summation order), each checked against the oracle:
  * "grid_mult" / "grid_mult_s2" / "update_grid_mult" / "gemm_grid_mult" (blocks per CU of the panel kernels: the number of
  * per-block partial sums a dot is assembled from);
@@ -147,7 +147,7 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * "gemm_prefetch_y" (default 1: the accumulating real MFMA product with <= 32 outputs -- the block Gram-Schmidt's updates -- loads the tile of Y
  * ahead of its k-loop; 0: after it; no result bit changes).
  * "wide_s3" (default 1: sweep 3 of a lane-split DGS holds both column groups of a wave-column in one wave's registers on tiles twice as
- * tall; 0: lane-split like sweep 2) changes NO result bit: it reproduces the lane split's summation order (tests/test_gpu_round3.py). */
+ * tall; 0: lane-split like sweep 2) changes NO result bit: it reproduces the lane split's summation order (tests/test_gpu_wide_bases.py). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
 
 /* Lazy batching of the per-object path (tuning key "lazy", off by default).  When on, k consecutive

@@ -88,6 +88,8 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
+    int gram_tiles = 1;        // real Gram matrix beyond 32 columns by panel_gram_mfma (upper tiles dealt to the waves, 32-row tiles; 0: panel_xhy_mfma<false, 8, 64>)
+    int gram_grid_mult = 3;    // ... its blocks per CU
     int gemm_3m = 1;           // complex MFMA kernels (tall-skinny product; X^H Y with <= 32 right-hand sides; Gram) with three real products per complex one (0: four, the doubled real problem)
     int kc32 = -1;             // real DGS update sweeps (2 and 3) of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 when the GLOBAL problem has >= 2^25 rows)
     int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
@@ -752,6 +754,36 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         if (out_dev) *out_dev = out3;
         return allreduce(c, out3, nslots);
     }
+    // real Gram matrix beyond 32 columns: upper tiles dealt to the waves in runs, 32-row tiles, three blocks per CU (panel_gram_mfma, round 5)
+    if (!cp && !small && c->gram_tiles && flags == 3) {
+        const int64_t nt32 = (Bx->n + 31) / 32;
+        int64_t gg = (int64_t)c->num_cu * c->gram_grid_mult;
+        if (gg > nt32) gg = nt32;
+        if (gg < 1) gg = 1;
+        int64_t needg = 2 * sect + npart_n + gg * nslots;
+        if (c->xhy_n < needg && !may_grow)
+            return fail(LK_ERR_INVALID, "internal: xhy workspace too small (%lld < %lld)", (long long)c->xhy_n, (long long)needg);
+        if (c->xhy_n < needg) {
+            const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
+            if (needg < fused) needg = fused;
+            if (c->xhy) HIPCHK(hipFree(c->xhy));
+            c->xhy = nullptr;
+            c->xhy_n = 0;
+            HIPCHK(hipMalloc((void **)&c->xhy, (size_t)needg * sizeof(double)));
+            c->xhy_n = needg;
+        }
+        double *outg = c->xhy + (int64_t)slot * XHY_SLOT, *npartg = c->xhy + 2 * sect, *partg = npartg + npart_n;
+        const size_t ldsg = (size_t)KP * 16 * 34 * sizeof(double);
+        {
+            ProfScope ps(c, "xhy_mfma", (double)Bx->n * 8.0 * k);
+            hipLaunchKernelGGL(panel_gram_mfma, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
+        }
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, partg, (int)gg, npartg, (int)gg, k, p, ED, flags, outg);
+        HIPCHK(hipGetLastError());
+        if (out_dev) *out_dev = outg;
+        return allreduce(c, outg, nslots);
+    }
     // complex kind, <= 32 right-hand sides: three real products per complex one on separate real / imaginary planes ("gemm_3m")
     const bool three = cp && small && c->gemm_3m && !(flags & 1);
     const size_t lds = three ? (size_t)(KP + PJ) * 16 * 18 * 2 * sizeof(double)
@@ -1398,6 +1430,8 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_prefetch_y")) { c->gemm_prefetch_y = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "gram_tiles")) { c->gram_tiles = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "gram_grid_mult")) { c->gram_grid_mult = value < 1 ? 1 : (value > 8 ? 8 : value); return LK_OK; }
     if (!strcmp(key, "kc32")) { c->kc32 = value < 0 ? -1 : value; return LK_OK; }
     if (!strcmp(key, "wide_s3")) { c->wide_s3 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "wide_regs")) { c->wide_regs = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }

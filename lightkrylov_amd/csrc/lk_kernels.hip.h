@@ -1,10 +1,13 @@
 // lk_kernels.hip.h -- gfx950 device kernels of the Krylov inner-loop engine.
 //
-// Everything here is HBM-bandwidth bound BLAS-1/2 work on a column-contiguous panel
-// (element (i, j) at X[j*ld + i]).  No MFMA: arithmetic intensity is ~1/6 flop/byte.
-// Wavefront = 64 lanes; every global access is 16 bytes per lane (1 KiB per wave
-// instruction); reductions are register -> wave shuffle -> LDS -> per-block partial ->
-// fixed-order finish kernel (deterministic, no float atomics).
+// Two families on a column-contiguous panel (element (i, j) at X[j*ld + i]):
+//   * the HBM-bandwidth bound BLAS-1/2 work of the graded path -- the abstract_vector primitives and the fused panel sweeps of the
+//     (double) Gram-Schmidt step, ~1/6 flop/byte: VALU only, no MFMA.  Wavefront = 64 lanes; every global access is 16 bytes per lane
+//     (1 KiB per wave instruction); reductions are register -> DPP wave sum -> LDS -> per-block partial -> fixed-order finish
+//     kernel (deterministic, no float atomics);
+//   * the tall-skinny CONTRACTIONS of the "next" rows (X Z of krylov_schur and the eigenvectors, X^H Y / X^H X with
+//     many right-hand sides, the block Gram-Schmidt) on the FP64 matrix cores: __builtin_amdgcn_mfma_f64_16x16x4f64 tiles staged
+//     through LDS (panel_gemm_mfma*, panel_xhy_mfma*, panel_gram_mfma*, panel_xhy_upd_mfma).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -1649,6 +1652,112 @@ __global__ __launch_bounds__(512) void panel_gram_mfma3m(const double *__restric
                     pb[((int64_t)j * (k + 1) + i) * 2] = p1[q][r] + p2[q][r];
                     pb[((int64_t)j * (k + 1) + i) * 2 + 1] = (p3[q][r] + p1[q][r]) - p2[q][r];
                 }
+            }
+        }
+    }
+}
+
+// Gram matrix G = X^T X of a REAL basis (33 <= k <= 128 columns), upper tiles only (round 5; gram_matrix, AbstractVectors.fypp:645-657).
+// panel_xhy_mfma<false, 8, 64> with flags = 3 gives every wave one tile ROW and keeps the accumulators of all 8 tiles of that row plus
+// sixteen staged 16-byte chunks in registers: 215 VGPRs, ONE 8-wave block per CU, whose two barriers and LDS staging per tile nothing
+// covers (4.1 ms at n = 10^7, k = 128: 45 TFLOP/s on the 1.84 10^11 flop of the 36 upper tiles).  Here the KP (KP + 1) / 2 upper tiles
+// (I <= J, row-major) are dealt to the 8 waves in CONTIGUOUS runs -- 36 tiles at k = 128: five for waves 0-3, four for waves 4-7, nine per
+// SIMD (waves w and w + 4 share one) -- so a wave holds at most five accumulators (20 registers) and mostly re-uses the A operand
+// from one tile to the next (same tile row); tiles are 32 rows (35 KB of LDS at k = 128) and four staged chunks per thread, so THREE
+// blocks share a CU and one block's staging and barriers run under the others' MFMAs.  Operand reads as panel_xhy_mfma (column
+// stride 34 words: conflict free); the next tile's loads are in flight while the current tile's MFMAs run.
+// Results: partial[block][slot], slot = j (k + 1) + i for i in tile row I, j in tile column J >= I -- panel_xhy_mfma's layout with
+// flags = 3 (Y is X, upper tiles only), summed by finish_xhy; no norm slots.
+__global__ __launch_bounds__(512) void panel_gram_mfma(const double *__restrict__ X, int64_t ldx, int k, int64_t n,
+                                                       double *__restrict__ partial) {
+    constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = 512 / CH, NXP = 128 / CPP;      // 32 columns staged per block-wide pass
+    constexpr int MAXT = 5;                                                                        // ceil(36 / 8) tiles per wave
+    extern __shared__ __attribute__((aligned(16))) double gr_lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int KP = (k + 15) >> 4, KS = (k + CPP - 1) / CPP;
+    double *Xt = gr_lds;
+    const int64_t ntiles = (n + TR - 1) / TR;
+    const int arow = lane >> 4, acol = lane & 15;
+
+    // this wave's run of upper tiles (row-major order (0,0), (0,1), ..., (0,KP-1), (1,1), ...)
+    int tI[MAXT], tJ[MAXT], nt;
+    {
+        const int ntot = KP * (KP + 1) / 2, base = ntot >> 3, rem = ntot & 7;
+        nt = base + (wave < rem ? 1 : 0);
+        const int first = wave * base + (wave < rem ? wave : rem);
+        int idx = 0, got = 0;
+        for (int q = 0; q < MAXT; ++q) { tI[q] = 0; tJ[q] = 0; }
+        for (int I = 0; I < KP; ++I)
+            for (int J = I; J < KP; ++J, ++idx)
+                if (idx >= first && got < nt) {
+#pragma unroll
+                    for (int q = 0; q < MAXT; ++q)
+                        if (q == got) { tI[q] = I; tJ[q] = J; }
+                    ++got;
+                }
+    }
+
+    v4d acc[MAXT];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+    v2d xs[NXP];
+
+    auto gload = [&](int64_t T) {
+        const int64_t rbase = T * TR;
+#pragma unroll
+        for (int s = 0; s < NXP; ++s) {
+            xs[s] = v2d{0.0, 0.0};
+            if (s < KS) {
+                const int c = t + 512 * s, col = c >> CHS;
+                const int64_t rr = rbase + 2 * (c & (CH - 1));
+                if (col < k) {
+                    const double *pc = X + (int64_t)col * ldx;
+                    if (rr + 1 < n) xs[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(pc + rr));
+                    else if (rr < n) xs[s].x = pc[rr];
+                }
+            }
+        }
+    };
+
+    int64_t T = blockIdx.x;
+    if (T < ntiles) gload(T);
+    for (; T < ntiles; T += gridDim.x) {
+        __syncthreads();                                            // the previous tile's operands have been read
+#pragma unroll
+        for (int s = 0; s < NXP; ++s)
+            if (s < KS) {
+                const int c = t + 512 * s;
+                if ((c >> CHS) < KP * 16) *reinterpret_cast<v2d *>(Xt + (c >> CHS) * S + 2 * (c & (CH - 1))) = xs[s];
+            }
+        __syncthreads();
+        if (T + gridDim.x < ntiles) gload(T + gridDim.x);           // in flight while this tile's MFMAs run
+#pragma unroll 1
+        for (int step = 0; step < TR / 4; ++step) {
+            const int ro = 4 * step + arow;
+            double a = 0.0;
+            int lastI = -1;
+#pragma unroll
+            for (int q = 0; q < MAXT; ++q) {
+                if (q < nt) {
+                    if (tI[q] != lastI) { a = Xt[(16 * tI[q] + acol) * S + ro]; lastI = tI[q]; }
+                    const double b = (tJ[q] == tI[q]) ? a : Xt[(16 * tJ[q] + acol) * S + ro];
+                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int64_t nslots = (int64_t)k * (k + 1);
+    double *pb = partial + (int64_t)blockIdx.x * nslots;
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        if (q < nt) {
+            const int j = 16 * tJ[q] + acol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tI[q] + arow + 4 * r;
+                if (i < k && j < k) pb[(int64_t)j * (k + 1) + i] = acc[q][r];
             }
         }
     }

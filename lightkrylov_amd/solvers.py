@@ -338,8 +338,9 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
             # towards the end of the cycle (16, ..., 16, 8, 4, 2, 1, 1 steps): when the final column arrives one or two `geev`s are
             # still to be started instead of sixteen (round 5; the tests no longer wait for each other segment by segment either).
             bounds = _tapered_segments(kstart, kdim_)
-            pool, device = _pool("geev", nthreads), _pool("device", 1)
+            pool, device, feeder = _pool("geev", nthreads), _pool("device", 1), _pool("feeder", 1)
             tests: dict = {}
+            fed = {a: threading.Event() for a, _b in bounds}
             cancel = threading.Event()
             last_cycle = max_restarts is not None and restarts > max_restarts        # the while loop ends after this cycle's restart
             ahead: dict = {}
@@ -352,14 +353,20 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                 klast = ainfo if ainfo > 0 else b                                  # an exhausted Krylov space ends the cycle's batch early
                 if ainfo > 0:
                     cancel.set()
-                for kk in range(a, klast + 1):
-                    tests[kk] = pool.submit(ritz_test, kk)
+                # (the tests are handed to the pool by ANOTHER thread: sixteen `submit`s cost this thread half a millisecond during
+                # which the device would idle between two segments)
+                feeder.submit(feed, a, klast, ainfo)
+                return a, klast, ainfo
+
+            def feed(a, klast, ainfo):
                 if ainfo == 0 and klast == kdim_:
                     # H is complete: unless one of the Ritz tests still to come stops the cycle early, the restart below factors
                     # exactly this H -- start its small-matrix half (gees, selector, trsen) now, on a spare host thread, beside
                     # the last tests (same LAPACK calls on the same data; discarded on an early stop) ...
                     ahead["schur"] = pool.submit(_schur_then_final_eig, H.copy(order="F"), kdim_, median_selector, last_cycle)
-                return a, klast, ainfo
+                for kk in range(a, klast + 1):
+                    tests[kk] = pool.submit(ritz_test, kk)
+                fed[a].set()
 
             with _hostlapack.blas_threads(1):
                 segs = [device.submit(run_segment, a, b) for a, b in bounds]
@@ -371,6 +378,7 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                         break
                     a, klast, ainfo = seg
                     kdone = klast
+                    fed[a].wait()
                     for k in range(a, klast + 1):
                         _vals, r = tests[k].result()
                         res[:k] = r
@@ -386,6 +394,7 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                     seg = sf.result()
                     if seg is not None:
                         kdone = max(kdone, seg[1])
+                        fed[seg[0]].wait()
                 for kk, tf in tests.items():                                       # tests beyond the stop: never started, or left to finish unread
                     if kk > k:
                         tf.cancel()

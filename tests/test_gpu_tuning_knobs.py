@@ -1,0 +1,115 @@
+"""Tuning knobs (lk_set_tuning) choose kernels and cache policies, never results: the store policies of the sweeps, both kernels of sweep 1,
+and the lazy path's batching rules (a dot batch stops at the columns ever written; the reference's Gram loop costs one pass)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import lightkrylov_amd as lk
+from lightkrylov_amd import _capi
+from oracle import oracle as ora
+from tests._gpu_helpers import KINDS, seeded, basis
+from tests._tol import assert_close, assert_columns_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_store_policy_knobs_are_result_invariant(dtype):
+    """The cache policy of the y'' store (plain / nt / sc1 / sc0 sc1) and the lane-split store only change HOW the same
+    bytes are written: coefficients and vector must be bit-identical."""
+    c = lk.Context(device=0)
+    n, k = 300_007, 37
+    Xh, yh = basis(n, k, dtype, 50), seeded(n, dtype, 99)
+    Q, _ = np.linalg.qr(Xh)
+    B = lk.krylov_basis_gpu(n, k + 1, dtype, c)
+    out = []
+    for pol, split in ((0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (1, 1)):
+        c.set_tuning("store_policy", pol); c.set_tuning("store_split", split)
+        B.upload(np.asfortranarray(Q)); B.upload(yh.reshape(-1, 1), k)
+        h = np.zeros(k, dtype=dtype)
+        lk.double_gram_schmidt_step(B[k], B[:k], False, h)
+        out.append((h.tobytes(), B.download(k, 1).tobytes()))
+    assert all(o == out[0] for o in out[1:])
+    c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("cfg", [dict(dot_colwise=0), dict(dot_colwise=1, cw_u=4), dict(dot_colwise=1, cw_u=8),
+                                 dict(dot_colwise=1, cw_u=8, cw_grid_mult=1)])
+def test_both_sweep1_kernels_match_the_oracle(dtype, cfg):
+    """DGS sweep 1 / innerprod by either kernel -- all columns per tile (panel_sweep<DOT>) or one column at a time
+    (panel_dot_cw, 4 or 8 loads per lane and column, more tiles than blocks) -- against the oracle's innerprod
+    (AbstractVectors.fypp:659-695), normwise 1e-12; ragged sizes around the tile sizes (512 / 1024 / 2048 / 4096 rows)."""
+    c = lk.Context(device=0)
+    for key, val in cfg.items():
+        c.set_tuning(key, val)
+    rng = np.random.default_rng(3)
+    try:
+        for n, k in [(1, 1), (2, 1), (511, 3), (1025, 17), (2047, 128), (4097, 33), (1_000_003, 8), (300_001, 128)]:
+            A = rng.standard_normal((n, k + 1)) + (1j * rng.standard_normal((n, k + 1)) if np.dtype(dtype).kind == "c" else 0)
+            A = np.asfortranarray(A.astype(dtype))
+            B = lk.krylov_basis_gpu(n, k + 1, dtype, c)
+            B.upload(A)
+            got = np.asarray(lk.innerprod(B[:k], B[k]))
+            want = ora.innerprod(A[:, :k], A[:, k])
+            scale = np.linalg.norm(A[:, k]) * np.linalg.norm(A[:, :k], axis=0).max()
+            assert np.abs(got - want).max() <= 1e-12 * scale, (n, k, cfg)
+            del B
+    finally:
+        c.close()
+
+
+def test_lazy_dot_batch_stops_at_the_columns_ever_written(ctx):
+    """A slab-like panel with 160 columns of which 5 hold vectors: X(i)%dot(y) with y in ANOTHER panel must sweep 5
+    columns, not 128 (the batch is capped by the panel's high-water mark)."""
+    n = 200_001
+    c = lk.Context(device=0)
+    c.set_tuning("lazy", 1)
+    P = lk.krylov_basis_gpu(n, 160, np.float64, c)
+    Xh = basis(n, 5, np.float64, 7)
+    P.upload(Xh, 0)
+    y = lk.dense_vector_gpu.from_array(seeded(n, np.float64, 70), c)
+    c.profile_reset(); c.profile_enable(True)
+    got = [P[i].dot(y) for i in range(5)]
+    c.sync()
+    cnt, _ms, by = c.profile_get("dgs_sweep1")
+    c.profile_enable(False)
+    hits, sweeps, _q, _f = c.lazy_stats()
+    assert (sweeps, hits) == (1, 4) and cnt == 1
+    assert by == pytest.approx(8.0 * n * (5 + 1))            # 5 columns + y, not 128 + 1
+    ref = ora.innerprod(Xh, y.to_array())
+    assert np.abs(np.array(got) - ref).max() <= 1e-12 * np.linalg.norm(Xh[:, 0]) * np.linalg.norm(y.to_array())
+    c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_lazy_gram_loop_of_the_reference_costs_one_pass(dtype):
+    """gram_matrix through the per-object calls an unchanged LightKrylov makes (AbstractVectors.fypp:651-656:
+    G(i,j) = X(i)%dot(X(j)), j = i..k; G(j,i) = G(i,j)) on a lazy context: the second call of the run computes X^H X on the
+    matrix cores, the other k(k+1)/2 - 2 are served from it -- against the oracle's Gram and an eager context; a write in
+    between invalidates."""
+    n, k = 20_011, 40
+    X = basis(n, k, dtype, 21)
+    Go = ora.gram(X)
+    res = {}
+    for lazy in (0, 1):
+        c = lk.Context(device=0)
+        c.set_tuning("lazy", lazy)
+        B = lk.krylov_basis_gpu(n, k, dtype, c); B.upload(X)
+        G = np.zeros((k, k), dtype=dtype)
+        for i in range(k):
+            for j in range(i, k):
+                G[i, j] = B[i].dot(B[j]); G[j, i] = G[i, j]
+        hits, sweeps, _q, _f = c.lazy_stats()
+        assert np.abs(G - Go).max() <= 1e-12 * np.linalg.norm(X, axis=0).max() ** 2
+        if lazy:
+            assert sweeps == 1 and hits >= k * (k + 1) // 2 - 2
+            B[3].scal(2.0)                                           # a write: the memo must not survive it
+            assert abs(B[3].dot(B[3]) - 4.0 * Go[3, 3]) <= 1e-12 * abs(Go[3, 3]) * 4
+            assert abs(B[2].dot(B[3]) - 2.0 * Go[2, 3]) <= 1e-12 * np.linalg.norm(X[:, 2]) * np.linalg.norm(X[:, 3]) * 2
+        res[lazy] = G
+        del B
+        c.close()
+    assert np.abs(res[0] - res[1]).max() <= 1e-12 * np.linalg.norm(X, axis=0).max() ** 2
