@@ -550,7 +550,8 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
             return launch_sweep<true, MODE, 16, 8, 4>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
         }
         if (k <= 2 * KMAX_FUSED) {
-            if (regs) return launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+            if constexpr (MODE != 1)       // (never instantiated for the dot-only sweep: its 32-column register tile spills)
+                if (regs) return launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
             if constexpr (MODE == 4)
                 if (c->wide_s3) return launch_sweep<false, 4, 32, 8, 1, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
             return launch_sweep<false, MODE, 16, 8, 2>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
@@ -582,7 +583,8 @@ int sweepm(lk_basis_t Bx, int c0, int k, double *y, const double *hin, const dou
         // update (MODE 3: lazy path, one-pass orthogonalisation) keeps the 16-column tile its A/B was recorded on.
         const int64_t nref = c->n_global > 0 ? c->n_global : Bx->n;
         const int kc32 = c->kc32 >= 0 ? c->kc32 : (nref >= ((int64_t)1 << 25) ? 32 : 0);
-        if (kc32 && k > kc32 && (MODE == 2 || MODE == 4)) return launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
+        if constexpr (MODE == 2 || MODE == 4)
+            if (kc32 && k > kc32) return launch_sweep<false, MODE, 32, 8, 1>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
     }
     return launch_sweep<false, MODE>(c, X, Bx->ld, k, y, Bx->n, hin, hin2, store, out);
 }
@@ -704,7 +706,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     // share a CU and cover each other's barriers and load latency (n = 10^7 real, k = 128, p = 16: 2.54 -> 1.92 ms on 3 blocks
     // per CU, one pass over X at 6.5 TB/s being 1.77; complex 3.73 -> 2.29 ms on 2)
     const bool small = c->xhy_small && PJ <= 2;
-    const int TR = small ? 32 : 64;
+    const int TR = (small || cp) ? 32 : 64;     // (complex, more than 32 right-hand sides: 32-row tiles too -- sixteen staged chunks beside 2 x 8 accumulators spilled 68 B)
     const int64_t ntiles = (Bx->n * ED + TR - 1) / TR;
     int64_t g = (int64_t)c->num_cu * (small ? (c->xhy_grid_mult ? c->xhy_grid_mult : (cp ? 2 : 3)) : 1);
     if (g > ntiles) g = ntiles;
@@ -798,7 +800,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
             return LK_OK;
         };
         if (three) LKCHK(go(&panel_xhy_mfma3m));
-        else if (cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32>) : go(&panel_xhy_mfma<true, 8, 64>));
+        else if (cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32>) : go(&panel_xhy_mfma<true, 8, 32>));
         else LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32>) : go(&panel_xhy_mfma<false, 8, 64>));
     }
     HIPCHK(hipGetLastError());
@@ -2380,7 +2382,7 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
                 // THREE passes over X for the group: multi-right-hand-side dots, then the fused update + dot sweep
                 // (Y' stays in registers), then the two-coefficient update that writes Y''
                 LKCHK(dots_p(Bx, 0, k, By, jy0 + j, pn, out1));
-                if (cpx) LKCHK((block_sweeps<true, 8, 16, 2>(Bx, k, By, jy0 + j, pn, out1, out2)));
+                if (cpx) LKCHK((block_sweeps<true, 16, 8, 2>(Bx, k, By, jy0 + j, pn, out1, out2)));   // 8 waves x 16 columns (16 x 8 on 1024 threads spilled)
                 else if (pn <= 2) LKCHK((block_sweeps<false, 16, 8, 2>(Bx, k, By, jy0 + j, pn, out1, out2)));
                 else LKCHK((block_sweeps<false, 8, 8, 4>(Bx, k, By, jy0 + j, pn, out1, out2)));   // 4 right-hand sides x 8 columns per wave: k <= 64
             } else {

@@ -631,6 +631,9 @@ __global__ __launch_bounds__(NW * 64) void panel_dot_p(const double *__restrict_
     nc = nc > kcw ? kcw : nc;
     nc = nc < 0 ? 0 : nc;
     constexpr int SLOTS = (KC * ED + 1) * P;
+    // real kind, four right-hand sides: ONE accumulator per (column, right-hand side) fed by a two-FMA chain over the lane's two rows (as
+    // panel_sweep_p does) -- sixteen two-row accumulators beside the tile do not fit the 128 registers of a 1024-thread block (12 B of scratch)
+    constexpr bool CHAIN = !CPLX && P == 4;
     __shared__ double red_lds[NW * SLOTS];
 
     v2d acc[P][KC];
@@ -658,6 +661,7 @@ __global__ __launch_bounds__(NW * 64) void panel_dot_p(const double *__restrict_
 #pragma unroll
             for (int jj = 0; jj < KC; ++jj) {
                 if constexpr (CPLX) acc[q][jj] += cmulconj(xv[jj], yv[q]);
+                else if constexpr (CHAIN) acc[q][jj].x = fma(xv[jj].y, yv[q].y, fma(xv[jj].x, yv[q].x, acc[q][jj].x));
                 else acc[q][jj] += xv[jj] * yv[q];
             }
             if (wc == 0) nrm[q] += yv[q].x * yv[q].x + yv[q].y * yv[q].y;
@@ -672,7 +676,7 @@ __global__ __launch_bounds__(NW * 64) void panel_dot_p(const double *__restrict_
                 double re = wave_sum(acc[q][jj].x), im = wave_sum(acc[q][jj].y);
                 if (lane == 0) { rl[2 * jj] = re; rl[2 * jj + 1] = im; }
             } else {
-                double sm = wave_sum(acc[q][jj].x + acc[q][jj].y);
+                double sm = wave_sum(CHAIN ? acc[q][jj].x : acc[q][jj].x + acc[q][jj].y);
                 if (lane == 0) rl[jj] = sm;
             }
         }
