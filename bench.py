@@ -210,6 +210,67 @@ def _oracle_sample(n: int, m: int, threads: int, fused: bool, repeat: int = 1):
     return dt, int(info)
 
 
+def _fused_leg(ns: int, ms: int, n4: int, m4: int, n_full: int, m_full: int) -> dict:
+    """The all-core leg itself (runs in the child process): thread scan on (ns, ms), then the timed sample (n4, m4) on the best count."""
+    from oracle import oracle as ora
+    fus_model = lambda nn, mm: sum(8.0 * nn * (3 * k + 5 + 2 + 3) for k in range(1, mm + 1))  # noqa: E731
+
+    def sample(n, m, T, repeat):
+        ora.set_threads(T)
+        X = np.zeros((n, m + 1), order="F")
+        ora.first_touch(X)                                   # pages placed by the threads that will stream them
+        H = np.zeros((m + 1, m), order="F")
+        A = ora.DiagLinOp(1.0, 1.0 / n)
+        dt = 0.0
+        for _ in range(repeat):
+            ora.fill_counter(X[:, 0], 7)
+            ora.scal(X[:, 0], 1.0 / ora.norm(X[:, 0]))
+            t0 = time.perf_counter()
+            ora.arnoldi_fused_allcores(A, X, H)
+            dt = time.perf_counter() - t0
+        return dt
+
+    tmax = ora.max_threads()
+    scan = {}
+    for T in sorted({t for t in (8, 16, 32, 64, 96, 128, 192, 256, tmax) if t <= tmax}):
+        scan[T] = sample(ns, ms, T, 2)
+    T = min(scan, key=scan.get)
+    ora.set_threads(T)
+    cpus = ora.thread_cpus()
+    dt4 = sample(n4, m4, T, 2)
+    bw4 = fus_model(n4, m4) / dt4
+    return {
+        "value": m_full / (fus_model(n_full, m_full) / bw4), "unit": "Arnoldi iterations/s", "cores": T,
+        "sample_seconds": dt4, "sample_iters_per_s": m4 / dt4, "effective_GBps_on_fused_schedule": bw4 / 1e9,
+        "thread_scan_seconds": {str(k): v for k, v in scan.items()},
+        "thread_scan_GBps": {str(k): fus_model(ns, ms) / v / 1e9 for k, v in scan.items()},
+        "host_threads_available": tmax,
+        "thread_scan_sample": {"n": ns, "m": ms, "basis_GB": 8e-9 * ns * (ms + 1)},
+        "binding": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
+                    "distinct_cpus_of_the_team": len(set(cpus)), "first_touch": "parallel, by the team that streams the rows"},
+        "sample": f"three-sweep fused CGS2 (the engine's schedule) with OpenMP on {T} bound threads (best of the scan), n={n4}, m={m4} "
+                  f"({dt4:.2f} s) scaled by sum_k 8n(3k+10) bytes",
+    }
+
+
+def _fused_leg_in_child(budget_n: int, budget_m: int, n_full: int, m_full: int, progress=None) -> dict:
+    import subprocess
+    ns, ms = budget_n, max(budget_m + budget_m // 2, 4) + 2           # the scan's own sample is DRAM-resident: >= 2 GB of basis
+    n4, m4 = min(4 * budget_n, n_full), min(2 * budget_m, m_full)
+    env = dict(os.environ, OMP_PROC_BIND="spread", OMP_PLACES="cores")
+    env.pop("OMP_NUM_THREADS", None)
+    spec = json.dumps([ns, ms, n4, m4, n_full, m_full])
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-fused-leg", spec], env=env, cwd=ROOT, capture_output=True,
+                             text=True, timeout=max(60.0, (progress.seconds - 30.0) if progress is not None and progress.seconds > 0 else 900.0))
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode != 0 or not line:
+            return {"value": None, "unit": "Arnoldi iterations/s", "cores": None, "sample": f"child failed (rc {out.returncode}): {out.stderr[-400:]}"}
+        return json.loads(line[-1])
+    except Exception as exc:  # noqa: BLE001
+        return {"value": None, "unit": "Arnoldi iterations/s", "cores": None, "sample": f"child failed: {exc!r}"}
+
+
 def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int, progress=None) -> dict:
     """Two legs, both on this host, both on a BOUNDED sample scaled to the metric's unit by a byte model:
       reference_schedule_1thread -- the oracle's Arnoldi in the reference's own schedule (per-primitive BLAS-1,
@@ -260,31 +321,14 @@ def cpu_baseline(n_full: int, m_full: int, budget_n: int, budget_m: int, progres
         "sample": (f"samples (n, m) = ({n1}, {m1}), ({n2}, {m2}) fit t = n(a m + b m(m+1)/2); validated on ({n3}, {m3}): "
                    f"{dt3:.2f} s measured vs {pred3:.2f} s predicted"),
     }
-    # -- leg 2: fused schedule on the host cores.  More threads is not monotonically faster on this kind of box (the
-    #    memory system saturates and then degrades), so a short scan picks the thread count, which is what a user tuning
-    #    OMP_NUM_THREADS would do; the scan is reported.
-    tmax = ora.max_threads()
-    scan = {}
-    ns, ms = budget_n, max(budget_m + budget_m // 2, 4) + 2           # the scan's own sample is DRAM-resident: >= 2 GB of basis
+    # -- leg 2: fused schedule on the host cores, in a CHILD process started with OMP_PROC_BIND=spread / OMP_PLACES=cores (thread binding is
+    #    read when the OpenMP runtime starts -- this process loaded it long ago with torch) so that the threads stay where they first touched
+    #    their rows of the basis: on a two-socket host an unbound team reads most of the basis across the socket link (round 4: best at 16 of
+    #    128 threads, 152 GB/s).  The child never touches the GPU.  More threads is still not monotonically faster, so a short scan picks the
+    #    thread count, which is what a user tuning OMP_NUM_THREADS would do; the scan is reported.
     if progress is not None:
-        progress.phase(f"cpu_baseline: thread scan of the fused schedule on a {8e-9 * ns * (ms + 1):.1f} GB basis")
-    for T in sorted({t for t in (8, 16, 32, 64, 128, tmax) if t <= tmax}):
-        dts, _ = _oracle_sample(ns, ms, T, fused=True, repeat=2)
-        scan[T] = dts
-        if progress is not None:
-            progress.tick()
-    T = min(scan, key=scan.get)
-    n4, m4 = min(4 * budget_n, n_full), min(2 * budget_m, m_full)
-    dt4, _ = _oracle_sample(n4, m4, T, fused=True, repeat=2)   # 2nd run timed: pages already first-touched in parallel
-    bw4 = fus_model(n4, m4) / dt4
-    leg2 = {
-        "value": m_full / (fus_model(n_full, m_full) / bw4), "unit": "Arnoldi iterations/s", "cores": T,
-        "sample_seconds": dt4, "sample_iters_per_s": m4 / dt4, "effective_GBps_on_fused_schedule": bw4 / 1e9,
-        "thread_scan_seconds": {str(k): v for k, v in scan.items()}, "host_threads_available": tmax,
-        "thread_scan_sample": {"n": ns, "m": ms, "basis_GB": 8e-9 * ns * (ms + 1)},
-        "sample": f"three-sweep fused CGS2 (the engine's schedule) with OpenMP on {T} threads (best of the scan), n={n4}, m={m4} "
-                  f"({dt4:.2f} s) scaled by sum_k 8n(3k+10) bytes",
-    }
+        progress.phase("cpu_baseline: all-core leg (fused schedule, bound threads, NUMA first touch) in a child process")
+    leg2 = _fused_leg_in_child(budget_n, budget_m, n_full, m_full, progress)
     return {
         "value": leg1["value"], "unit": "Arnoldi iterations/s", "cores": 1, "kind": "port", "info": info1,
         "host_cpus": os.cpu_count(),
@@ -343,6 +387,9 @@ def _laplacian_csr_rows(N: int, row0: int, n_local: int):
 
 
 def main() -> None:
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-fused-leg":      # the child of cpu_baseline's all-core leg: host only, no torch, no GPU
+        print(json.dumps(_fused_leg(*json.loads(sys.argv[2]))), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None,
                     help="ranks = GPUs of this node (default: the launcher's WORLD_SIZE when there is one, else 1); an EXPLICIT value that "

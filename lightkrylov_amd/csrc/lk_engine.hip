@@ -88,8 +88,10 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
-    int gram_tiles = 1;        // real Gram matrix beyond 32 columns by panel_gram_mfma (upper tiles dealt to the waves, 32-row tiles; 0: panel_xhy_mfma<false, 8, 64>)
-    int gram_grid_mult = 3;    // ... its blocks per CU
+    int xhy_db = 1;            // panel_xhy_mfma with a double-buffered LDS tile (1: the 128-column variants; 2: the <= 32 right-hand-side ones too; 0: never)
+    int gram_tiles = 1;        // real Gram matrix by panel_gram_mfma (upper tiles dealt to the waves, 32-row tiles): 1 = for 33..64 columns (measured: 1.80 / 1.38 ms
+                               // at k = 64 / 48, n = 10^7, against 1.90 / 1.60; slower beyond -- 4.6 vs 4.1 ms at k = 128), 2 = up to 128, 0 = never (panel_xhy_mfma<false, 8, 64>)
+    int gram_grid_mult = 2;    // ... its blocks per CU (two are resident: 87 VGPRs)
     int gemm_3m = 1;           // complex MFMA kernels (tall-skinny product; X^H Y with <= 32 right-hand sides; Gram) with three real products per complex one (0: four, the doubled real problem)
     int kc32 = -1;             // real DGS update sweeps (2 and 3) of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 when the GLOBAL problem has >= 2^25 rows)
     int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
@@ -757,7 +759,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         return allreduce(c, out3, nslots);
     }
     // real Gram matrix beyond 32 columns: upper tiles dealt to the waves in runs, 32-row tiles, three blocks per CU (panel_gram_mfma, round 5)
-    if (!cp && !small && c->gram_tiles && flags == 3) {
+    if (!cp && !small && flags == 3 && (c->gram_tiles == 2 || (c->gram_tiles == 1 && k <= 64))) {
         const int64_t nt32 = (Bx->n + 31) / 32;
         int64_t gg = (int64_t)c->num_cu * c->gram_grid_mult;
         if (gg > nt32) gg = nt32;
@@ -788,8 +790,12 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     }
     // complex kind, <= 32 right-hand sides: three real products per complex one on separate real / imaginary planes ("gemm_3m")
     const bool three = cp && small && c->gemm_3m && !(flags & 1);
-    const size_t lds = three ? (size_t)(KP + PJ) * 16 * 18 * 2 * sizeof(double)
-                             : (size_t)(KP + ((flags & 1) ? 0 : PJ)) * 16 * (TR + 2) * sizeof(double);
+    size_t lds = three ? (size_t)(KP + PJ) * 16 * 18 * 2 * sizeof(double)
+                       : (size_t)(KP + ((flags & 1) ? 0 : PJ)) * 16 * (TR + 2) * sizeof(double);
+    // double-buffered tile (one barrier per tile, staging under the MFMAs): the big variants when two buffers fit the 160 KB of a CU
+    // ("xhy_db": 1 = the 128-column variants, 2 = the <= 32 right-hand-side variants too, 0 = never)
+    const bool db = !three && c->xhy_db && (small ? c->xhy_db >= 2 : true) && 2 * lds <= (size_t)160 * 1024;
+    if (db) lds *= 2;
     {
         ProfScope ps(c, "xhy_mfma", (double)Bx->n * ED * 8.0 * (k + ((flags & 1) ? 0 : p)));
         auto go = [&](auto kern) -> int {
@@ -800,6 +806,8 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
             return LK_OK;
         };
         if (three) LKCHK(go(&panel_xhy_mfma3m));
+        else if (db && cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32, true>) : go(&panel_xhy_mfma<true, 8, 32, true>));
+        else if (db) LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32, true>) : go(&panel_xhy_mfma<false, 8, 64, true>));
         else if (cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32>) : go(&panel_xhy_mfma<true, 8, 32>));
         else LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32>) : go(&panel_xhy_mfma<false, 8, 64>));
     }
@@ -1432,7 +1440,8 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_prefetch_y")) { c->gemm_prefetch_y = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
-    if (!strcmp(key, "gram_tiles")) { c->gram_tiles = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "xhy_db")) { c->xhy_db = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
+    if (!strcmp(key, "gram_tiles")) { c->gram_tiles = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "gram_grid_mult")) { c->gram_grid_mult = value < 1 ? 1 : (value > 8 ? 8 : value); return LK_OK; }
     if (!strcmp(key, "kc32")) { c->kc32 = value < 0 ? -1 : value; return LK_OK; }
     if (!strcmp(key, "wide_s3")) { c->wide_s3 = value ? 1 : 0; return LK_OK; }

@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(256) void pack_coef_mfma3m(const double *__restrict
 // PJM = J tiles a wave can hold (8: up to 128 right-hand sides; 2: up to 32, half the registers), TR = real rows per tile
 // (64, or 32 for the small variant: 40 KB of LDS at k = 128, so that two or three blocks share a CU and cover each other's
 // barriers when there are only a few MFMAs per tile).
-template <bool CPLX, int PJM, int TR>
+template <bool CPLX, int PJM, int TR, bool DB = false>
 __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                       const double *__restrict__ Y, int64_t ldy, int p, int64_t n, int flags,
                                                       int NI, double *__restrict__ partial, double *__restrict__ npartial) {
@@ -1355,44 +1355,71 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
         }
     };
 
-    int64_t T = blockIdx.x;
-    if (T < ntiles) gload(T);
-    for (; T < ntiles; T += gridDim.x) {
-        __syncthreads();                                            // the previous tile's operands have been read
+    // staged chunks -> LDS tile `Xb` / `Yb` (and the norms of Y, once per tile)
+    auto stage = [&](double *Xb, double *Yb) {
 #pragma unroll
         for (int s = 0; s < NXP; ++s)
             if (s < KS) {
                 const int c = t + 512 * s;
-                if ((c >> CHS) < KP * 16) *reinterpret_cast<v2d *>(Xt + (c >> CHS) * S + 2 * (c & (CH - 1))) = xs[s];
+                if ((c >> CHS) < KP * 16) *reinterpret_cast<v2d *>(Xb + (c >> CHS) * S + 2 * (c & (CH - 1))) = xs[s];
             }
         if (!alias) {
 #pragma unroll
             for (int s = 0; s < NYP; ++s)
                 if (s < PS) {
                     const int c = t + 512 * s;
-                    if ((c >> CHS) < PJ * 16) *reinterpret_cast<v2d *>(Yt + (c >> CHS) * S + 2 * (c & (CH - 1))) = ys[s];
+                    if ((c >> CHS) < PJ * 16) *reinterpret_cast<v2d *>(Yb + (c >> CHS) * S + 2 * (c & (CH - 1))) = ys[s];
                     nacc[s] += ys[s].x * ys[s].x + ys[s].y * ys[s].y;
                 }
         }
-        __syncthreads();
-        if (T + gridDim.x < ntiles) gload(T + gridDim.x);           // in flight while this tile's MFMAs run
+    };
+    // this wave's MFMAs on the tile staged in `Xb` / `Yb`
+    auto contract = [&](const double *Xb, const double *Yb) {
         if (active) {
             for (int step = wr; step < TR / 4; step += WR) {
                 const int ro = 4 * step + arow;
-                const double a = Xt[(16 * wi + acol) * S + ro];
+                const double a = Xb[(16 * wi + acol) * S + ro];
 #pragma unroll
                 for (int J = 0; J < PJM; ++J) {
                     if (J < PJ && (!upper || J >= wi)) {
-                        const double b = Yt[(16 * J + acol) * S + ro];
+                        const double b = Yb[(16 * J + acol) * S + ro];
                         acc_re[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc_re[J], 0, 0, 0);
                         if constexpr (CPLX) {
-                            double b2 = Yt[(16 * J + acol) * S + (ro ^ 1)];
+                            double b2 = Yb[(16 * J + acol) * S + (ro ^ 1)];
                             b2 = (ro & 1) ? -b2 : b2;
                             acc_im[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b2, acc_im[J], 0, 0, 0);
                         }
                     }
                 }
             }
+        }
+    };
+
+    int64_t T = blockIdx.x;
+    if constexpr (DB) {
+        // DOUBLE-BUFFERED tile (round 5): ONE barrier per tile.  While the MFMAs of tile T run out of one buffer, every wave -- as it
+        // finishes its own share -- stages tile T + grid (in its registers since the previous iteration) into the other buffer and
+        // sends the loads of tile T + 2 grid on their way; a light wave does that under a heavy wave's MFMAs (the two share a SIMD),
+        // and the matrix pipe no longer idles through a second barrier and a block-wide staging phase per tile.
+        const int BUF = (KP + (alias ? 0 : PJ)) * 16 * S;            // doubles per buffer
+        if (T < ntiles) { gload(T); stage(Xt, Yt); }
+        if (T + gridDim.x < ntiles) gload(T + gridDim.x);
+        __syncthreads();
+        int buf = 0;
+        for (; T < ntiles; T += gridDim.x, buf ^= 1) {
+            contract(Xt + buf * BUF, Yt + buf * BUF);
+            if (T + gridDim.x < ntiles) stage(Xt + (buf ^ 1) * BUF, Yt + (buf ^ 1) * BUF);
+            if (T + 2 * (int64_t)gridDim.x < ntiles) gload(T + 2 * (int64_t)gridDim.x);
+            __syncthreads();                                        // buffer `buf` has been read by all, buffer `buf ^ 1` is complete
+        }
+    } else {
+        if (T < ntiles) gload(T);
+        for (; T < ntiles; T += gridDim.x) {
+            __syncthreads();                                        // the previous tile's operands have been read
+            stage(Xt, Yt);
+            __syncthreads();
+            if (T + gridDim.x < ntiles) gload(T + gridDim.x);       // in flight while this tile's MFMAs run
+            contract(Xt, Yt);
         }
     }
 

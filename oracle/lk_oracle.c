@@ -1,3 +1,5 @@
+#define _GNU_SOURCE
+#include <sched.h>
 /* lk_oracle.c -- CPU ORACLE for the LightKrylov hot path.  TEST INFRASTRUCTURE, NOT PRODUCT.
  *
  * This file is a plain-C restatement of the reference's algorithm for the path
@@ -56,6 +58,28 @@ void ora_set_threads(int nt)
     ora_nthreads = nt;
 }
 int ora_get_threads(void) { return ora_nthreads; }
+
+/* Parallel FIRST TOUCH of a freshly mapped (calloc / np.zeros) n x ncols array of 8-byte words: every thread writes zeros into the
+ * rows a `schedule(static)` loop over n gives it, in every column, so that on a multi-socket host each page lands on the memory of
+ * the socket whose threads will stream it (the all-core leg of bench.py's cpu_baseline; pointless without OMP_PROC_BIND). */
+void ora_first_touch(int64_t n, int ncols, double *X, int64_t ldx)
+{
+#pragma omp parallel for schedule(static) num_threads(ora_nthreads) if (ora_nthreads > 1)
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < ncols; ++j) X[(int64_t)j * ldx + i] = 0.0;
+}
+/* where the OpenMP runtime put thread t of a team of ora_nthreads: out[t] = CPU number (sched_getcpu), -1 if unknown */
+void ora_thread_cpus(int *out)
+{
+#pragma omp parallel num_threads(ora_nthreads)
+    {
+#ifdef _OPENMP
+        out[omp_get_thread_num()] = sched_getcpu();
+#else
+        out[0] = -1;
+#endif
+    }
+}
 int ora_max_threads(void)
 {
 #ifdef _OPENMP

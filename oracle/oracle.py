@@ -180,6 +180,22 @@ def dot_mode(x: np.ndarray, y: np.ndarray, mode: int):
     return out[0]
 
 
+def first_touch(X: np.ndarray) -> None:
+    """Parallel first touch (zeros) of a freshly allocated real F-order array by the current thread team: NUMA placement for the
+    all-core leg of bench.py's cpu_baseline."""
+    X2 = X.reshape(X.shape[0], -1, order="F")
+    assert X2.dtype == np.float64
+    lib().ora_first_touch(C.c_int64(X2.shape[0]), C.c_int(X2.shape[1]), _p(X2), C.c_int64(_ld(X2)))
+
+
+def thread_cpus() -> list:
+    """CPU number each thread of the current team runs on (diagnostic of the binding)."""
+    nt = int(lib().ora_get_threads())
+    out = (C.c_int * nt)()
+    lib().ora_thread_cpus(out)
+    return list(out)
+
+
 def fill_counter(x: np.ndarray, seed: int, i0: int = 0) -> None:
     """x_i = 2u-1 with u = (splitmix64(seed*2^32 + i0+i) >> 11) 2^-53."""
     getattr(lib(), "ora_fill_counter" + _sfx(x))(C.c_int64(x.size), C.c_int64(i0),

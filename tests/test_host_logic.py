@@ -514,3 +514,14 @@ def test_eigs_segments_taper_towards_the_end_of_a_cycle():
             steps = [k for a, b in segs for k in range(a, b + 1)]
             assert steps == list(range(kstart, kdim + 1)), (kstart, kdim, segs)
             assert segs[-1][0] == segs[-1][1] == kdim and all(b - a + 1 <= 16 for a, b in segs)
+
+
+def test_bench_all_core_baseline_leg_runs_bound_in_a_child_process():
+    """cpu_baseline's all-core leg: a child process started with OMP_PROC_BIND=spread / OMP_PLACES=cores (the binding is read when the
+    OpenMP runtime starts), parallel first touch of the basis, thread scan, the timed sample -- its JSON says how the team was bound."""
+    import bench
+    leg = bench._fused_leg_in_child(200_000, 4, 100_000_000, 128)
+    assert leg["value"] and leg["value"] > 0 and leg["cores"] >= 1, leg
+    assert leg["binding"]["OMP_PROC_BIND"] == "spread" and leg["binding"]["OMP_PLACES"] == "cores"
+    assert leg["binding"]["distinct_cpus_of_the_team"] == min(leg["cores"], os.cpu_count())       # every thread on a CPU of its own
+    assert set(leg["thread_scan_GBps"]) == set(leg["thread_scan_seconds"]) and str(leg["cores"]) in leg["thread_scan_seconds"]
