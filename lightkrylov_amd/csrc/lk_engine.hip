@@ -88,6 +88,7 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
+    int xhy_tr32 = 1;          // the 128-column real variant of panel_xhy_mfma on 32-row tiles (half the staged chunks in registers: room for the operand prefetch)
     int xhy_db = 1;            // panel_xhy_mfma with a double-buffered LDS tile (1: the 128-column variants; 2: the <= 32 right-hand-side ones too; 0: never)
     int gram_tiles = 1;        // real Gram matrix by panel_gram_mfma (upper tiles dealt to the waves, 32-row tiles): 1 = for 33..64 columns (measured: 1.80 / 1.38 ms
                                // at k = 64 / 48, n = 10^7, against 1.90 / 1.60; slower beyond -- 4.6 vs 4.1 ms at k = 128), 2 = up to 128, 0 = never (panel_xhy_mfma<false, 8, 64>)
@@ -708,7 +709,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     // share a CU and cover each other's barriers and load latency (n = 10^7 real, k = 128, p = 16: 2.54 -> 1.92 ms on 3 blocks
     // per CU, one pass over X at 6.5 TB/s being 1.77; complex 3.73 -> 2.29 ms on 2)
     const bool small = c->xhy_small && PJ <= 2;
-    const int TR = (small || cp) ? 32 : 64;     // (complex, more than 32 right-hand sides: 32-row tiles too -- sixteen staged chunks beside 2 x 8 accumulators spilled 68 B)
+    const int TR = (small || cp || c->xhy_tr32) ? 32 : 64;     // (complex, more than 32 right-hand sides: 32-row tiles too -- sixteen staged chunks beside 2 x 8 accumulators spilled 68 B)
     const int64_t ntiles = (Bx->n * ED + TR - 1) / TR;
     int64_t g = (int64_t)c->num_cu * (small ? (c->xhy_grid_mult ? c->xhy_grid_mult : (cp ? 2 : 3)) : 1);
     if (g > ntiles) g = ntiles;
@@ -807,9 +808,9 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         };
         if (three) LKCHK(go(&panel_xhy_mfma3m));
         else if (db && cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32, true>) : go(&panel_xhy_mfma<true, 8, 32, true>));
-        else if (db) LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32, true>) : go(&panel_xhy_mfma<false, 8, 64, true>));
+        else if (db) LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32, true>) : (TR == 32 ? go(&panel_xhy_mfma<false, 8, 32, true>) : go(&panel_xhy_mfma<false, 8, 64, true>)));
         else if (cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32>) : go(&panel_xhy_mfma<true, 8, 32>));
-        else LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32>) : go(&panel_xhy_mfma<false, 8, 64>));
+        else LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32>) : (TR == 32 ? go(&panel_xhy_mfma<false, 8, 32>) : go(&panel_xhy_mfma<false, 8, 64>)));
     }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, part, nvb, npart, grid, k, p, ED, flags, out);
@@ -1440,6 +1441,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_prefetch_y")) { c->gemm_prefetch_y = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "xhy_tr32")) { c->xhy_tr32 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "xhy_db")) { c->xhy_db = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "gram_tiles")) { c->gram_tiles = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "gram_grid_mult")) { c->gram_grid_mult = value < 1 ? 1 : (value > 8 ? 8 : value); return LK_OK; }

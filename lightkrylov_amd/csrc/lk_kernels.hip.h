@@ -1375,7 +1375,46 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     };
     // this wave's MFMAs on the tile staged in `Xb` / `Yb`
     auto contract = [&](const double *Xb, const double *Yb) {
-        if (active) {
+        constexpr bool PF = !CPLX && PJM == 8 && TR == 32;      // (the variants with registers to spare: 64-row tiles and the complex kind spill with it)
+        if (PF && active && WR == 1) {
+            // one tile row per wave (k > 64): the operands of row step s + 1 are read from LDS BEFORE the MFMAs of step s are issued, so
+            // the LDS latency of a step (one A and up to eight B operands, then a full s_waitcnt) runs under 8 x 64 cycles of matrix
+            // pipe instead of in front of them (round 5: the waves of this kernel were parked in s_waitcnt for half their cycles)
+            double a_n = Xb[(16 * wi + acol) * S + arow], b_n[PJM], b2_n[CPLX ? PJM : 1];
+#pragma unroll
+            for (int J = 0; J < PJM; ++J) {
+                b_n[J] = 0.0;
+                if constexpr (CPLX) b2_n[J] = 0.0;
+                if (J < PJ && (!upper || J >= wi)) {
+                    b_n[J] = Yb[(16 * J + acol) * S + arow];
+                    if constexpr (CPLX) b2_n[J] = Yb[(16 * J + acol) * S + (arow ^ 1)];
+                }
+            }
+#pragma unroll 1
+            for (int step = 0; step < TR / 4; ++step) {
+                const double a = a_n;
+                double b[PJM], b2[CPLX ? PJM : 1];
+#pragma unroll
+                for (int J = 0; J < PJM; ++J) { b[J] = b_n[J]; if constexpr (CPLX) b2[J] = b2_n[J]; }
+                if (step + 1 < TR / 4) {
+                    const int ro = 4 * (step + 1) + arow;
+                    a_n = Xb[(16 * wi + acol) * S + ro];
+#pragma unroll
+                    for (int J = 0; J < PJM; ++J)
+                        if (J < PJ && (!upper || J >= wi)) {
+                            b_n[J] = Yb[(16 * J + acol) * S + ro];
+                            if constexpr (CPLX) b2_n[J] = Yb[(16 * J + acol) * S + (ro ^ 1)];
+                        }
+                }
+#pragma unroll
+                for (int J = 0; J < PJM; ++J) {
+                    if (J < PJ && (!upper || J >= wi)) {
+                        acc_re[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[J], acc_re[J], 0, 0, 0);
+                        if constexpr (CPLX) acc_im[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (arow & 1) ? -b2[J] : b2[J], acc_im[J], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (active) {
             for (int step = wr; step < TR / 4; step += WR) {
                 const int ro = 4 * step + arow;
                 const double a = Xb[(16 * wi + acol) * S + ro];
