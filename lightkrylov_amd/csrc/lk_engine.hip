@@ -88,6 +88,8 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
+    int xhy_debug = 0;         // diagnostic only (wrong results): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
+    int gemm_roll = 1;         // MFMA tall-skinny product: rolling prefetch of X (a ring of 4 k-steps refilled as they are consumed; 0: batches of 4 k-steps, loaded, waited for, multiplied)
     int xhy_tr32 = 1;          // the 128-column real variant of panel_xhy_mfma on 32-row tiles (half the staged chunks in registers: room for the operand prefetch)
     int xhy_db = 1;            // panel_xhy_mfma with a double-buffered LDS tile (1: the 128-column variants; 2: the <= 32 right-hand-side ones too; 0: never)
     int gram_tiles = 1;        // real Gram matrix by panel_gram_mfma (upper tiles dealt to the waves, 32-row tiles): 1 = for 33..64 columns (measured: 1.80 / 1.38 ms
@@ -803,7 +805,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
             if (lds > 48 * 1024)
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, c->stream, (const double *)Bx->col(c0), Bx->ld, k, (const double *)By->col(jy0), By->ld,
-                               p, Bx->n, flags, NI, part, npart);
+                               p, Bx->n, flags | (c->xhy_debug << 4), NI, part, npart);
             return LK_OK;
         };
         if (three) LKCHK(go(&panel_xhy_mfma3m));
@@ -929,8 +931,11 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     const int nt = (kk + 3) / 4;
     const size_t lds = (size_t)NG * nt * 64 * sizeof(double);
     if (lds > 48 * 1024)                         // more than the default dynamic-LDS limit needs the opt-in (gfx950: 160 KB per workgroup)
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
+    {
+        if constexpr (!(CPLX && NG >= 8))
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     constexpr int tile_rows = 8 * 2 * (CPLX ? 16 : 32);
     int64_t g = (n + tile_rows - 1) / tile_rows;
     const int64_t cap = (int64_t)c->num_cu * (NG >= 8 ? 1 : (NG >= 4 && CPLX ? 2 : c->gemm_grid_mult));
@@ -939,15 +944,26 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     if constexpr (!CPLX && NG <= 2) {
         if (accumulate && c->gemm_prefetch_y) {          // the accumulating update of the block Gram-Schmidt: Y's tile loaded ahead of the k-loop
             if (lds > 48 * 1024)
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            // (the rolling prefetch of X beside the prefetched tile of Y does not fit the register file: batch schedule here)
+            hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, true, false>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
                                c->gemm_store_policy);
             HIPCHK(hipGetLastError());
             return LK_OK;
         }
     }
-    hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                       c->gemm_store_policy);
+    constexpr bool CAN_ROLL = !(CPLX && NG >= 8);          // (64 complex outputs as the doubled real problem: the ring does not fit the register file)
+    bool rolled = false;
+    if constexpr (CAN_ROLL) {
+        if (c->gemm_roll) {
+            hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                               c->gemm_store_policy);
+            rolled = true;
+        }
+    }
+    if (!rolled)
+        hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, false, false>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                           c->gemm_store_policy);
     HIPCHK(hipGetLastError());
     return LK_OK;
 }
@@ -1441,6 +1457,8 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_prefetch_y")) { c->gemm_prefetch_y = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "xhy_debug")) { c->xhy_debug = value & 3; return LK_OK; }
+    if (!strcmp(key, "gemm_roll")) { c->gemm_roll = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "xhy_tr32")) { c->xhy_tr32 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "xhy_db")) { c->xhy_db = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "gram_tiles")) { c->gram_tiles = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }

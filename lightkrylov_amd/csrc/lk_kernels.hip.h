@@ -1022,7 +1022,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // the result is added to is loaded BEFORE the k-loop, 16 more 16-byte loads in flight per lane under the MFMAs, instead of after it, where a
 // wave had nothing else to issue: block DGS k = 128, p = 32: 10.3 -> 9.8 ms, k = 32, p = 32: 4.9 -> 4.5 ms.  (Compiled into the plain
 // product as well it cost that one 13 %, so it is a template flag; for the complex three-product kernel it changed nothing and is not built.)
-template <bool CPLX, int NG, bool PFY = false>
+template <bool CPLX, int NG, bool PFY = false, bool ROLL = true>
 __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                        double *__restrict__ Y, int64_t ldy, int qn,
                                                        const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
@@ -1073,6 +1073,66 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                         }
             }
         }
+        // ROLLING prefetch (round 5): a ring of U k-steps of X in registers; the moment a k-step's two 16-byte loads have been handed to
+        // the MFMAs, the loads of the k-step U further on take their place -- 2 U loads per lane stay in flight under the MFMAs all
+        // the way through the k-loop.  (Rounds 2-4 loaded a BATCH of U k-steps, waited for all of it -- s_waitcnt vmcnt(0) -- and
+        // only then issued its 4 U NG MFMAs: every batch paid an HBM round trip with an idle matrix pipe and nothing in flight behind
+        // it; a double-buffered variant of that with half-size batches had measured slower.)  ROLL = false keeps the batch schedule.
+        if constexpr (ROLL) {
+            v2d x[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x[u][0] = v2d{0.0, 0.0};
+                x[u][1] = v2d{0.0, 0.0};
+                if (u < nt) {
+                    const double *__restrict__ xc = Xl + (int64_t)(4 * u) * xstride;
+                    if (fast) {
+                        x[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xc + r0 * ED));
+                        x[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xc + r1 * ED));
+                    } else if ((4 * u + kk) < k) {
+                        x[u][0] = load_y<CPLX>(xc, r0, n, false);
+                        x[u][1] = load_y<CPLX>(xc, r1, n, false);
+                    }
+                }
+            }
+            for (int t0 = 0; t0 < nt; t0 += U) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = t0 + u;
+                    const v2d xa = x[u][0], xb = x[u][1];
+                    x[u][0] = v2d{0.0, 0.0};
+                    x[u][1] = v2d{0.0, 0.0};
+                    if (t + U < nt) {
+                        const double *__restrict__ xc = Xl + (int64_t)(4 * (t + U)) * xstride;
+                        if (fast) {
+                            x[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xc + r0 * ED));
+                            x[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xc + r1 * ED));
+                        } else if ((4 * (t + U) + kk) < k) {
+                            x[u][0] = load_y<CPLX>(xc, r0, n, false);
+                            x[u][1] = load_y<CPLX>(xc, r1, n, false);
+                        }
+                    }
+                    if (t < nt) {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            const double a0 = tiles[(g * nt + t) * 64 + lane];
+                            if constexpr (CPLX) {
+                                const double a1 = tiles[(g * nt + t) * 64 + (lane ^ 8)] * sgn;
+                                acc[g][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xa.x, acc[g][0][0], 0, 0, 0);
+                                acc[g][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xb.x, acc[g][1][0], 0, 0, 0);
+                                acc[g][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xa.y, acc[g][0][0], 0, 0, 0);
+                                acc[g][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xb.y, acc[g][1][0], 0, 0, 0);
+                            } else {
+                                acc[g][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xa.x, acc[g][0][0], 0, 0, 0);
+                                acc[g][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xa.y, acc[g][0][1], 0, 0, 0);
+                                acc[g][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xb.x, acc[g][1][0], 0, 0, 0);
+                                acc[g][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xb.y, acc[g][1][1], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
         // U k-steps per batch: 2 U loads of 16 B per lane in flight, then their MFMAs.  (A software-pipelined variant with
         // the next batch's loads issued ahead was measured 2-18 % SLOWER: it needs smaller batches to fit the register
         // file, and the two waves per SIMD already overlap each other's load latency.)
@@ -1119,6 +1179,7 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                     }
                 }
             }
+        }
         }
         // D[n = kk + 4 reg][row j] of group g
         const bool full = (tile + 1) * tile_rows <= n;
@@ -1323,7 +1384,9 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     for (int s = 0; s < NYP; ++s) nacc[s] = 0.0;
     v2d xs[NXP], ys[NYP];
 
+    const bool dbg_nomfma = flags & 16, dbg_noload = flags & 32;      // diagnostics (tools/bench_gram.py xhy_debug=...): wrong results, phase timing only
     auto gload = [&](int64_t T) {
+        if (dbg_noload && T != (int64_t)blockIdx.x) return;
         const int64_t rbase = T * TR;
 #pragma unroll
         for (int s = 0; s < NXP; ++s) {
@@ -1375,6 +1438,7 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     };
     // this wave's MFMAs on the tile staged in `Xb` / `Yb`
     auto contract = [&](const double *Xb, const double *Yb) {
+        if (dbg_nomfma) return;
         constexpr bool PF = !CPLX && PJM == 8 && TR == 32;      // (the variants with registers to spare: 64-row tiles and the complex kind spill with it)
         if (PF && active && WR == 1) {
             // one tile row per wave (k > 64): the operands of row step s + 1 are read from LDS BEFORE the MFMAs of step s are issued, so
