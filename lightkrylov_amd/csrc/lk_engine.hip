@@ -88,9 +88,13 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
+    int upd_debug = 0;         // diagnostic only (wrong results): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
     int xhy_debug = 0;         // diagnostic only (wrong results): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
-    int gemm_roll = 1;         // MFMA tall-skinny product: rolling prefetch of X (a ring of 4 k-steps refilled as they are consumed; 0: batches of 4 k-steps, loaded, waited for, multiplied)
-    int xhy_tr32 = 1;          // the 128-column real variant of panel_xhy_mfma on 32-row tiles (half the staged chunks in registers: room for the operand prefetch)
+    int gemm_roll = 0;         // MFMA tall-skinny product: rolling prefetch of X (a ring of 4 k-steps refilled as they are consumed) instead of batches of 4 k-steps (loaded, waited for,
+                               // multiplied).  Measured SLOWER for the real kind (k = 64, q = 32: 1.39 -> 1.87 ms; k = 128, q = 64: 3.50 -> 3.61) and +2-5 % for narrow complex products
+                               // (profiles/r05_ab_gemm_roll.jsonl): off
+    int xhy_tr32 = 0;          // the 128-column real variant of panel_xhy_mfma on 32-row tiles with the next row step's operands read ahead of the current step's MFMAs: measured SLOWER
+                               // (Gram k = 128: 5.5 vs 4.2 ms, profiles/r05_gram_phases.jsonl -- the MFMA phase already runs at the pipe's sustained rate): off
     int xhy_db = 1;            // panel_xhy_mfma with a double-buffered LDS tile (1: the 128-column variants; 2: the <= 32 right-hand-side ones too; 0: never)
     int gram_tiles = 1;        // real Gram matrix by panel_gram_mfma (upper tiles dealt to the waves, 32-row tiles): 1 = for 33..64 columns (measured: 1.80 / 1.38 ms
                                // at k = 64 / 48, n = 10^7, against 1.90 / 1.60; slower beyond -- 4.6 vs 4.1 ms at k = 128), 2 = up to 128, 0 = never (panel_xhy_mfma<false, 8, 64>)
@@ -848,7 +852,7 @@ int upd_dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, c
         auto go = [&](auto kern) -> int {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, (const double *)Bx->col(c0), Bx->ld, k, By->col(jy0), By->ld, p, Bx->n,
-                               H1dev, part, npart, c->gemm_store_policy);
+                               H1dev, part, npart, c->gemm_store_policy | (c->upd_debug << 4));
             return LK_OK;
         };
         if (cp) LKCHK(go(&panel_xhy_upd_mfma<true>));
@@ -1457,6 +1461,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_prefetch_y")) { c->gemm_prefetch_y = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "upd_debug")) { c->upd_debug = value & 15; return LK_OK; }
     if (!strcmp(key, "xhy_debug")) { c->xhy_debug = value & 3; return LK_OK; }
     if (!strcmp(key, "gemm_roll")) { c->gemm_roll = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "xhy_tr32")) { c->xhy_tr32 = value ? 1 : 0; return LK_OK; }

@@ -1965,7 +1965,10 @@ __global__ __launch_bounds__(256) void panel_xhy_upd_mfma(const double *__restri
     for (int s = 0; s < NYP; ++s) nacc[s] = 0.0;
     v2d xs[NXP], ys[NYP];
 
+    const int dbg = policy >> 4;                    // diagnostics (upd_debug): wrong results, phase timing only
+    policy &= 15;
     auto gload = [&](int64_t T) {
+        if ((dbg & 4) && T != (int64_t)blockIdx.x) return;
         const int64_t rbase = T * TR;
 #pragma unroll
         for (int s = 0; s < NXP; ++s) {
@@ -2018,7 +2021,7 @@ __global__ __launch_bounds__(256) void panel_xhy_upd_mfma(const double *__restri
         // ---- update: this wave's 16 x 16 tile of U = X H1, then Y' = Y - U into the LDS tile
         {
             const int rb = wave & 1, J = wave >> 1;
-            if (J < PJ) {
+            if (J < PJ && !(dbg & 1)) {
                 // four independent accumulator chains (k-steps tt, tt + 4 of every column group share one)
                 v4d ua[4];
 #pragma unroll
@@ -2063,7 +2066,8 @@ __global__ __launch_bounds__(256) void panel_xhy_upd_mfma(const double *__restri
                         const v2d v = *reinterpret_cast<const v2d *>(Yt + col * S + 2 * (c & (CH - 1)));
                         const int64_t rr = rbase + 2 * (c & (CH - 1));
                         double *pc = Y + (int64_t)col * ycs;
-                        if (rr + 1 < nr) { store16(reinterpret_cast<v2d *>(pc + rr), v, policy); nacc[s] += v.x * v.x + v.y * v.y; }
+                        if (dbg & 8) { nacc[s] += v.x * v.x + v.y * v.y; }
+                        else if (rr + 1 < nr) { store16(reinterpret_cast<v2d *>(pc + rr), v, policy); nacc[s] += v.x * v.x + v.y * v.y; }
                         else if (rr < nr) { pc[rr] = v.x; nacc[s] += v.x * v.x; }
                     }
                 }
@@ -2073,7 +2077,7 @@ __global__ __launch_bounds__(256) void panel_xhy_upd_mfma(const double *__restri
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int I = wave + 4 * h;
-            if (I < KP) {
+            if (I < KP && !(dbg & 2)) {
                 for (int s0 = 0; s0 < TR / 4; s0 += 4) {
                     double a[4], b[4][PJM], b2[4][CPLX ? PJM : 1];
 #pragma unroll

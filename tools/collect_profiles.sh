@@ -11,6 +11,10 @@ hdr="{\"commit\": \"$C\", \"box\": \"1 x MI355X (gpurun), tools/run_profiles.sh 
 j() { grep -h '^{' "$@" 2>/dev/null || true; }
 (echo "$hdr"; j "$D/wide_f64.log" "$D/wide_c128.log") > "profiles/${TAG}_wide_dgs.jsonl"
 (echo "$hdr"; j "$D/block.log") > "profiles/${TAG}_block_mfma.jsonl"
+if [ -f "$D/block_wide.log" ]; then (echo "$hdr"; j "$D/block_wide.log") > "profiles/${TAG}_block_wide.jsonl"; fi
+if [ -f "$D/gram.log" ]; then (echo "$hdr"; j "$D/gram.log") > "profiles/${TAG}_gram.jsonl"; fi
+if [ -f "$D/shard_2.log" ]; then (echo "$hdr"; j "$D/shard_2.log" "$D/shard_4.log" "$D/shard_8.log") > "profiles/${TAG}_shard_lines_one_gpu.jsonl"; fi
+if [ -f "$D/cfg5_8rank_one_gpu.log" ]; then (echo "$hdr"; j "$D/cfg5_2rank_one_gpu.log" "$D/cfg5_8rank_one_gpu.log") > "profiles/${TAG}_cfg5_ranks_sharing_one_gpu.jsonl"; fi
 (echo "$hdr"; for op in dense lap5 csr; do j "$D/bench_$op.log"; done) > "profiles/${TAG}_operators.jsonl"
 (echo "$hdr"; j "$D/blas1.log") > "profiles/${TAG}_blas1_n1e8.jsonl"
 (echo "$hdr"; j "$D/per_object_arnoldi.log") > "profiles/${TAG}_per_object_arnoldi.jsonl"
@@ -36,9 +40,11 @@ PY
 ) > "profiles/${TAG}_lincomb_scan.txt"
 (echo "# rocprofv3 --pmc FETCH_SIZE (KB, x2 on gfx950) per kernel; commit $C"
  echo "## tools/bench_block_dgs.py 32 1  (n = 1e7 real, p = 32 against k = 64 and k = 128, 6 calls each: X 5.12 / 10.24 GB + Y 2.56 GB per pass => 122.88 GB per kernel = ONE pass each: three passes per block DGS)"
- python tools/pmc_sum.py "$D/pmc_block_fetch" FETCH_SIZE
+ if [ -d "$D/pmc_block_fetch" ]; then python tools/pmc_sum.py "$D/pmc_block_fetch" FETCH_SIZE; fi
+ if [ -d "$D/pmc_block_wide_fetch" ]; then echo "## tools/bench_block_wide.py 4e6 (k = 256 / 192 / 512 against p = 32 / 4 / 8 / 32, both kinds, 4 x (1 warm-up + 3) calls each: panel schedule 4k - |last panel| columns of X per group of 32 columns of Y)"; python tools/pmc_sum.py "$D/pmc_block_wide_fetch" FETCH_SIZE; fi
+ if [ -d "$D/pmc_wide_fetch" ]; then
  echo "## tools/bench_wide.py 4e6 f64  (k = 64..640, 5 calls each; panel_sweep<f64, KC, 8, UPDATE, DOT, TWO, SC, G>: <32,..,1,1> = k 129..256 (sum of k+1 = 749 columns x 160 MB = 119.84 GB), <24,..,2,1> sweep 2 and <48,..,1,2> sweep 3 = k 257..384 (964 columns = 154.24 GB), <16,..,4,1> = k 512: (k + 1) columns of 32 MB per launch = ONE pass each)"
- python tools/pmc_sum.py "$D/pmc_wide_fetch" FETCH_SIZE
+ python tools/pmc_sum.py "$D/pmc_wide_fetch" FETCH_SIZE; fi
  if [ -f profiles/${TAG}_pmc_lds_note.txt ]; then cat profiles/${TAG}_pmc_lds_note.txt; fi) > "profiles/${TAG}_pmc_wide_and_block.txt"
 find "$D/dense" -name "*kernel_stats.csv" -exec cp {} "profiles/${TAG}_dense_n65536_kernel_stats.csv" \;
 if [ -d "$D/block_stats" ]; then find "$D/block_stats" -name "*kernel_stats.csv" -exec cp {} "profiles/${TAG}_block_dgs_kernel_stats.csv" \;; fi

@@ -1,19 +1,27 @@
-// FP64 MFMA issue-rate microbenchmark (calibration of the tall-skinny product's ceiling): every wave of a full grid issues
-// back-to-back v_mfma_f64_16x16x4_f64 on 8 independent accumulators; prints TFLOP/s.
+// FP64 MFMA issue-rate microbenchmark (calibration of the ceiling of every matrix-core kernel of this library): every wave of a full grid
+// issues back-to-back v_mfma_f64_16x16x4_f64 on NACC independent accumulators, nothing else.  Prints, per configuration (waves per SIMD,
+// accumulators per wave): TFLOP/s by wall clock, shader cycles per MFMA and SIMD by s_memtime, and the shader clock the two imply.
 //   hipcc --offload-arch=gfx950 -O3 -o mfma_f64_peak tools/mfma_f64_peak.hip && ./mfma_f64_peak
+// Spec (AMD): 78.6 TFLOP/s FP64 matrix = 256 CUs x 4 SIMDs x 2.4 GHz x 2048 flop / 64 cycles.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdint>
 typedef double v4d __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void k(double *out, int iters, double a, double b) {
-    v4d acc[8];
-    for (int i = 0; i < 8; ++i) acc[i] = v4d{0, 0, 0, 0};
+template <int NACC>
+__global__ __launch_bounds__(256) void k(double *out, unsigned long long *cyc, int iters, double a, double b) {
+    v4d acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = v4d{0, 0, 0, 0};
+    const double av = a + 1e-3 * (threadIdx.x & 15), bv = b - 1e-3 * (threadIdx.x >> 4);      // operands that differ between lanes
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
     }
     double s = 0;
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 __global__ __launch_bounds__(256) void kfma(double *out, int iters, double a, double b) {
     double acc[16];
@@ -26,25 +34,40 @@ __global__ __launch_bounds__(256) void kfma(double *out, int iters, double a, do
     for (int i = 0; i < 16; ++i) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-int main() {
-    double *d;
-    const int blocks = 256 * 8, iters = 20000;
-    hipMalloc(&d, sizeof(double) * blocks * 256);
+template <int NACC>
+void run(double *d, unsigned long long *c, int blocks_per_cu, int iters) {
+    const int blocks = 256 * blocks_per_cu;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int rep = 0; rep < 2; ++rep) {
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0000001, 0.9999999);
+        hipLaunchKernelGGL(k<NACC>, dim3(blocks), dim3(256), 0, 0, d, c, iters, 1.0000001, 0.9999999);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        const double flop = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
-        printf("mfma_f64_16x16x4: %.3f ms  %.1f TFLOP/s\n", ms, flop / ms / 1e9);
-        hipEventRecord(e0);
-        hipLaunchKernelGGL(kfma, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0000001, 1e-9);
-        hipEventRecord(e1); hipEventSynchronize(e1);
-        hipEventElapsedTime(&ms, e0, e1);
-        const double flop2 = (double)blocks * 256 * iters * 16.0 * 2.0;
-        printf("v_fma_f64       : %.3f ms  %.1f TFLOP/s\n", ms, flop2 / ms / 1e9);
+        if (ms < best) best = ms;
     }
+    unsigned long long hc[8];
+    hipMemcpy(hc, c, sizeof(hc), hipMemcpyDeviceToHost);
+    const double nm = (double)iters * NACC;                        // MFMAs per wave
+    const double flop = (double)blocks * 4 * nm * 2048.0;
+    // one block = 4 waves = one per SIMD; blocks_per_cu waves share a SIMD: cycles per MFMA and SIMD = block cycles / (nm * blocks_per_cu)
+    const double cpm = (double)hc[0] / (nm * blocks_per_cu);
+    const double mfma_per_simd = nm * blocks_per_cu;
+    printf("{\"waves_per_simd\": %d, \"accumulators\": %d, \"ms\": %.3f, \"TFLOPs\": %.1f, \"frac_of_78.6\": %.3f, \"s_memtime_ticks_per_mfma_and_simd\": %.1f, "
+           "\"mfma_per_simd_per_us\": %.1f}\n", blocks_per_cu, NACC, best, flop / best / 1e9, flop / best / 1e9 / 78.6, cpm, mfma_per_simd / (best * 1e3));
+}
+int main() {
+    double *d; unsigned long long *c;
+    hipMalloc(&d, sizeof(double) * 256 * 8 * 256);
+    hipMalloc(&c, sizeof(unsigned long long) * 256 * 8);
+    const int iters = 4000;
+    for (int bpc : {1, 2, 4, 8}) { run<4>(d, c, bpc, iters * 2); run<8>(d, c, bpc, iters); run<16>(d, c, bpc, iters / 2); }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kfma, dim3(2048), dim3(256), 0, 0, d, 20000, 1.0000001, 1e-9);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("{\"v_fma_f64\": true, \"ms\": %.3f, \"TFLOPs\": %.1f}\n", ms, (double)2048 * 256 * 20000 * 16.0 * 2.0 / ms / 1e9);
     return 0;
 }
