@@ -1022,7 +1022,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // the result is added to is loaded BEFORE the k-loop, 16 more 16-byte loads in flight per lane under the MFMAs, instead of after it, where a
 // wave had nothing else to issue: block DGS k = 128, p = 32: 10.3 -> 9.8 ms, k = 32, p = 32: 4.9 -> 4.5 ms.  (Compiled into the plain
 // product as well it cost that one 13 %, so it is a template flag; for the complex three-product kernel it changed nothing and is not built.)
-template <bool CPLX, int NG, bool PFY = false, bool ROLL = true>
+template <bool CPLX, int NG, bool PFY = false, bool ROLL = false>
 __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                        double *__restrict__ Y, int64_t ldy, int qn,
                                                        const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
@@ -1030,7 +1030,8 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
     constexpr int RG = CPLX ? 16 : 32;           // rows per row group (one MFMA N extent; x2 rows per lane for real)
     constexpr int NACC = CPLX ? 1 : 2;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
-    constexpr int U = 4;                         // k-steps of X in flight per wave: 2 U loads of 16 B per lane (8 k-steps: null, DESIGN.md tuning log 19)
+    constexpr int U = 4;                         // k-steps of X in flight per wave: 2 U loads of 16 B per lane (8 k-steps: null, tuning log 19; a 124-register variant with
+                                                 // U = 2 and TWO blocks per CU measured the same as this one, profiles/r05_ab_gemm_roll.jsonl)
     extern __shared__ double tiles[];            // [NG][nt][64]
     const int nt = (k + 3) >> 2;
     for (int i = threadIdx.x; i < NG * nt * 64; i += blockDim.x) tiles[i] = Cp[i];
