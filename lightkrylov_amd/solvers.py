@@ -216,11 +216,18 @@ def _mark(label: str) -> None:
 
 
 def _tapered_segments(kstart: int, kdim: int, seg: int = 0):
-    """Step ranges [(a, b), ...] covering kstart..kdim: full segments of `seg` steps, the LAST `seg` steps split 8, 4, 2, 1, 1 (halves down
-    to single steps), so that the host work that can only start after a segment's last column shrinks towards the end of the cycle."""
+    """Step ranges [(a, b), ...] covering kstart..kdim: the first half as one segment, then segments of `seg` steps, the LAST `seg` steps
+    split 8, 4, 2, 1, 1 (halves down to single steps), so that the host work that can only start after a segment's last column shrinks
+    towards the end of the cycle."""
     seg = seg or _EIGS_SEGMENT
     out, a = [], kstart
     tail_from = max(kstart, kdim - seg + 1)
+    # the first half of the range in ONE segment: its eigenproblems are the small ones (a geev of order <= kdim / 2 costs an eighth of the
+    # last one) and are all done long before the cycle's device work ends, and every segment boundary costs the device ~0.4 ms of idling
+    head = kstart + (kdim - kstart + 1) // 2 - 1
+    if head - a + 1 > seg and head < tail_from:
+        out.append((a, head))
+        a = head + 1
     while a < tail_from:
         b = min(a + seg - 1, tail_from - 1)
         out.append((a, b))

@@ -93,6 +93,12 @@ def test_two_processes_on_the_row_sharded_dense_and_csr_operators(operator, rows
     assert abs(two["config"]["H_fro"] - one["config"]["H_fro"]) <= 1e-12 * one["config"]["H_fro"]
     assert abs(two["config"]["H_last_subdiag"] - one["config"]["H_last_subdiag"]) <= 1e-11 * one["config"]["H_last_subdiag"]
     assert one["roofline"]["matvec"]["launches"] == 12
+    # the line times the operator's exchange too (round 5): one all-gather per application for the row-sharded dense / CSR operators,
+    # one neighbour exchange for the stencil; none of either on a single rank
+    kind = "halo" if operator == "lap5" else "allgather"
+    other = "allgather" if operator == "lap5" else "halo"
+    assert two["comm"][kind]["launches"] == 12 and two["comm"][kind]["avg_us"] > 0 and two["comm"][other]["launches"] == 0
+    assert one["comm"][kind]["launches"] == 0 and two["comm"]["allreduce"]["launches"] >= 3 * 12
 
 
 @pytest.mark.parametrize("P", [2, 3, 4, 8])

@@ -505,7 +505,8 @@ def test_eigs_segments_taper_towards_the_end_of_a_cycle():
     exactly once, in order, whatever kstart / kdim (a restarted cycle starts mid-way; a short cycle is all taper)."""
     from lightkrylov_amd.solvers import _tapered_segments
     assert _tapered_segments(1, 128)[-5:] == [(113, 120), (121, 124), (125, 126), (127, 127), (128, 128)]
-    assert _tapered_segments(1, 128)[:7] == [(16 * i + 1, 16 * i + 16) for i in range(7)]
+    assert _tapered_segments(1, 128)[:4] == [(1, 64), (65, 80), (81, 96), (97, 112)]            # the first half in one segment
+    assert _tapered_segments(1, 30) == [(1, 14), (15, 22), (23, 26), (27, 28), (29, 29), (30, 30)]
     for kstart in (1, 2, 7, 65, 120, 128):
         for kdim in (1, 2, 5, 16, 17, 31, 33, 128, 200):
             if kstart > kdim:
@@ -513,7 +514,7 @@ def test_eigs_segments_taper_towards_the_end_of_a_cycle():
             segs = _tapered_segments(kstart, kdim)
             steps = [k for a, b in segs for k in range(a, b + 1)]
             assert steps == list(range(kstart, kdim + 1)), (kstart, kdim, segs)
-            assert segs[-1][0] == segs[-1][1] == kdim and all(b - a + 1 <= 16 for a, b in segs)
+            assert segs[-1][0] == segs[-1][1] == kdim and all(b - a + 1 <= max(16, (kdim - kstart + 1) // 2) for a, b in segs)
 
 
 def test_bench_all_core_baseline_leg_runs_bound_in_a_child_process():
