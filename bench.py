@@ -174,9 +174,12 @@ def predicted_iters_per_s(n: int, m: int, world: int, operator: str, dtype: str)
             return None
         t1 = mod["single_gpu_ms_per_factorisation"] * 1e-3
         fixed = 0.0 if world == 1 else m * 3 * (mod["allreduce_us_assumed"] + mod["finish_partials_us"]) * 1e-6
-        t = t1 / world + fixed
+        shard = mod.get("shard_ms_per_factorisation", {}).get(str(world))
+        local = shard * 1e-3 if shard else t1 / world
+        t = local + fixed
         return {"predicted_it_s": m / t, "predicted_ms_per_step": 1e3 * t,
-                "model": f"T1/N + m*3*(allreduce + finish) = {1e3 * t1:.1f} ms / {world} + {m}*3*({mod['allreduce_us_assumed']} + {mod['finish_partials_us']}) us",
+                "model": (f"local work of a rank ({'measured on one GPU: bench.py --shard-of ' + str(world) if shard else 'T1 / N = ' + format(1e3 * t1, '.1f') + ' ms / ' + str(world)}"
+                          f" = {1e3 * local:.1f} ms) + m*3*(allreduce + finish) = {m}*3*({mod['allreduce_us_assumed']} + {mod['finish_partials_us']}) us"),
                 "single_gpu_record": mod.get("source"), "note": "a model from single-GPU measurements (DESIGN.md section 6), not a measurement"}
     except Exception as exc:  # noqa: BLE001
         return {"predicted_it_s": None, "note": f"profiles/scaling_model.json unreadable: {exc!r}"}
@@ -210,6 +213,25 @@ def _oracle_sample(n: int, m: int, threads: int, fused: bool, repeat: int = 1):
     return dt, int(info)
 
 
+def _cpu_quota_cores():
+    """CPUs' worth of time this process's cgroup may use (cpu.max of cgroup v2, cfs quota of v1), or None when unlimited / unknown: a container
+    that SEES every hardware thread of the host may still be allowed only a few of them -- threads beyond the quota are throttled, not run."""
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            return float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def _fused_leg(ns: int, ms: int, n4: int, m4: int, n_full: int, m_full: int) -> dict:
     """The all-core leg itself (runs in the child process): thread scan on (ns, ms), then the timed sample (n4, m4) on the best count."""
     from oracle import oracle as ora
@@ -231,8 +253,12 @@ def _fused_leg(ns: int, ms: int, n4: int, m4: int, n_full: int, m_full: int) -> 
         return dt
 
     tmax = ora.max_threads()
+    quota = _cpu_quota_cores()
     scan = {}
-    for T in sorted({t for t in (8, 16, 32, 64, 96, 128, 192, 256, tmax) if t <= tmax}):
+    # (a team more than four times the cgroup's CPU quota is not tried: every thread beyond the quota only adds throttling -- 256 threads
+    # on a 16-CPU grant took 20 s for the 0.6 s sample)
+    tcap = tmax if quota is None else min(tmax, max(8, int(4 * quota)))
+    for T in sorted({t for t in (8, 16, 32, 64, 96, 128, 192, 256, tmax) if t <= tcap}):
         scan[T] = sample(ns, ms, T, 2)
     T = min(scan, key=scan.get)
     ora.set_threads(T)
@@ -245,6 +271,9 @@ def _fused_leg(ns: int, ms: int, n4: int, m4: int, n_full: int, m_full: int) -> 
         "thread_scan_seconds": {str(k): v for k, v in scan.items()},
         "thread_scan_GBps": {str(k): fus_model(ns, ms) / v / 1e9 for k, v in scan.items()},
         "host_threads_available": tmax,
+        "cgroup_cpu_quota_cores": quota,
+        "why_not_more_threads": (f"the job's cgroup grants {quota:.0f} CPUs' worth of time on a host that shows {tmax} hardware threads: a team larger than that is "
+                                 "throttled by the scheduler, not run (the scan above shows it)") if quota is not None and quota < tmax else None,
         "thread_scan_sample": {"n": ns, "m": ms, "basis_GB": 8e-9 * ns * (ms + 1)},
         "binding": {"OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"), "OMP_PLACES": os.environ.get("OMP_PLACES"),
                     "distinct_cpus_of_the_team": len(set(cpus)), "first_touch": "parallel, by the team that streams the rows"},
@@ -737,14 +766,15 @@ def main() -> None:
         }
         out["comm"] = comm
         out["step_time_attribution_rank0"] = attribution
-        pred = predicted_iters_per_s(n, m, world, args.operator, args.dtype)
+        pred = predicted_iters_per_s(n, m, args.shard_of if args.shard_of else world, args.operator, args.dtype)
         out["predicted_it_s"] = pred["predicted_it_s"] if pred else None
         out["predicted"] = pred
         if pred and pred.get("predicted_it_s"):
             out["predicted"]["value_over_predicted"] = out["value"] / pred["predicted_it_s"]
         if args.shard_of:
             out["shard_emulation"] = {"of_ranks": args.shard_of, "note": "ONE row block of a P-rank job alone on this GPU (no communicator): "
-                                      "per-shard kernel measurements only -- `value` is NOT the metric"}
+                                      "per-shard kernel measurements only -- `value` is NOT the metric, it is what the P-rank job would make with free collectives; "
+                                      "`predicted` is the model for that P-rank job"}
             out["config"]["parity"] = None
         if mv_ms > sweep_ms and mv_ms > 0:
             # the operator, not the orthogonalisation, is the dominant kernel of this workload (dense GEMV): its roofline leads

@@ -423,6 +423,21 @@ module lightkrylov_hip_c
             integer(c_int), intent(out) :: info
             integer(c_int) :: rc
         end function
+        !> lk_arnoldi delivered in segments while it runs: fn(user, kfirst, klast) (bind(C), returns c_int: non-zero = stop) is called
+        !> as soon as columns kfirst..klast of H are final; seg_last(1:nseg) = last step of each segment (ascending)
+        function lk_arnoldi_segments(A, X, H, ldh, kstart, kend, tol, trans, seg_last, nseg, fn, user, info) &
+            bind(C, name="lk_arnoldi_segments") result(rc)
+            import :: c_int, c_ptr, c_funptr, c_double, c_int64_t
+            type(c_ptr), value :: A, X, user
+            real(c_double), intent(inout) :: H(*)
+            integer(c_int64_t), value :: ldh
+            integer(c_int), value :: kstart, kend, trans, nseg
+            real(c_double), value :: tol
+            integer(c_int), intent(in) :: seg_last(*)
+            type(c_funptr), value :: fn
+            integer(c_int), intent(out) :: info
+            integer(c_int) :: rc
+        end function
         function lk_bidiag(A, U, V, B, ldb, kstart, kend, tol, info) bind(C, name="lk_bidiag") result(rc)
             import :: c_int, c_ptr, c_double, c_int64_t
             type(c_ptr), value :: A, U, V

@@ -381,6 +381,19 @@ int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t B
  * asynchronously (one host synchronisation per call); beyond that one round trip per step. */
 int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend,
                double tol, int trans, int *info);
+/* The same factorisation (same bits), delivered IN SEGMENTS while it runs: the steps are enqueued back to back as one asynchronous batch,
+ * and as soon as the device has produced the steps up to seg_last[i] (nseg ascending step numbers within [kstart, kend]) their columns of H
+ * are written and fn(user, kfirst, klast) is called on the calling thread -- while the later steps are still running on the device.  The
+ * per-step host work of a caller overlaps the rest of the call with no idle gap on the device between segments: eigs tests the Ritz pairs of
+ * H(1:k, 1:k) after every step (src/IterativeSolvers/IterativeSolvers.fypp:1059-1093); one blocking lk_arnoldi call per segment cost its
+ * Krylov-Schur cycle ~0.4 ms of device idling per boundary.  fn is called for every step range exactly once, in order, the last time
+ * before the call returns; columns beyond a breakdown are never reported.  fn returns 0 to go on, non-zero to STOP: nothing more is
+ * enqueued (the device is kept at most 24 steps ahead of the segment being delivered, so at most that many steps beyond the last
+ * reported one have touched the basis), nothing more is reported, and the call returns with info = 0 (eigs stops a cycle at the first
+ * step with enough converged pairs, :1087-1093).  fn must not call into the same context.  fn may be NULL (then this is lk_arnoldi). */
+typedef int (*lk_progress_fn)(void *user, int kfirst, int klast);
+int lk_arnoldi_segments(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend, double tol, int trans,
+                        const int *seg_last, int nseg, lk_progress_fn fn, void *user, int *info);
 
 /* ---- Lanczos tridiagonalisation (symmetric / Hermitian operators) ------------------------
  * lanczos_tridiagonalization(A, X, T, info, kstart, kend, tol): src/Krylov/lanczos.fypp:7-64.

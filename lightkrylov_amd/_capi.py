@@ -20,6 +20,7 @@ LK_COMM_ID_BYTES = 128
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_void_p)
 
 _p = C.c_void_p
@@ -94,6 +95,7 @@ SIGNATURES = {
     "lk_linop_destroy": (_int, [_p]),
     "lk_linop_apply": (_int, [_p, _int, _p, _int, _p, _int]),
     "lk_arnoldi": (_int, [_p, _p, _dp, _i64, _int, _int, C.c_double, _int, _ip]),
+    "lk_arnoldi_segments": (_int, [_p, _p, _dp, _i64, _int, _int, C.c_double, _int, _ip, _int, PROGRESS_FN, _p, _ip]),
     "lk_lanczos": (_int, [_p, _p, _dp, _i64, _int, _int, C.c_double, _ip]),
     "lk_bidiag": (_int, [_p, _p, _p, _dp, _i64, _int, _int, C.c_double, _ip]),
 }

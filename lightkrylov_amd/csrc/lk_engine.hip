@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <set>
@@ -201,6 +202,9 @@ struct lk_context_s {
     // asynchronous Arnoldi pipeline (lk_arnoldi): per-step result slots + device-side breakdown flag
     int *stop_dev = nullptr;               // device int: 0, or the step that asked every later step to stop
     int *stop_host = nullptr;              // pinned mirror
+    int *seg_stop_host = nullptr;          // pinned: the stop flag as it stood after each segment of a segmented batch (lk_arnoldi_segments)
+    std::vector<hipEvent_t> seg_events;    // ... and the event recorded behind each segment's copies
+    int seg_cap = 0;
     bool guard_on = false;                 // launches carry the guard only inside an asynchronous batch
     int guard_step = 0;
     double *step_red = nullptr;            // device: nsteps x RED_SECTIONS x RED_SECTION doubles
@@ -1378,6 +1382,9 @@ int lk_finalize(lk_context_t c) {
     if (c->coef_ev) (void)hipEventDestroy(c->coef_ev);
     if (c->stop_dev) (void)hipFree(c->stop_dev);
     if (c->stop_host) (void)hipHostFree(c->stop_host);
+    if (c->seg_stop_host) (void)hipHostFree(c->seg_stop_host);
+    for (auto e : c->seg_events) (void)hipEventDestroy(e);
+    c->seg_events.clear();
     if (c->step_red) (void)hipFree(c->step_red);
     if (c->step_red_host) (void)hipHostFree(c->step_red_host);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -3158,44 +3165,103 @@ static int ensure_step_buffers(lk_context_t c, int nsteps, int stride) {
 // the normalise of step s write their reduction results into step slot s - k0; the normalise kernel raises the device
 // stop flag on breakdown (||y''|| < max(tol, atol_dp)) or NaN, which turns every kernel of a later step into a
 // no-op.  One D2H copy + one synchronisation per batch.  *done = last step whose results are valid.
-static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, double tol, int trans, int *done) {
+// `seg_last` (nseg ascending step numbers within [k0, k1), or nullptr): SEGMENTED delivery -- behind the last step of every segment the
+// batch copies that segment's result slots and the stop flag to the host and records an event; the host keeps the device SEG_LOOKAHEAD
+// steps ahead of the segment it is waiting for, waits for the events in order and calls deliver(first, last) for the steps of each segment
+// while the device runs the later ones (lk_arnoldi_segments: the per-step host work of a caller -- eigs' Ritz tests -- overlaps the rest of
+// the cycle with NO idle gap on the device between segments, which one blocking lk_arnoldi call per segment costs).  deliver returns
+// LK_OK, an error, or LK_STOP_REQUESTED (the caller's progress function asked to stop): nothing more is enqueued then -- at most
+// SEG_LOOKAHEAD steps beyond the delivered ones have run -- and *cancelled is set.  A device-side stop inside a segment ends the
+// deliveries there; the caller processes the stopped step after the final synchronisation, exactly as in the unsegmented case.
+constexpr int SEG_LOOKAHEAD = 24;
+constexpr int LK_STOP_REQUESTED = 1;
+static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, double tol, int trans, int *done, const int *seg_last, int nseg,
+                               const std::function<int(int, int)> &deliver, int *delivered_to, bool *cancelled) {
     lk_context_t c = X->ctx;
     const int nsteps = k1 - k0 + 1;
     const int rs = red_stride(k1);                  // one section size for every step of the batch
     LKCHK(ensure_step_buffers(c, nsteps, rs));
+    if (nseg > c->seg_cap) {
+        if (c->seg_stop_host) HIPCHK(hipHostFree(c->seg_stop_host));
+        c->seg_stop_host = nullptr;
+        HIPCHK(hipHostMalloc((void **)&c->seg_stop_host, (size_t)nseg * sizeof(int), hipHostMallocDefault));
+        while ((int)c->seg_events.size() < nseg) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->seg_events.push_back(e);
+        }
+        c->seg_cap = nseg;
+    }
     HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
     const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
     const int ED = X->ed();
-    c->guard_on = true;
-    c->prof_sweeps_only = true;
-    int rc = LK_OK;
-    for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
-        c->guard_step = k;
-        double *slot = c->step_red + (size_t)(k - k0) * RED_SECTIONS * rs;
-        rc = lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, k - 1, X, k);
-        if (rc != LK_OK) break;
-        c->span_first = nullptr;
-        rc = dgs_device(X, k, X->col(k), true, slot, rs);
-        if (rc != LK_OK) break;
-        if (c->prof && c->span_first) {          // "dgs" = first sweep's start .. last sweep's stop, no events of its own
-            ProfRec span;
-            span.e0 = c->span_first; span.e1 = c->span_last; span.tag = "dgs"; span.borrowed = true;
-            span.bytes = (double)X->n * ED * 8.0 * (3.0 * k + 5.0);
-            c->prof_pending.push_back(span);
+    const size_t slot_doubles = (size_t)RED_SECTIONS * rs;
+    int enq = k0;                                    // next step to enqueue
+    int si = 0, seg_first = k0;                      // next segment to close, first step of it
+    auto enqueue_until = [&](int kto) -> int {
+        c->guard_on = true;
+        c->prof_sweeps_only = true;
+        int rc = LK_OK;
+        for (; enq <= kto && rc == LK_OK; ++enq) {
+            const int k = enq;
+            c->guard_step = k;
+            double *slot = c->step_red + (size_t)(k - k0) * slot_doubles;
+            rc = lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, k - 1, X, k);
+            if (rc != LK_OK) break;
+            c->span_first = nullptr;
+            rc = dgs_device(X, k, X->col(k), true, slot, rs);
+            if (rc != LK_OK) break;
+            if (c->prof && c->span_first) {          // "dgs" = first sweep's start .. the end of the last reduction, no events of its own
+                ProfRec span;
+                span.e0 = c->span_first; span.e1 = c->span_last; span.tag = "dgs"; span.borrowed = true;
+                span.bytes = (double)X->n * ED * 8.0 * (3.0 * k + 5.0);
+                c->prof_pending.push_back(span);
+            }
+            rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
+            if (rc == LK_OK && si < nseg && k == seg_last[si]) {
+                // close a segment: its slots and the stop flag as it stands now travel to the host behind this step
+                const size_t off = (size_t)(seg_first - k0) * slot_doubles;
+                const hipError_t e1 = hipMemcpyAsync(c->step_red_host + off, c->step_red + off, (size_t)(k - seg_first + 1) * slot_doubles * sizeof(double),
+                                                     hipMemcpyDeviceToHost, c->stream);
+                const hipError_t e2 = hipMemcpyAsync(c->seg_stop_host + si, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream);
+                const hipError_t e3 = hipEventRecord(c->seg_events[si], c->stream);
+                if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) rc = fail(LK_ERR_HIP, "lk_arnoldi_segments: copy behind a segment failed");
+                seg_first = k + 1;
+                ++si;
+            }
         }
-        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
+        c->guard_on = false;
+        c->guard_step = 0;
+        c->prof_sweeps_only = false;
+        return rc;
+    };
+    *delivered_to = k0 - 1;
+    *cancelled = false;
+    bool device_stop = false;
+    int first = k0;
+    for (int i = 0; i < nseg && !device_stop && !*cancelled; ++i) {
+        const int ahead = seg_last[i] + SEG_LOOKAHEAD < k1 ? seg_last[i] + SEG_LOOKAHEAD : k1;
+        LKCHK(enqueue_until(ahead));
+        HIPCHK(hipEventSynchronize(c->seg_events[i]));
+        if (c->seg_stop_host[i] != 0) { device_stop = true; break; }   // handled by the caller after the final synchronisation
+        const int drc = deliver(first, seg_last[i]);
+        if (drc == LK_STOP_REQUESTED) *cancelled = true;
+        else LKCHK(drc);
+        *delivered_to = seg_last[i];
+        first = seg_last[i] + 1;
     }
-    c->guard_on = false;
-    c->guard_step = 0;
-    c->prof_sweeps_only = false;
-    LKCHK(rc);
-    HIPCHK(hipMemcpyAsync(c->step_red_host, c->step_red, (size_t)nsteps * RED_SECTIONS * rs * sizeof(double),
-                          hipMemcpyDeviceToHost, c->stream));
+    if (!*cancelled && !device_stop) LKCHK(enqueue_until(k1));   // (after a device-side stop every later step would be a no-op: not enqueued)
+    const int klast = enq - 1;                       // last step enqueued
+    if (klast >= seg_first) {                        // the rest (everything, without segments)
+        const size_t off = (size_t)(seg_first - k0) * slot_doubles;
+        HIPCHK(hipMemcpyAsync(c->step_red_host + off, c->step_red + off, (size_t)(klast - seg_first + 1) * slot_doubles * sizeof(double),
+                              hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(hipMemcpyAsync(c->stop_host, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->prof) prof_collect(c);
     const int stop_step = *c->stop_host;
-    *done = stop_step ? stop_step : k1;
+    *done = stop_step ? stop_step : klast;
     return LK_OK;
 }
 
@@ -3376,60 +3442,102 @@ int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, 
     return LK_OK;
 }
 
-int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend, double tol, int trans, int *info) {
+static int arnoldi_impl(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend, double tol, int trans, int *info,
+                        const int *seg_last, int nseg, lk_progress_fn fn, void *user) {
     if (!A || !X || !H || !info) return fail(LK_ERR_INVALID, "lk_arnoldi: null argument");
     const int kdim = X->ncols - 1;                               // arnoldi.fypp:26 (p = 1)
     if (kdim < 1) return fail(LK_ERR_INVALID, "lk_arnoldi: basis needs at least 2 columns");
     if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_arnoldi: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
     if (ldh < kdim + 1) return fail(LK_ERR_INVALID, "lk_arnoldi: ldh too small");
+    for (int i = 0; i < nseg; ++i)
+        if (seg_last[i] < kstart || seg_last[i] > kend || (i > 0 && seg_last[i] <= seg_last[i - 1]))
+            return fail(LK_ERR_INVALID, "lk_arnoldi_segments: segment ends must ascend within [kstart, kend]");
     lk_context_t c = X->ctx;
     DevGuard dev_guard(c);
     const int ED = X->ed();
     *info = 0;
     std::vector<double> h((size_t)kdim * ED);
     int k = kstart;
+    int reported = kstart - 1;                                   // last step handed to `fn`
+    bool stop_requested = false;
+    auto report = [&](int upto) {
+        if (fn && upto > reported) {
+            if (fn(user, reported + 1, upto) != 0) stop_requested = true;
+            reported = upto;
+        }
+    };
     while (k <= kend) {
         int stop = 0;
         if (!c->async_arnoldi || k > KMAX_WIDE || k == kend) {
             // single step, a basis beyond KMAX_WIDE columns, or the round-1 schedule: one host round trip per step
             LKCHK(arnoldi_step_sync(A, X, H, ldh, k, tol, trans, h, info, &stop));
-            if (stop) break;
+            report(k);
+            if (stop || stop_requested) break;
             ++k;
             continue;
         }
         const int k1 = kend < KMAX_WIDE ? kend : KMAX_WIDE;
         const int rs = red_stride(k1);
         LKCHK(lazy_enter(c, true));
-        int done = 0;
-        LKCHK(arnoldi_batch_async(A, X, k, k1, tol, trans, &done));
-        const bool stopped_early = *c->stop_host != 0;
-        for (int s = k; s <= done; ++s) {
-            const double *slot = c->step_red_host + (size_t)(s - k) * RED_SECTIONS * rs;
-            const double *r0 = slot, *r1 = slot + rs, *r2 = slot + 2 * rs;
-            double *Hk = H + (size_t)(s - 1) * ldh * ED;
-            for (int i = 0; i < s * ED; ++i) Hk[i] = r0[i] + r1[i];                 // gram_schmidt.fypp:49
-            const double beta = std::sqrt(std::fabs(r2[s * ED]));
-            if (beta != beta) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
-            Hk[(size_t)s * ED] = 0.0;
-            if (ED == 2) Hk[(size_t)s * ED + 1] = 0.0;
-            if (beta < ATOL_DP) {
-                // colinear column (the device left y'' unnormalised and stopped): R(1,1) = 0, rand, re-normalise  qr.fypp:146-162
-                LKCHK(lk_vec_rand(X, s, 0x5EEDull + (uint64_t)s, c->row0, 1));
-            } else {
-                Hk[(size_t)s * ED] = beta;
+        const int kb = k;                                        // first step of this batch (slot 0)
+        // columns [sa, sb] of H from the batch's result slots; *stop_out = 1 when the reference's loop exits at a step (info set)
+        auto fill = [&](int sa, int sb, int *stop_out) -> int {
+            for (int s = sa; s <= sb; ++s) {
+                const double *slot = c->step_red_host + (size_t)(s - kb) * RED_SECTIONS * rs;
+                const double *r0 = slot, *r1 = slot + rs, *r2 = slot + 2 * rs;
+                double *Hk = H + (size_t)(s - 1) * ldh * ED;
+                for (int i = 0; i < s * ED; ++i) Hk[i] = r0[i] + r1[i];                 // gram_schmidt.fypp:49
+                const double beta = std::sqrt(std::fabs(r2[s * ED]));
+                if (beta != beta) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+                Hk[(size_t)s * ED] = 0.0;
+                if (ED == 2) Hk[(size_t)s * ED + 1] = 0.0;
+                if (beta < ATOL_DP) {
+                    // colinear column (the device left y'' unnormalised and stopped): R(1,1) = 0, rand, re-normalise  qr.fypp:146-162
+                    LKCHK(lk_vec_rand(X, s, 0x5EEDull + (uint64_t)s, c->row0, 1));
+                } else {
+                    Hk[(size_t)s * ED] = beta;
+                }
+                if (std::fabs(Hk[(size_t)s * ED]) < tol) {                              // arnoldi.fypp:58-71
+                    *info = s;
+                    *stop_out = 1;
+                    return LK_OK;
+                }
             }
-            if (std::fabs(Hk[(size_t)s * ED]) < tol) {                              // arnoldi.fypp:58-71
-                *info = s;
-                stop = 1;
-                break;
-            }
-        }
-        if (stop) break;
+            return LK_OK;
+        };
+        // segments of THIS batch: the caller's boundaries that fall inside (k, k1)
+        std::vector<int> segs;
+        for (int i = 0; i < nseg; ++i)
+            if (seg_last[i] >= k && seg_last[i] < k1) segs.push_back(seg_last[i]);
+        auto deliver = [&](int sa, int sb) -> int {              // (only steps the device finished without raising the stop flag)
+            int st = 0;
+            LKCHK(fill(sa, sb, &st));
+            if (st) return fail(LK_ERR_INVALID, "internal: a delivered segment stopped");   // cannot happen: tol_break >= tol on the device
+            report(sb);
+            return stop_requested ? LK_STOP_REQUESTED : LK_OK;
+        };
+        int done = 0, delivered_to = k - 1;
+        bool cancelled = false;
+        LKCHK(arnoldi_batch_async(A, X, k, k1, tol, trans, &done, segs.empty() ? nullptr : segs.data(), (int)segs.size(), deliver, &delivered_to,
+                                  &cancelled));
+        if (cancelled) break;                                    // the caller asked to stop: columns beyond the last report are not delivered
+        LKCHK(fill(delivered_to + 1, done, &stop));
+        report(stop ? *info : done);
+        if (stop || stop_requested) break;
         // a stop the reference would NOT have taken (tol below atol_dp with a colinear column): resume after it
         k = done + 1;
-        (void)stopped_early;
     }
     return LK_OK;
+}
+
+int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend, double tol, int trans, int *info) {
+    return arnoldi_impl(A, X, H, ldh, kstart, kend, tol, trans, info, nullptr, 0, nullptr, nullptr);
+}
+
+int lk_arnoldi_segments(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend, double tol, int trans, const int *seg_last,
+                        int nseg, lk_progress_fn fn, void *user, int *info) {
+    if (nseg < 0 || (nseg > 0 && !seg_last)) return fail(LK_ERR_INVALID, "lk_arnoldi_segments: bad segment list");
+    return arnoldi_impl(A, X, H, ldh, kstart, kend, tol, trans, info, seg_last, nseg, fn, user);
 }
 
 }  // extern "C"

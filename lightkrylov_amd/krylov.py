@@ -151,10 +151,12 @@ def qr(Q, R: np.ndarray, tol: float = atol_dp) -> int:
 
 # ------------------------------------------------------------------------------------------
 def arnoldi(A: abstract_linop, X, H: np.ndarray, kstart: int = 1, kend: int | None = None,
-            tol: float = atol_dp, transpose: bool = False, blksize: int = 1) -> int:
+            tol: float = atol_dp, transpose: bool = False, blksize: int = 1, _segments=None, _progress=None) -> int:
     """(block) Arnoldi factorisation A X(:, :k) = X(:, :k+1) H(:k+1, :k).
     src/Krylov/arnoldi.fypp:8-76.  X holds (kdim+1)*blksize vectors, H is ((kdim+1)p, kdim p).
-    Returns info: 0, or kp when the residual block is below tol (invariant subspace)."""
+    Returns info: 0, or kp when the residual block is below tol (invariant subspace).
+    (`_segments` / `_progress`: engine extra on the fused path -- lk_arnoldi_segments: `_progress(kfirst, klast)` is called as soon as the
+    columns kfirst..klast of H are final, segment by segment (`_segments` = last step of each), while the device runs the later steps.)"""
     p = int(blksize)
     kdim = (len(X) - p) // p                                                       # :26
     kend = kdim if kend is None else kend
@@ -164,8 +166,25 @@ def arnoldi(A: abstract_linop, X, H: np.ndarray, kstart: int = 1, kend: int | No
     if (p == 1 and isinstance(X, krylov_basis_gpu) and isinstance(A, _engine_linop)
             and H.flags.f_contiguous and H.dtype == X.dtype and H.shape[0] >= kdim + 1):
         cinfo = C.c_int()
-        _capi.check(X._lib.lk_arnoldi(A._h, X._h, H.ctypes.data_as(_DP), H.shape[0], int(kstart), int(kend),
-                                      float(tol), 1 if transpose else 0, C.byref(cinfo)))
+        if _progress is not None:
+            segs = [int(b) for b in (_segments or []) if kstart <= int(b) <= kend]
+            arr = (C.c_int * max(len(segs), 1))(*segs)
+            failure = []
+
+            def _cb(_user, kfirst, klast):
+                try:
+                    return 1 if _progress(int(kfirst), int(klast)) else 0          # a true return value asks the engine to stop
+                except BaseException as exc:  # noqa: BLE001 - must not propagate through C; re-raised below
+                    failure.append(exc)
+                    return 1
+            cb = _capi.PROGRESS_FN(_cb)
+            _capi.check(X._lib.lk_arnoldi_segments(A._h, X._h, H.ctypes.data_as(_DP), H.shape[0], int(kstart), int(kend), float(tol),
+                                                   1 if transpose else 0, arr, len(segs), cb, None, C.byref(cinfo)))
+            if failure:
+                raise failure[0]
+        else:
+            _capi.check(X._lib.lk_arnoldi(A._h, X._h, H.ctypes.data_as(_DP), H.shape[0], int(kstart), int(kend),
+                                          float(tol), 1 if transpose else 0, C.byref(cinfo)))
         n_steps = (cinfo.value if cinfo.value else kend) - kstart + 1
         if transpose:
             A.rmatvec_counter += max(n_steps, 0)

@@ -13,6 +13,7 @@ import numpy as np
 from scipy.linalg import lapack as _lapack
 
 import os
+import queue
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -338,55 +339,54 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
         schur_ahead = None
         eig_ahead = None
         if pipelined and kstart <= kdim_:
-            # The cycle's steps run on the device in SEGMENTS (asynchronous lk_arnoldi calls queued on one helper thread; ctypes drops
-            # the interpreter lock for their duration); the moment a segment has delivered its columns of H, the Ritz test of every
-            # step in it is handed to the host pool, and this thread collects the tests IN STEP ORDER and stops where the reference
-            # would have stopped.  The tests of the last columns can only start when the device has finished, so the segments TAPER
-            # towards the end of the cycle (16, ..., 16, 8, 4, 2, 1, 1 steps): when the final column arrives one or two `geev`s are
-            # still to be started instead of sixteen (round 5; the tests no longer wait for each other segment by segment either).
+            # The whole cycle is ONE call into the engine (lk_arnoldi_segments, on a helper thread; ctypes drops the interpreter lock for its
+            # duration): the steps are enqueued back to back and the engine reports the columns of H segment by segment while the device runs
+            # on -- no idle gap on the device between segments (round 5; one blocking lk_arnoldi call per segment cost ~0.4 ms each).  The moment
+            # a segment's columns exist the Ritz test of every step in it is handed to the host pool, and this thread collects the tests IN
+            # STEP ORDER and stops where the reference would have stopped; the engine is then told to enqueue nothing more (it keeps the
+            # device at most 24 steps ahead of the segment it reports).  The tests of the last columns can only start when the device has
+            # finished, so the segments TAPER towards the end of the cycle (..., 16, 8, 4, 2, 1, 1 steps): when the final column arrives one
+            # or two `geev`s are still to be started instead of sixteen.
             bounds = _tapered_segments(kstart, kdim_)
             pool, device, feeder = _pool("geev", nthreads), _pool("device", 1), _pool("feeder", 1)
             tests: dict = {}
-            fed = {a: threading.Event() for a, _b in bounds}
-            cancel = threading.Event()
             last_cycle = max_restarts is not None and restarts > max_restarts        # the while loop ends after this cycle's restart
             ahead: dict = {}
+            arrived: queue.Queue = queue.Queue()                                   # (kfirst, klast) ranges whose tests have been submitted; None = cycle over
+            enough = threading.Event()                                             # set by this thread at the step the reference stops at
 
-            def run_segment(a, b):
-                if cancel.is_set():
-                    return None
-                ainfo = arnoldi(A, Xwrk, H, a, b, atol_dp, transpose)
-                _mark(f"device segment {a}..{b} done")
-                klast = ainfo if ainfo > 0 else b                                  # an exhausted Krylov space ends the cycle's batch early
-                if ainfo > 0:
-                    cancel.set()
-                # (the tests are handed to the pool by ANOTHER thread: sixteen `submit`s cost this thread half a millisecond during
-                # which the device would idle between two segments)
-                feeder.submit(feed, a, klast, ainfo)
-                return a, klast, ainfo
+            def on_progress(kfirst, klast):
+                # columns kfirst..klast of H are final (called by the engine on the device helper thread while the device runs on): the tests
+                # are handed to the pool by the FEEDER thread -- sixteen `submit`s would hold the engine's loop for half a millisecond
+                feeder.submit(feed, kfirst, klast)
+                return enough.is_set()                                             # true: enqueue nothing more
 
-            def feed(a, klast, ainfo):
-                if ainfo == 0 and klast == kdim_:
+            def feed(kfirst, klast):
+                _mark(f"columns {kfirst}..{klast} delivered")
+                if klast == kdim_:
                     # H is complete: unless one of the Ritz tests still to come stops the cycle early, the restart below factors
                     # exactly this H -- start its small-matrix half (gees, selector, trsen) now, on a spare host thread, beside
                     # the last tests (same LAPACK calls on the same data; discarded on an early stop) ...
                     ahead["schur"] = pool.submit(_schur_then_final_eig, H.copy(order="F"), kdim_, median_selector, last_cycle)
-                for kk in range(a, klast + 1):
+                for kk in range(kfirst, klast + 1):
                     tests[kk] = pool.submit(ritz_test, kk)
-                fed[a].set()
+                arrived.put((kfirst, klast))
+
+            def run_cycle():
+                try:
+                    return arnoldi(A, Xwrk, H, kstart, kdim_, atol_dp, transpose, _segments=[b_ for _a, b_ in bounds], _progress=on_progress)
+                finally:
+                    _mark("device cycle done")
+                    feeder.submit(arrived.put, None)                               # behind every delivery of this cycle
 
             with _hostlapack.blas_threads(1):
-                segs = [device.submit(run_segment, a, b) for a, b in bounds]
-                kdone = kstart - 1                                                 # last step any segment has computed
-                ainfo = 0
-                for sf in segs:
-                    seg = sf.result()
-                    if seg is None:
+                cycle = device.submit(run_cycle)
+                k = kstart - 1
+                while True:
+                    item = arrived.get()
+                    if item is None:
                         break
-                    a, klast, ainfo = seg
-                    kdone = klast
-                    fed[a].wait()
-                    for k in range(a, klast + 1):
+                    for k in range(item[0], item[1] + 1):
                         _vals, r = tests[k].result()
                         res[:k] = r
                         niter += 1
@@ -394,15 +394,13 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                         if conv >= nev:
                             stopped = True
                             break
-                    if stopped or ainfo > 0:
+                    if stopped:
+                        enough.set()
                         break
-                cancel.set()                                                       # segments not started yet are skipped ...
-                for sf in segs:                                                    # ... one still in flight when the loop stopped is waited for
-                    seg = sf.result()
-                    if seg is not None:
-                        kdone = max(kdone, seg[1])
-                        fed[seg[0]].wait()
-                for kk, tf in tests.items():                                       # tests beyond the stop: never started, or left to finish unread
+                ainfo = cycle.result()                                             # (steps the device ran beyond an early stop only touched
+                kdone = ainfo if ainfo > 0 else kdim_                              #  eigs' private work basis; they are wiped below)
+                feeder.submit(lambda: None).result()                               # every delivery has been handed to the pool
+                for kk, tf in list(tests.items()):                                 # tests beyond the stop: never started, or left to finish unread
                     if kk > k:
                         tf.cancel()
                 _mark(f"tests collected up to step {k}")

@@ -54,6 +54,79 @@ def test_async_arnoldi_equals_the_step_by_step_schedule(dtype):
     c.close()
 
 
+@pytest.mark.parametrize("dtype", KINDS)
+def test_arnoldi_delivered_in_segments_is_the_same_factorisation(dtype):
+    """lk_arnoldi_segments (round 5): the same steps, enqueued as one batch, with the columns of H reported segment by segment while the
+    device runs on.  H and the basis are bit-identical to lk_arnoldi; every step is reported exactly once, in order, in the ranges asked for;
+    a progress function that asks to stop ends the call with at most 24 more steps run and nothing more reported; a breakdown inside a
+    segment gives the same info and H, reports nothing beyond it and leaves the columns beyond it untouched."""
+    c = lk.Context(device=0)
+    n, m = 120_007, 100
+    g = np.arange(n) / n
+    d = (1.0 + g).astype(dtype) if np.dtype(dtype).kind == "f" else ((1.0 + g) * np.exp(1j * g)).astype(dtype)
+    A = lk.diag_linop_gpu(d, c)
+    X0 = lk.krylov_basis_gpu(n, m + 1, dtype, c); X0[0].rand(True, seed=7)
+    H0 = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.arnoldi(A, X0, H0) == 0
+    ref = (H0.tobytes(), X0.download().tobytes())
+    for segs in ([16, 32, 48, 64, 80, 88, 92, 96, 98, 99, 100], [50], [1, 2, 3, 99], []):
+        X = lk.krylov_basis_gpu(n, m + 1, dtype, c); X[0].rand(True, seed=7)
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        seen, snapshots = [], []
+
+        def progress(kfirst, klast, H=H, seen=seen, snapshots=snapshots):
+            seen.append((kfirst, klast))
+            snapshots.append(H[:klast + 1, kfirst - 1:klast].copy())       # the reported columns are final when reported
+            return False
+        assert lk.arnoldi(A, X, H, _segments=segs, _progress=progress) == 0
+        assert (H.tobytes(), X.download().tobytes()) == ref, segs
+        ends = [b for _a, b in seen]
+        assert [a for a, _b in seen] == [1] + [b + 1 for b in ends[:-1]] and ends[-1] == m, (segs, seen)
+        assert set(s_ for s_ in segs if s_ < m) <= set(ends), (segs, seen)
+        for (a, b), snap in zip(seen, snapshots):
+            assert np.array_equal(snap, H0[:b + 1, a - 1:b])
+    # a restart range (kstart > 1) with segments
+    X = lk.krylov_basis_gpu(n, m + 1, dtype, c); X[0].rand(True, seed=7)
+    H = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.arnoldi(A, X, H, kstart=1, kend=37) == 0
+    seen = []
+    assert lk.arnoldi(A, X, H, kstart=38, kend=m, _segments=[40, 70, 100], _progress=lambda a, b: seen.append((a, b)) and False) == 0
+    assert (H.tobytes(), X.download().tobytes()) == ref and seen == [(38, 40), (41, 70), (71, 100)]
+    # stop on request: nothing reported after the request, at most 24 steps run beyond the last reported one
+    X = lk.krylov_basis_gpu(n, m + 1, dtype, c); X[0].rand(True, seed=7)
+    mark = seeded(n, dtype, 321)
+    for j in range(45, m + 1):
+        X.upload(mark.reshape(-1, 1), j)
+    H = np.zeros((m + 1, m), dtype=dtype, order="F")
+    seen = []
+
+    def stop_at_20(kfirst, klast):
+        seen.append((kfirst, klast))
+        return klast >= 20
+    assert lk.arnoldi(A, X, H, _segments=list(range(4, m + 1, 4)), _progress=stop_at_20) == 0
+    assert seen[-1] == (17, 20) and np.array_equal(H[:21, :20], H0[:21, :20]) and not H[:, 20:].any()
+    Xg = X.download()
+    assert np.array_equal(Xg[:, :21], X0.download()[:, :21])
+    assert np.array_equal(Xg[:, 45], mark) and np.array_equal(Xg[:, m], mark)           # 20 + 24 steps at most touched columns <= 44
+    # breakdown inside a segment: invariant subspace after 6 steps
+    d6 = (1.0 + (np.arange(n) % 6)).astype(dtype)
+    res = {}
+    for use_segments in (False, True):
+        X = lk.krylov_basis_gpu(n, m + 1, dtype, c); X[0].rand(True, seed=9)
+        for j in range(7, m + 1):
+            X.upload(mark.reshape(-1, 1), j)
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        seen = []
+        kw = dict(_segments=[4, 8, 16, 64], _progress=lambda a, b, seen=seen: seen.append((a, b)) and False) if use_segments else {}
+        info = lk.arnoldi(lk.diag_linop_gpu(d6, c), X, H, tol=1e-10, **kw)
+        res[use_segments] = (info, H.tobytes(), X.download().tobytes())
+        assert info == 6 and np.array_equal(X.download(7, 1)[:, 0], mark) and np.array_equal(X.download(m, 1)[:, 0], mark)
+        if use_segments:
+            assert seen == [(1, 4), (5, 6)], seen
+    assert res[False] == res[True]
+    c.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.complex128])
 def test_pipelined_eigs_cycle_equals_the_step_by_step_one(ctx, dtype):
     """eigs' whole-cycle pipeline (one asynchronous lk_arnoldi per Krylov-Schur cycle, the per-step geev tests afterwards

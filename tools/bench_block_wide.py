@@ -9,9 +9,11 @@ import lightkrylov_amd as lk
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 ctx = lk.Context(device=0)
+panels_only = "panels_only" in sys.argv[2:]          # (PMC passes: the panel schedule alone, default knobs, ONE warm-up + 3 calls per shape)
 for kv in sys.argv[2:]:
-    key, val = kv.split("=")
-    ctx.set_tuning(key, int(val))
+    if "=" in kv:
+        key, val = kv.split("=")
+        ctx.set_tuning(key, int(val))
 for dtype in (np.float64, np.complex128):
     nn = n if dtype == np.float64 else n // 2
     s = np.dtype(dtype).itemsize
@@ -25,7 +27,8 @@ for dtype in (np.float64, np.complex128):
         for j in range(p):
             Y[j].rand(True, seed=500 + j)
         res = {}
-        for name, mf, fused in (("per_column", 0, 1), ("panels_4pass", 1, 0), ("panels_fused_last", 1, 2), ("panels_default", 1, 1)):
+        for name, mf, fused in ((("panels_default", 1, 1),) if panels_only else
+                                (("per_column", 0, 1), ("panels_4pass", 1, 0), ("panels_fused_last", 1, 2), ("panels_default", 1, 1))):
             ctx.set_tuning("xhy_mfma", mf); ctx.set_tuning("block_fused", fused)
             fn = lambda: lk.double_gram_schmidt_step(Y, B, if_chk_orthonormal=False)   # noqa: E731
             fn(); ctx.sync()
@@ -37,5 +40,6 @@ for dtype in (np.float64, np.complex128):
         last = k - (k - 1) // 128 * 128
         cols = (4 * k - last) * ((p + 31) // 32) + 6 * p           # X columns per block DGS + Y traffic (read + write per update, read per product)
         print(json.dumps({"dtype": np.dtype(dtype).name, "n": nn, "k": k, "p": p, "columns_moved_by_the_panel_schedule": cols,
+                          "GB_of_X_per_block_dgs_(4k-last)": round((4 * k - last) * ((p + 31) // 32) * nn * s / 1e9, 3),
                           "ms_at_6.5TBps_for_those": round(cols * nn * s / 6.5e12 * 1e3, 3), "per_column_schedule_columns": 3 * k * p + 4 * p, **res}), flush=True)
         del B, Y

@@ -127,4 +127,25 @@ if records:
                "note": "one record per n_local (rows per rank): the sweep kernels of a rank see only their row block, so one GPU measures every shard "
                        "size (bench.py --shard-of P under rocprofv3 --pmc, tools/run_profiles.sh); written by tools/make_profiles.py"},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+# the scaling model bench.py prints next to `value`: the single-GPU factorisation and, measured on ONE GPU, the local work of
+# a rank of the 2 / 4 / 8-rank jobs (bench.py --shard-of P: rank 0's row block alone, no collectives); the collective cost stays an assumption
+b1 = bench_line(os.path.join(src, "bench_default.log"))
+if b1 and b1.get("config", {}).get("operator") == "diag" and tag != "onbox":
+    shard = {}
+    for P in (2, 4, 8):
+        bs = bench_line(os.path.join(src, f"shard_{P}.log"))
+        if bs and bs.get("shard_emulation", {}).get("of_ranks") == P:
+            shard[str(P)] = bs["ms_per_step"]
+    json.dump({
+        "workload": {"operator": "diag", "dtype": b1["dtype"], "n_global": b1["config"]["n_global"], "m": b1["config"]["m"]},
+        "single_gpu_ms_per_factorisation": b1["ms_per_step"],
+        "shard_ms_per_factorisation": shard,
+        "source": f"tools/run_profiles_final.sh at commit {commit} (1 x MI355X): python bench.py ({b1['steps']} x {b1['ms_per_step']:.1f} ms, {b1['value']:.2f} Arnoldi it/s); "
+                  "shards: python bench.py --steps 3 --warmup 1 --shard-of P",
+        "allreduce_us_assumed": 30.0,
+        "finish_partials_us": 4.0,
+        "note": "DESIGN.md section 6: a factorisation on N ranks costs the local work of a rank -- measured on one GPU for N = 2, 4, 8 (a rank's sweeps see only its "
+                "row block), T1 / N otherwise -- plus m*3*(allreduce + finish); the all-reduce latency is an ASSUMPTION until an 8-GPU node has run "
+                "(<= 129 doubles, ring over xGMI, LL protocol: launch + N-1 hops)",
+    }, open(os.path.join(out, "scaling_model.json"), "w"), indent=1)
 print(json.dumps(rec))

@@ -26,5 +26,5 @@ for r in csv.DictReader(open(path)):
         continue
     k = r["Kernel_Name"].split("(")[0]
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
-for k, (c, kb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:8]:
+for k, (c, kb) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:14]:
     print(f"{k[:70]:70s} launches {c:4d}   {ctr} {kb * 1024 * (2 if ctr == 'FETCH_SIZE' else 1) / 1e9:8.2f} GB")

@@ -40,7 +40,7 @@ python3 "$R/tools/bench_wide.py" 1e7 f64 > "$D/wide_f64.log" 2>&1
 python3 "$R/tools/bench_wide.py" 5e6 c128 > "$D/wide_c128.log" 2>&1
 python3 "$R/tools/bench_per_object_arnoldi.py" 1e7 64 > "$D/per_object_arnoldi.log" 2>&1
 for op in dense lap5 csr; do python3 "$R/bench.py" --operator $op --steps 3 --warmup 1 > "$D/bench_$op.log" 2> "$D/bench_$op.err"; done
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_block_wide_fetch" -o block -- python3 "$R/tools/bench_block_wide.py" 4e6 > "$D/pmc_block_wide_fetch.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_block_wide_fetch" -o block -- python3 "$R/tools/bench_block_wide.py" 4e6 panels_only > "$D/pmc_block_wide_fetch.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/block_stats" -o block -- python3 "$R/tools/bench_block_dgs.py" 32 1 > "$D/block_stats.log" 2>&1
 python3 "$R/tools/profile_eigs_cycle.py" 5 > "$D/eigs_profile.log" 2>&1
 # -- 4. the GPU suite
