@@ -171,7 +171,10 @@ def arnoldi(A: abstract_linop, X, H: np.ndarray, kstart: int = 1, kend: int | No
             arr = (C.c_int * max(len(segs), 1))(*segs)
             failure = []
 
+            reported = [int(kstart) - 1]
+
             def _cb(_user, kfirst, klast):
+                reported[0] = int(klast)
                 try:
                     return 1 if _progress(int(kfirst), int(klast)) else 0          # a true return value asks the engine to stop
                 except BaseException as exc:  # noqa: BLE001 - must not propagate through C; re-raised below
@@ -182,6 +185,12 @@ def arnoldi(A: abstract_linop, X, H: np.ndarray, kstart: int = 1, kend: int | No
                                                    1 if transpose else 0, arr, len(segs), cb, None, C.byref(cinfo)))
             if failure:
                 raise failure[0]
+            n_rep = reported[0] - int(kstart) + 1                                  # (a stopped factorisation: the steps reported; up to 24 more ran)
+            if transpose:
+                A.rmatvec_counter += max(n_rep, 0)
+            else:
+                A.matvec_counter += max(n_rep, 0)
+            return cinfo.value
         else:
             _capi.check(X._lib.lk_arnoldi(A._h, X._h, H.ctypes.data_as(_DP), H.shape[0], int(kstart), int(kend),
                                           float(tol), 1 if transpose else 0, C.byref(cinfo)))

@@ -146,7 +146,36 @@ def gmres(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float
         if m.n_outer == 0:
             m.res = [abs(beta)]
         k = 0
-        for k in range(1, kdim + 1):
+        fused = (preconditioner is None and isinstance(V, krylov_basis_gpu) and isinstance(A, _engine_linop)
+                 and H.flags.f_contiguous and kdim >= 2 and _GMRES_FUSED)
+        if fused:
+            # The inner cycle as ONE call into the engine (lk_arnoldi_segments, round 5): an inner iteration of gmres IS an Arnoldi step --
+            # matvec, double Gram-Schmidt with beta = H(:k, k), H(k+1, k) = the norm, scale unless it is below tol (:155-172) -- so the
+            # kdim steps are enqueued back to back and the engine reports every column of H the moment it is final; the Givens rotations
+            # and the residual test (:178-196) run here while the device is already on the next steps, and a converged residual stops
+            # the factorisation (at most 24 steps beyond it have run: they touched columns of V the solution does not use).  One host
+            # round trip per CYCLE instead of one per step (which left the device idle for ~0.1 ms of every ~1 ms step at configs[2]).
+            last = [0]
+
+            def on_columns(kfirst, klast):
+                for kk in range(kfirst, klast + 1):
+                    apply_givens_rotation(H[:kk + 1, kk - 1], c[:kk], s[:kk])      # :178
+                    e[kk] = -s[kk - 1] * e[kk - 1]
+                    e[kk - 1] = c[kk - 1] * e[kk - 1]                              # :180
+                    m.n_iter += 1
+                    m.n_inner += 1
+                    m.res.append(abs(e[kk]))
+                    last[0] = kk
+                    if abs(e[kk]) < tol:
+                        m.converged = True
+                        return True
+                return False
+            arnoldi(A, V, H, 1, kdim, tol, transpose, _segments=list(range(1, kdim + 1)), _progress=on_columns)
+            k = last[0]
+            beta = abs(e[k])
+        # (fused and not converged with steps left: H(k+1, k) fell below tol with the residual still above it -- the reference goes on with the
+        # unscaled vector, :171-172; so do the remaining steps, one by one)
+        for k in range(1 if not fused else (kdim + 1 if m.converged else last[0] + 1), kdim + 1):
             if preconditioner is None and isinstance(V, krylov_basis_gpu):
                 mv(V[k - 1], V[k])             # wrk is only a copy of V(k) for the preconditioner to overwrite (:155-165)
             else:
@@ -206,6 +235,7 @@ def gmres(A: abstract_linop, b: abstract_vector, x: abstract_vector, rtol: float
 
 
 # ------------------------------------------------------------------------------------------
+_GMRES_FUSED = True          # gmres' inner cycle as one lk_arnoldi_segments call (False: one engine round trip per inner step, the round-1..4 schedule)
 _EIGS_SEGMENT = 16          # Arnoldi steps per asynchronous device batch of the pipelined eigs cycle
 _eigs_trace = None          # diagnostic (tools/profile_eigs_cycle.py): a list that receives (label, perf_counter()) marks of a cycle
 

@@ -377,3 +377,39 @@ def test_anticipated_first_pass_is_result_neutral_and_disarms_when_unused(dtype)
         c.close()
     for j in range(m):
         assert np.abs(out[1][:, j] - out[0][:, j]).max() <= 1e-12 * np.abs(out[0][:, j]).max()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_gmres_inner_cycle_as_one_engine_call_equals_the_step_by_step_one(ctx, dtype):
+    """gmres' inner cycle through lk_arnoldi_segments (round 5: the kdim steps enqueued as one batch, the Givens rotations and the residual
+    test run on the columns of H as they arrive, a converged residual stops the factorisation) against the one-round-trip-per-step loop:
+    same info, same residual history, same solution -- converging inside a cycle (the steps the device ran beyond the stop are not used),
+    after restarts, and not at all (maxiter exhausted); against the oracle's gmres as well."""
+    from lightkrylov_amd import solvers
+    n = 30_011
+    rng = np.random.default_rng(4)
+    d = (2.0 + np.arange(n) % 23 + rng.random(n)).astype(dtype)
+    if np.dtype(dtype).kind == "c":
+        d = d * np.exp(0.3j * rng.random(n))
+    bvec = seeded(n, dtype, 17)
+    out = {}
+    for kdim, maxiter, rtol, tag in ((40, 5, 1e-10, "converges inside the first cycle"), (6, 30, 1e-10, "converges after restarts"),
+                                     (5, 2, 1e-14, "does not converge")):
+        for fused in (False, True):
+            solvers._GMRES_FUSED = fused
+            try:
+                A = lk.diag_linop_gpu(d, ctx)
+                x = lk.dense_vector_gpu(n, dtype, ctx); x.zero()
+                meta = lk.gmres_dp_metadata()
+                info = lk.gmres(A, lk.dense_vector_gpu.from_array(bvec, ctx), x, rtol=rtol, atol=0.0,
+                                options=lk.gmres_dp_opts(kdim=kdim, maxiter=maxiter), meta=meta)
+            finally:
+                solvers._GMRES_FUSED = True
+            out[fused] = (info, np.array(meta.res), x.to_array(), A.matvec_counter)
+        (i0, r0, x0, c0), (i1, r1, x1, c1) = out[False], out[True]
+        assert i0 == i1 and len(r0) == len(r1) and c0 == c1, tag
+        assert np.abs(r1 - r0).max() <= 1e-13 * r0[0] and np.abs(x1 - x0).max() <= 1e-13 * np.abs(x0).max(), tag
+        xo = np.zeros(n, dtype=dtype)
+        info_o, res_o = ora.gmres(ora.DiagOp(d), bvec, xo, rtol=rtol, atol=0.0, kdim=kdim, maxiter=maxiter)
+        assert info_o == i1 and np.abs(np.array(res_o) - r1).max() <= 1e-12 * res_o[0] and np.abs(xo - x1).max() <= 1e-12 * np.abs(xo).max(), tag
+    assert out[True][0] < 0                                    # the last configuration ran out of iterations
