@@ -2,9 +2,28 @@
 !> Arnoldi on the diagonal operator d_i = 1 + (i-1)/n, x0_i = sin(i)/||.||, n = 1000, m = 8 --
 !> the case SURVEY.md Appendix A records for the reference's own arnoldi.  Prints H(1,1), H(2,1),
 !> H(m+1,m) and max |X^T X - I| so tests/test_fortran_binding.py can compare with the oracle.
+!> progress function for lk_arnoldi_segments (a bind(C) module procedure: c_funloc needs an interoperable procedure)
+module test_iso_c_progress
+    use, intrinsic :: iso_c_binding
+    implicit none
+    integer :: ncalls = 0, last_reported = 0
+    logical :: in_order = .true.
+contains
+    function on_columns(user, kfirst, klast) bind(C) result(stop_now)
+        type(c_ptr), value :: user
+        integer(c_int), value :: kfirst, klast
+        integer(c_int) :: stop_now
+        if (kfirst /= last_reported + 1 .or. klast < kfirst) in_order = .false.
+        last_reported = klast
+        ncalls = ncalls + 1
+        stop_now = 0_c_int
+    end function
+end module test_iso_c_progress
+
 program test_iso_c
     use, intrinsic :: iso_c_binding
     use lightkrylov_hip_c
+    use test_iso_c_progress
     implicit none
     integer, parameter :: n = 1000, m = 8
     type(c_ptr) :: ctx, X, A
@@ -52,6 +71,25 @@ program test_iso_c
     print '(A,ES24.16)', 'Hlast ', H(m + 1, m)
     print '(A,ES12.4)', 'orth ', orth
     print '(A,ES24.16)', 'norm_last ', nrm
+    ! ---- the same factorisation delivered in segments through a Fortran progress function (lk_arnoldi_segments, round 5)
+    block
+        type(c_ptr) :: X2
+        real(c_double) :: H2(m + 1, m)
+        integer(c_int) :: info2, segs(2)
+        rc = lk_basis_create(ctx, LK_F64, int(n, c_int64_t), int(m + 1, c_int), X2); call chk(rc, 'lk_basis_create(X2)')
+        rc = lk_basis_upload(X2, 0_c_int, 1_c_int, c_loc(x0), int(n, c_int64_t)); call chk(rc, 'lk_basis_upload(X2)')
+        H2 = 0.0d0
+        segs = [3_c_int, 6_c_int]
+        rc = lk_arnoldi_segments(A, X2, H2, int(m + 1, c_int64_t), 1_c_int, int(m, c_int), 1.0d-15, 0_c_int, segs, 2_c_int, &
+                                 c_funloc(on_columns), c_null_ptr, info2)
+        call chk(rc, 'lk_arnoldi_segments')
+        print '(A,I0)', 'seg_info ', info2
+        print '(A,I0)', 'seg_calls ', ncalls
+        print '(A,I0)', 'seg_last ', last_reported
+        print '(A,I0)', 'seg_in_order ', merge(1, 0, in_order)
+        print '(A,ES12.4)', 'seg_H_diff ', maxval(abs(H2 - H))
+        rc = lk_basis_destroy(X2)
+    end block
     ! ---- the reference's per-object schedule (innerprod loop, then linear_combination loop, then sub:
     !      gram_schmidt.fypp:141-145 through AbstractVectors.fypp:672-674, 600-602) driven from Fortran with
     !      the engine in lazy mode: m dots must cost ONE sweep; proj stays virtual and y%sub(proj) + the next norm ONE more.

@@ -22,6 +22,15 @@ extern int hipDeviceSynchronize(void);
 #define EXPECT(cond)                                                                   \
     do { if (!(cond)) { printf("FAIL expectation %s (line %d)\n", #cond, __LINE__); return 1; } } while (0)
 
+/* progress function of lk_arnoldi_segments: records the ranges reported; asks to stop once column `stop_at` (> 0) has been reported */
+typedef struct { int calls, first[32], last[32], stop_at; } progress_log;
+static int on_columns(void *user, int kfirst, int klast) {
+    progress_log *p = (progress_log *)user;
+    if (p->calls < 32) { p->first[p->calls] = kfirst; p->last[p->calls] = klast; }
+    p->calls += 1;
+    return p->stop_at > 0 && klast >= p->stop_at;
+}
+
 int main(void) {
     const int64_t n = 50001; const int m = 16;
     lk_context_t ctx; lk_basis_t X, W; lk_linop_t A;
@@ -37,6 +46,28 @@ int main(void) {
     int info = -99;
     CHECK(lk_arnoldi(A, X, H, m + 1, 1, m, 1e-15, 0, &info));
     EXPECT(info == 0);
+
+    /* the same factorisation delivered in segments (round 5): same H bit for bit, every step reported once, in order; stop on request */
+    {
+        lk_basis_t X2; int info2 = -99, nranks = -1, rank = -1;
+        CHECK(lk_comm_info(ctx, &nranks, &rank)); EXPECT(nranks == 1 && rank == 0);
+        CHECK(lk_basis_create(ctx, LK_F64, n, m + 1, &X2));
+        CHECK(lk_vec_rand(X2, 0, 7, 0, 1));
+        double *H2 = calloc((size_t)(m + 1) * m, sizeof(double));
+        const int segs[3] = {4, 10, 15};
+        progress_log log = {0};
+        CHECK(lk_arnoldi_segments(A, X2, H2, m + 1, 1, m, 1e-15, 0, segs, 3, on_columns, &log, &info2));
+        EXPECT(info2 == 0 && memcmp(H, H2, (size_t)(m + 1) * m * sizeof(double)) == 0);
+        EXPECT(log.calls == 4 && log.first[0] == 1 && log.last[0] == 4 && log.first[1] == 5 && log.last[1] == 10 && log.first[2] == 11 &&
+               log.last[2] == 15 && log.first[3] == 16 && log.last[3] == m);
+        memset(H2, 0, (size_t)(m + 1) * m * sizeof(double));
+        CHECK(lk_vec_rand(X2, 0, 7, 0, 1));
+        progress_log log2 = {0}; log2.stop_at = 4;
+        CHECK(lk_arnoldi_segments(A, X2, H2, m + 1, 1, m, 1e-15, 0, segs, 3, on_columns, &log2, &info2));
+        EXPECT(info2 == 0 && log2.calls == 1 && memcmp(H, H2, (size_t)(m + 1) * 4 * sizeof(double)) == 0);   /* columns 1..4, nothing reported after the request */
+        EXPECT(lk_arnoldi_segments(A, X2, H2, m + 1, 1, m, 1e-15, 0, (const int[]){10, 4}, 2, on_columns, &log2, &info2) == LK_ERR_INVALID);   /* not ascending */
+        free(H2); lk_basis_destroy(X2);
+    }
 
     /* orthonormality via lk_gram */
     double *G = malloc((size_t)(m + 1) * (m + 1) * sizeof(double));

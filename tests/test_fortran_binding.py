@@ -38,6 +38,8 @@ def test_fortran_host_program_runs_arnoldi_on_the_gpu():
         assert abs(vals[key] - ref) <= 1e-12 * abs(ref), (key, vals[key], ref)
     assert vals["orth"] < 1e-13
     assert abs(vals["norm_last"] - 1.0) < 1e-14
+    # lk_arnoldi_segments with a Fortran bind(C) progress function: three reports (1..3, 4..6, 7..8), in order, the same H bit for bit
+    assert (vals["seg_info"], vals["seg_calls"], vals["seg_last"], vals["seg_in_order"]) == (0, 3, 8, 1) and vals["seg_H_diff"] == 0.0
     # the per-object (type-bound-procedure) schedule driven from Fortran in lazy mode, compared with the fused single-pass call.
     # m = 8 dots: one batched sweep + 7 memo hits; the 8 axpbys are queued onto a virtual proj; y%sub(proj) + y%norm()
     # = one fused sweep (the norm is the 8th memo hit); nothing was flushed as a plain panel update, proj never written

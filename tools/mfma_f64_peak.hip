@@ -34,6 +34,31 @@ __global__ __launch_bounds__(256) void kfma(double *out, int iters, double a, do
     for (int i = 0; i < 16; ++i) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// MFMA and VALU side by side: the odd waves of every block issue v_fma_f64 chains, the even waves MFMAs -- does the chip deliver the SUM
+// of the two sustained rates (separate pipes), or is there one budget (power / issue) that both draw from?
+__global__ __launch_bounds__(256) void kmix(double *out, int iters_mfma, int iters_fma, double a, double b) {
+    const int wave = threadIdx.x >> 6;
+    double s = 0;
+    if (wave & 1) {
+        double acc[16];
+        for (int i = 0; i < 16; ++i) acc[i] = threadIdx.x * 1e-9 + i;
+        for (int it = 0; it < iters_fma; ++it) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = fma(acc[i], a, 1e-9);
+        }
+        for (int i = 0; i < 16; ++i) s += acc[i];
+    } else {
+        v4d acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = v4d{0, 0, 0, 0};
+        const double av = a + 1e-3 * (threadIdx.x & 15), bv = b - 1e-3 * ((threadIdx.x & 63) >> 4);
+        for (int it = 0; it < iters_mfma; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 template <int NACC>
 void run(double *d, unsigned long long *c, int blocks_per_cu, int iters) {
     const int blocks = 256 * blocks_per_cu;
@@ -69,5 +94,16 @@ int main() {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("{\"v_fma_f64\": true, \"ms\": %.3f, \"TFLOPs\": %.1f}\n", ms, (double)2048 * 256 * 20000 * 16.0 * 2.0 / ms / 1e9);
+    // mixed: 8 blocks per CU, in every block two waves of MFMAs and two of FMAs, iteration counts chosen so that both halves take about as long alone
+    for (int rep = 0; rep < 2; ++rep) {
+        const int im = 4000, ifm = 13000;
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kmix, dim3(2048), dim3(256), 0, 0, d, im, ifm, 1.0000001, 0.9999999);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        const double fm = (double)2048 * 2 * im * 8.0 * 2048.0, ff = (double)2048 * 128 * (double)ifm * 16.0 * 2.0;
+        printf("{\"mixed_mfma_and_fma\": true, \"ms\": %.3f, \"MFMA_TFLOPs\": %.1f, \"FMA_TFLOPs\": %.1f, \"sum_TFLOPs\": %.1f}\n", ms, fm / ms / 1e9, ff / ms / 1e9,
+               (fm + ff) / ms / 1e9);
+    }
     return 0;
 }
