@@ -141,13 +141,21 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * "wide_regs" (shape of the update sweeps against 129..384 basis columns: 2 [default] = 8 waves x 32 / 24 register columns for
  * 129..256 real / 129..192 complex columns and the lane split on 24-column groups up to 384; 1 = the first only; 0 = round 3's lane
  * split on 16-column groups everywhere) and "kc32" (the 32-column register tile for the real update sweeps of k <= 128 columns too:
- * -1 [default] = for k > 32 on panels of >= 2^25 rows, 0 = never, v = for k > v).
+ * -1 [default] = for k > 32 when the GLOBAL problem (lk_set_partition; the local rows without one) has >= 2^25 rows -- every rank of a
+ * sharded run picks the same shape --, 0 = never, v = for k > v; sweeps 2 and 3 of the DGS only).
  * "gemm_3m" (default 1: the complex MFMA kernels -- tall-skinny product, X^H Y with <= 32 right-hand sides, Gram -- use three real products per
  * complex one, Re = P1 - P2, Im = P3 - P1 - P2; 0: four, the doubled real problem; same results normwise).
  * "gemm_prefetch_y" (default 1: the accumulating real MFMA product with <= 32 outputs -- the block Gram-Schmidt's updates -- loads the tile of Y
  * ahead of its k-loop; 0: after it; no result bit changes).
  * "wide_s3" (default 1: sweep 3 of a lane-split DGS holds both column groups of a wave-column in one wave's registers on tiles twice as
- * tall; 0: lane-split like sweep 2) changes NO result bit: it reproduces the lane split's summation order (tests/test_gpu_wide_bases.py). */
+ * tall; 0: lane-split like sweep 2) changes NO result bit: it reproduces the lane split's summation order (tests/test_gpu_wide_bases.py).
+ * Round 5, matrix-core kernels (same results to rounding): "xhy_db" (default 1: panel_xhy_mfma with a double-buffered LDS tile, one barrier per
+ * tile, for the 128-column variants; 2: the <= 32 right-hand-side variants too; 0: never); "gram_tiles" (default 1: the real Gram matrix of 33..64
+ * columns by panel_gram_mfma -- upper tiles dealt to the waves, two blocks per CU --; 2: up to 128 columns; 0: never) with "gram_grid_mult";
+ * "xhy_tr32" and "gemm_roll" (default 0: operand prefetch on 32-row tiles / rolling prefetch of X in the tall-skinny product -- both measured
+ * slower, kept for A/B, profiles/r05_*).  DIAGNOSTIC keys that switch parts of a kernel off -- WRONG RESULTS, phase timing only, used by
+ * tools/bench_gram.py and tools/bench_upd_phases.py: "xhy_debug" (1 = panel_xhy_mfma without its MFMAs, 2 = without its global loads after
+ * the first tile), "upd_debug" (bits: 1 update MFMAs, 2 dot MFMAs, 4 global loads, 8 store of Y' of panel_xhy_upd_mfma). */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
 
 /* Lazy batching of the per-object path (tuning key "lazy", off by default).  When on, k consecutive

@@ -275,3 +275,19 @@ def test_block_arnoldi_beyond_128_columns_against_the_oracle(dtype, p, steps):
     del X
     c.close()
     _ = rng
+
+
+@pytest.mark.parametrize("k", [3, 8, 40, 128, 200])
+def test_complex_gram_diagonal_has_an_imaginary_part_of_exactly_zero(ctx, k):
+    """conj(x) . x has an imaginary part of exactly zero in the reference's dotc (every term is re*im - im*re); the matrix-core kernels --
+    three real products per complex one, or the doubled real problem -- would leave O(eps |x|^2) there.  lk_gram and lk_innerprod(X, X)
+    return exactly zero on the diagonal whatever kernel served them (round-4 advisor), and real, positive squared norms."""
+    n = 20_011
+    X = basis(n, k, np.complex128, 900)
+    B = lk.krylov_basis_gpu(n, k, np.complex128, ctx); B.upload(X)
+    G = lk.Gram(B)
+    assert np.all(np.diag(G).imag == 0.0) and np.all(np.diag(G).real > 0)
+    M = lk.innerprod(B, B)
+    assert np.all(np.diag(M).imag == 0.0)
+    ref = X.conj().T @ X
+    assert np.abs(np.triu(G) - np.triu(ref)).max() <= 1e-12 * np.abs(ref).max()
