@@ -409,7 +409,8 @@ int lk_arnoldi_segments(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int 
  * re-orthogonalisation by a double Gram-Schmidt step without beta (:62); T(k+1, k) = ||X(k+1)||; beta < tol => info = k and
  * the loop exits WITHOUT scaling (:32-36), else X(k+1) is normalised.  All steps of a call are enqueued asynchronously
  * (device-side stop flag), one host synchronisation per call.  T: host (ldt x m) column-major array of the basis dtype;
- * only T(k-1:k+1, k) of each step is written.  kend <= 512. */
+ * only T(k-1:k+1, k) of each step is written.  Steps against more than 512 basis columns run one host round trip each (the reference has no
+ * cap, lanczos.fypp:20). */
 int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, int kend, double tol, int *info);
 
 /* ---- Golub-Kahan bidiagonalisation -----------------------------------------------------------
@@ -418,7 +419,8 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
  * U(k+1) = A V(k), double Gram-Schmidt against U(:k), B(k+1, k) = beta = ||U(k+1)||, normalise (:45-58); a norm not above
  * tol => info = k and the loop exits without scaling.  All steps of a call are enqueued asynchronously (device-side stop flag
  * per half step), one host synchronisation per call.  U: kdim + 1 columns, V: >= kdim columns (two different bases); B: host
- * (ldb x kdim) column-major array of the basis dtype, only B(k, k) and B(k+1, k) are written.  kend <= 512, tol >= atol_dp. */
+ * (ldb x kdim) column-major array of the basis dtype, only B(k, k) and B(k+1, k) are written.  tol >= atol_dp.  Steps against more than
+ * 512 basis columns run one host round trip each (the reference has no cap, golub_kahan.fypp:18). */
 int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, int kstart, int kend, double tol, int *info);
 
 #ifdef __cplusplus

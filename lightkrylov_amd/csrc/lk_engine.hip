@@ -2130,6 +2130,16 @@ static int innerprod_impl(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, d
     lk_context_t c = Bx->ctx;
     LKCHK(lazy_enter(c, false));
     const int ED = Bx->ed();
+    // X^H X entries on the diagonal, complex kind: conj(x) . x has an imaginary part of exactly zero in the reference's dotc (every term is
+    // re*im - im*re, no contraction across the two products); the three-product matrix-core kernels form Im as P3 + P1 - P2, the doubled real
+    // problem and the FMA-contracted vector kernels round one of the two products -- each leaves O(eps |x|^2) there.  Zeroed, whatever kernel ran.
+    auto real_diagonal = [&]() {
+        if (ED != 2 || Bx->data != By->data) return;
+        for (int q = 0; q < p; ++q) {
+            const int i = jy0 + q;                     // column i of X is column q of Y
+            if (i < k) M[((size_t)q * k + i) * 2 + 1] = 0.0;
+        }
+    };
     if (c->xhy_mfma && p >= XHY_MIN_P) {
         // many right-hand sides: one pass over X per 128 x 128 block of M on the matrix cores
         std::vector<double> host((size_t)XHY_MAX * (XHY_MAX + 1) * 2);
@@ -2145,12 +2155,9 @@ static int innerprod_impl(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, d
                 if (c->prof) prof_collect(c);
                 for (int q = 0; q < pn; ++q)
                     memcpy(M + ((size_t)(j + q) * k + c0) * ED, host.data() + (size_t)q * (kk + 1) * ED, (size_t)kk * ED * sizeof(double));
-                // diagonal of X^H X, complex kind: conj(x) . x has an imaginary part of exactly zero in the reference's dotc (every term
-                // is re*im - im*re); the three-product kernels form Im as P3 + P1 - P2 and would leave O(eps |x|^2) there
-                if (same && ED == 2)
-                    for (int q = 0; q < pn; ++q) M[((size_t)(j + q) * k + c0 + q) * 2 + 1] = 0.0;
             }
         }
+        real_diagonal();
         return LK_OK;
     }
     for (int j = 0; j < p; j += 4) {
@@ -2175,6 +2182,7 @@ static int innerprod_impl(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, d
             }
         }
     }
+    real_diagonal();
     return LK_OK;
 }
 
@@ -3319,12 +3327,36 @@ static int lanczos_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
     return LK_OK;
 }
 
+// One Lanczos step on the host-synchronous schedule (bases beyond KMAX_WIDE columns): lanczos.fypp:25-39, 57-62 through the ABI's own entries.
+static int lanczos_step_sync(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int k, double tol, int *info, int *stop) {
+    const int ED = X->ed();
+    *stop = 0;
+    LKCHK(lk_linop_apply(A, LK_OP_N, X, k - 1, X, k));                                       // :26
+    double *Tk = T + (size_t)(k - 1) * ldt * ED;
+    for (int i = (k > 1 ? k - 1 : 1); i <= k; ++i) {                                         // :57-60
+        double t[2] = {0.0, 0.0};
+        LKCHK(lk_vec_dot(X, i - 1, X, k, t));
+        for (int e = 0; e < ED; ++e) Tk[(size_t)(i - 1) * ED + e] = t[e];
+        const double mt[2] = {-t[0], -t[1]}, one[2] = {1.0, 0.0};
+        LKCHK(lk_vec_axpby(mt, X, i - 1, one, X, k));
+    }
+    int dinfo = 0;
+    double norms[3];
+    LKCHK(lk_dgs(X, k, X, k, nullptr, norms, 0, &dinfo));                                    // :62 (no beta)
+    const double beta = norms[2];
+    if (beta != beta) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+    Tk[(size_t)k * ED] = beta;                                                               // :29
+    if (ED == 2) Tk[(size_t)k * ED + 1] = 0.0;
+    if (beta < tol) { *info = k; *stop = 1; return LK_OK; }                                  // :32-36 (no scaling)
+    const double inv[2] = {1.0 / beta, 0.0};
+    return lk_vec_scal(X, k, inv);                                                           // :39
+}
+
 int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, int kend, double tol, int *info) {
     if (!A || !X || !T || !info) return fail(LK_ERR_INVALID, "lk_lanczos: null argument");
     const int kdim = X->ncols - 1;                               // lanczos.fypp:20
     if (kdim < 1) return fail(LK_ERR_INVALID, "lk_lanczos: basis needs at least 2 columns");
     if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_lanczos: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
-    if (kend > KMAX_WIDE) return fail(LK_ERR_INVALID, "lk_lanczos: steps beyond %d basis columns are not fused (run them through the per-object calls)", KMAX_WIDE);
     if (ldt < kdim + 1) return fail(LK_ERR_INVALID, "lk_lanczos: ldt too small");
     lk_context_t c = X->ctx;
     DevGuard dev_guard(c);
@@ -3332,12 +3364,22 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
     *info = 0;
     LKCHK(lazy_enter(c, true));
     int k = kstart;
+    const int kfused = kend < KMAX_WIDE ? kend : KMAX_WIDE;          // the asynchronous batch holds up to KMAX_WIDE basis columns per sweep
     while (k <= kend) {
+        if (k > KMAX_WIDE) {
+            // beyond 512 basis columns (round 5; the reference has no cap, lanczos.fypp:20): one step at a time on the host-synchronous
+            // schedule -- operator, the two local orthogonalisations (:57-60), the full re-orthogonalisation on column panels (:62), norm, scale
+            int stop = 0;
+            LKCHK(lanczos_step_sync(A, X, T, ldt, k, tol, info, &stop));
+            if (stop) break;
+            ++k;
+            continue;
+        }
         int done = 0;
-        LKCHK(lanczos_batch_async(A, X, k, kend, tol, &done));
+        LKCHK(lanczos_batch_async(A, X, k, kfused, tol, &done));
         const bool stopped_early = *c->stop_host != 0;
         double beta = 0.0;
-        const int rs = red_stride(kend);
+        const int rs = red_stride(kfused);
         for (int s = k; s <= done; ++s) {
             const double *r2 = c->step_red_host + ((size_t)(s - k) * RED_SECTIONS + 2) * rs;
             const int i0 = s > 1 ? s - 1 : 1;
@@ -3351,7 +3393,7 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
             Ts[(size_t)s * ED] = beta;                                                      // T(k+1, k) :29
             if (ED == 2) Ts[(size_t)s * ED + 1] = 0.0;
         }
-        if (!stopped_early) break;
+        if (!stopped_early) { k = done + 1; continue; }                                       // (on to the steps beyond KMAX_WIDE, if any)
         if (beta < tol) { *info = done; break; }                                            // :32-36 (no scaling)
         // the device stops at max(tol, atol_dp); a caller's smaller tol lets the reference go on: normalise and resume
         const double inv[2] = {1.0 / beta, 0.0};
@@ -3413,7 +3455,6 @@ int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, 
     const int kdim = U->ncols - 1;                               // golub_kahan.fypp:18
     if (kdim < 1 || V->ncols < kdim) return fail(LK_ERR_INVALID, "lk_bidiag: U needs kdim + 1 columns and V kdim");
     if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_bidiag: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
-    if (kend > KMAX_WIDE) return fail(LK_ERR_INVALID, "lk_bidiag: steps beyond %d basis columns are not fused (run them through the per-object calls)", KMAX_WIDE);
     if (!(tol >= ATOL_DP)) return fail(LK_ERR_INVALID, "lk_bidiag: tol below atol_dp is not fused (the device-side stop is at max(tol, atol_dp))");
     if (ldb < kdim + 1) return fail(LK_ERR_INVALID, "lk_bidiag: ldb too small");
     if (U->data == V->data) return fail(LK_ERR_INVALID, "lk_bidiag: U and V must be different bases");
@@ -3423,10 +3464,13 @@ int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, 
     *info = 0;
     if (kstart > kend) return LK_OK;
     LKCHK(lazy_enter(c, true));
-    int done_half = 0;
-    LKCHK(bidiag_batch_async(A, U, V, kstart, kend, tol, &done_half));
-    const bool stopped_early = *c->stop_host != 0;
-    const int rs = red_stride(kend);
+    const int kfused = kend < KMAX_WIDE ? kend : KMAX_WIDE;
+    int done_half = 2 * (kstart - 1);
+    bool stopped_early = false;
+    if (kstart <= kfused) {
+    LKCHK(bidiag_batch_async(A, U, V, kstart, kfused, tol, &done_half));
+    stopped_early = *c->stop_host != 0;
+    const int rs = red_stride(kfused);
     for (int hs = 2 * kstart - 1; hs <= done_half; ++hs) {
         const int k = (hs + 1) / 2;
         const bool right = hs & 1;
@@ -3438,7 +3482,33 @@ int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, 
         Bk[row * ED] = nrm;
         if (ED == 2) Bk[row * ED + 1] = 0.0;
     }
-    if (stopped_early) *info = (done_half + 1) / 2;                                        // :41, :57
+    }
+    if (stopped_early) { *info = (done_half + 1) / 2; return LK_OK; }                     // :41, :57
+    // beyond 512 basis columns (round 5; the reference has no cap, golub_kahan.fypp:18): one step at a time, host-synchronous
+    for (int k = (kstart > kfused + 1 ? kstart : kfused + 1); k <= kend; ++k) {
+        double *Bk = B + (size_t)(k - 1) * ldb * ED;
+        double norms[3];
+        int dinfo = 0;
+        LKCHK(lk_linop_apply(A, LK_OP_H, U, k - 1, V, k - 1));                             // :27
+        if (k > 1) LKCHK(lk_dgs(V, k - 1, V, k - 1, nullptr, norms, 0, &dinfo));           // :30-33
+        else LKCHK(lk_vec_norm(V, 0, &norms[2]));
+        const double alpha = norms[2];                                                     // :36
+        if (alpha != alpha) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+        Bk[(size_t)(k - 1) * ED] = alpha;
+        if (ED == 2) Bk[(size_t)(k - 1) * ED + 1] = 0.0;
+        if (!(std::fabs(alpha) > tol)) { *info = k; return LK_OK; }                        // :37-42
+        const double ia[2] = {1.0 / alpha, 0.0};
+        LKCHK(lk_vec_scal(V, k - 1, ia));
+        LKCHK(lk_linop_apply(A, LK_OP_N, V, k - 1, U, k));                                 // :45
+        LKCHK(lk_dgs(U, k, U, k, nullptr, norms, 0, &dinfo));                              // :48-49
+        const double beta = norms[2];                                                      // :52
+        if (beta != beta) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+        Bk[(size_t)k * ED] = beta;
+        if (ED == 2) Bk[(size_t)k * ED + 1] = 0.0;
+        if (!(std::fabs(beta) > tol)) { *info = k; return LK_OK; }                         // :53-58
+        const double ib[2] = {1.0 / beta, 0.0};
+        LKCHK(lk_vec_scal(U, k, ib));
+    }
     return LK_OK;
 }
 

@@ -247,17 +247,15 @@ def lanczos(A: abstract_linop, X, T: np.ndarray, kstart: int = 1, kend: int | No
     kdim = len(X) - 1
     kend = kdim if kend is None else kend
     info = 0
-    # whole step loop inside the engine (asynchronous, one synchronisation per call) for the first 512 basis columns
+    # whole step loop inside the engine (asynchronous, one synchronisation per call, for the first 512 basis columns; one round trip per
+    # step beyond)
     if (isinstance(X, krylov_basis_gpu) and isinstance(A, _engine_linop) and T.flags.f_contiguous and T.dtype == X.dtype
-            and T.shape[0] >= kdim + 1 and kstart <= min(kend, 512)):
-        k1 = min(kend, 512)
+            and T.shape[0] >= kdim + 1 and kstart <= kend):
         cinfo = C.c_int()
-        _capi.check(X._lib.lk_lanczos(A._h, X._h, T.ctypes.data_as(_DP), T.shape[0], int(kstart), int(k1), float(tol),
+        _capi.check(X._lib.lk_lanczos(A._h, X._h, T.ctypes.data_as(_DP), T.shape[0], int(kstart), int(kend), float(tol),
                                       C.byref(cinfo)))
-        A.matvec_counter += (cinfo.value if cinfo.value else k1) - kstart + 1
-        if cinfo.value or k1 == kend:
-            return cinfo.value
-        kstart = k1 + 1
+        A.matvec_counter += (cinfo.value if cinfo.value else kend) - kstart + 1
+        return cinfo.value
     for k in range(kstart, kend + 1):
         A.apply_matvec(X[k - 1], X[k])                                              # :26
         for i in range(max(1, k - 1), k + 1):                                       # :57-60
@@ -281,19 +279,17 @@ def bidiagonalization(A: abstract_linop, U, V, B: np.ndarray, kstart: int = 1, k
     kend = kdim if kend is None else kend
     info = 0
     gpu = isinstance(U, krylov_basis_gpu) and isinstance(V, krylov_basis_gpu)
-    # whole step loop inside the engine (asynchronous, one synchronisation per call) for the first 512 basis columns
+    # whole step loop inside the engine (asynchronous, one synchronisation per call, for the first 512 basis columns; one round trip per
+    # step beyond)
     if (gpu and isinstance(A, _engine_linop) and B.flags.f_contiguous and B.dtype == U.dtype and B.shape[0] >= kdim + 1
-            and tol >= atol_dp and kstart <= min(kend, 512) and len(V) >= kdim):
-        k1 = min(kend, 512)
+            and tol >= atol_dp and kstart <= kend and len(V) >= kdim):
         cinfo = C.c_int()
-        _capi.check(U._lib.lk_bidiag(A._h, U._h, V._h, B.ctypes.data_as(_DP), B.shape[0], int(kstart), int(k1), float(tol),
+        _capi.check(U._lib.lk_bidiag(A._h, U._h, V._h, B.ctypes.data_as(_DP), B.shape[0], int(kstart), int(kend), float(tol),
                                      C.byref(cinfo)))
-        ksteps = (cinfo.value if cinfo.value else k1) - kstart + 1
+        ksteps = (cinfo.value if cinfo.value else kend) - kstart + 1
         A.rmatvec_counter += ksteps
         A.matvec_counter += ksteps if not cinfo.value or B[cinfo.value - 1, cinfo.value - 1].real > tol else ksteps - 1
-        if cinfo.value or k1 == kend:
-            return cinfo.value
-        kstart = k1 + 1
+        return cinfo.value
     for k in range(kstart, kend + 1):
         A.apply_rmatvec(U[k - 1], V[k - 1])                                         # :27
         norms: list = []

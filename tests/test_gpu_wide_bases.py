@@ -285,3 +285,50 @@ def test_pipelined_eighs_beyond_128_lanczos_steps(ctx, dtype):
     assert i0 == i1 == kdim
     assert np.array_equal(v0, v1) and np.array_equal(r0, r1) and np.array_equal(X0, X1)
     assert (np.diff(v0) <= 0).all() and 1.99 < v0[0] <= 2.0 + 1e-12
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_lanczos_and_bidiagonalization_beyond_512_columns_through_the_c_entries(ctx, dtype):
+    """lk_lanczos / lk_bidiag have no cap on the basis any more (round 5; the reference has none, lanczos.fypp:20, golub_kahan.fypp:18):
+    kend = 530 in ONE call -- the first 512 steps as the asynchronous batch, the rest one host round trip each -- and a restart range that
+    starts beyond 512; T and B against the oracle column by column, a breakdown beyond 512 reported like one below."""
+    n, m = 1500, 530
+    rng = np.random.default_rng(8)
+    d = (1.0 + rng.random(n) * 3.0).astype(dtype)                           # (a spread spectrum: 530 steps without a breakdown)
+    x0 = seeded(n, dtype, 21); x0 /= np.linalg.norm(x0)
+    A = lk.diag_linop_gpu(d, ctx)
+    X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X.upload(x0.reshape(-1, 1), 0)
+    T = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.lanczos(A, X, T) == 0
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F"); Xo[:, 0] = x0
+    To = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.lanczos(ora.DiagOp(d), Xo, To) == 0
+    for j in range(m):
+        assert np.abs(T[:, j] - To[:, j]).max() <= 1e-12 * np.abs(To[:, j]).max(), j
+    Xg = X.download()
+    assert np.abs(Xg.conj().T @ Xg - np.eye(m + 1)).max() <= 1e-12
+    # the same factorisation in two calls, the second one starting beyond 512 columns
+    X2 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X2.upload(x0.reshape(-1, 1), 0)
+    T2 = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.lanczos(A, X2, T2, kstart=1, kend=520) == 0 and lk.lanczos(A, X2, T2, kstart=521, kend=m) == 0
+    assert np.array_equal(T2, T) and np.array_equal(X2.download(), Xg)
+    # Golub-Kahan, both bases beyond 512 columns
+    g = np.arange(n) / n
+    dz = (1.0 + 3.0 * rng.random(n)).astype(dtype) if np.dtype(dtype).kind == "f" else ((1.0 + 3.0 * rng.random(n)) * np.exp(1j * g)).astype(dtype)
+    Az = lk.diag_linop_gpu(dz, ctx)
+    U = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); U.upload(x0.reshape(-1, 1), 0)
+    V = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+    B = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert lk.bidiagonalization(Az, U, V, B) == 0
+    Uo = np.zeros((n, m + 1), dtype=dtype, order="F"); Uo[:, 0] = x0
+    Vo = np.zeros((n, m + 1), dtype=dtype, order="F")
+    Bo = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.bidiagonalization(ora.DiagOp(dz), ora.DiagOp(dz.conj()), Uo, Vo, Bo) == 0
+    for j in range(m):
+        assert np.abs(B[:, j] - Bo[:, j]).max() <= 1e-12 * np.abs(Bo[:, j]).max(), j
+    # an invariant subspace reached beyond 512 columns: 520 distinct eigenvalues
+    d520 = (1.0 + (np.arange(n) % 520) / 520.0).astype(dtype)
+    X3 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X3.upload(x0.reshape(-1, 1), 0)
+    T3 = np.zeros((m + 1, m), dtype=dtype, order="F")
+    info = lk.lanczos(lk.diag_linop_gpu(d520, ctx), X3, T3, tol=1e-9)
+    assert info == 520, info
