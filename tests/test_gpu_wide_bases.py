@@ -326,9 +326,11 @@ def test_lanczos_and_bidiagonalization_beyond_512_columns_through_the_c_entries(
     assert ora.bidiagonalization(ora.DiagOp(dz), ora.DiagOp(dz.conj()), Uo, Vo, Bo) == 0
     for j in range(m):
         assert np.abs(B[:, j] - Bo[:, j]).max() <= 1e-12 * np.abs(Bo[:, j]).max(), j
-    # an invariant subspace reached beyond 512 columns: 520 distinct eigenvalues
-    d520 = (1.0 + (np.arange(n) % 520) / 520.0).astype(dtype)
-    X3 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X3.upload(x0.reshape(-1, 1), 0)
-    T3 = np.zeros((m + 1, m), dtype=dtype, order="F")
-    info = lk.lanczos(lk.diag_linop_gpu(d520, ctx), X3, T3, tol=1e-9)
-    assert info == 520, info
+    # a stop beyond 512 columns (the tolerance is set above the next beta: info = that step, T(k+1, k) = beta, the vector left unscaled, :32-36)
+    X3 = lk.krylov_basis_gpu(n, m + 1, dtype, ctx); X3.upload(Xg[:, :521], 0)
+    T3 = T.copy(order="F")
+    T3[:, 520:] = 0
+    info = lk.lanczos(A, X3, T3, kstart=521, kend=m, tol=10.0)
+    assert info == 521 and abs(T3[521, 520] - T[521, 520]) <= 1e-12 * abs(T[521, 520]) and not T3[:, 521:].any()
+    y = X3.download(521, 1)[:, 0]
+    assert abs(np.linalg.norm(y) - abs(T[521, 520])) <= 1e-12 * abs(T[521, 520])           # not normalised
