@@ -89,6 +89,8 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
+    int mfma_4x4 = 1;          // matrix-core kernels issue their products as v_mfma_f64_4x4x4_4b_f64 (72 TFLOP/s sustained) instead of v_mfma_f64_16x16x4_f64 (49): same lanes, same
+                               // accumulators, four A operands per step (lk_kernels.hip.h, mfma_f64_16x16x4_by4); 0: the 16x16x4 instruction
     int upd_debug = 0;         // diagnostic only (wrong results): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
     int xhy_debug = 0;         // diagnostic only (wrong results): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
     int gemm_roll = 0;         // MFMA tall-skinny product: rolling prefetch of X (a ring of 4 k-steps refilled as they are consumed) instead of batches of 4 k-steps (loaded, waited for,
@@ -816,11 +818,20 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
                                p, Bx->n, flags | (c->xhy_debug << 4), NI, part, npart);
             return LK_OK;
         };
+        // variant = (kind, <= 32 | <= 128 right-hand sides, rows per tile, double-buffered, 4x4x4 MFMAs)
+        auto pick = [&](auto cplx, auto m4) -> int {
+            constexpr bool CP = decltype(cplx)::value, M4 = decltype(m4)::value;
+            if (small) return db ? go(&panel_xhy_mfma<CP, 2, 32, true, M4>) : go(&panel_xhy_mfma<CP, 2, 32, false, M4>);
+            if constexpr (CP) return db ? go(&panel_xhy_mfma<true, 8, 32, true, M4>) : go(&panel_xhy_mfma<true, 8, 32, false, M4>);
+            else {
+                if (TR == 32) return db ? go(&panel_xhy_mfma<false, 8, 32, true, M4>) : go(&panel_xhy_mfma<false, 8, 32, false, M4>);
+                return db ? go(&panel_xhy_mfma<false, 8, 64, true, M4>) : go(&panel_xhy_mfma<false, 8, 64, false, M4>);
+            }
+        };
+        using T_ = std::true_type; using F_ = std::false_type;
         if (three) LKCHK(go(&panel_xhy_mfma3m));
-        else if (db && cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32, true>) : go(&panel_xhy_mfma<true, 8, 32, true>));
-        else if (db) LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32, true>) : (TR == 32 ? go(&panel_xhy_mfma<false, 8, 32, true>) : go(&panel_xhy_mfma<false, 8, 64, true>)));
-        else if (cp) LKCHK(small ? go(&panel_xhy_mfma<true, 2, 32>) : go(&panel_xhy_mfma<true, 8, 32>));
-        else LKCHK(small ? go(&panel_xhy_mfma<false, 2, 32>) : (TR == 32 ? go(&panel_xhy_mfma<false, 8, 32>) : go(&panel_xhy_mfma<false, 8, 64>)));
+        else if (cp) LKCHK(c->mfma_4x4 ? pick(T_{}, T_{}) : pick(T_{}, F_{}));
+        else LKCHK(c->mfma_4x4 ? pick(F_{}, T_{}) : pick(F_{}, F_{}));
     }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, part, nvb, npart, grid, k, p, ED, flags, out);
@@ -1468,6 +1479,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_prefetch_y")) { c->gemm_prefetch_y = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "mfma_4x4")) { c->mfma_4x4 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "upd_debug")) { c->upd_debug = value & 15; return LK_OK; }
     if (!strcmp(key, "xhy_debug")) { c->xhy_debug = value & 3; return LK_OK; }
     if (!strcmp(key, "gemm_roll")) { c->gemm_roll = value ? 1 : 0; return LK_OK; }

@@ -1018,6 +1018,23 @@ __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, 
 // Cp: coefficient tiles packed per lane by pack_coef_mfma: [group][k-step t][64 lanes].
 typedef double v4d __attribute__((ext_vector_type(4)));
 
+// D(16 x 16) += A(16 x 4) B(4 x 16) in the lane layout of v_mfma_f64_16x16x4_f64 -- A[i = l & 15][kk = l >> 4], B[kk = l >> 4][j = l & 15],
+// D[i = (l >> 4) + 4 reg][j = l & 15] -- issued as FOUR v_mfma_f64_4x4x4_4b_f64 (round 5).  On gfx950 the 16x16x4 instruction sustains
+// 49 TFLOP/s (0.63 of the 78.6 spec) whatever feeds it, the 4x4x4 one 72 (tools/mfma_f64_peak.hip, profiles/r05_fp64_mfma_peak.txt).
+// The 4x4x4 instruction multiplies four independent 4 x 4 x 4 blocks; its lanes (found empirically: tools/mfma_f64_4x4_probe.hip) are
+//     A: lane 16 k + 4 blk + i      B: lane 16 k + 4 blk + j      D: lane 16 i + 4 blk + j
+// so with the SAME B register (row kk = l >> 4, column j = l & 15 = 4 blk + j') and A_m[lane] = A[i = 4 m + (l & 3)][kk = l >> 4] -- the four
+// output rows 4m .. 4m + 3 of the tile, replicated over the four blocks -- instruction m leaves D[i = (l >> 4) + 4 m][j = l & 15] in its lane:
+// component m of the 16x16x4 accumulator.  Only the A operand changes: four values per lane instead of one (in an LDS tile: the entries
+// 4 m + (l & 3) of the lane's 16-entry row instead of entry l & 15; four lanes read the same word -- a broadcast).
+__device__ __forceinline__ v4d mfma_f64_16x16x4_by4(const double (&a4)[4], double b, v4d acc) {
+    acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[0], b, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[1], b, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[2], b, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[3], b, acc[3], 0, 0, 0);
+    return acc;
+}
+
 // PF (round 4; real kind, <= 32 outputs, launched for accumulating calls only: the block Gram-Schmidt's updates Y -= X H): the tile of Y that
 // the result is added to is loaded BEFORE the k-loop, 16 more 16-byte loads in flight per lane under the MFMAs, instead of after it, where a
 // wave had nothing else to issue: block DGS k = 128, p = 32: 10.3 -> 9.8 ms, k = 32, p = 32: 4.9 -> 4.5 ms.  (Compiled into the plain
@@ -1350,7 +1367,7 @@ __global__ __launch_bounds__(256) void pack_coef_mfma3m(const double *__restrict
 // PJM = J tiles a wave can hold (8: up to 128 right-hand sides; 2: up to 32, half the registers), TR = real rows per tile
 // (64, or 32 for the small variant: 40 KB of LDS at k = 128, so that two or three blocks share a CU and cover each other's
 // barriers when there are only a few MFMAs per tile).
-template <bool CPLX, int PJM, int TR, bool DB = false>
+template <bool CPLX, int PJM, int TR, bool DB = false, bool M4 = false>
 __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                       const double *__restrict__ Y, int64_t ldy, int p, int64_t n, int flags,
                                                       int NI, double *__restrict__ partial, double *__restrict__ npartial) {
@@ -1385,6 +1402,7 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     for (int s = 0; s < NYP; ++s) nacc[s] = 0.0;
     v2d xs[NXP], ys[NYP];
 
+    constexpr bool m4 = M4;                                           // the products on v_mfma_f64_4x4x4_4b_f64 (tuning key "mfma_4x4")
     const bool dbg_nomfma = flags & 16, dbg_noload = flags & 32;      // diagnostics (tools/bench_gram.py xhy_debug=...): wrong results, phase timing only
     auto gload = [&](int64_t T) {
         if (dbg_noload && T != (int64_t)blockIdx.x) return;
@@ -1476,6 +1494,27 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
                     if (J < PJ && (!upper || J >= wi)) {
                         acc_re[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[J], acc_re[J], 0, 0, 0);
                         if constexpr (CPLX) acc_im[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (arow & 1) ? -b2[J] : b2[J], acc_im[J], 0, 0, 0);
+                    }
+                }
+            }
+        } else if (m4 && active) {
+            // the same products on the 4x4x4 instruction (72 instead of 49 TFLOP/s sustained): four A operands per row step -- the columns
+            // 16 wi + 4 m + (lane & 3) of X's tile --, the B operands and the accumulators exactly as below
+            for (int step = wr; step < TR / 4; step += WR) {
+                const int ro = 4 * step + arow;
+                double a4[4];
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) a4[mm] = Xb[(16 * wi + 4 * mm + (lane & 3)) * S + ro];
+#pragma unroll
+                for (int J = 0; J < PJM; ++J) {
+                    if (J < PJ && (!upper || J >= wi)) {
+                        const double b = Yb[(16 * J + acol) * S + ro];
+                        acc_re[J] = mfma_f64_16x16x4_by4(a4, b, acc_re[J]);
+                        if constexpr (CPLX) {
+                            double b2 = Yb[(16 * J + acol) * S + (ro ^ 1)];
+                            b2 = (ro & 1) ? -b2 : b2;
+                            acc_im[J] = mfma_f64_16x16x4_by4(a4, b2, acc_im[J]);
+                        }
                     }
                 }
             }

@@ -23,6 +23,19 @@ __global__ __launch_bounds__(256) void k(double *out, unsigned long long *cyc, i
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// the other FP64 MFMA instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per instruction, 512 flop, one result per lane)
+__global__ __launch_bounds__(256) void k4(double *out, int iters, double a, double b) {
+    double acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0;
+    const double av = a + 1e-3 * (threadIdx.x & 15), bv = b - 1e-3 * ((threadIdx.x & 63) >> 4);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(av, bv, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 __global__ __launch_bounds__(256) void kfma(double *out, int iters, double a, double b) {
     double acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = threadIdx.x * 1e-9 + i;
@@ -94,6 +107,14 @@ int main() {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("{\"v_fma_f64\": true, \"ms\": %.3f, \"TFLOPs\": %.1f}\n", ms, (double)2048 * 256 * 20000 * 16.0 * 2.0 / ms / 1e9);
+    for (int bpc : {2, 8}) {
+        const int it4 = 16000;
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k4, dim3(256 * bpc), dim3(256), 0, 0, d, it4, 1.0000001, 0.9999999);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("{\"v_mfma_f64_4x4x4_4b\": true, \"waves_per_simd\": %d, \"ms\": %.3f, \"TFLOPs\": %.1f}\n", bpc, ms, (double)256 * bpc * 4 * it4 * 8.0 * 512.0 / ms / 1e9);
+    }
     // mixed: 8 blocks per CU, in every block two waves of MFMAs and two of FMAs, iteration counts chosen so that both halves take about as long alone
     for (int rep = 0; rep < 2; ++rep) {
         const int im = 4000, ifm = 13000;
