@@ -721,7 +721,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     // share a CU and cover each other's barriers and load latency (n = 10^7 real, k = 128, p = 16: 2.54 -> 1.92 ms on 3 blocks
     // per CU, one pass over X at 6.5 TB/s being 1.77; complex 3.73 -> 2.29 ms on 2)
     const bool small = c->xhy_small && PJ <= 2;
-    const int TR = (small || cp || c->xhy_tr32) ? 32 : 64;     // (complex, more than 32 right-hand sides: 32-row tiles too -- sixteen staged chunks beside 2 x 8 accumulators spilled 68 B)
+    const int TR = (small || cp || c->xhy_tr32 || c->mfma_4x4 >= 2) ? 32 : 64;     // ("mfma_4x4" = 2: the pipelined 4x4x4 loop lives on the 32-row tiles)     // (complex, more than 32 right-hand sides: 32-row tiles too -- sixteen staged chunks beside 2 x 8 accumulators spilled 68 B)
     const int64_t ntiles = (Bx->n * ED + TR - 1) / TR;
     int64_t g = (int64_t)c->num_cu * (small ? (c->xhy_grid_mult ? c->xhy_grid_mult : (cp ? 2 : 3)) : 1);
     if (g > ntiles) g = ntiles;
@@ -965,6 +965,12 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
             if (lds > 48 * 1024)
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             // (the rolling prefetch of X beside the prefetched tile of Y does not fit the register file: batch schedule here)
+            if (c->mfma_4x4) {
+                if (lds > 48 * 1024)
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, true, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                                   c->gemm_store_policy);
+            } else
             hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, true, false>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
                                c->gemm_store_policy);
             HIPCHK(hipGetLastError());
@@ -976,6 +982,15 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     if constexpr (CAN_ROLL) {
         if (c->gemm_roll) {
             hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                               c->gemm_store_policy);
+            rolled = true;
+        }
+    }
+    if constexpr (!CPLX) {
+        if (!rolled && c->mfma_4x4) {          // the real kind's products on v_mfma_f64_4x4x4_4b_f64
+            if (lds > 48 * 1024)
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<false, NG, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((panel_gemm_mfma<false, NG, false, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
                                c->gemm_store_policy);
             rolled = true;
         }
@@ -1479,7 +1494,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_prefetch_y")) { c->gemm_prefetch_y = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
-    if (!strcmp(key, "mfma_4x4")) { c->mfma_4x4 = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "mfma_4x4")) { c->mfma_4x4 = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "upd_debug")) { c->upd_debug = value & 15; return LK_OK; }
     if (!strcmp(key, "xhy_debug")) { c->xhy_debug = value & 3; return LK_OK; }
     if (!strcmp(key, "gemm_roll")) { c->gemm_roll = value ? 1 : 0; return LK_OK; }

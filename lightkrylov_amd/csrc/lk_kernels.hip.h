@@ -1039,7 +1039,7 @@ __device__ __forceinline__ v4d mfma_f64_16x16x4_by4(const double (&a4)[4], doubl
 // the result is added to is loaded BEFORE the k-loop, 16 more 16-byte loads in flight per lane under the MFMAs, instead of after it, where a
 // wave had nothing else to issue: block DGS k = 128, p = 32: 10.3 -> 9.8 ms, k = 32, p = 32: 4.9 -> 4.5 ms.  (Compiled into the plain
 // product as well it cost that one 13 %, so it is a template flag; for the complex three-product kernel it changed nothing and is not built.)
-template <bool CPLX, int NG, bool PFY = false, bool ROLL = false>
+template <bool CPLX, int NG, bool PFY = false, bool ROLL = false, bool M4 = false>
 __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                        double *__restrict__ Y, int64_t ldy, int qn,
                                                        const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
@@ -1187,6 +1187,17 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
 #pragma unroll
                             for (int g2 = 0; g2 < 2; ++g2)
                                 acc[g][g2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x[u][g2].y, acc[g][g2][0], 0, 0, 0);
+                        } else if constexpr (M4) {
+                            // the same products on v_mfma_f64_4x4x4_4b_f64 (mfma_f64_16x16x4_by4): the four A operands are the entries
+                            // 4 m + (lane & 3) of the lane's 16-output row of the coefficient tile
+                            double a4[4];
+#pragma unroll
+                            for (int mm = 0; mm < 4; ++mm) a4[mm] = tiles[(g * nt + t) * 64 + (lane & 48) + 4 * mm + (lane & 3)];
+#pragma unroll
+                            for (int g2 = 0; g2 < 2; ++g2) {
+                                acc[g][g2][0] = mfma_f64_16x16x4_by4(a4, x[u][g2].x, acc[g][g2][0]);
+                                acc[g][g2][1] = mfma_f64_16x16x4_by4(a4, x[u][g2].y, acc[g][g2][1]);
+                            }
                         } else {
 #pragma unroll
                             for (int g2 = 0; g2 < 2; ++g2) {
@@ -1496,6 +1507,34 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
                         if constexpr (CPLX) acc_im[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (arow & 1) ? -b2[J] : b2[J], acc_im[J], 0, 0, 0);
                     }
                 }
+            }
+        } else if (m4 && active && TR == 32 && PJM == 8 && !CPLX) {
+            // 4x4x4 products, software-pipelined: the twelve operands of row step s + 1 (four A, up to eight B) are read from LDS BEFORE the 32
+            // MFMAs of step s are issued -- at 16 cycles per MFMA a `ds_read -> s_waitcnt -> 4 MFMAs` chain per tile would expose the LDS
+            // latency in front of every 64 cycles of matrix work (measured: 5.4 ms against 4.3 for the 16x16x4 loop below)
+            double a4n[4], bn[PJM];
+            auto fetch = [&](int step) {
+                const int ro = 4 * step + arow;
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) a4n[mm] = Xb[(16 * wi + 4 * mm + (lane & 3)) * S + ro];
+#pragma unroll
+                for (int J = 0; J < PJM; ++J)
+                    if (J < PJ && (!upper || J >= wi)) bn[J] = Yb[(16 * J + acol) * S + ro];
+            };
+#pragma unroll
+            for (int J = 0; J < PJM; ++J) bn[J] = 0.0;
+            fetch(wr);
+#pragma unroll 1
+            for (int step = wr; step < TR / 4; step += WR) {
+                double a4[4], b[PJM];
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) a4[mm] = a4n[mm];
+#pragma unroll
+                for (int J = 0; J < PJM; ++J) b[J] = bn[J];
+                if (step + WR < TR / 4) fetch(step + WR);
+#pragma unroll
+                for (int J = 0; J < PJM; ++J)
+                    if (J < PJ && (!upper || J >= wi)) acc_re[J] = mfma_f64_16x16x4_by4(a4, b[J], acc_re[J]);
             }
         } else if (m4 && active) {
             // the same products on the 4x4x4 instruction (72 instead of 49 TFLOP/s sustained): four A operands per row step -- the columns
