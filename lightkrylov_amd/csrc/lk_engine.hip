@@ -89,7 +89,7 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
-    int mfma_4x4 = 1;          // matrix-core kernels issue their products as v_mfma_f64_4x4x4_4b_f64 (72 TFLOP/s sustained) instead of v_mfma_f64_16x16x4_f64 (49): same lanes, same
+    int mfma_4x4 = 0;          // matrix-core kernels issue their products as v_mfma_f64_4x4x4_4b_f64 (72 TFLOP/s sustained) instead of v_mfma_f64_16x16x4_f64 (49): same lanes, same
                                // accumulators, four A operands per step (lk_kernels.hip.h, mfma_f64_16x16x4_by4); 0: the 16x16x4 instruction
     int upd_debug = 0;         // diagnostic only (wrong results): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
     int xhy_debug = 0;         // diagnostic only (wrong results): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
@@ -793,7 +793,8 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         const size_t ldsg = (size_t)KP * 16 * 34 * sizeof(double);
         {
             ProfScope ps(c, "xhy_mfma", (double)Bx->n * 8.0 * k);
-            hipLaunchKernelGGL(panel_gram_mfma, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
+            if (c->mfma_4x4) hipLaunchKernelGGL(panel_gram_mfma<true>, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
+            else hipLaunchKernelGGL(panel_gram_mfma<false>, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
         }
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, partg, (int)gg, npartg, (int)gg, k, p, ED, flags, outg);
@@ -979,6 +980,16 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     }
     constexpr bool CAN_ROLL = !(CPLX && NG >= 8);          // (64 complex outputs as the doubled real problem: the ring does not fit the register file)
     bool rolled = false;
+    if constexpr (!CPLX) {
+        if (c->gemm_roll && c->mfma_4x4) {          // rolling prefetch of X + the 4x4x4 products
+            if (lds > 48 * 1024)
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<false, NG, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((panel_gemm_mfma<false, NG, false, true, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                               c->gemm_store_policy);
+            HIPCHK(hipGetLastError());
+            return LK_OK;
+        }
+    }
     if constexpr (CAN_ROLL) {
         if (c->gemm_roll) {
             hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,

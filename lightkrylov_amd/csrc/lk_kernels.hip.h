@@ -1140,6 +1140,14 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                                 acc[g][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xb.x, acc[g][1][0], 0, 0, 0);
                                 acc[g][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xa.y, acc[g][0][0], 0, 0, 0);
                                 acc[g][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xb.y, acc[g][1][0], 0, 0, 0);
+                            } else if constexpr (M4) {
+                                double a4[4];
+#pragma unroll
+                                for (int mm = 0; mm < 4; ++mm) a4[mm] = tiles[(g * nt + t) * 64 + (lane & 48) + 4 * mm + (lane & 3)];
+                                acc[g][0][0] = mfma_f64_16x16x4_by4(a4, xa.x, acc[g][0][0]);
+                                acc[g][0][1] = mfma_f64_16x16x4_by4(a4, xa.y, acc[g][0][1]);
+                                acc[g][1][0] = mfma_f64_16x16x4_by4(a4, xb.x, acc[g][1][0]);
+                                acc[g][1][1] = mfma_f64_16x16x4_by4(a4, xb.y, acc[g][1][1]);
                             } else {
                                 acc[g][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xa.x, acc[g][0][0], 0, 0, 0);
                                 acc[g][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xa.y, acc[g][0][1], 0, 0, 0);
@@ -1172,6 +1180,36 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                     }
                 }
             }
+            if constexpr (M4 && !CPLX) {
+                // the products on v_mfma_f64_4x4x4_4b_f64 (mfma_f64_16x16x4_by4), software-pipelined over the U NG (k-step, output group) pairs of
+                // the batch: the four A operands of pair i + 1 -- the entries 4 m + (lane & 3) of the lane's 16-output row of its coefficient
+                // tile -- are read from LDS BEFORE the sixteen MFMAs of pair i are issued (256 cycles of matrix pipe cover the LDS latency; read
+                // just ahead of their use, as the compiler schedules them on its own, every pair waited ~100 cycles for them)
+                double a4c[4], a4n[4];
+                auto geta = [&](int idx, double (&dst)[4]) {
+                    const int u = idx / NG, g = idx % NG, t = t0 + u;
+                    const int tt = t < nt ? t : nt - 1;
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm) dst[mm] = tiles[(g * nt + tt) * 64 + (lane & 48) + 4 * mm + (lane & 3)];
+                };
+                geta(0, a4c);
+#pragma unroll
+                for (int idx = 0; idx < U * NG; ++idx) {
+                    const int u = idx / NG, g = idx % NG;
+                    if (idx + 1 < U * NG) geta(idx + 1, a4n);
+                    __builtin_amdgcn_sched_barrier(0);                 // (keep the reads AHEAD of the MFMAs: the scheduler sinks them to their use)
+                    if (t0 + u < nt) {
+#pragma unroll
+                        for (int g2 = 0; g2 < 2; ++g2) {
+                            acc[g][g2][0] = mfma_f64_16x16x4_by4(a4c, x[u][g2].x, acc[g][g2][0]);
+                            acc[g][g2][1] = mfma_f64_16x16x4_by4(a4c, x[u][g2].y, acc[g][g2][1]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm) a4c[mm] = a4n[mm];
+                }
+            } else
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int t = t0 + u;
@@ -1187,17 +1225,6 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
 #pragma unroll
                             for (int g2 = 0; g2 < 2; ++g2)
                                 acc[g][g2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x[u][g2].y, acc[g][g2][0], 0, 0, 0);
-                        } else if constexpr (M4) {
-                            // the same products on v_mfma_f64_4x4x4_4b_f64 (mfma_f64_16x16x4_by4): the four A operands are the entries
-                            // 4 m + (lane & 3) of the lane's 16-output row of the coefficient tile
-                            double a4[4];
-#pragma unroll
-                            for (int mm = 0; mm < 4; ++mm) a4[mm] = tiles[(g * nt + t) * 64 + (lane & 48) + 4 * mm + (lane & 3)];
-#pragma unroll
-                            for (int g2 = 0; g2 < 2; ++g2) {
-                                acc[g][g2][0] = mfma_f64_16x16x4_by4(a4, x[u][g2].x, acc[g][g2][0]);
-                                acc[g][g2][1] = mfma_f64_16x16x4_by4(a4, x[u][g2].y, acc[g][g2][1]);
-                            }
                         } else {
 #pragma unroll
                             for (int g2 = 0; g2 < 2; ++g2) {
@@ -1532,9 +1559,11 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
 #pragma unroll
                 for (int J = 0; J < PJM; ++J) b[J] = bn[J];
                 if (step + WR < TR / 4) fetch(step + WR);
+                __builtin_amdgcn_sched_barrier(0);                     // (the scheduler sinks the reads to their use otherwise)
 #pragma unroll
                 for (int J = 0; J < PJM; ++J)
                     if (J < PJ && (!upper || J >= wi)) acc_re[J] = mfma_f64_16x16x4_by4(a4, b[J], acc_re[J]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else if (m4 && active) {
             // the same products on the 4x4x4 instruction (72 instead of 49 TFLOP/s sustained): four A operands per row step -- the columns
@@ -1881,6 +1910,7 @@ __global__ __launch_bounds__(512) void panel_gram_mfma3m(const double *__restric
 // stride 34 words: conflict free); the next tile's loads are in flight while the current tile's MFMAs run.
 // Results: partial[block][slot], slot = j (k + 1) + i for i in tile row I, j in tile column J >= I -- panel_xhy_mfma's layout with
 // flags = 3 (Y is X, upper tiles only), summed by finish_xhy; no norm slots.
+template <bool M4>
 __global__ __launch_bounds__(512) void panel_gram_mfma(const double *__restrict__ X, int64_t ldx, int k, int64_t n,
                                                        double *__restrict__ partial) {
     constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = 512 / CH, NXP = 128 / CPP;      // 32 columns staged per block-wide pass
@@ -1948,14 +1978,31 @@ __global__ __launch_bounds__(512) void panel_gram_mfma(const double *__restrict_
 #pragma unroll 1
         for (int step = 0; step < TR / 4; ++step) {
             const int ro = 4 * step + arow;
-            double a = 0.0;
             int lastI = -1;
+            if constexpr (M4) {
+                // the same products on v_mfma_f64_4x4x4_4b_f64 (mfma_f64_16x16x4_by4): four A operands per tile row, the B operand as below
+                double a4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < MAXT; ++q) {
-                if (q < nt) {
-                    if (tI[q] != lastI) { a = Xt[(16 * tI[q] + acol) * S + ro]; lastI = tI[q]; }
-                    const double b = (tJ[q] == tI[q]) ? a : Xt[(16 * tJ[q] + acol) * S + ro];
-                    acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+                for (int q = 0; q < MAXT; ++q) {
+                    if (q < nt) {
+                        if (tI[q] != lastI) {
+#pragma unroll
+                            for (int mm = 0; mm < 4; ++mm) a4[mm] = Xt[(16 * tI[q] + 4 * mm + (lane & 3)) * S + ro];
+                            lastI = tI[q];
+                        }
+                        const double b = Xt[(16 * tJ[q] + acol) * S + ro];
+                        acc[q] = mfma_f64_16x16x4_by4(a4, b, acc[q]);
+                    }
+                }
+            } else {
+                double a = 0.0;
+#pragma unroll
+                for (int q = 0; q < MAXT; ++q) {
+                    if (q < nt) {
+                        if (tI[q] != lastI) { a = Xt[(16 * tI[q] + acol) * S + ro]; lastI = tI[q]; }
+                        const double b = (tJ[q] == tI[q]) ? a : Xt[(16 * tJ[q] + acol) * S + ro];
+                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+                    }
                 }
             }
         }

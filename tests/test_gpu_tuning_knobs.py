@@ -113,3 +113,46 @@ def test_lazy_gram_loop_of_the_reference_costs_one_pass(dtype):
         del B
         c.close()
     assert np.abs(res[0] - res[1]).max() <= 1e-12 * np.linalg.norm(X, axis=0).max() ** 2
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("cfg", [dict(), dict(xhy_db=0), dict(xhy_db=2), dict(gram_tiles=0), dict(gram_tiles=2), dict(gram_tiles=2, gram_grid_mult=3),
+                                 dict(xhy_tr32=1), dict(gemm_roll=1), dict(mfma_4x4=1), dict(mfma_4x4=2), dict(mfma_4x4=1, gram_tiles=2),
+                                 dict(mfma_4x4=1, gemm_roll=1)],
+                         ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "defaults")
+def test_matrix_core_kernel_variants_agree_with_the_oracle(dtype, cfg):
+    """Round 5's kernel variants behind lk_set_tuning (double-buffered tiles, dealt Gram tiles, operand / rolling prefetch, the products on
+    v_mfma_f64_4x4x4_4b_f64) are schedules of the SAME sums: Gram (AbstractVectors.fypp:645-657), innerprod_matrix (:670-695), the block
+    DGS (gram_schmidt.fypp:59-105) and linear_combination (AbstractVectors.fypp:596-642) against the oracle at ragged sizes."""
+    c = lk.Context(device=0)
+    for key, val in cfg.items():
+        c.set_tuning(key, val)
+    n = 10_037
+    for k, p in ((128, 40), (72, 64), (48, 9)):
+        X, Y = basis(n, k, dtype, 7), basis(n, p, dtype, 400)
+        Bx = lk.krylov_basis_gpu(n, k, dtype, c); Bx.upload(X)
+        By = lk.krylov_basis_gpu(n, p, dtype, c); By.upload(Y)
+        scale = np.linalg.norm(X, axis=0).max() * max(np.linalg.norm(X, axis=0).max(), np.linalg.norm(Y, axis=0).max())
+        assert np.abs(lk.Gram(Bx) - ora.gram(X)).max() <= 1e-13 * scale
+        assert np.abs(lk.innerprod(Bx, By) - X.conj().T @ Y).max() <= 1e-13 * scale
+        # X <- X Z (the restart update) on a copy
+        rng = np.random.default_rng(5)
+        Z = rng.standard_normal((k, p)) + (1j * rng.standard_normal((k, p)) if dtype == np.complex128 else 0)
+        Z = np.asfortranarray(Z.astype(dtype))
+        Bz = lk.linear_combination(Bx, Z)
+        ref = X @ Z
+        assert np.abs(Bz.download(0, p) - ref).max() <= 1e-13 * np.abs(X).max() * np.abs(Z).sum(axis=0).max() * 4
+        # block DGS of Y against an orthonormal X
+        Q, _ = np.linalg.qr(X)
+        Bx.upload(np.asfortranarray(Q))
+        beta = np.zeros((k, p), dtype=dtype, order="F")
+        assert lk.double_gram_schmidt_step(By, Bx, False, beta) == 0
+        Yo = Y.copy(order="F")
+        ho = np.zeros((k, p), dtype=dtype, order="F")
+        for j in range(p):
+            hj, _ = ora.double_gram_schmidt_step(Yo[:, j], Q)
+            ho[:, j] = hj
+        assert np.abs(beta - ho).max() <= 1e-12 * np.linalg.norm(Y, axis=0).max()
+        assert_columns_close(By.download(0, p), Yo, f"block DGS k={k} p={p} {cfg}")
+        del Bx, By, Bz
+    c.close()

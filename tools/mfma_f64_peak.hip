@@ -36,6 +36,71 @@ __global__ __launch_bounds__(256) void k4(double *out, int iters, double a, doub
     for (int i = 0; i < 8; ++i) s += acc[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// the same two instructions with operands that DIFFER from instruction to instruction (eight A and eight B registers of pseudo-random values):
+// does the rate depend on the data / the operand registers?  which = 0: 16x16x4, 1: 4x4x4_4b
+template <int WHICH>
+__global__ __launch_bounds__(256) void kvar(double *out, int iters, const double *seed) {
+    double a[8], b[8];
+    for (int i = 0; i < 8; ++i) { a[i] = seed[(threadIdx.x * 17 + i * 5) & 1023]; b[i] = seed[(threadIdx.x * 29 + i * 11 + 3) & 1023]; }
+    double s = 0;
+    if constexpr (WHICH == 0) {
+        v4d acc[8];
+        for (int i = 0; i < 8; ++i) acc[i] = v4d{0, 0, 0, 0};
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[(i + it) & 7], acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        double acc[32];
+        for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[i & 7], b[(i >> 2)], acc[i], 0, 0, 0);
+        }
+        for (int i = 0; i < 32; ++i) s += acc[i];
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// 4x4x4 MFMAs fed like the library's kernels feed them: per step twelve operands read from LDS (four A, eight B) for 32 MFMAs, the reads of step
+// s + 1 issued before the MFMAs of step s (MODE 1), or read right before their use (MODE 0); MODE 2: no LDS at all, but the register copies of
+// the pipelined loop.  What does an LDS-fed 4x4x4 loop sustain?
+template <int MODE>
+__global__ __launch_bounds__(256) void klds(double *out, int iters, const double *seed) {
+    __shared__ double tile[64 * 34];
+    for (int i = threadIdx.x; i < 64 * 34; i += 256) tile[i] = seed[i & 1023];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, arow = lane >> 4, acol = lane & 15;
+    double acc[32];
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    double an[4], bn[8];
+    auto fetch = [&](int step) {
+        const int ro = 4 * (step & 7) + arow;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) an[m] = tile[(4 * m + (lane & 3)) * 34 + ro];
+#pragma unroll
+        for (int J = 0; J < 8; ++J) bn[J] = tile[((16 + 4 * J + acol) & 63) * 34 + ro];
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        double a[4], b[8];
+        if constexpr (MODE == 0) fetch(it);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = an[m];
+#pragma unroll
+        for (int J = 0; J < 8; ++J) b[J] = bn[J];
+        if constexpr (MODE == 1) { fetch(it + 1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+        for (int J = 0; J < 8; ++J)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[4 * J + m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[m], b[J], acc[4 * J + m], 0, 0, 0);
+        if constexpr (MODE == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    double s = 0;
+    for (int i = 0; i < 32; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 __global__ __launch_bounds__(256) void kfma(double *out, int iters, double a, double b) {
     double acc[16];
     for (int i = 0; i < 16; ++i) acc[i] = threadIdx.x * 1e-9 + i;
@@ -114,6 +179,39 @@ int main() {
         hipEventRecord(e1); hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
         printf("{\"v_mfma_f64_4x4x4_4b\": true, \"waves_per_simd\": %d, \"ms\": %.3f, \"TFLOPs\": %.1f}\n", bpc, ms, (double)256 * bpc * 4 * it4 * 8.0 * 512.0 / ms / 1e9);
+    }
+    {
+        double hs[1024];
+        unsigned long long z = 88172645463325252ull;
+        for (int i = 0; i < 1024; ++i) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; hs[i] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+        double *ds; hipMalloc(&ds, sizeof(hs)); hipMemcpy(ds, hs, sizeof(hs), hipMemcpyHostToDevice);
+        for (int bpc : {2, 8}) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kvar<0>, dim3(256 * bpc), dim3(256), 0, 0, d, 4000, ds);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            printf("{\"random_operands\": \"16x16x4\", \"waves_per_simd\": %d, \"ms\": %.3f, \"TFLOPs\": %.1f}\n", bpc, ms, (double)256 * bpc * 4 * 4000 * 8.0 * 2048.0 / ms / 1e9);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(kvar<1>, dim3(256 * bpc), dim3(256), 0, 0, d, 4000, ds);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            printf("{\"random_operands\": \"4x4x4_4b\", \"waves_per_simd\": %d, \"ms\": %.3f, \"TFLOPs\": %.1f}\n", bpc, ms, (double)256 * bpc * 4 * 4000 * 32.0 * 512.0 / ms / 1e9);
+        }
+    }
+    {
+        double hs2[1024];
+        for (int i = 0; i < 1024; ++i) hs2[i] = 0.001 * (i % 97) - 0.04;
+        double *ds2; hipMalloc(&ds2, sizeof(hs2)); hipMemcpy(ds2, hs2, sizeof(hs2), hipMemcpyHostToDevice);
+        for (int bpc : {2, 4}) {
+            for (int mode = 0; mode < 3; ++mode) {
+                hipEventRecord(e0);
+                if (mode == 0) hipLaunchKernelGGL(klds<0>, dim3(256 * bpc), dim3(256), 0, 0, d, 4000, ds2);
+                else if (mode == 1) hipLaunchKernelGGL(klds<1>, dim3(256 * bpc), dim3(256), 0, 0, d, 4000, ds2);
+                else hipLaunchKernelGGL(klds<2>, dim3(256 * bpc), dim3(256), 0, 0, d, 4000, ds2);
+                hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+                printf("{\"lds_fed_4x4x4\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"TFLOPs\": %.1f}\n",
+                       mode == 0 ? "12 reads right before 32 MFMAs" : (mode == 1 ? "reads of step s+1 before the MFMAs of step s" : "no LDS, register copies only"), bpc, ms,
+                       (double)256 * bpc * 4 * 4000 * 32.0 * 512.0 / ms / 1e9);
+            }
+        }
     }
     // mixed: 8 blocks per CU, in every block two waves of MFMAs and two of FMAs, iteration counts chosen so that both halves take about as long alone
     for (int rep = 0; rep < 2; ++rep) {
