@@ -152,8 +152,10 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * Round 5, matrix-core kernels (same results to rounding): "xhy_db" (default 1: panel_xhy_mfma with a double-buffered LDS tile, one barrier per
  * tile, for the 128-column variants; 2: the <= 32 right-hand-side variants too; 0: never); "gram_tiles" (default 1: the real Gram matrix of 33..64
  * columns by panel_gram_mfma -- upper tiles dealt to the waves, two blocks per CU --; 2: up to 128 columns; 0: never) with "gram_grid_mult";
- * "xhy_tr32" and "gemm_roll" (default 0: operand prefetch on 32-row tiles / rolling prefetch of X in the tall-skinny product -- both measured
- * slower, kept for A/B, profiles/r05_*); "mfma_4x4" (default 0; 1: the real kind's matrix-core kernels issue every 16x16x4 product as four
+ * "gemm_roll" (default 1: the real tall-skinny product with 33..64 outputs per pass keeps a ring of four k-steps of X in flight, refilled as
+ * they are consumed and carried across tiles, on straight-line code; 2: every variant that has a ring; 0: batches of four k-steps everywhere --
+ * same MFMAs in the same order, bit-identical results); "xhy_tr32" (default 0: operand prefetch on 32-row tiles -- measured slower, kept
+ * for A/B, profiles/r05_*); "mfma_4x4" (default 0; 1: the real kind's matrix-core kernels issue every 16x16x4 product as four
  * v_mfma_f64_4x4x4_4b_f64 -- 1.5 x the issue rate in isolation, slower in every kernel, profiles/r05_fp64_mfma_peak.txt --; 2: panel_xhy_mfma
  * on 32-row tiles with the software-pipelined loop as well).  DIAGNOSTIC keys that switch parts of a kernel off -- WRONG RESULTS, phase timing only, used by
  * tools/bench_gram.py and tools/bench_upd_phases.py: "xhy_debug" (1 = panel_xhy_mfma without its MFMAs, 2 = without its global loads after

@@ -93,9 +93,10 @@ struct lk_context_s {
                                // accumulators, four A operands per step (lk_kernels.hip.h, mfma_f64_16x16x4_by4); 0: the 16x16x4 instruction
     int upd_debug = 0;         // diagnostic only (wrong results): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
     int xhy_debug = 0;         // diagnostic only (wrong results): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
-    int gemm_roll = 0;         // MFMA tall-skinny product: rolling prefetch of X (a ring of 4 k-steps refilled as they are consumed) instead of batches of 4 k-steps (loaded, waited for,
-                               // multiplied).  Measured SLOWER for the real kind (k = 64, q = 32: 1.39 -> 1.87 ms; k = 128, q = 64: 3.50 -> 3.61) and +2-5 % for narrow complex products
-                               // (profiles/r05_ab_gemm_roll.jsonl): off
+    int gemm_roll = 1;         // MFMA tall-skinny product: rolling prefetch of X (a ring of 4 k-steps refilled as they are consumed, carried across tiles) instead of batches of 4
+                               // k-steps (loaded, waited for, multiplied).  1: the real kind with 33..64 outputs per pass, on the STRAIGHT-LINE ring (no branch between loads and MFMAs,
+                               // exact vmcnt counts; k = 128, q = 64 at n = 10^7: 3.45-3.73 -> 3.16-3.24 ms); 2: every variant that has a ring (the narrow real ones measure the same
+                               // as the batch schedule, the complex doubled-real ones keep the guarded ring, +2-5 % on narrow products); 0: never (profiles/r05_ab_gemm_roll.jsonl)
     int xhy_tr32 = 0;          // the 128-column real variant of panel_xhy_mfma on 32-row tiles with the next row step's operands read ahead of the current step's MFMAs: measured SLOWER
                                // (Gram k = 128: 5.5 vs 4.2 ms, profiles/r05_gram_phases.jsonl -- the MFMA phase already runs at the pipe's sustained rate): off
     int xhy_db = 1;            // panel_xhy_mfma with a double-buffered LDS tile (1: the 128-column variants; 2: the <= 32 right-hand-side ones too; 0: never)
@@ -981,7 +982,7 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     constexpr bool CAN_ROLL = !(CPLX && NG >= 8);          // (64 complex outputs as the doubled real problem: the ring does not fit the register file)
     bool rolled = false;
     if constexpr (!CPLX) {
-        if (c->gemm_roll && c->mfma_4x4) {          // rolling prefetch of X + the 4x4x4 products
+        if ((c->gemm_roll >= 2 || (c->gemm_roll == 1 && NG == 4)) && c->mfma_4x4 && (kk & 15) == 0) {          // rolling prefetch of X + the 4x4x4 products
             if (lds > 48 * 1024)
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<false, NG, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((panel_gemm_mfma<false, NG, false, true, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
@@ -991,7 +992,11 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
         }
     }
     if constexpr (CAN_ROLL) {
-        if (c->gemm_roll) {
+        // "gemm_roll" = 1 (default): the real product with 33..64 outputs per pass -- the restart update X <- X Z of krylov_schur -- on the straight-line
+        // ring (k = 128, q = 64 at n = 10^7: 3.45-3.73 -> 3.16-3.24 ms, 51 TFLOP/s); the narrower ones measured the same on either schedule
+        // (k = 64, q = 32: 1.38-1.44 ms both) and keep the batch schedule's three blocks per CU; 2 = every variant that has a ring
+        // (the real kind's straight-line ring is unrolled for the basis widths 128 and 64: any other width keeps the batch schedule)
+        if ((CPLX || kk == 128 || kk == 64) && (c->gemm_roll >= 2 || (c->gemm_roll == 1 && !CPLX && NG == 4))) {
             hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
                                c->gemm_store_policy);
             rolled = true;
@@ -1019,15 +1024,22 @@ int gemm_mfma3m_one(lk_context_t c, const double *X, int64_t ldx, int kk, double
                     int accumulate) {
     const int nt = (kk + 3) / 4;
     const size_t lds = (size_t)NG * nt * 128 * sizeof(double);
-    if (lds > 48 * 1024)
+    const bool roll = c->gemm_roll >= 1 && (kk == 128 || kk == 64);       // "gemm_roll": see gemm_mfma_one (the complex kind: every width of product measured faster on the ring)
+    if (lds > 48 * 1024) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma3m<NG, NR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma3m<NG, NR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     constexpr int tile_rows = 8 * NR * 16;
     int64_t g = (n + tile_rows - 1) / tile_rows;
     const int64_t cap = (int64_t)c->num_cu * (NG >= 4 ? 2 : (NG >= 2 ? 2 : c->gemm_grid_mult));
     if (g > cap) g = cap;
     if (g < 1) g = 1;
-    hipLaunchKernelGGL((panel_gemm_mfma3m<NG, NR>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                       c->gemm_store_policy);
+    if (roll)
+        hipLaunchKernelGGL((panel_gemm_mfma3m<NG, NR, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                           c->gemm_store_policy);
+    else
+        hipLaunchKernelGGL((panel_gemm_mfma3m<NG, NR>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
+                           c->gemm_store_policy);
     HIPCHK(hipGetLastError());
     return LK_OK;
 }
@@ -1508,7 +1520,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "mfma_4x4")) { c->mfma_4x4 = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "upd_debug")) { c->upd_debug = value & 15; return LK_OK; }
     if (!strcmp(key, "xhy_debug")) { c->xhy_debug = value & 3; return LK_OK; }
-    if (!strcmp(key, "gemm_roll")) { c->gemm_roll = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "gemm_roll")) { c->gemm_roll = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "xhy_tr32")) { c->xhy_tr32 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "xhy_db")) { c->xhy_db = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "gram_tiles")) { c->gram_tiles = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }

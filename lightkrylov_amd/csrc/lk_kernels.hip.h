@@ -1064,6 +1064,9 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
     const double *__restrict__ Xl = X + (int64_t)kk * xstride;      // this lane's column within a k-step
     const bool kfast = (k & 3) == 0;
 
+    constexpr int RING = 4;                      // (eight k-steps for the narrow products, NG <= 2: the same 1.41 / 2.28 ms at k = 64 / 128, q = 32 as four, and as the batch schedule)
+    v2d xring[ROLL ? RING : 1][2];               // ROLL, straight-line path: the ring of k-steps of X, alive ACROSS tiles
+    bool primed = false;                         // ... and whether it already holds the first U k-steps of the tile about to start
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * tile_rows + (int64_t)wave * (2 * RG) + (CPLX ? j : 2 * j), r1 = r0 + RG;
         const bool fast = kfast && (tile + 1) * tile_rows <= n;
@@ -1096,7 +1099,89 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
         // the way through the k-loop.  (Rounds 2-4 loaded a BATCH of U k-steps, waited for all of it -- s_waitcnt vmcnt(0) -- and
         // only then issued its 4 U NG MFMAs: every batch paid an HBM round trip with an idle matrix pipe and nothing in flight behind
         // it; a double-buffered variant of that with half-size batches had measured slower.)  ROLL = false keeps the batch schedule.
-        if constexpr (ROLL) {
+        if constexpr (ROLL && !CPLX && !M4) {
+          constexpr int UR = RING;              // ring depth in k-steps: 2 UR loads of 16 B per lane in flight
+          if (fast && (nt == 32 || nt == 16)) {
+            // straight-line ring (full tile, k = 128 or 64: the launcher sends no other width here): NO branch between the loads and the MFMAs of a k-step, so the compiler keeps
+            // exact s_waitcnt vmcnt(2 (UR - 1)) counts instead of draining the queue at every basic-block boundary of the guarded version
+            // below.  The ring never runs dry: the refills of the last UR k-steps are the FIRST UR k-steps of this block's next tile (when
+            // that one is a full tile too; its own first columns otherwise -- cache hits, never consumed), in flight under the epilogue's stores.
+            auto &x = xring;
+            // ONE running (scalar) column offset, advanced by a k-step (4 columns) per refill and kept opaque: left to itself the compiler
+            // forms the 32 column addresses of the unrolled k-loop ahead of the tile loop and spills them
+            const double *__restrict__ xb = Xl + r0;
+            const bool next_fast = (tile + gridDim.x + 1) * tile_rows <= n;
+            const int64_t dnext = next_fast ? (int64_t)gridDim.x * tile_rows : (int64_t)0;      // (scalar: rows from this tile to the block's next one)
+            const int64_t xstep = 4 * xstride;
+            if (!primed) {
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    x[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xb + u * xstep));
+                    x[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xb + u * xstep + RG));
+                }
+            }
+            primed = next_fast;
+            int64_t xo = UR * xstep, xo2 = dnext;
+            asm volatile("" : "+s"(xo), "+s"(xo2));
+            // one k-step: this step's A operands from LDS, its MFMAs on ring slot u, then the slot's refill -- pinned in that order (the
+            // scheduler otherwise hoists the refills of all UR slots to the top of the body and consumes them in the same iteration:
+            // the batch schedule again)
+            auto kstep = [&](int t, int u, bool tail) {
+                double a0[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) a0[g] = tiles[(g * nt + t) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    acc[g][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[g], x[u][0].x, acc[g][0][0], 0, 0, 0);
+                    acc[g][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[g], x[u][0].y, acc[g][0][1], 0, 0, 0);
+                    acc[g][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[g], x[u][1].x, acc[g][1][0], 0, 0, 0);
+                    acc[g][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[g], x[u][1].y, acc[g][1][1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const double *__restrict__ src = xb + (tail ? xo2 : xo);
+                x[u][0] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(src));
+                x[u][1] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(src + RG));
+                xo += tail ? (int64_t)0 : xstep;
+                xo2 += tail ? xstep : (int64_t)0;
+                asm volatile("" : "+s"(xo), "+s"(xo2));
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // the two basis widths of the restart update and the block Gram-Schmidt (k = 128, 64) fully unrolled: the waitcnt pass drains the
+            // whole ring -- s_waitcnt vmcnt(0) -- at the head of a LOOP over the ring (it merges the back edge conservatively), but counts
+            // exactly (vmcnt(2 (UR - 1))) along straight-line code
+            if (nt == 32) {
+#pragma unroll
+                for (int t = 0; t < 32; ++t) kstep(t, t & (UR - 1), t + UR >= 32);
+            } else if (nt == 16) {                 // (spelled out: the compiler folds the LDS offsets of the unrolled steps only for a known nt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) kstep(t, t & (UR - 1), t + UR >= 16);
+            }
+          } else {
+            // (the ragged last tile, or a basis width that is not a multiple of 16: one guarded k-step at a time -- at most one tile per launch takes this path)
+            int jl = j, kl = kk;
+            asm volatile("" : "+v"(jl), "+v"(kl));                    // (this rare path's addresses formed here, not kept in registers across the unrolled k-loops)
+            const int64_t r0s = tile * tile_rows + (int64_t)wave * (2 * RG) + 2 * jl;
+            const double *__restrict__ Xs = X + (int64_t)kl * xstride;
+#pragma unroll 1
+            for (int t = 0; t < nt; ++t) {
+                v2d xa = v2d{0.0, 0.0}, xc2 = v2d{0.0, 0.0};
+                if ((4 * t + kl) < k) {
+                    const double *__restrict__ xc = Xs + (int64_t)(4 * t) * xstride;
+                    xa = load_y<CPLX>(xc, r0s, n, false);
+                    xc2 = load_y<CPLX>(xc, r0s + RG, n, false);
+                }
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const double a0 = tiles[(g * nt + t) * 64 + lane];
+                    acc[g][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xa.x, acc[g][0][0], 0, 0, 0);
+                    acc[g][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xa.y, acc[g][0][1], 0, 0, 0);
+                    acc[g][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xc2.x, acc[g][1][0], 0, 0, 0);
+                    acc[g][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xc2.y, acc[g][1][1], 0, 0, 0);
+                }
+            }
+          }
+        } else if constexpr (ROLL) {
             v2d x[U][2];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1283,7 +1368,9 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
 // Rounding: Im(X C) carries the cancellation of P3 - P1 - P2, i.e. an error of order eps (|Xr| + |Xi|)(|Cr| + |Ci|) per term --
 // bounded NORMWISE like the 4-multiplication form (the comparisons of this suite are normwise), not componentwise.
 // Cp: [group][k-step][Cr | Ci][64 lanes] from pack_coef_mfma3m.
-template <int NG, int NR>                     // NR: row groups of 16 rows per wave (2; 1 for 64 outputs, whose 12 accumulators of 8 registers leave no room for 24)
+// ROLL (round 5): the k-steps of X as a ring refilled step by step on straight-line code and carried across tiles, as panel_gemm_mfma's
+// (full tiles, k = 128 or 64); the batch schedule otherwise.
+template <int NG, int NR, bool ROLL = false>  // NR: row groups of 16 rows per wave (2; 1 for 64 outputs, whose 12 accumulators of 8 registers leave no room for 24)
 __global__ __launch_bounds__(512) void panel_gemm_mfma3m(const double *__restrict__ X, int64_t ldx, int k,
                                                          double *__restrict__ Y, int64_t ldy, int qn,
                                                          const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
@@ -1304,6 +1391,9 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma3m(const double *__restric
     const double *__restrict__ Xl = X + (int64_t)kk * xstride;      // this lane's column within a k-step
     const bool kfast = (k & 3) == 0;
 
+    constexpr int UR = 4;                        // ring depth in k-steps
+    v2d xring[ROLL ? UR : 1][NR];                // ROLL: the ring of k-steps of X, alive ACROSS tiles
+    bool primed = false;                         // ... and whether it already holds the first U k-steps of the tile about to start
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * tile_rows + (int64_t)wave * (NR * RG) + j;
         const bool fast = kfast && (tile + 1) * tile_rows <= n;
@@ -1315,6 +1405,93 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma3m(const double *__restric
 #pragma unroll
                 for (int e = 0; e < 3; ++e) acc[g][g2][e] = v4d{0.0, 0.0, 0.0, 0.0};
 
+        bool done = false;
+        int64_t xs = xstride;
+        if constexpr (ROLL) asm volatile("" : "+s"(xs));      // (the lane's column base re-formed per tile: kept across the unrolled k-loop it was spilled)
+        const double *__restrict__ Xt = X + (int64_t)kk * xs;
+        if constexpr (ROLL) {
+            if (fast && (nt == 32 || nt == 16)) {
+                // (see panel_gemm_mfma: one running scalar column offset kept opaque, sched_barriers pinning `operands | MFMAs | refill` per
+                // k-step, the k-loop fully unrolled for k = 128 / 64 so that the waitcnt pass counts exactly, and the refills of the last UR
+                // k-steps being the first UR k-steps of this block's next tile)
+                auto &x = xring;
+                const double *__restrict__ xb = Xt + r0 * 2;
+                const bool next_fast = (tile + gridDim.x + 1) * tile_rows <= n;
+                const int64_t dnext = next_fast ? (int64_t)gridDim.x * tile_rows * 2 : (int64_t)0;
+                const int64_t xstep = 4 * xstride;
+                if (!primed) {
+#pragma unroll
+                    for (int u = 0; u < UR; ++u)
+#pragma unroll
+                        for (int g2 = 0; g2 < NR; ++g2)
+                            x[u][g2] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(xb + u * xstep + g2 * RG * 2));
+                }
+                primed = next_fast;
+                int64_t xo = UR * xstep, xo2 = dnext;
+                asm volatile("" : "+s"(xo), "+s"(xo2));
+                auto kstep = [&](int t, int u, bool tail) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const double ar = tiles3[((g * nt + t) * 2 + 0) * 64 + lane];
+                        const double ai = tiles3[((g * nt + t) * 2 + 1) * 64 + lane];
+                        const double as = ar + ai;
+#pragma unroll
+                        for (int g2 = 0; g2 < NR; ++g2) {
+                            acc[g][g2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, x[u][g2].x, acc[g][g2][0], 0, 0, 0);
+                            acc[g][g2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, x[u][g2].y, acc[g][g2][1], 0, 0, 0);
+                            acc[g][g2][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, x[u][g2].x + x[u][g2].y, acc[g][g2][2], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const double *__restrict__ src = xb + (tail ? xo2 : xo);
+#pragma unroll
+                    for (int g2 = 0; g2 < NR; ++g2) x[u][g2] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(src + g2 * RG * 2));
+                    xo += tail ? (int64_t)0 : xstep;
+                    xo2 += tail ? xstep : (int64_t)0;
+                    asm volatile("" : "+s"(xo), "+s"(xo2));
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                if (nt == 32) {
+#pragma unroll
+                    for (int t = 0; t < 32; ++t) kstep(t, t & (UR - 1), t + UR >= 32);
+                } else if (nt == 16) {             // (spelled out: the compiler folds the LDS offsets of the unrolled steps only for a known nt)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) kstep(t, t & (UR - 1), t + UR >= 16);
+                }
+                done = true;
+            }
+        }
+        if constexpr (ROLL) {
+            // (the ragged last tile: one guarded k-step at a time -- at most one tile per launch)
+            if (!done) {
+                int jl = j, kl = kk;
+                asm volatile("" : "+v"(jl), "+v"(kl));                // (this rare path's addresses formed here, not kept in registers across the unrolled k-loops)
+                const int64_t r0s = tile * tile_rows + (int64_t)wave * (NR * RG) + jl;
+                const double *__restrict__ Xs = X + (int64_t)kl * xs;
+#pragma unroll 1
+                for (int t = 0; t < nt; ++t) {
+                    v2d xg[NR];
+#pragma unroll
+                    for (int g2 = 0; g2 < NR; ++g2) {
+                        xg[g2] = v2d{0.0, 0.0};
+                        if ((4 * t + kl) < k) xg[g2] = load_y<true>(Xs + (int64_t)(4 * t) * xstride, r0s + g2 * RG, n, false);
+                    }
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const double ar = tiles3[((g * nt + t) * 2 + 0) * 64 + lane];
+                        const double ai = tiles3[((g * nt + t) * 2 + 1) * 64 + lane];
+                        const double as = ar + ai;
+#pragma unroll
+                        for (int g2 = 0; g2 < NR; ++g2) {
+                            acc[g][g2][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, xg[g2].x, acc[g][g2][0], 0, 0, 0);
+                            acc[g][g2][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai, xg[g2].y, acc[g][g2][1], 0, 0, 0);
+                            acc[g][g2][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(as, xg[g2].x + xg[g2].y, acc[g][g2][2], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        } else
         for (int t0 = 0; t0 < nt; t0 += U) {
             v2d x[U][NR];
 #pragma unroll
@@ -1351,6 +1528,8 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma3m(const double *__restric
         }
         // D[output i = kk + 4 reg][row j] of group g: (Re, Im) = (P1 - P2, P3 - P1 - P2)
         const bool full = (tile + 1) * tile_rows <= n;
+        int64_t ys = ystride;
+        if constexpr (ROLL) asm volatile("" : "+s"(ys));      // (keeps the 4 NG column addresses of Y out of the registers the unrolled k-loop needs: they were hoisted and spilled)
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
 #pragma unroll
@@ -1360,7 +1539,7 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma3m(const double *__restric
                 for (int reg = 0; reg < 4; ++reg) {
                     const int qq = g * QB + kk + 4 * reg;
                     if (qq < qn) {
-                        double *yc = Y + (int64_t)qq * ystride;
+                        double *yc = Y + (int64_t)qq * ys;
                         const double p1 = acc[g][g2][0][reg], p2 = acc[g][g2][1][reg], p3 = acc[g][g2][2][reg];
                         v2d out = v2d{p1 - p2, (p3 - p1) - p2};
                         if (accumulate) out += load_y<true>(yc, r, n, full);

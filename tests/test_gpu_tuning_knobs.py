@@ -117,8 +117,8 @@ def test_lazy_gram_loop_of_the_reference_costs_one_pass(dtype):
 
 @pytest.mark.parametrize("dtype", KINDS)
 @pytest.mark.parametrize("cfg", [dict(), dict(xhy_db=0), dict(xhy_db=2), dict(gram_tiles=0), dict(gram_tiles=2), dict(gram_tiles=2, gram_grid_mult=3),
-                                 dict(xhy_tr32=1), dict(gemm_roll=1), dict(mfma_4x4=1), dict(mfma_4x4=2), dict(mfma_4x4=1, gram_tiles=2),
-                                 dict(mfma_4x4=1, gemm_roll=1)],
+                                 dict(xhy_tr32=1), dict(gemm_roll=0), dict(gemm_roll=2), dict(mfma_4x4=1), dict(mfma_4x4=2), dict(mfma_4x4=1, gram_tiles=2),
+                                 dict(mfma_4x4=1, gemm_roll=2)],
                          ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "defaults")
 def test_matrix_core_kernel_variants_agree_with_the_oracle(dtype, cfg):
     """Round 5's kernel variants behind lk_set_tuning (double-buffered tiles, dealt Gram tiles, operand / rolling prefetch, the products on
@@ -143,8 +143,8 @@ def test_matrix_core_kernel_variants_agree_with_the_oracle(dtype, cfg):
         ref = X @ Z
         assert np.abs(Bz.download(0, p) - ref).max() <= 1e-13 * np.abs(X).max() * np.abs(Z).sum(axis=0).max() * 4
         # block DGS of Y against an orthonormal X
-        Q, _ = np.linalg.qr(X)
-        Bx.upload(np.asfortranarray(Q))
+        Q = np.asfortranarray(np.linalg.qr(X)[0])
+        Bx.upload(Q)
         beta = np.zeros((k, p), dtype=dtype, order="F")
         assert lk.double_gram_schmidt_step(By, Bx, False, beta) == 0
         Yo = Y.copy(order="F")
@@ -155,4 +155,31 @@ def test_matrix_core_kernel_variants_agree_with_the_oracle(dtype, cfg):
         assert np.abs(beta - ho).max() <= 1e-12 * np.linalg.norm(Y, axis=0).max()
         assert_columns_close(By.download(0, p), Yo, f"block DGS k={k} p={p} {cfg}")
         del Bx, By, Bz
+    c.close()
+
+
+@pytest.mark.parametrize("k,q", [(128, 64), (64, 48), (48, 64), (128, 33)])
+def test_rolling_prefetch_product_over_many_tiles_per_block(k, q):
+    """linear_combination (AbstractVectors.fypp:596-642; the restart update of BaseKrylov.fypp:816-824) with "gemm_roll": panels long enough
+    that every block runs SEVERAL 512-row tiles, so the ring of k-steps carries the next tile's first columns across the epilogue -- the same
+    MFMAs in the same order as the batch schedule: bit-identical results, and the sampled rows agree with numpy; a ragged last tile and a
+    basis width that is not a multiple of 16 take the guarded path."""
+    c = lk.Context(device=0)
+    n = 1_200_007
+    X = lk.krylov_basis_gpu(n, k, np.float64, c)
+    for j in range(k):
+        X[j].rand(True, seed=100 + j)
+    rng = np.random.default_rng(11)
+    Z = np.asfortranarray(rng.standard_normal((k, q)))
+    out = {}
+    for roll in (0, 2):
+        c.set_tuning("gemm_roll", roll)
+        Y = lk.linear_combination(X, Z)
+        out[roll] = Y.download(0, q)
+        del Y
+    assert np.array_equal(out[0], out[2])
+    rows = np.r_[0:600, 511_900:512_700, n - 700:n]
+    Xh = X.download(0, k)[rows]
+    ref = Xh @ Z
+    assert np.abs(out[2][rows] - ref).max() <= 1e-13 * np.abs(Xh).max() * np.abs(Z).sum(axis=0).max() * 4
     c.close()
