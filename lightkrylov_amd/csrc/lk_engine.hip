@@ -89,7 +89,7 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
-    int mfma_4x4 = 0;          // matrix-core kernels issue their products as v_mfma_f64_4x4x4_4b_f64 (72 TFLOP/s sustained) instead of v_mfma_f64_16x16x4_f64 (49): same lanes, same
+    int mfma_4x4 = 0;          // matrix-core kernels issue their products as v_mfma_f64_4x4x4_4b_f64 instead of v_mfma_f64_16x16x4_f64 (A/B; slower in every kernel): same lanes, same
                                // accumulators, four A operands per step (lk_kernels.hip.h, mfma_f64_16x16x4_by4); 0: the 16x16x4 instruction
     int upd_debug = 0;         // diagnostic only (wrong results): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
     int xhy_debug = 0;         // diagnostic only (wrong results): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
@@ -98,7 +98,7 @@ struct lk_context_s {
                                // exact vmcnt counts; k = 128, q = 64 at n = 10^7: 3.45-3.73 -> 3.16-3.24 ms); 2: every variant that has a ring (the narrow real ones measure the same
                                // as the batch schedule, the complex doubled-real ones keep the guarded ring, +2-5 % on narrow products); 0: never (profiles/r05_ab_gemm_roll.jsonl)
     int xhy_tr32 = 0;          // the 128-column real variant of panel_xhy_mfma on 32-row tiles with the next row step's operands read ahead of the current step's MFMAs: measured SLOWER
-                               // (Gram k = 128: 5.5 vs 4.2 ms, profiles/r05_gram_phases.jsonl -- the MFMA phase already runs at the pipe's sustained rate): off
+                               // (Gram k = 128: 5.5 vs 4.2 ms, profiles/r05_gram_phases.jsonl -- twice the barriers per row cost more than the reads gain): off
     int xhy_db = 1;            // panel_xhy_mfma with a double-buffered LDS tile (1: the 128-column variants; 2: the <= 32 right-hand-side ones too; 0: never)
     int gram_tiles = 1;        // real Gram matrix by panel_gram_mfma (upper tiles dealt to the waves, 32-row tiles): 1 = for 33..64 columns (measured: 1.80 / 1.38 ms
                                // at k = 64 / 48, n = 10^7, against 1.90 / 1.60; slower beyond -- 4.6 vs 4.1 ms at k = 128), 2 = up to 128, 0 = never (panel_xhy_mfma<false, 8, 64>)

@@ -1019,8 +1019,8 @@ __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // D(16 x 16) += A(16 x 4) B(4 x 16) in the lane layout of v_mfma_f64_16x16x4_f64 -- A[i = l & 15][kk = l >> 4], B[kk = l >> 4][j = l & 15],
-// D[i = (l >> 4) + 4 reg][j = l & 15] -- issued as FOUR v_mfma_f64_4x4x4_4b_f64 (round 5).  On gfx950 the 16x16x4 instruction sustains
-// 49 TFLOP/s (0.63 of the 78.6 spec) whatever feeds it, the 4x4x4 one 72 (tools/mfma_f64_peak.hip, profiles/r05_fp64_mfma_peak.txt).
+// D[i = (l >> 4) + 4 reg][j = l & 15] -- issued as FOUR v_mfma_f64_4x4x4_4b_f64 (round 5).  Both instructions sustain
+// 0.9+ of the 78.6 TFLOP/s spec back to back (tools/mfma_f64_peak.hip, profiles/r05_fp64_mfma_peak.txt: 77.6 / 70-76).
 // The 4x4x4 instruction multiplies four independent 4 x 4 x 4 blocks; its lanes (found empirically: tools/mfma_f64_4x4_probe.hip) are
 //     A: lane 16 k + 4 blk + i      B: lane 16 k + 4 blk + j      D: lane 16 i + 4 blk + j
 // so with the SAME B register (row kk = l >> 4, column j = l & 15 = 4 blk + j') and A_m[lane] = A[i = 4 m + (l & 3)][kk = l >> 4] -- the four
@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
 
 // Complex tall-skinny product with THREE real products per complex one (round 4).  panel_gemm_mfma<true> computes a complex
 // product as a real one of doubled size -- four real multiplications per complex multiplication, 8 flop -- and runs AT the
-// matrix pipe's sustained FP64 rate (49-50 TFLOP/s, tools/mfma_f64_peak.hip), so the only way down is fewer flops:
+// rate the batch schedule reaches (47-50 TFLOP/s of the 77.6 the instruction sustains, tools/mfma_f64_peak.hip); fewer flops is the other way down:
 //     P1 = Xr Cr,   P2 = Xi Ci,   P3 = (Xr + Xi)(Cr + Ci)      =>      Re(X C) = P1 - P2,   Im(X C) = P3 - P1 - P2
 // (Karatsuba / "3M": 6 flop per complex multiplication).  A group is 16 COMPLEX outputs (all 16 rows of the A operand); per
 // k-step of four basis columns and row group three MFMAs -- A = Cr | Ci | Cr + Ci, B = xr | xi | xr + xi of the lane's row -- into
@@ -1706,6 +1706,7 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
                             if constexpr (CPLX) b2_n[J] = Yb[(16 * J + acol) * S + (ro ^ 1)];
                         }
                 }
+                __builtin_amdgcn_sched_barrier(0);                     // (the reads stay AHEAD of the MFMAs: the scheduler sinks them to their use otherwise)
 #pragma unroll
                 for (int J = 0; J < PJM; ++J) {
                     if (J < PJ && (!upper || J >= wi)) {
@@ -1713,6 +1714,7 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
                         if constexpr (CPLX) acc_im[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (arow & 1) ? -b2[J] : b2[J], acc_im[J], 0, 0, 0);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else if (m4 && active && TR == 32 && PJM == 8 && !CPLX) {
             // 4x4x4 products, software-pipelined: the twelve operands of row step s + 1 (four A, up to eight B) are read from LDS BEFORE the 32
@@ -1745,7 +1747,7 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else if (m4 && active) {
-            // the same products on the 4x4x4 instruction (72 instead of 49 TFLOP/s sustained): four A operands per row step -- the columns
+            // the same products on the 4x4x4 instruction (A/B knob; slower in every kernel): four A operands per row step -- the columns
             // 16 wi + 4 m + (lane & 3) of X's tile --, the B operands and the accumulators exactly as below
             for (int step = wr; step < TR / 4; step += WR) {
                 const int ro = 4 * step + arow;
@@ -2224,7 +2226,7 @@ __global__ __launch_bounds__(512) void panel_gram_mfma(const double *__restrict_
 // H1: device coefficients in panel_dot_p's layout [q][k + 1][ED].  Results as panel_xhy_mfma (partial[block][slot], norms in
 // npartial[block][q]).
 template <bool CPLX>
-__global__ __launch_bounds__(256) void panel_xhy_upd_mfma(const double *__restrict__ X, int64_t ldx, int k,
+__global__ __launch_bounds__(256, CPLX ? 1 : 2) void panel_xhy_upd_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                           double *__restrict__ Y, int64_t ldy, int p, int64_t n,
                                                           const double *__restrict__ H1, double *__restrict__ partial,
                                                           double *__restrict__ npartial, int policy) {

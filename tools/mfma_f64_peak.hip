@@ -23,6 +23,43 @@ __global__ __launch_bounds__(256) void k(double *out, unsigned long long *cyc, i
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
+// the k-step of the library's tall-skinny product without its loads: 16 accumulators, acc[4 g + h] += A[g] B[h] (every A operand feeds four
+// consecutive MFMAs), STEPS such steps per loop iteration -- what the 16x16x4 instruction sustains in that shape, loop overhead amortised
+template <int STEPS>
+__global__ __launch_bounds__(256) void kpat(double *out, int iters, double a, double b) {
+    v4d acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = v4d{0, 0, 0, 0};
+    double A[4], B[4];
+    for (int i = 0; i < 4; ++i) { A[i] = a + 1e-3 * (threadIdx.x & 15) + 0.01 * i; B[i] = b - 1e-3 * (threadIdx.x >> 4) - 0.01 * i; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) acc[4 * g + h] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[g], B[h], acc[4 * g + h], 0, 0, 0);
+    }
+    double s = 0;
+    for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// The instruction itself, in its VGPR form by inline assembly (no compiler choice of accumulator registers, no copies): NACC independent accumulators,
+// 64 / NACC rounds per loop iteration.  THIS is the issue-rate ceiling; k<> above is kept because rounds 4-5 quoted it.
+template <int NACC>
+__global__ __launch_bounds__(256) void kasm(double *out, int iters, double a, double b) {
+    v4d acc[NACC];
+    for (int i = 0; i < NACC; ++i) acc[i] = v4d{0, 0, 0, 0};
+    const double av = a + 1e-3 * (threadIdx.x & 15), bv = b - 1e-3 * (threadIdx.x >> 4);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 64 / NACC; ++r)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(av), "v"(bv));
+    }
+    double s = 0;
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
 // the other FP64 MFMA instruction: v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per instruction, 512 flop, one result per lane)
 __global__ __launch_bounds__(256) void k4(double *out, int iters, double a, double b) {
     double acc[8];
@@ -211,6 +248,29 @@ int main() {
                        mode == 0 ? "12 reads right before 32 MFMAs" : (mode == 1 ? "reads of step s+1 before the MFMAs of step s" : "no LDS, register copies only"), bpc, ms,
                        (double)256 * bpc * 4 * 4000 * 32.0 * 512.0 / ms / 1e9);
             }
+        }
+    }
+    for (int bpc : {1, 2, 4, 8}) {
+        for (int nacc : {2, 4, 8}) {
+            const int iters = 1000;
+            hipEventRecord(e0);
+            if (nacc == 2) hipLaunchKernelGGL(kasm<2>, dim3(256 * bpc), dim3(256), 0, 0, d, iters, 1.0000001, 0.9999999);
+            else if (nacc == 4) hipLaunchKernelGGL(kasm<4>, dim3(256 * bpc), dim3(256), 0, 0, d, iters, 1.0000001, 0.9999999);
+            else hipLaunchKernelGGL(kasm<8>, dim3(256 * bpc), dim3(256), 0, 0, d, iters, 1.0000001, 0.9999999);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            printf("{\"vgpr_form_inline_asm\": true, \"accumulators\": %d, \"waves_per_simd\": %d, \"ms\": %.3f, \"TFLOPs\": %.1f, \"frac_of_78.6\": %.3f}\n", nacc, bpc, ms,
+                   (double)256 * bpc * 4 * iters * 64.0 * 2048.0 / ms / 1e9, (double)256 * bpc * 4 * iters * 64.0 * 2048.0 / ms / 1e9 / 78.6);
+        }
+    }
+    for (int bpc : {1, 2, 4}) {
+        for (int steps : {1, 8}) {
+            const int iters = 8000 / steps;
+            hipEventRecord(e0);
+            if (steps == 1) hipLaunchKernelGGL(kpat<1>, dim3(256 * bpc), dim3(256), 0, 0, d, iters, 1.0000001, 0.9999999);
+            else hipLaunchKernelGGL(kpat<8>, dim3(256 * bpc), dim3(256), 0, 0, d, iters, 1.0000001, 0.9999999);
+            hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+            printf("{\"product_shaped_16_accumulators\": true, \"k_steps_per_loop_iteration\": %d, \"waves_per_simd\": %d, \"ms\": %.3f, \"TFLOPs\": %.1f}\n", steps, bpc, ms,
+                   (double)256 * bpc * 4 * iters * steps * 16.0 * 2048.0 / ms / 1e9);
         }
     }
     // mixed: 8 blocks per CU, in every block two waves of MFMAs and two of FMAs, iteration counts chosen so that both halves take about as long alone
