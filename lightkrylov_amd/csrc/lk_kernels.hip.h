@@ -2204,6 +2204,133 @@ __global__ __launch_bounds__(512) void panel_gram_mfma(const double *__restrict_
     }
 }
 
+// Gram matrix G = X^T X of a REAL basis of 113..128 columns with the upper tiles dealt CYCLICALLY (round 5; gram_matrix, AbstractVectors.fypp:645-657).
+// panel_gram_mfma deals runs of the row-major tile list, which makes every wave's list different: its k-loop is a chain of uniform branches with
+// one `ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma` per tile (hipcc -S), and panel_xhy_mfma gives wave w the whole tile row w -- eight tiles for
+// wave 0, one for wave 7.  Here wave w owns the tiles (w, (w + d) mod 8), d = 0..3 -- the 8 diagonal and 24 of the 28 off-diagonal upper tiles, a
+// wrapped one being the transpose of its upper twin -- and HALF of tile (w, (w + 4) mod 8): waves w and w + 4 both hold that tile (one of
+// them transposed), w < 4 takes it on the even row steps, w >= 4 on the odd ones, chosen by the LDS address, not by a branch.  So all eight waves
+// run the SAME straight-line code -- per pair of row steps ten operand reads and nine MFMAs, the reads of pair i + 1 issued before the MFMAs
+// of pair i (pinned with sched_barrier) -- on operands whose LDS column offsets are the only thing that depends on the wave.  Tiles, staging,
+// strides and the prefetch of the next tile's global loads as panel_gram_mfma (32 rows x 128 columns, S = 34: conflict-free operand reads).
+// The two halves of the d = 4 tiles meet in LDS once, at the end.  Results: partial[block][slot] as panel_gram_mfma.
+__global__ __launch_bounds__(512, 4) void panel_gram_cyc(const double *__restrict__ X, int64_t ldx, int k, int64_t n, double *__restrict__ partial, int dbg) {
+    constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = 512 / CH, NXP = 128 / CPP;
+    extern __shared__ __attribute__((aligned(16))) double gc_lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int KS = (k + CPP - 1) / CPP;
+    double *Xt = gc_lds;
+    const int64_t ntiles = (n + TR - 1) / TR;
+    const int arow = lane >> 4, acol = lane & 15;
+    const int par = wave >= 4 ? 1 : 0;
+    int ob[5];                                              // LDS offsets of this lane's operand column in the column blocks (w + d) mod 8
+#pragma unroll
+    for (int d = 0; d < 5; ++d) ob[d] = (16 * ((wave + d) & 7) + acol) * S + arow;
+
+    v4d acc[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) acc[d] = v4d{0.0, 0.0, 0.0, 0.0};
+    // Two tile buffers in LDS and the global loads TWO tiles ahead: while the MFMAs of tile T run out of buffer b, every wave -- as it finishes its
+    // share -- writes tile T + grid (in its registers since the iteration before) into buffer b ^ 1 and sends the loads of tile T + 3 grid on their
+    // way; ONE barrier per tile, and 2 x 4 loads of 16 B per lane in flight for two tile times (one tile time -- 36 MFMAs -- is about the HBM
+    // latency under load: with the loads one tile ahead the staging waited for them, 5.4 TB/s with the MFMAs switched off).
+    v2d xs[2][NXP];
+    auto gload = [&](int64_t T, v2d (&x)[NXP]) {
+        if ((dbg & 2) && T != (int64_t)blockIdx.x) return;                 // diagnostics (xhy_debug): wrong results, phase timing only
+        const int64_t rbase = T * TR;
+#pragma unroll
+        for (int s = 0; s < NXP; ++s) {
+            x[s] = v2d{0.0, 0.0};
+            if (s < KS) {
+                const int c = t + 512 * s, col = c >> CHS;
+                const int64_t rr = rbase + 2 * (c & (CH - 1));
+                if (col < k) {
+                    const double *pc = X + (int64_t)col * ldx;
+                    if (rr + 1 < n) x[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(pc + rr));
+                    else if (rr < n) x[s].x = pc[rr];
+                }
+            }
+        }
+    };
+    auto stage = [&](double *Xb, const v2d (&x)[NXP]) {
+#pragma unroll
+        for (int s = 0; s < NXP; ++s)
+            if (s < KS) {
+                const int c = t + 512 * s;
+                if ((c >> CHS) < k) *reinterpret_cast<v2d *>(Xb + (c >> CHS) * S + 2 * (c & (CH - 1))) = x[s];
+            }
+    };
+    constexpr int BUF = 128 * S;
+    // columns k .. 127 of both buffers stay zero
+    for (int i = t; i < 2 * BUF; i += 512) Xt[i] = 0.0;
+    __syncthreads();
+
+    const int64_t G = gridDim.x;
+    int64_t T = blockIdx.x;
+    if (T < ntiles) { gload(T, xs[0]); stage(Xt, xs[0]); }
+    if (T + G < ntiles) gload(T + G, xs[0]);
+    if (T + 2 * G < ntiles) gload(T + 2 * G, xs[1]);
+    __syncthreads();
+    // (two tiles per trip so that the register sets xs[0] / xs[1] and the buffers alternate at compile time)
+    auto tile = [&](const double *Xb, double *Xo, v2d (&xnext)[NXP], int64_t Tn, int64_t Tl) {
+        if (!(dbg & 1)) {
+#pragma unroll
+            for (int pr = 0; pr < TR / 8; ++pr) {
+                // (no operand prefetch across pairs: with two blocks per CU four waves share a SIMD and cover each other's LDS round trips, and the
+                //  twenty registers of a second operand set are what keeps the kernel from two blocks per CU)
+                double r[2][4], r4[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) r[h][d] = Xb[ob[d] + 4 * (2 * pr + h)];
+                r4[0] = Xb[ob[0] + 4 * (2 * pr + par)];
+                r4[1] = Xb[ob[4] + 4 * (2 * pr + par)];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) acc[d] = __builtin_amdgcn_mfma_f64_16x16x4f64(r[h][0], r[h][d], acc[d], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(r4[0], r4[1], acc[4], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (Tn < ntiles) stage(Xo, xnext);                          // the next tile into the other buffer (its loads were issued two tiles ago)
+        if (Tl < ntiles) gload(Tl, xnext);                          // ... and that register set goes out again, for the tile three grids on
+        __syncthreads();                                            // buffer Xb has been read by all, buffer Xo is complete
+    };
+    for (; T < ntiles; T += 2 * G) {
+        tile(Xt, Xt + BUF, xs[0], T + G, T + 3 * G);
+        if (T + G < ntiles) tile(Xt + BUF, Xt, xs[1], T + 2 * G, T + 4 * G);
+    }
+
+    // waves 4-7 hand their half of tile (w - 4, w) -- held transposed, as tile (w, w - 4) -- to waves 0-3 (the tile buffers are free by now)
+    if (par) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xt[(wave - 4) * 256 + (arow + 4 * r) * 16 + acol] = acc[4][r];
+    }
+    __syncthreads();
+    if (!par) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[4][r] += Xt[wave * 256 + acol * 16 + (arow + 4 * r)];
+    }
+    const int64_t nslots = (int64_t)k * (k + 1);
+    double *pb = partial + (int64_t)blockIdx.x * nslots;
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        if (d < 4 || !par) {
+            const int I = wave, J = (wave + d) & 7;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * I + arow + 4 * r, j = 16 * J + acol;
+                if (i < k && j < k) {
+                    if (J >= I) pb[(int64_t)j * (k + 1) + i] = acc[d][r];
+                    else pb[(int64_t)i * (k + 1) + j] = acc[d][r];
+                }
+            }
+        }
+    }
+}
+
 // Pass B of the block Gram-Schmidt with many right-hand sides, FUSED on the matrix cores (gram_schmidt.fypp:59-105):
 //     Y' = Y - X H1   (stored)      M2 = X^H Y'      ||Y'_q||^2
 // in ONE pass over X(:, :k) (k <= 128) and Y(:, :p) (p <= 32) -- the update and the second coefficient pass of

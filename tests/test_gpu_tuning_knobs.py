@@ -116,7 +116,7 @@ def test_lazy_gram_loop_of_the_reference_costs_one_pass(dtype):
 
 
 @pytest.mark.parametrize("dtype", KINDS)
-@pytest.mark.parametrize("cfg", [dict(), dict(xhy_db=0), dict(xhy_db=2), dict(gram_tiles=0), dict(gram_tiles=2), dict(gram_tiles=2, gram_grid_mult=3),
+@pytest.mark.parametrize("cfg", [dict(), dict(xhy_db=0), dict(xhy_db=2), dict(gram_tiles=0), dict(gram_tiles=2), dict(gram_tiles=2, gram_grid_mult=3), dict(gram_cyc=1), dict(gram_cyc=3),
                                  dict(xhy_tr32=1), dict(gemm_roll=0), dict(gemm_roll=2), dict(mfma_4x4=1), dict(mfma_4x4=2), dict(mfma_4x4=1, gram_tiles=2),
                                  dict(mfma_4x4=1, gemm_roll=2)],
                          ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "defaults")
@@ -128,7 +128,7 @@ def test_matrix_core_kernel_variants_agree_with_the_oracle(dtype, cfg):
     for key, val in cfg.items():
         c.set_tuning(key, val)
     n = 10_037
-    for k, p in ((128, 40), (72, 64), (48, 9)):
+    for k, p in ((128, 40), (120, 6), (72, 64), (48, 9)):
         X, Y = basis(n, k, dtype, 7), basis(n, p, dtype, 400)
         Bx = lk.krylov_basis_gpu(n, k, dtype, c); Bx.upload(X)
         By = lk.krylov_basis_gpu(n, p, dtype, c); By.upload(Y)
