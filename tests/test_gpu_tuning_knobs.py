@@ -183,3 +183,23 @@ def test_rolling_prefetch_product_over_many_tiles_per_block(k, q):
     ref = Xh @ Z
     assert np.abs(out[2][rows] - ref).max() <= 1e-13 * np.abs(Xh).max() * np.abs(Z).sum(axis=0).max() * 4
     c.close()
+
+
+@pytest.mark.parametrize("n,k", [(200_003, 128), (70_001, 113), (16_400, 128)])
+def test_cyclic_gram_kernel_over_many_tiles_per_block(n, k):
+    """gram_matrix (AbstractVectors.fypp:645-657) of 113..128 real columns by panel_gram_cyc on panels long enough that every block runs SEVERAL
+    32-row tiles -- both tile buffers, both register sets of the loads two tiles ahead, an odd and an even number of tiles per block, a ragged last
+    tile, a width that is not a multiple of 16 -- against numpy and against the staged kernel it replaces ("gram_cyc" = 0)."""
+    c = lk.Context(device=0)
+    X = basis(n, k, np.float64, 31)
+    B = lk.krylov_basis_gpu(n, k, np.float64, c); B.upload(X)
+    ref = X.T @ X
+    scale = np.linalg.norm(X, axis=0).max() ** 2
+    out = {}
+    for cyc in (2, 1, 0):
+        c.set_tuning("gram_cyc", cyc)
+        out[cyc] = lk.Gram(B)
+        assert np.abs(out[cyc] - ref).max() <= 1e-13 * scale, cyc
+        assert np.array_equal(out[cyc], out[cyc].T)
+    assert np.abs(out[2] - out[0]).max() <= 1e-13 * scale
+    c.close()
