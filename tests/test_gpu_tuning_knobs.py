@@ -158,6 +158,30 @@ def test_matrix_core_kernel_variants_agree_with_the_oracle(dtype, cfg):
     c.close()
 
 
+@pytest.mark.parametrize("k,q", [(128, 64), (64, 32), (128, 16), (64, 64)])
+def test_rolling_prefetch_complex_product_over_many_tiles_per_block(k, q):
+    """The same for the complex three-product kernel (panel_gemm_mfma3m<NG, NR, ROLL>; 1, 2 and 4 output groups): ring against batch schedule bit for
+    bit on panels of several tiles per block with a ragged last tile, sampled rows against numpy."""
+    c = lk.Context(device=0)
+    n = 300_007
+    X = lk.krylov_basis_gpu(n, k, np.complex128, c)
+    for j in range(k):
+        X[j].rand(True, seed=300 + j)
+    rng = np.random.default_rng(12)
+    Z = np.asfortranarray(rng.standard_normal((k, q)) + 1j * rng.standard_normal((k, q)))
+    out = {}
+    for roll in (0, 1):
+        c.set_tuning("gemm_roll", roll)
+        Y = lk.linear_combination(X, Z)
+        out[roll] = Y.download(0, q)
+        del Y
+    assert np.array_equal(out[0], out[1])
+    rows = np.r_[0:300, 131_000:131_400, n - 400:n]
+    Xh = X.download(0, k)[rows]
+    assert np.abs(out[1][rows] - Xh @ Z).max() <= 1e-13 * np.abs(Xh).max() * np.abs(Z).sum(axis=0).max() * 8
+    c.close()
+
+
 @pytest.mark.parametrize("k,q", [(128, 64), (64, 48), (48, 64), (128, 33)])
 def test_rolling_prefetch_product_over_many_tiles_per_block(k, q):
     """linear_combination (AbstractVectors.fypp:596-642; the restart update of BaseKrylov.fypp:816-824) with "gemm_roll": panels long enough
