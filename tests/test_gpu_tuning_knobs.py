@@ -227,3 +227,30 @@ def test_cyclic_gram_kernel_over_many_tiles_per_block(n, k):
         assert np.array_equal(out[cyc], out[cyc].T)
     assert np.abs(out[2] - out[0]).max() <= 1e-13 * scale
     c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_block_dgs_updates_on_the_ring_over_many_tiles_per_block(dtype):
+    """DGS_basis_against_basis (gram_schmidt.fypp:59-105), k = 128, p = 32 / 64, on a panel of several tiles per block: the ACCUMULATING products Y -= X H (complex:
+    panel_gemm_mfma3m on the ring, the next tile's loads of X in flight under the read-modify-write of Y; real p = 64: panel_gemm_mfma<..., ROLL>) give the same
+    bits as the batch schedule, and Y comes out orthogonal to X."""
+    n, k = 150_001, 128
+    res = {}
+    for roll in (0, 1):
+        c = lk.Context(device=0)
+        c.set_tuning("gemm_roll", roll)
+        B = lk.krylov_basis_gpu(n, k + 64, dtype, c)
+        for j in range(k + 64):
+            B[j].rand(True, seed=700 + j)
+        R = np.zeros((k, k), dtype=dtype, order="F")
+        assert lk.qr(B[:k], R) == 0                                  # (qr.fypp:116-167: the basis orthonormal, as DGS_basis_against_basis expects)
+        out = []
+        for p0, p in ((k, 32), (k, 64)):
+            beta = np.zeros((k, p), dtype=dtype, order="F")
+            assert lk.double_gram_schmidt_step(B[p0:p0 + p], B[:k], False, beta) == 0
+            out.append((beta.copy(), B.download(p0, p)))
+            assert np.abs(lk.innerprod(B[:k], B[p0:p0 + p])).max() <= 1e-13 * np.sqrt(n)
+        res[roll] = out
+        c.close()
+    for (b0, y0), (b1, y1) in zip(res[0], res[1]):
+        assert np.array_equal(b0, b1) and np.array_equal(y0, y1)
