@@ -775,7 +775,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         return allreduce(c, out3, nslots);
     }
     // real Gram matrix of 113..128 columns: upper tiles dealt cyclically, every wave the same straight-line code (panel_gram_cyc, round 5)
-    if (!cp && !small && flags == 3 && k > 112 && k <= 128 && c->gram_cyc > 0) {
+    if (!cp && !small && flags == 3 && k > 112 && k <= 128 && c->gram_cyc > 0 && Bx->n >= 2) {          // (its clamped loads want two rows)
         const int64_t nt32 = (Bx->n + 31) / 32;
         int64_t gg = (int64_t)c->num_cu * c->gram_cyc;
         if (gg > nt32) gg = nt32;

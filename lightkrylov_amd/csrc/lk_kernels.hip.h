@@ -2219,7 +2219,6 @@ __global__ __launch_bounds__(512, 4) void panel_gram_cyc(const double *__restric
     extern __shared__ __attribute__((aligned(16))) double gc_lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int KS = (k + CPP - 1) / CPP;
     double *Xt = gc_lds;
     const int64_t ntiles = (n + TR - 1) / TR;
     const int arow = lane >> 4, acol = lane & 15;
@@ -2235,31 +2234,39 @@ __global__ __launch_bounds__(512, 4) void panel_gram_cyc(const double *__restric
     // share -- writes tile T + grid (in its registers since the iteration before) into buffer b ^ 1 and sends the loads of tile T + 3 grid on their
     // way; ONE barrier per tile, and 2 x 4 loads of 16 B per lane in flight for two tile times (one tile time -- 36 MFMAs -- is about the HBM
     // latency under load: with the loads one tile ahead the staging waited for them, 5.4 TB/s with the MFMAs switched off).
+    // The loads are UNCONDITIONAL -- column, row and tile clamped into the panel, what was out of range zeroed when the registers are written to LDS --: a
+    // guarded load (`if (col < k) ... if (rr + 1 < n) ...`) compiles to a chain of basic blocks, and the waitcnt pass puts `s_waitcnt vmcnt(0)` in
+    // front of the loads and LDS writes in them: the four loads of a set went out one round trip at a time (hipcc -S of the first version).
     v2d xs[2][NXP];
     auto gload = [&](int64_t T, v2d (&x)[NXP]) {
         if ((dbg & 2) && T != (int64_t)blockIdx.x) return;                 // diagnostics (xhy_debug): wrong results, phase timing only
-        const int64_t rbase = T * TR;
+        const int64_t rbase = (T < ntiles ? T : ntiles - 1) * TR;          // (a tile beyond the panel re-reads the last one: never staged)
+        int tv = t;
+        asm volatile("" : "+v"(tv));                                       // (addresses formed per tile: hoisted out of the unrolled trip they are spilled)
 #pragma unroll
         for (int s = 0; s < NXP; ++s) {
-            x[s] = v2d{0.0, 0.0};
-            if (s < KS) {
-                const int c = t + 512 * s, col = c >> CHS;
-                const int64_t rr = rbase + 2 * (c & (CH - 1));
-                if (col < k) {
-                    const double *pc = X + (int64_t)col * ldx;
-                    if (rr + 1 < n) x[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(pc + rr));
-                    else if (rr < n) x[s].x = pc[rr];
-                }
-            }
+            const int c = tv + 512 * s, col = c >> CHS;
+            const int64_t rr = rbase + 2 * (c & (CH - 1));
+            const int colc = col < k ? col : k - 1;
+            const int64_t rrc = rr + 1 < n ? rr : n - 2;
+            x[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(X + (int64_t)colc * ldx + rrc));
         }
     };
-    auto stage = [&](double *Xb, const v2d (&x)[NXP]) {
+    auto stage = [&](double *Xb, const v2d (&x)[NXP], int64_t T) {        // T: the tile these registers hold
+        const bool ragged = (T + 1) * TR > n;
+        int tv = t;
+        asm volatile("" : "+v"(tv));
 #pragma unroll
-        for (int s = 0; s < NXP; ++s)
-            if (s < KS) {
-                const int c = t + 512 * s;
-                if ((c >> CHS) < k) *reinterpret_cast<v2d *>(Xb + (c >> CHS) * S + 2 * (c & (CH - 1))) = x[s];
+        for (int s = 0; s < NXP; ++s) {
+            const int c = tv + 512 * s;
+            v2d v = x[s];
+            if (ragged) {
+                const int64_t rr = T * TR + 2 * (c & (CH - 1));
+                if (rr >= n) v = v2d{0.0, 0.0};
+                else if (rr + 1 >= n) v = v2d{v.y, 0.0};               // (the clamped load fetched rows n - 2, n - 1)
             }
+            if ((c >> CHS) < k) *reinterpret_cast<v2d *>(Xb + (c >> CHS) * S + 2 * (c & (CH - 1))) = v;
+        }
     };
     constexpr int BUF = 128 * S;
     // columns k .. 127 of both buffers stay zero
@@ -2268,12 +2275,12 @@ __global__ __launch_bounds__(512, 4) void panel_gram_cyc(const double *__restric
 
     const int64_t G = gridDim.x;
     int64_t T = blockIdx.x;
-    if (T < ntiles) { gload(T, xs[0]); stage(Xt, xs[0]); }
-    if (T + G < ntiles) gload(T + G, xs[0]);
-    if (T + 2 * G < ntiles) gload(T + 2 * G, xs[1]);
+    if (T < ntiles) { gload(T, xs[0]); stage(Xt, xs[0], T); }
+    gload(T + G, xs[0]);
+    gload(T + 2 * G, xs[1]);
     __syncthreads();
     // (two tiles per trip so that the register sets xs[0] / xs[1] and the buffers alternate at compile time)
-    auto tile = [&](const double *Xb, double *Xo, v2d (&xnext)[NXP], int64_t Tn, int64_t Tl) {
+    auto tile = [&](auto main_loop, const double *Xb, double *Xo, v2d (&xnext)[NXP], int64_t Tn, int64_t Tl) {
         if (!(dbg & 1)) {
 #pragma unroll
             for (int pr = 0; pr < TR / 8; ++pr) {
@@ -2294,13 +2301,17 @@ __global__ __launch_bounds__(512, 4) void panel_gram_cyc(const double *__restric
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (Tn < ntiles) stage(Xo, xnext);                          // the next tile into the other buffer (its loads were issued two tiles ago)
-        if (Tl < ntiles) gload(Tl, xnext);                          // ... and that register set goes out again, for the tile three grids on
+        if (decltype(main_loop)::value || Tn < ntiles) stage(Xo, xnext, Tn);   // the next tile into the other buffer (its loads were issued two tiles ago)
+        gload(Tl, xnext);                                           // ... and that register set goes out again, for the tile three grids on
         __syncthreads();                                            // buffer Xb has been read by all, buffer Xo is complete
     };
+    using TailLoop = std::integral_constant<bool, false>;
+    // (two tiles per trip so that the register sets and the buffers alternate at compile time.  Eight tiles per trip -- the queue drain the waitcnt pass puts at
+    //  the head of a loop that carries loads across iterations would come once in eight tiles -- made the allocator carry the register sets as 32-register
+    //  tuples through the unrolled body: 290-360 B of scratch, not kept)
     for (; T < ntiles; T += 2 * G) {
-        tile(Xt, Xt + BUF, xs[0], T + G, T + 3 * G);
-        if (T + G < ntiles) tile(Xt + BUF, Xt, xs[1], T + 2 * G, T + 4 * G);
+        tile(TailLoop{}, Xt, Xt + BUF, xs[0], T + G, T + 3 * G);
+        if (T + G < ntiles) tile(TailLoop{}, Xt + BUF, Xt, xs[1], T + 2 * G, T + 4 * G);
     }
 
     // waves 4-7 hand their half of tile (w - 4, w) -- held transposed, as tile (w, w - 4) -- to waves 0-3 (the tile buffers are free by now)
