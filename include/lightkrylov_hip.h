@@ -153,7 +153,8 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  * tile, for the 128-column variants; 2: the <= 32 right-hand-side variants too; 0: never); "gram_tiles" (default 1: the real Gram matrix of 33..64
  * columns by panel_gram_mfma -- upper tiles dealt to the waves, two blocks per CU --; 2: up to 128 columns; 0: never) with "gram_grid_mult";
  * "gram_cyc" (default 2: the real Gram matrix of 113..128 columns by panel_gram_cyc -- upper tiles dealt cyclically, all waves on the same
- * straight-line code, two tile buffers --, value = blocks per CU in the grid; 0: panel_xhy_mfma);
+ * straight-line code, two tile buffers --, value = blocks per CU in the grid; 0: panel_xhy_mfma) and "gram_cyc4" (default 3: the same deal for
+ * 49..64 columns, four column blocks x two row halves, panel_gram_cyc4; 0: panel_gram_mfma);
  * "gemm_roll" (default 1: the real tall-skinny product with 33..64 outputs per pass keeps a ring of four k-steps of X in flight, refilled as
  * they are consumed and carried across tiles, on straight-line code; 2: every variant that has a ring; 0: batches of four k-steps everywhere --
  * same MFMAs in the same order, bit-identical results); "xhy_tr32" (default 0: operand prefetch on 32-row tiles -- measured slower, kept

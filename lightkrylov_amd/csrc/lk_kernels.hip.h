@@ -2342,6 +2342,114 @@ __global__ __launch_bounds__(512, 4) void panel_gram_cyc(const double *__restric
     }
 }
 
+// The cyclic deal for 49..64 real columns (round 5; gram_matrix, AbstractVectors.fypp:645-657): FOUR column blocks, so the eight waves are four blocks x two
+// ROW halves -- wave w owns column block I = w & 3 on the row steps s == h (mod 2), h = w >> 2: the tiles (I, (I + d) mod 4), d = 0, 1, on each of its four
+// steps of a 32-row tile, and tile (I, (I + 2) mod 4) -- which the waves of block I + 2 hold transposed -- on two of them (chosen by the LDS address, not by a
+// branch): ten MFMAs per wave and tile, the same straight-line code on every wave.  Tile buffers, unconditional loads two tiles ahead and the one barrier per
+// tile as panel_gram_cyc; 17 KB per buffer.  A tile of G is held in pieces by two to four waves: they meet in LDS at the end, wave after wave in a fixed order.
+// Results: partial[block][slot] as panel_gram_mfma.
+__global__ __launch_bounds__(512, 4) void panel_gram_cyc4(const double *__restrict__ X, int64_t ldx, int k, int64_t n, double *__restrict__ partial) {
+    constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = 512 / CH, NXP = 64 / CPP;      // two 16-byte chunks per thread and tile
+    constexpr int BUF = 64 * S;
+    extern __shared__ __attribute__((aligned(16))) double g4_lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    double *Xt = g4_lds;
+    const int64_t ntiles = (n + TR - 1) / TR;
+    const int arow = lane >> 4, acol = lane & 15;
+    const int I = wave & 3, h = wave >> 2, par2 = I >= 2 ? 1 : 0;
+    int ob[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) ob[d] = (16 * ((I + d) & 3) + acol) * S + arow;
+    v4d acc[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) acc[d] = v4d{0.0, 0.0, 0.0, 0.0};
+    v2d xs[2][NXP];
+    auto gload = [&](int64_t T, v2d (&x)[NXP]) {
+        const int64_t rbase = (T < ntiles ? T : ntiles - 1) * TR;          // (a tile beyond the panel re-reads the last one: never staged)
+#pragma unroll
+        for (int s = 0; s < NXP; ++s) {
+            const int c = t + 512 * s, col = c >> CHS;
+            const int64_t rr = rbase + 2 * (c & (CH - 1));
+            const int colc = col < k ? col : k - 1;
+            const int64_t rrc = rr + 1 < n ? rr : n - 2;
+            x[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(X + (int64_t)colc * ldx + rrc));
+        }
+    };
+    auto stage = [&](double *Xb, const v2d (&x)[NXP], int64_t T) {
+        const bool ragged = (T + 1) * TR > n;
+#pragma unroll
+        for (int s = 0; s < NXP; ++s) {
+            const int c = t + 512 * s;
+            v2d v = x[s];
+            if (ragged) {
+                const int64_t rr = T * TR + 2 * (c & (CH - 1));
+                if (rr >= n) v = v2d{0.0, 0.0};
+                else if (rr + 1 >= n) v = v2d{v.y, 0.0};
+            }
+            if ((c >> CHS) < k) *reinterpret_cast<v2d *>(Xb + (c >> CHS) * S + 2 * (c & (CH - 1))) = v;
+        }
+    };
+    for (int i = t; i < 2 * BUF; i += 512) Xt[i] = 0.0;       // columns k .. 63 of both buffers stay zero
+    __syncthreads();
+    const int64_t G = gridDim.x;
+    int64_t T = blockIdx.x;
+    if (T < ntiles) { gload(T, xs[0]); stage(Xt, xs[0], T); }
+    gload(T + G, xs[0]);
+    gload(T + 2 * G, xs[1]);
+    __syncthreads();
+    auto tile = [&](const double *Xb, double *Xo, v2d (&xnext)[NXP], int64_t Tn, int64_t Tl) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                                   // two pairs of own row steps
+            double r[2][2], r2[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) r[e][d] = Xb[ob[d] + 4 * (2 * (2 * q + e) + h)];
+            r2[0] = Xb[ob[0] + 4 * (2 * (2 * q + par2) + h)];
+            r2[1] = Xb[ob[2] + 4 * (2 * (2 * q + par2) + h)];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[d] = __builtin_amdgcn_mfma_f64_16x16x4f64(r[e][0], r[e][d], acc[d], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(r2[0], r2[1], acc[2], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (Tn < ntiles) stage(Xo, xnext, Tn);
+        gload(Tl, xnext);
+        __syncthreads();
+    };
+    for (; T < ntiles; T += 2 * G) {
+        tile(Xt, Xt + BUF, xs[0], T + G, T + 3 * G);
+        if (T + G < ntiles) tile(Xt + BUF, Xt, xs[1], T + 2 * G, T + 4 * G);
+    }
+    // the pieces of every tile meet in LDS: G(64 x 64) zeroed, then the eight waves add theirs one after the other (a wrapped tile lands transposed, on its upper twin)
+    double *Gs = Xt;                                                    // 64 x 65 doubles: the tile buffers are free by now
+    for (int i = t; i < 64 * 65; i += 512) Gs[i] = 0.0;
+    __syncthreads();
+    for (int w = 0; w < 8; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int J = (I + d) & 3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = 16 * I + arow + 4 * r, j = 16 * J + acol;
+                    if (J >= I) Gs[j * 65 + i] += acc[d][r];
+                    else Gs[i * 65 + j] += acc[d][r];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t nslots = (int64_t)k * (k + 1);
+    double *pb = partial + (int64_t)blockIdx.x * nslots;
+    for (int e = t; e < 64 * 64; e += 512) {
+        const int j = e >> 6, i = e & 63;                               // slot (row i, column j) with tile(i) <= tile(j)
+        if ((i >> 4) <= (j >> 4) && i < k && j < k) pb[(int64_t)j * (k + 1) + i] = Gs[j * 65 + i];
+    }
+}
+
 // Pass B of the block Gram-Schmidt with many right-hand sides, FUSED on the matrix cores (gram_schmidt.fypp:59-105):
 //     Y' = Y - X H1   (stored)      M2 = X^H Y'      ||Y'_q||^2
 // in ONE pass over X(:, :k) (k <= 128) and Y(:, :p) (p <= 32) -- the update and the second coefficient pass of

@@ -254,3 +254,23 @@ def test_block_dgs_updates_on_the_ring_over_many_tiles_per_block(dtype):
         c.close()
     for (b0, y0), (b1, y1) in zip(res[0], res[1]):
         assert np.array_equal(b0, b1) and np.array_equal(y0, y1)
+
+
+@pytest.mark.parametrize("n,k", [(200_003, 64), (70_001, 49), (16_400, 64), (33, 56)])
+def test_cyclic_gram_kernel_for_four_column_blocks(n, k):
+    """gram_matrix (AbstractVectors.fypp:645-657) of 49..64 real columns by panel_gram_cyc4 (four column blocks x two row halves; the pieces of a tile held by two to four
+    waves meet in LDS in a fixed order): several tiles per block, a ragged last tile, a width that is not a multiple of 16, a panel shorter than two tiles -- against
+    numpy and the kernel it replaces."""
+    c = lk.Context(device=0)
+    X = basis(n, k, np.float64, 77)
+    B = lk.krylov_basis_gpu(n, k, np.float64, c); B.upload(X)
+    ref = X.T @ X
+    scale = np.linalg.norm(X, axis=0).max() ** 2
+    out = {}
+    for cyc in (3, 2, 0):
+        c.set_tuning("gram_cyc4", cyc)
+        out[cyc] = lk.Gram(B)
+        assert np.abs(out[cyc] - ref).max() <= 1e-13 * scale, cyc
+        assert np.array_equal(out[cyc], out[cyc].T)
+    assert np.array_equal(out[3], out[2]) or np.abs(out[3] - out[2]).max() <= 1e-13 * scale
+    c.close()
