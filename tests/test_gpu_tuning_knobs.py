@@ -274,3 +274,21 @@ def test_cyclic_gram_kernel_for_four_column_blocks(n, k):
         assert np.array_equal(out[cyc], out[cyc].T)
     assert np.array_equal(out[3], out[2]) or np.abs(out[3] - out[2]).max() <= 1e-13 * scale
     c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_gram_across_the_kernel_dispatch_boundaries(dtype):
+    """gram_matrix (AbstractVectors.fypp:645-657) at every width and length where lk_gram changes kernels (32 | 33, 48 | 49, 64 | 65, 112 | 113, 128 | 129 columns;
+    panels of 1, 2, 3 rows, one row short of / at / beyond a tile, a few tiles) against numpy."""
+    c = lk.Context(device=0)
+    for n in (1, 2, 3, 31, 32, 33, 63, 64, 65, 1000, 4097):
+        Xall = basis(n, 130, dtype, 5)
+        for k in (5, 32, 33, 47, 48, 49, 50, 63, 64, 65, 111, 112, 113, 127, 128, 129):
+            X = np.asfortranarray(Xall[:, :k])
+            B = lk.krylov_basis_gpu(n, k, dtype, c); B.upload(X)
+            G = lk.Gram(B)
+            ref = ora.gram(X)
+            scale = max(np.linalg.norm(X, axis=0).max() ** 2, 1e-300)
+            assert np.abs(G - ref).max() <= 1e-13 * scale, (n, k)
+            del B
+    c.close()
