@@ -292,3 +292,26 @@ def test_gram_across_the_kernel_dispatch_boundaries(dtype):
             assert np.abs(G - ref).max() <= 1e-13 * scale, (n, k)
             del B
     c.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_lincomb_across_the_kernel_dispatch_boundaries(dtype):
+    """linear_combination (AbstractVectors.fypp:596-642) at the widths and lengths where lk_lincomb changes kernels or schedules (VALU | MFMA, 1 / 2 / 4 output groups, batch
+    schedule | ring for k = 64 / 128, a basis wider than one 128-column chunk; panels shorter than a tile, one row short of / beyond a tile) against numpy."""
+    c = lk.Context(device=0)
+    rng = np.random.default_rng(3)
+    for n in (1, 7, 255, 256, 257, 511, 512, 513, 3000):
+        Xall = basis(n, 130, dtype, 9)
+        for k in (4, 63, 64, 65, 127, 128, 129, 130):
+            X = np.asfortranarray(Xall[:, :k])
+            B = lk.krylov_basis_gpu(n, k, dtype, c); B.upload(X)
+            for q in (1, 4, 5, 9, 16, 17, 32, 33, 48, 64, 65):
+                Z = rng.standard_normal((k, q)) + (1j * rng.standard_normal((k, q)) if dtype == np.complex128 else 0)
+                Z = np.asfortranarray(Z.astype(dtype))
+                Y = lk.linear_combination(B, Z)
+                got = Y.download(0, q)
+                del Y
+                tol = 1e-13 * max(np.abs(X).max(), 1e-300) * np.abs(Z).sum(axis=0).max() * 8
+                assert np.abs(got - X @ Z).max() <= tol, (n, k, q)
+            del B
+    c.close()
