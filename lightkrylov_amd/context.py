@@ -338,6 +338,12 @@ class Context:
         _capi.check(self._lib.lk_lazy_fusion_stats(self._h, out))
         return tuple(out)
 
+    def resident_stats(self):
+        """(single-launch Gram-Schmidt steps enqueued, launches that gave up) -- see lk_resident_stats in the header."""
+        out = (C.c_int64 * 2)()
+        _capi.check(self._lib.lk_resident_stats(self._h, out))
+        return tuple(out)
+
     def lazy_speculation_stats(self):
         """(anticipated first-pass sweeps, of which unused) -- see lk_lazy_speculation_stats in the header."""
         out = (C.c_int64 * 2)()

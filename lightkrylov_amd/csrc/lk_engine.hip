@@ -2,6 +2,7 @@
 // HIP only: there is no CPU code path in this library.
 #include "lk_internal.h"
 #include "lk_kernels.hip.h"
+#include "lk_resident.hip.h"
 #include <hip/hip_ext.h>
 #include <type_traits>
 
@@ -149,6 +150,17 @@ struct lk_context_s {
     int csr_stream = 1;        // CSR product through LDS for matrices with short rows (mean <= 32 entries); 0: lanes-per-row kernel
     int csr_lanes = 0;         // 0: lanes per row of the CSR product chosen from the mean row length; 2..64 forces it
     int blas1_grid_mult = 2;   // blocks of 256 threads per CU for the one-to-three-stream kernels
+    // single-launch Gram-Schmidt step for cache-resident panels (lk_resident.hip.h)
+    int resident = 1;          // 0: never; 1: when the panel X(:, :k) | y fits `resident_max_mb` (one rank only: the phases meet inside the launch)
+    int resident_max_mb = 192; // ... MB of panel the single launch takes (the memory-side cache holds 256 MB)
+    int resident_nt = 0;       // its X loads non-temporal (1) or plain (0: lines stay in L2 / the memory-side cache for the next phase)
+    int resident_rev = 1;      // phase 2 walks a block's tiles backwards (starts on what phase 1 read last)
+    int resident_grid_mult = 1;// blocks per CU (every block must be resident at once: 1, or 2 where the registers allow)
+    int resident_spin_ms = 2000;   // bound on the first grid-wide wait; beyond it the launch gives up and the three-sweep schedule runs
+    bool resident_off = false; // a launch gave up once (the device is shared with another persistent kernel): not tried again
+    double *res_part = nullptr, *res_xsum = nullptr;
+    unsigned *res_cnt = nullptr;
+    int64_t resident_stats[2] = {0, 0};   // single launches enqueued, launches that gave up
     int lazy = 0;
     struct {
         bool valid = false;
@@ -1394,6 +1406,79 @@ int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass, double *red_base 
     return fail(LK_ERR_INVALID, "internal: dgs_device called with k=%d > %d", k, KMAX_WIDE);
 }
 
+// ---- single-launch step (lk_resident.hip.h) -------------------------------------------------------------------
+constexpr int RES_S = RED_SECTION;                   // slot stride of the hand-off buffers: (128 + 1) * 2 doubles
+constexpr int RES_MAX_GRID = 1024;
+
+int resident_ws(lk_context_t c, ResidentWs *ws) {
+    if (!c->res_cnt) {
+        HIPCHK(hipMalloc((void **)&c->res_part, (size_t)RES_EPISODES * RES_MAX_GRID * RES_S * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&c->res_xsum, (size_t)RES_EPISODES * RES_GROUPS * RES_S * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&c->res_cnt, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned)));
+        HIPCHK(hipMemsetAsync(c->res_cnt, 0, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned), c->stream));
+    }
+    ws->part = c->res_part;
+    ws->xsum = c->res_xsum;
+    ws->cnt = c->res_cnt;
+    ws->S = RES_S;
+    return LK_OK;
+}
+
+// the counters of a launch that gave up are left as they stood: clear them (stream ordered) and stop trying on this context
+int resident_recover(lk_context_t c) {
+    c->resident_off = true;
+    c->resident_stats[1] += 1;
+    if (c->res_cnt) HIPCHK(hipMemsetAsync(c->res_cnt, 0, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned), c->stream));
+    return LK_OK;
+}
+
+// does the two-pass step of k columns against y run as ONE launch?  Only on a single rank (the phases' sums meet inside the
+// launch; a sharded run needs the all-reduce between them), for k <= 128, and while the panel fits the memory-side cache.
+bool resident_applies(lk_basis_t Bx, int k) {
+    lk_context_t c = Bx->ctx;
+    if (!c->resident || c->resident_off || c->nranks > 1 || c->allreduce || k < 1 || k > KMAX_FUSED) return false;
+    const double mb = (double)Bx->n * Bx->ed() * 8.0 * (k + 1) / (1024.0 * 1024.0);
+    return mb <= (double)c->resident_max_mb;
+}
+
+// h1 | h2 | ||y''||^2 into the three sections at `out` (stride rs) exactly where dgs_device leaves them, + the normalise and the
+// device-side stop test of scal_launch when `normalize` (tol_scale: no scaling below it; tol_break: raises *stop_out).
+int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bool normalize, double tol_scale, double tol_break, int *stop_out) {
+    lk_context_t c = Bx->ctx;
+    ResidentWs ws;
+    LKCHK(resident_ws(c, &ws));
+    const bool cp = Bx->dtype == LK_C128;
+    const int ED = Bx->ed();
+    constexpr int KC = 16, NW = 8;
+    int wcn = (k + KC - 1) / KC, WC = 1;
+    while (WC < wcn) WC <<= 1;
+    if (WC > NW) WC = NW;
+    const int kcw = (k + WC - 1) / WC;
+    const int64_t tile_rows = (int64_t)(NW / WC) * 64 * (cp ? 1 : 2);
+    const int64_t ntiles = (Bx->n + tile_rows - 1) / tile_rows;
+    int64_t g = (int64_t)c->num_cu * c->resident_grid_mult;
+    if (g > ntiles) g = ntiles;
+    if (g > RES_MAX_GRID) g = RES_MAX_GRID;
+    if (g < 1) g = 1;
+    const int flags = (normalize ? 1 : 0) | (c->resident_rev ? 2 : 0);
+    const long long spin = (long long)c->resident_spin_ms * 100000ll;          // wall_clock64 ticks at 100 MHz
+    const double bytes = (double)Bx->n * ED * 8.0 * (3.0 * k + 5.0);
+    ProfScope ps(c, "dgs_sweep_resident", bytes, c->prof_ext);
+    auto go = [&](auto kern) {
+        if (ps.on && ps.ext)
+            hipExtLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), 0, c->stream, ps.rec.e0, ps.rec.e1, 0, Bx->col(0), Bx->ld, k, y, Bx->n, ws,
+                                  out, rs, WC, kcw, flags, tol_scale, tol_break, stop_out, spin, c->guard());
+        else
+            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), 0, c->stream, Bx->col(0), Bx->ld, k, y, Bx->n, ws, out, rs, WC, kcw, flags,
+                               tol_scale, tol_break, stop_out, spin, c->guard());
+    };
+    if (cp) { if (c->resident_nt) go(dgs_resident<true, KC, NW, true>); else go(dgs_resident<true, KC, NW, false>); }
+    else { if (c->resident_nt) go(dgs_resident<false, KC, NW, true>); else go(dgs_resident<false, KC, NW, false>); }
+    HIPCHK(hipGetLastError());
+    c->resident_stats[0] += 1;
+    return LK_OK;
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -1501,6 +1586,9 @@ int lk_finalize(lk_context_t c) {
     c->seg_events.clear();
     if (c->step_red) (void)hipFree(c->step_red);
     if (c->step_red_host) (void)hipHostFree(c->step_red_host);
+    if (c->res_part) (void)hipFree(c->res_part);
+    if (c->res_xsum) (void)hipFree(c->res_xsum);
+    if (c->res_cnt) (void)hipFree(c->res_cnt);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LK_OK;
@@ -1564,6 +1652,12 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         c->blas1_grid_mult = value;
         return LK_OK;
     }
+    if (!strcmp(key, "resident")) { c->resident = value != 0; if (value) c->resident_off = false; return LK_OK; }
+    if (!strcmp(key, "resident_max_mb")) { c->resident_max_mb = value < 0 ? 0 : value; return LK_OK; }
+    if (!strcmp(key, "resident_nt")) { c->resident_nt = value != 0; return LK_OK; }
+    if (!strcmp(key, "resident_rev")) { c->resident_rev = value != 0; return LK_OK; }
+    if (!strcmp(key, "resident_grid_mult")) { c->resident_grid_mult = value < 1 ? 1 : (value > 2 ? 2 : value); return LK_OK; }
+    if (!strcmp(key, "resident_spin_ms")) { c->resident_spin_ms = value < 0 ? 0 : (value > 20000 ? 20000 : value); return LK_OK; }
     if (!strcmp(key, "stream_update")) { c->stream_update = value != 0; return LK_OK; }
     if (!strcmp(key, "lazy")) {
         LKCHK(lazy_flush(c));
@@ -1668,6 +1762,13 @@ int lk_lazy_speculation_stats(lk_context_t c, int64_t *out2) {
     if (!c || !out2) return fail(LK_ERR_INVALID, "lk_lazy_speculation_stats: null argument");
     out2[0] = c->spec_stats[0];
     out2[1] = c->spec_stats[1];
+    return LK_OK;
+}
+
+int lk_resident_stats(lk_context_t c, int64_t *out2) {
+    if (!c || !out2) return fail(LK_ERR_INVALID, "lk_resident_stats: null argument");
+    out2[0] = c->resident_stats[0];
+    out2[1] = c->resident_stats[1];
     return LK_OK;
 }
 
@@ -2363,12 +2464,28 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
     ProfScope ps(c, "dgs", (double)Bx->n * ED * 8.0 * (two_pass ? (3.0 * k + 5.0) : (2.0 * k + 3.0)));
     if (k <= KMAX_WIDE) {
         const int rs = red_stride(k);
-        LKCHK(dgs_device(Bx, k, y, two_pass));
         const int last = two_pass ? 2 : 1;
-        if (flags & LK_DGS_NORMALIZE)
-            LKCHK(scal_launch(By, jy, 1.0, 0.0, c->red + last * rs + (size_t)k * ED, ATOL_DP));
-        ps.end();
-        LKCHK(fetch(c, 0, 3, rs));
+        bool single = two_pass && resident_applies(Bx, k);
+        if (single) {
+            // the whole step -- both passes and the normalise -- as ONE persistent launch (lk_resident.hip.h)
+            LKCHK(dgs_resident_launch(Bx, k, y, c->red, rs, (flags & LK_DGS_NORMALIZE) != 0, ATOL_DP, 0.0, nullptr));
+            ps.end();
+            LKCHK(fetch(c, 0, 3, rs));
+            const double status = c->red_host[2 * rs + (size_t)k * ED + 1];
+            if (status == 1.0) {            // gave up before touching y (the chip is shared with another persistent kernel)
+                LKCHK(resident_recover(c));
+                single = false;
+            } else if (status != 0.0) {
+                return fail(LK_ERR_HIP, "double_gram_schmidt_step: the single-launch step failed after its first phase (status %g)", status);
+            }
+        }
+        if (!single) {
+            LKCHK(dgs_device(Bx, k, y, two_pass));
+            if (flags & LK_DGS_NORMALIZE)
+                LKCHK(scal_launch(By, jy, 1.0, 0.0, c->red + last * rs + (size_t)k * ED, ATOL_DP));
+            ps.end();
+            LKCHK(fetch(c, 0, 3, rs));
+        }
         const double *r0 = c->red_host, *r1 = c->red_host + rs, *r2 = c->red_host + 2 * rs;
         if (h)
             for (int i = 0; i < k * ED; ++i) h[i] = two_pass ? (r0[i] + r1[i]) : r0[i];   // gram_schmidt.fypp:49
@@ -3334,7 +3451,10 @@ static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
             rc = lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, k - 1, X, k);
             if (rc != LK_OK) break;
             c->span_first = nullptr;
-            rc = dgs_device(X, k, X->col(k), true, slot, rs);
+            const bool single = resident_applies(X, k);
+            // cache-resident panel: both passes, the normalise and the breakdown test in ONE launch (lk_resident.hip.h)
+            if (single) rc = dgs_resident_launch(X, k, X->col(k), slot, rs, true, ATOL_DP, tol_break, c->stop_dev);
+            else rc = dgs_device(X, k, X->col(k), true, slot, rs);
             if (rc != LK_OK) break;
             if (c->prof && c->span_first) {          // "dgs" = first sweep's start .. the end of the last reduction, no events of its own
                 ProfRec span;
@@ -3342,7 +3462,7 @@ static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
                 span.bytes = (double)X->n * ED * 8.0 * (3.0 * k + 5.0);
                 c->prof_pending.push_back(span);
             }
-            rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
+            if (!single) rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, ATOL_DP, c->stop_dev, tol_break);
             if (rc == LK_OK && si < nseg && k == seg_last[si]) {
                 // close a segment: its slots and the stop flag as it stands now travel to the host behind this step
                 const size_t off = (size_t)(seg_first - k0) * slot_doubles;
@@ -3668,10 +3788,20 @@ static int arnoldi_impl(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int 
         LKCHK(lazy_enter(c, true));
         const int kb = k;                                        // first step of this batch (slot 0)
         // columns [sa, sb] of H from the batch's result slots; *stop_out = 1 when the reference's loop exits at a step (info set)
+        int redo = 0;                                            // step whose single-launch Gram-Schmidt gave up (the batch stopped there)
         auto fill = [&](int sa, int sb, int *stop_out) -> int {
             for (int s = sa; s <= sb; ++s) {
                 const double *slot = c->step_red_host + (size_t)(s - kb) * RED_SECTIONS * rs;
                 const double *r0 = slot, *r1 = slot + rs, *r2 = slot + 2 * rs;
+                if (resident_applies(X, s)) {
+                    const double status = r2[(size_t)s * ED + 1];
+                    if (status == 1.0) {                          // y untouched: this step runs again on the three-sweep schedule
+                        LKCHK(resident_recover(c));
+                        redo = s;
+                        return LK_OK;
+                    }
+                    if (status != 0.0) return fail(LK_ERR_HIP, "lk_arnoldi: the single-launch Gram-Schmidt step failed after its first phase (status %g)", status);
+                }
                 double *Hk = H + (size_t)(s - 1) * ldh * ED;
                 for (int i = 0; i < s * ED; ++i) Hk[i] = r0[i] + r1[i];                 // gram_schmidt.fypp:49
                 const double beta = std::sqrt(std::fabs(r2[s * ED]));
@@ -3709,6 +3839,12 @@ static int arnoldi_impl(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int 
                                   &cancelled));
         if (cancelled) break;                                    // the caller asked to stop: columns beyond the last report are not delivered
         LKCHK(fill(delivered_to + 1, done, &stop));
+        if (redo) {                                              // (the device stop flag was raised by the launch that gave up)
+            report(redo - 1);
+            if (stop_requested) break;
+            k = redo;
+            continue;
+        }
         report(stop ? *info : done);
         if (stop || stop_requested) break;
         // a stop the reference would NOT have taken (tol below atol_dp with a colinear column): resume after it

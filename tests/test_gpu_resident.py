@@ -1,0 +1,215 @@
+"""Single-launch Gram-Schmidt step (csrc/lk_resident.hip.h) against the oracle and against the three-sweep schedule:
+double_gram_schmidt_step (gram_schmidt.fypp:12-57) + qr_no_pivoting's norm and scale (qr.fypp:135-165) in ONE persistent
+kernel for panels that fit the memory-side cache.  Tolerance: north_star's 1e-12, normwise per column."""
+import numpy as np
+import pytest
+
+import lightkrylov_amd as lk
+from oracle import oracle as ora
+from tests._gpu_helpers import KINDS, orthonormal_basis, seeded
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+# every size of test_gpu_parity.DGS_CASES the single launch takes (k <= 128), + the tile-shape boundaries of its launcher
+# (16 columns per wave: WC = 1 | 2 | 4 | 8 at k = 16 | 32 | 64 | 128) and ragged / tiny row counts (fewer tiles than CUs)
+CASES = [(1000, 1), (1001, 2), (999, 3), (4096, 15), (4097, 16), (4099, 17), (10_000, 31), (10_001, 33), (30_000, 64),
+         (30_011, 100), (30_011, 127), (30_011, 128), (129, 64), (65, 8), (1, 1), (300_007, 32), (2, 1), (127, 5), (128, 16),
+         (257, 32), (1025, 65), (175_003, 48), (600_001, 8), (1_000_003, 24)]
+
+
+@pytest.fixture()
+def rctx(ctx):
+    """the shared context with the single launch ON for everything it can take; restored afterwards"""
+    ctx.set_tuning("resident", 1)
+    ctx.set_tuning("resident_max_mb", 192)
+    yield ctx
+    ctx.set_tuning("resident", 1)
+    ctx.set_tuning("resident_max_mb", 192)
+    ctx.set_tuning("resident_spin_ms", 2000)
+    ctx.set_tuning("resident_nt", 0)
+    ctx.set_tuning("resident_rev", 1)
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("n,k", CASES)
+def test_single_launch_step_against_oracle_and_three_sweeps(rctx, dtype, n, k):
+    ctx = rctx
+    k = min(k, n)
+    Q = orthonormal_basis(n, k, dtype, 3)
+    y = seeded(n, dtype, 77)
+    B = lk.krylov_basis_gpu(n, k + 1, dtype, ctx)
+    B.upload(Q, 0)
+    yo = y.copy()
+    ho, info_o = ora.double_gram_schmidt_step(yo, Q)
+    ynorm = np.linalg.norm(y)
+    res = {}
+    for route in (1, 0):
+        ctx.set_tuning("resident", route)
+        B.upload(y.reshape(-1, 1), k)
+        beta = np.zeros(k, dtype=dtype)
+        before = ctx.resident_stats()
+        info = lk.double_gram_schmidt_step(B[k], B[:k], if_chk_orthonormal=False, beta=beta)
+        after = ctx.resident_stats()
+        assert after[0] - before[0] == route, "the route the knob asks for is the route that ran"
+        assert after[1] == before[1]
+        assert info == info_o
+        yg = B.download(k, 1)[:, 0]
+        assert np.abs(beta - ho).max() <= RTOL * ynorm
+        assert np.abs(yg - yo).max() <= RTOL * ynorm
+        if k < n:
+            assert np.abs(Q.conj().T @ yg).max() <= 1e-13 * ynorm
+        res[route] = (beta, yg)
+    assert np.abs(res[1][0] - res[0][0]).max() <= 1e-13 * ynorm        # the two schedules agree to rounding
+    assert np.abs(res[1][1] - res[0][1]).max() <= 1e-13 * ynorm
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("knobs", [{"resident_nt": 1}, {"resident_rev": 0}, {"resident_nt": 1, "resident_rev": 0}])
+def test_load_policy_and_tile_order_change_no_result_bit(rctx, dtype, knobs):
+    ctx = rctx
+    n, k = 200_003, 40
+    Q = orthonormal_basis(n, k, dtype, 5)
+    y = seeded(n, dtype, 9)
+    B = lk.krylov_basis_gpu(n, k + 1, dtype, ctx)
+    B.upload(Q, 0)
+    outs = []
+    for kn in ({}, knobs):
+        ctx.set_tuning("resident_nt", kn.get("resident_nt", 0))
+        ctx.set_tuning("resident_rev", kn.get("resident_rev", 1))
+        B.upload(y.reshape(-1, 1), k)
+        beta = np.zeros(k, dtype=dtype)
+        lk.double_gram_schmidt_step(B[k], B[:k], False, beta=beta)
+        outs.append((beta, B.download(k, 1)[:, 0]))
+    # the load policy changes nothing; walking phase 2 backwards changes the order a block adds its tiles in (rounding only)
+    exact = "resident_rev" not in knobs
+    for a, b in zip(outs[0], outs[1]):
+        if exact:
+            assert np.array_equal(a, b)
+        else:
+            assert np.abs(a - b).max() <= 1e-14 * np.linalg.norm(y)
+
+
+def test_dispatch_boundary_follows_the_panel_size(rctx):
+    ctx = rctx
+    n, k = 100_000, 20                       # panel = 21 columns x 0.8 MB = 16.02 MB
+    Q = orthonormal_basis(n, k, np.float64, 1)
+    B = lk.krylov_basis_gpu(n, k + 1, np.float64, ctx)
+    B.upload(Q, 0)
+    y = seeded(n, np.float64, 2)
+    for mb, want in ((17, 1), (16, 0), (0, 0), (192, 1)):
+        ctx.set_tuning("resident_max_mb", mb)
+        B.upload(y.reshape(-1, 1), k)
+        before = ctx.resident_stats()[0]
+        lk.double_gram_schmidt_step(B[k], B[:k], False)
+        assert ctx.resident_stats()[0] - before == want
+    # beyond 128 columns: always the three-sweep schedule
+    n2, k2 = 5003, 129
+    Q2 = orthonormal_basis(n2, k2, np.float64, 1)
+    B2 = lk.krylov_basis_gpu(n2, k2 + 1, np.float64, ctx)
+    B2.upload(Q2, 0)
+    B2.upload(seeded(n2, np.float64, 2).reshape(-1, 1), k2)
+    before = ctx.resident_stats()[0]
+    lk.double_gram_schmidt_step(B2[k2], B2[:k2], False)
+    assert ctx.resident_stats()[0] == before
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+@pytest.mark.parametrize("n,m", [(1000, 8), (100_000, 64), (175_000, 128), (1_000_000, 32)])
+def test_arnoldi_on_the_single_launch_against_oracle(rctx, dtype, n, m):
+    ctx = rctx
+    d = (1.0 + np.arange(n) / n).astype(dtype)
+    if dtype is np.complex128:
+        d = d * np.exp(0.3j * np.arange(n) / n)
+    x0 = seeded(n, dtype, 7)
+    x0 /= np.linalg.norm(x0)
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F")
+    Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), dtype=dtype, order="F")
+    info_o = ora.arnoldi(ora.DiagOp(d), Xo, Ho)
+    Hs = {}
+    for route in (1, 0):
+        ctx.set_tuning("resident", route)
+        X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+        X.upload(x0.reshape(-1, 1), 0)
+        H = np.zeros((m + 1, m), dtype=dtype, order="F")
+        before = ctx.resident_stats()
+        info = lk.arnoldi(lk.diag_linop_gpu(d, ctx), X, H)
+        after = ctx.resident_stats()
+        assert info == info_o == 0
+        assert after[0] - before[0] == (m if route else 0)          # every step: the batched ones and the last, host-synchronous one
+        for j in range(m):
+            assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL * np.abs(Ho[:, j]).max()
+        Xg = X.download()
+        assert np.abs(Xg.conj().T @ Xg - np.eye(m + 1)).max() <= 1e-12
+        Hs[route] = H
+    assert np.abs(Hs[1] - Hs[0]).max() <= 1e-13 * np.abs(Ho).max()
+
+
+def test_breakdown_stops_the_batch_on_the_single_launch(rctx):
+    """an invariant subspace after 3 steps (arnoldi.fypp:58-71): info = 3, the basis beyond it untouched"""
+    ctx = rctx
+    n, m = 50_000, 10
+    d = np.ones(n)
+    d[: n // 3] = 2.0
+    d[n // 3: 2 * n // 3] = 3.0                    # three distinct eigenvalues: the Krylov space has dimension 3
+    x0 = seeded(n, np.float64, 4)
+    x0 /= np.linalg.norm(x0)
+    Xo = np.zeros((n, m + 1), order="F")
+    Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), order="F")
+    info_o = ora.arnoldi(ora.DiagOp(d), Xo, Ho, tol=1e-10)
+    X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
+    X.upload(x0.reshape(-1, 1), 0)
+    H = np.zeros((m + 1, m), order="F")
+    before = ctx.resident_stats()[0]
+    info = lk.arnoldi(lk.diag_linop_gpu(d, ctx), X, H, tol=1e-10)
+    assert ctx.resident_stats()[0] > before
+    assert info == info_o == 3
+    assert np.abs(H[:4, :3] - Ho[:4, :3]).max() <= 1e-10
+    assert np.abs(X.download()[:, 5:]).max() == 0.0
+
+
+def test_a_launch_that_cannot_get_the_chip_gives_up_cleanly_and_the_step_still_runs():
+    """resident_spin_ms = 0: the first grid-wide wait of the launch times out at once (what happens when another persistent
+    kernel holds the CUs) -- nothing has been written, the three-sweep schedule redoes the step, the context stops trying."""
+    n, m = 300_000, 12
+    d = 1.0 + np.arange(n) / n
+    x0 = seeded(n, np.float64, 7)
+    x0 /= np.linalg.norm(x0)
+    Xo = np.zeros((n, m + 1), order="F")
+    Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), order="F")
+    ora.arnoldi(ora.DiagOp(d), Xo, Ho)
+    for sync_first in (False, True):
+        ctx = lk.Context(device=0)
+        try:
+            ctx.set_tuning("resident_spin_ms", 0)
+            X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
+            X.upload(x0.reshape(-1, 1), 0)
+            if sync_first:                                     # the host-synchronous entry gives up first
+                Y = lk.krylov_basis_gpu(n, 2, np.float64, ctx)
+                Y.upload(seeded(n, np.float64, 3).reshape(-1, 1), 1)
+                Y.upload(x0.reshape(-1, 1), 0)
+                yo = seeded(n, np.float64, 3)
+                ho, _ = ora.double_gram_schmidt_step(yo, x0.reshape(-1, 1).copy(order="F"))
+                beta = np.zeros(1)
+                lk.double_gram_schmidt_step(Y[1], Y[:1], False, beta=beta)
+                assert abs(beta[0] - ho[0]) <= RTOL * np.linalg.norm(yo) + 1e-12
+                assert ctx.resident_stats() == (1, 1)
+            H = np.zeros((m + 1, m), order="F")
+            assert lk.arnoldi(lk.diag_linop_gpu(d, ctx), X, H) == 0
+            st = ctx.resident_stats()
+            assert st[1] == 1, st                               # gave up exactly once; never tried again
+            for j in range(m):
+                assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL * np.abs(Ho[:, j]).max()
+            # and a fresh opt-in works again once the chip is free
+            ctx.set_tuning("resident_spin_ms", 2000)
+            ctx.set_tuning("resident", 1)
+            X.upload(x0.reshape(-1, 1), 0)
+            H2 = np.zeros((m + 1, m), order="F")
+            assert lk.arnoldi(lk.diag_linop_gpu(d, ctx), X, H2) == 0
+            assert ctx.resident_stats()[0] > st[0] and ctx.resident_stats()[1] == 1
+            assert np.abs(H2 - H).max() <= 1e-13 * np.abs(H).max()
+        finally:
+            ctx.close()
