@@ -71,10 +71,16 @@ module lightkrylov_hip_c
             integer(c_int64_t), intent(out) :: out2(2)
             integer(c_int) :: rc
         end function
-        function lk_resident_stats(ctx, out2) bind(C, name="lk_resident_stats") result(rc)
+        function lk_resident_stats(ctx, out3) bind(C, name="lk_resident_stats") result(rc)
             import :: c_int, c_ptr, c_int64_t
             type(c_ptr), value :: ctx
-            integer(c_int64_t), intent(out) :: out2(2)
+            integer(c_int64_t), intent(out) :: out3(3)
+            integer(c_int) :: rc
+        end function
+        function lk_resident_phase_ticks(ctx, out8) bind(C, name="lk_resident_phase_ticks") result(rc)
+            import :: c_int, c_ptr, c_int64_t
+            type(c_ptr), value :: ctx
+            integer(c_int64_t), intent(out) :: out8(8)
             integer(c_int) :: rc
         end function
         function lk_lazy_fusion_stats(ctx, out4) bind(C, name="lk_lazy_fusion_stats") result(rc)

@@ -191,14 +191,19 @@ int lk_lazy_speculation_stats(lk_context_t ctx, int64_t *out2);
 /* Single-launch Gram-Schmidt step (round 6; csrc/lk_resident.hip.h).  When the panel X(:, :k) | y fits the 256 MB memory-side
  * cache -- the launch-bound regime of the reference's own use cases (1.75 10^5 unknowns, paper/paper.md:103-113) -- lk_dgs and every
  * step of lk_arnoldi run double_gram_schmidt_step (gram_schmidt.fypp:12-57) AND qr_no_pivoting's norm + scale (qr.fypp:135-165) as ONE
- * persistent kernel: each block keeps its rows for the three phases, the phases' sums meet inside the launch in a fixed order.  Tuning
- * keys: "resident" (default 1; 0 = always the three-sweep schedule), "resident_max_mb" (default 192: MB of panel the single launch
- * takes), "resident_nt" / "resident_rev" / "resident_grid_mult" (its load policy, tile order of phase 2, blocks per CU), and
- * "resident_spin_ms" (default 2000: bound on the first grid-wide wait; a launch that cannot get all its blocks on the chip gives up
- * BEFORE writing anything, the step runs on the three-sweep schedule and the context stops trying).  One rank only: a row-sharded
- * context keeps the three launches, whose sums meet in the all-reduce.  Same results to rounding (different summation order).
- * out2 = {single launches enqueued, launches that gave up}. */
-int lk_resident_stats(lk_context_t ctx, int64_t *out2);
+ * persistent kernel: each block keeps its rows for the three phases, the phases' sums meet inside the launch in a fixed order.  Panels
+ * up to the register files' capacity (64 MB on the chip) stay IN REGISTERS for the whole step: X is read once, k + 2 columns of
+ * traffic instead of 3k + 5.  Tuning keys: "resident" (default 1; 0 = always the three-sweep schedule), "resident_max_mb" (default 192:
+ * MB of panel the single launch takes), "resident_onchip" (default 1; 0 = never the register-resident kernel), "resident_rev" (tile
+ * order of the cache-resident kernel's phase 2) and "resident_spin_ms" (default 2000: bound on the first grid-wide wait; a launch
+ * that cannot get all its blocks on the chip gives up BEFORE writing anything, the step runs on the three-sweep schedule and the
+ * context stops trying).  One rank only: a row-sharded context keeps the three launches, whose sums meet in the all-reduce.  Same
+ * results to rounding (different summation order).
+ * out3 = {single launches enqueued, launches that gave up, launches that kept the panel in registers}. */
+int lk_resident_stats(lk_context_t ctx, int64_t *out3);
+/* In-kernel timeline of the LAST single launch (profiling aid, like lk_profile_get): the 100 MHz wall clock of block 0 at
+ * start | phase 1 done | sum 1 done | phase 2 done | sum 2 done | phase 3 done | sum 3 done | scaled.  Synchronises the stream. */
+int lk_resident_phase_ticks(lk_context_t ctx, int64_t *out8);
 
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg).
  * tags: "dgs_sweep1|2|3" (the three panel sweeps; "dgs_sweep*" sums them -- a trailing '*' is a

@@ -52,6 +52,7 @@ SIGNATURES = {
     "lk_lazy_fusion_stats": (_int, [_p, C.POINTER(_i64)]),
     "lk_lazy_speculation_stats": (_int, [_p, C.POINTER(_i64)]),
     "lk_resident_stats": (_int, [_p, C.POINTER(_i64)]),
+    "lk_resident_phase_ticks": (_int, [_p, C.POINTER(_i64)]),
     "lk_profile_enable": (_int, [_p, _int]),
     "lk_profile_get": (_int, [_p, C.c_char_p, C.POINTER(_i64), _dp, _dp]),
     "lk_profile_reset": (_int, [_p]),

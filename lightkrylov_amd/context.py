@@ -339,10 +339,17 @@ class Context:
         return tuple(out)
 
     def resident_stats(self):
-        """(single-launch Gram-Schmidt steps enqueued, launches that gave up) -- see lk_resident_stats in the header."""
-        out = (C.c_int64 * 2)()
+        """(single-launch Gram-Schmidt steps enqueued, launches that gave up, launches that kept the panel in registers) --
+        see lk_resident_stats in the header."""
+        out = (C.c_int64 * 3)()
         _capi.check(self._lib.lk_resident_stats(self._h, out))
         return tuple(out)
+
+    def resident_phase_us(self):
+        """Durations in microseconds of the last single launch as block 0 saw it: (phase 1, sum 1, phase 2, sum 2, phase 3, sum 3, scale)."""
+        out = (C.c_int64 * 8)()
+        _capi.check(self._lib.lk_resident_phase_ticks(self._h, out))
+        return tuple((out[i + 1] - out[i]) / 100.0 for i in range(7))
 
     def lazy_speculation_stats(self):
         """(anticipated first-pass sweeps, of which unused) -- see lk_lazy_speculation_stats in the header."""

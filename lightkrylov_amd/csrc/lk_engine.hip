@@ -153,14 +153,14 @@ struct lk_context_s {
     // single-launch Gram-Schmidt step for cache-resident panels (lk_resident.hip.h)
     int resident = 1;          // 0: never; 1: when the panel X(:, :k) | y fits `resident_max_mb` (one rank only: the phases meet inside the launch)
     int resident_max_mb = 192; // ... MB of panel the single launch takes (the memory-side cache holds 256 MB)
-    int resident_nt = 0;       // its X loads non-temporal (1) or plain (0: lines stay in L2 / the memory-side cache for the next phase)
+    int resident_onchip = 1;   // panels that fit the register files (64 MB on the chip) stay there for the whole step: X is read once
     int resident_rev = 1;      // phase 2 walks a block's tiles backwards (starts on what phase 1 read last)
-    int resident_grid_mult = 1;// blocks per CU (every block must be resident at once: 1, or 2 where the registers allow)
     int resident_spin_ms = 2000;   // bound on the first grid-wide wait; beyond it the launch gives up and the three-sweep schedule runs
     bool resident_off = false; // a launch gave up once (the device is shared with another persistent kernel): not tried again
     double *res_part = nullptr, *res_xsum = nullptr;
     unsigned *res_cnt = nullptr;
-    int64_t resident_stats[2] = {0, 0};   // single launches enqueued, launches that gave up
+    long long *res_tim = nullptr;
+    int64_t resident_stats[3] = {0, 0, 0};   // single launches enqueued, launches that gave up, launches that kept the panel in registers
     int lazy = 0;
     struct {
         bool valid = false;
@@ -1416,7 +1416,10 @@ int resident_ws(lk_context_t c, ResidentWs *ws) {
         HIPCHK(hipMalloc((void **)&c->res_xsum, (size_t)RES_EPISODES * RES_GROUPS * RES_S * sizeof(double)));
         HIPCHK(hipMalloc((void **)&c->res_cnt, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned)));
         HIPCHK(hipMemsetAsync(c->res_cnt, 0, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned), c->stream));
+        HIPCHK(hipMalloc((void **)&c->res_tim, 8 * sizeof(long long)));
+        HIPCHK(hipMemsetAsync(c->res_tim, 0, 8 * sizeof(long long), c->stream));
     }
+    ws->tim = c->res_tim;
     ws->part = c->res_part;
     ws->xsum = c->res_xsum;
     ws->cnt = c->res_cnt;
@@ -1443,22 +1446,37 @@ bool resident_applies(lk_basis_t Bx, int k) {
 
 // h1 | h2 | ||y''||^2 into the three sections at `out` (stride rs) exactly where dgs_device leaves them, + the normalise and the
 // device-side stop test of scal_launch when `normalize` (tol_scale: no scaling below it; tol_break: raises *stop_out).
+// Kernel choice: dgs_onchip (the panel stays in registers, X read once) when the row tiles of some shape -- 16 / 8 / 4 columns per wave,
+// 2 / 4 / 8 tiles per block -- fit one block per CU; else dgs_resident (three walks served from the caches).
 int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bool normalize, double tol_scale, double tol_break, int *stop_out) {
     lk_context_t c = Bx->ctx;
     ResidentWs ws;
     LKCHK(resident_ws(c, &ws));
     const bool cp = Bx->dtype == LK_C128;
     const int ED = Bx->ed();
-    constexpr int KC = 16, NW = 8;
-    int wcn = (k + KC - 1) / KC, WC = 1;
-    while (WC < wcn) WC <<= 1;
-    if (WC > NW) WC = NW;
-    const int kcw = (k + WC - 1) / WC;
-    const int64_t tile_rows = (int64_t)(NW / WC) * 64 * (cp ? 1 : 2);
-    const int64_t ntiles = (Bx->n + tile_rows - 1) / tile_rows;
-    int64_t g = (int64_t)c->num_cu * c->resident_grid_mult;
-    if (g > ntiles) g = ntiles;
-    if (g > RES_MAX_GRID) g = RES_MAX_GRID;
+    constexpr int NW = 8;
+    const int maxg = c->num_cu < RES_MAX_GRID ? c->num_cu : RES_MAX_GRID;
+    struct Shape { int KC, WC, kcw; int64_t ntiles; };
+    auto shape = [&](int KC) {
+        Shape sh;
+        sh.KC = KC;
+        int wcn = (k + KC - 1) / KC, WC = 1;
+        while (WC < wcn) WC <<= 1;
+        sh.WC = WC;
+        sh.kcw = (k + WC - 1) / WC;
+        const int64_t tile_rows = (int64_t)(NW / WC) * 64 * (cp ? 1 : 2);
+        sh.ntiles = (Bx->n + tile_rows - 1) / tile_rows;
+        return sh;
+    };
+    int onchip_kc = 0;
+    if (c->resident_onchip)
+        for (int KC : {16, 8, 4}) {
+            if (k > KC * NW) continue;
+            const Shape sh = shape(KC);
+            if (sh.ntiles <= (int64_t)(32 / KC) * maxg) { onchip_kc = KC; break; }
+        }
+    const Shape sh = shape(onchip_kc ? onchip_kc : 16);
+    int64_t g = sh.ntiles < maxg ? sh.ntiles : maxg;
     if (g < 1) g = 1;
     const int flags = (normalize ? 1 : 0) | (c->resident_rev ? 2 : 0);
     const long long spin = (long long)c->resident_spin_ms * 100000ll;          // wall_clock64 ticks at 100 MHz
@@ -1467,15 +1485,20 @@ int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bo
     auto go = [&](auto kern) {
         if (ps.on && ps.ext)
             hipExtLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), 0, c->stream, ps.rec.e0, ps.rec.e1, 0, Bx->col(0), Bx->ld, k, y, Bx->n, ws,
-                                  out, rs, WC, kcw, flags, tol_scale, tol_break, stop_out, spin, c->guard());
+                                  out, rs, sh.WC, sh.kcw, flags, tol_scale, tol_break, stop_out, spin, c->guard());
         else
-            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), 0, c->stream, Bx->col(0), Bx->ld, k, y, Bx->n, ws, out, rs, WC, kcw, flags,
-                               tol_scale, tol_break, stop_out, spin, c->guard());
+            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), 0, c->stream, Bx->col(0), Bx->ld, k, y, Bx->n, ws, out, rs, sh.WC, sh.kcw,
+                               flags, tol_scale, tol_break, stop_out, spin, c->guard());
     };
-    if (cp) { if (c->resident_nt) go(dgs_resident<true, KC, NW, true>); else go(dgs_resident<true, KC, NW, false>); }
-    else { if (c->resident_nt) go(dgs_resident<false, KC, NW, true>); else go(dgs_resident<false, KC, NW, false>); }
+    switch (onchip_kc) {
+    case 16: if (cp) go(dgs_onchip<true, 16, NW>); else go(dgs_onchip<false, 16, NW>); break;
+    case 8: if (cp) go(dgs_onchip<true, 8, NW>); else go(dgs_onchip<false, 8, NW>); break;
+    case 4: if (cp) go(dgs_onchip<true, 4, NW>); else go(dgs_onchip<false, 4, NW>); break;
+    default: if (cp) go(dgs_resident<true, 16, NW>); else go(dgs_resident<false, 16, NW>);
+    }
     HIPCHK(hipGetLastError());
     c->resident_stats[0] += 1;
+    if (onchip_kc) c->resident_stats[2] += 1;
     return LK_OK;
 }
 
@@ -1589,6 +1612,7 @@ int lk_finalize(lk_context_t c) {
     if (c->res_part) (void)hipFree(c->res_part);
     if (c->res_xsum) (void)hipFree(c->res_xsum);
     if (c->res_cnt) (void)hipFree(c->res_cnt);
+    if (c->res_tim) (void)hipFree(c->res_tim);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LK_OK;
@@ -1654,9 +1678,8 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     }
     if (!strcmp(key, "resident")) { c->resident = value != 0; if (value) c->resident_off = false; return LK_OK; }
     if (!strcmp(key, "resident_max_mb")) { c->resident_max_mb = value < 0 ? 0 : value; return LK_OK; }
-    if (!strcmp(key, "resident_nt")) { c->resident_nt = value != 0; return LK_OK; }
+    if (!strcmp(key, "resident_onchip")) { c->resident_onchip = value != 0; return LK_OK; }
     if (!strcmp(key, "resident_rev")) { c->resident_rev = value != 0; return LK_OK; }
-    if (!strcmp(key, "resident_grid_mult")) { c->resident_grid_mult = value < 1 ? 1 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "resident_spin_ms")) { c->resident_spin_ms = value < 0 ? 0 : (value > 20000 ? 20000 : value); return LK_OK; }
     if (!strcmp(key, "stream_update")) { c->stream_update = value != 0; return LK_OK; }
     if (!strcmp(key, "lazy")) {
@@ -1765,10 +1788,21 @@ int lk_lazy_speculation_stats(lk_context_t c, int64_t *out2) {
     return LK_OK;
 }
 
-int lk_resident_stats(lk_context_t c, int64_t *out2) {
-    if (!c || !out2) return fail(LK_ERR_INVALID, "lk_resident_stats: null argument");
-    out2[0] = c->resident_stats[0];
-    out2[1] = c->resident_stats[1];
+int lk_resident_stats(lk_context_t c, int64_t *out3) {
+    if (!c || !out3) return fail(LK_ERR_INVALID, "lk_resident_stats: null argument");
+    for (int i = 0; i < 3; ++i) out3[i] = c->resident_stats[i];
+    return LK_OK;
+}
+
+int lk_resident_phase_ticks(lk_context_t c, int64_t *out8) {
+    if (!c || !out8) return fail(LK_ERR_INVALID, "lk_resident_phase_ticks: null argument");
+    DevGuard dev_guard(c);
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    if (!c->res_tim) return LK_OK;
+    long long t[8];
+    HIPCHK(hipMemcpyAsync(t, c->res_tim, sizeof(t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; ++i) out8[i] = (int64_t)t[i];
     return LK_OK;
 }
 

@@ -3,24 +3,32 @@
 // For panels that fit the 256 MB memory-side cache the three-sweep schedule of lk_kernels.hip.h is bound by its launches, not by
 // bytes: three sweeps + three finish kernels + the normalise = seven kernel boundaries around 10-20 us of streaming
 // (profiles/r05_dgs_size_scan.jsonl: n = 3 10^5, k = 32 -> 96 us per step at 2.5 TB/s).  Here every block OWNS a contiguous run of
-// row tiles for the whole step and walks it once per phase
+// row tiles for the whole step:
 //   phase 1   h1 = X^H y , ||y||^2                              (gram_schmidt.fypp:126, 141)
 //   phase 2   y' = y - X h1 in registers ; h2 = X^H y' , ||y'||^2      (:144-145, second pass :126, 141)
-//   phase 3   y'' = (y - X h1) - X h2 stored ; ||y''||^2       (:144-145; y' re-formed exactly as phase 2 formed it)
+//   phase 3   y'' = y' - X h2 ; ||y''||^2                       (:144-145)
 //   phase 4   y'' <- y'' / ||y''||  (qr_no_pivoting's scale, qr.fypp:165) with the breakdown test of the asynchronous batch
-// with a grid-wide SUM between the phases: block partials -> group sums (the blocks b, b + 8, ... that share an XCD under
-// round-robin placement: their hand-off stays in one L2; placement is speed only, every access below is agent scope) -> totals,
-// every level added in a FIXED order (deterministic, no floating-point atomics).  The second and third walk of a block's rows are
-// served from the XCD's L2 / the memory-side cache as far as the panel fits them; phase 2 walks the tiles backwards so that it
-// starts on the rows phase 1 touched last.
+// with a grid-wide SUM between the phases (fixed order at every level: deterministic, no floating-point atomics).
+//
+// Two kernels:
+//   dgs_onchip    the block's tiles of X and y stay IN REGISTERS from phase 1 to the end: X is read from memory ONCE (k + 1 columns
+//                 in, one out, against 3k + 5 for the three sweeps), phases 2-4 touch no memory but the sums.  Takes panels up to the
+//                 register files' capacity: 32 16-byte values per lane, 512 lanes per CU = 256 KB per CU, 64 MB on the chip.
+//   dgs_resident  larger panels that still fit the memory-side cache: the block walks its tiles once per phase (the second and third
+//                 walk are served from L2 / the memory-side cache; measured 8-11 TB/s, profiles/r06_resident_phases.jsonl), phase 3
+//                 re-forms y' from y as sweep 3 of the three-sweep schedule does.
+// In-kernel timeline that shaped them (block 0's clock, first version of dgs_resident): an EMPTY phase cost 4.6 us -- 2 us of it
+// the 16 dependent wave_sum chains of the dot epilogue, replaced here by a transpose through LDS --, a grid-wide sum 6 us: seven
+// dependent memory round trips (payload drain, ticket, group reduce, drain, top counter, poll, read), cut to four for small payloads
+// (every block adds all partials itself: "flat").
 //
 // Hand-off protocol (MI355X_MICROARCH.md, "inter-workgroup visibility", table row 1): payload written with agent-scope (sc1,
 // write-through) 8-byte stores, every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds to an agent-scope
-// counter; the block whose add came last reduces its group and adds to the top counter; ONE lane per block polls the top counter
-// with agent-scope loads (+ s_sleep), joins a workgroup barrier, and every payload load is an agent-scope (sc1) load.
-// All blocks must be co-resident: the grid is at most one block per CU.  A spin that outlasts its deadline (another persistent
-// kernel holding the CUs) raises the abort word: nothing has been written to y at that point (the first wait comes before any
-// store), the launcher falls back to the three-sweep schedule and resets the counters.
+// counter; ONE wave per block polls the counters with agent-scope loads (+ s_sleep), joins a workgroup barrier, and every payload
+// load is an agent-scope (sc1) load.  Counters are sharded over 8 block groups (b % 8: the blocks that share an XCD under round-robin
+// placement; placement is speed only).  All blocks must be co-resident: the grid is at most one block per CU.  A spin that outlasts
+// its deadline (another persistent kernel holding the CUs) raises the abort word: nothing has been written to y at that point (the
+// first wait comes before any store), the launcher falls back to the three-sweep schedule and resets the counters.
 #pragma once
 #include "lk_kernels.hip.h"
 
@@ -32,34 +40,97 @@ constexpr int RES_CNT_STRIDE = 32;   // unsigneds between two counters: a 128-by
 constexpr int RES_NCNT = RES_EPISODES * (RES_GROUPS + 1) + 2;   // per episode: 8 group counters + top ; exit counter ; abort word
 constexpr int RES_EXIT = RES_EPISODES * (RES_GROUPS + 1);
 constexpr int RES_ABORT = RES_EXIT + 1;
+constexpr int RES_ROW = 68;          // doubles per row of the transpose buffer: 64 lanes + 4 (the quarter sums then read conflict-free)
 
 struct ResidentWs {
     double *part;     // [RES_EPISODES][grid][S]        block partials
     double *xsum;     // [RES_EPISODES][RES_GROUPS][S]  group sums
     unsigned *cnt;    // [RES_NCNT][RES_CNT_STRIDE]     all zero between launches (the last block to leave clears them)
     int S;            // slot stride (>= (k + 1) * ED)
+    long long *tim;   // [8] wall_clock64 of block 0 at the phase boundaries of the last launch (lk_resident_phase_ticks)
 };
 
 __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned *res_ctr(const ResidentWs &ws, int i) { return ws.cnt + (size_t)i * RES_CNT_STRIDE; }
 
+// One lane waits until counter `ctr` reaches `target`.  Returns 0 when the launch was given up (abort word raised, by this block
+// past its deadline or by another one).
+__device__ __forceinline__ int res_wait(const ResidentWs &ws, const unsigned *ctr, unsigned target, long long deadline) {
+    unsigned *abortw = res_ctr(ws, RES_ABORT);
+    for (unsigned it = 0;; ++it) {
+        if (ld_agent(ctr) >= target) return 1;
+        if ((it & 15) == 0) {
+            if (ld_agent(abortw) != 0u) return 0;
+            if (wall_clock64() > deadline) {
+                __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return 0;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 // Sum over the grid of this block's partials mine[first, nslots) (LDS) -> tot[first, nslots) (LDS), identical bits in every block.
-// Returns false when the launch was aborted (block-uniform).  `ctl` = 2 ints of LDS.
+// Returns false when the launch was given up (block-uniform).  `ctl` = 2 ints, `scr` = NT doubles of LDS.
+//   flat (small payloads): every block adds ALL blocks' partials itself -- block order b = r, r + R, ... within R interleaved runs,
+//     then the runs in order -- after one wave has seen the 8 group counters full: four dependent round trips (drain, add, poll, read)
+//   else: the last block to arrive in a group adds its members in member order and publishes the group sum, every block adds the
+//     8 group sums: seven round trips, but G + 8 instead of G loads per slot and block.
 template <int NT>
 __device__ __forceinline__ bool grid_sum(const ResidentWs &ws, int ep, int first, int nslots, const double *mine, double *tot, int *ctl,
-                                         long long deadline) {
+                                         double *scr, long long deadline) {
     const int b = blockIdx.x, G = gridDim.x;
     const int g = b % RES_GROUPS;
     const int ngroups = G < RES_GROUPS ? G : RES_GROUPS;
     const int members = (G - g + RES_GROUPS - 1) / RES_GROUPS;       // blocks g, g + 8, ... < G
+    const int cnt = nslots - first;
     double *part = ws.part + ((size_t)ep * G) * ws.S;
     double *xs = ws.xsum + ((size_t)ep * RES_GROUPS) * ws.S;
+    unsigned *ctr0 = res_ctr(ws, ep * (RES_GROUPS + 1));
     for (int o = first + threadIdx.x; o < nslots; o += NT) st_agent(part + (size_t)b * ws.S + o, mine[o]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const bool flat = (int64_t)cnt * G <= (int64_t)NT * 16 && cnt <= NT;   // <= 16 loads per thread
+    if (flat) {
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr0 + (size_t)g * RES_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < 64) {
+            int ok = 1;
+            if ((int)threadIdx.x < ngroups) {
+                const int mi = (G - (int)threadIdx.x + RES_GROUPS - 1) / RES_GROUPS;
+                ok = res_wait(ws, ctr0 + (size_t)threadIdx.x * RES_CNT_STRIDE, (unsigned)mi, deadline);
+            }
+            ok = __all(ok);
+            if (threadIdx.x == 0) ctl[1] = ok;
+        }
+        __syncthreads();
+        if (!ctl[1]) return false;
+        int R = NT / cnt;                                            // interleaved runs of blocks, one thread per (run, slot)
+        R = R > 32 ? 32 : R;
+        const int run = threadIdx.x / cnt, o = first + (int)threadIdx.x % cnt;
+        if (run < R) {
+            double s = 0.0;
+            for (int bb = run; bb < G; bb += 8 * R) {                // eight loads in flight, added in block order
+                double v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = bb + i * R < G ? ld_agent(part + (size_t)(bb + i * R) * ws.S + o) : 0.0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += v[i];
+            }
+            scr[threadIdx.x] = s;
+        }
+        __syncthreads();
+        for (int oo = threadIdx.x; oo < cnt; oo += NT) {
+            double s = 0.0;
+            for (int r = 0; r < R; ++r) s += scr[r * cnt + oo];
+            tot[first + oo] = s;
+        }
+        __syncthreads();
+        return true;
+    }
     if (threadIdx.x == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(res_ctr(ws, ep * (RES_GROUPS + 1) + g), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned ticket = __hip_atomic_fetch_add(ctr0 + (size_t)g * RES_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ctl[0] = ticket == (unsigned)(members - 1);
     }
     __syncthreads();
@@ -79,27 +150,9 @@ __device__ __forceinline__ bool grid_sum(const ResidentWs &ws, int ep, int first
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0)
-            (void)__hip_atomic_fetch_add(res_ctr(ws, ep * (RES_GROUPS + 1) + RES_GROUPS), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr0 + (size_t)RES_GROUPS * RES_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x == 0) {
-        const unsigned *top = res_ctr(ws, ep * (RES_GROUPS + 1) + RES_GROUPS);
-        unsigned *abortw = res_ctr(ws, RES_ABORT);
-        int ok = 1;
-        for (unsigned it = 0;; ++it) {
-            if (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)ngroups) break;
-            if ((it & 15) == 15) {
-                if (__hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-                if (wall_clock64() > deadline) {
-                    __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = 0;
-                    break;
-                }
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        ctl[1] = ok;
-    }
+    if (threadIdx.x == 0) ctl[1] = res_wait(ws, ctr0 + (size_t)RES_GROUPS * RES_CNT_STRIDE, (unsigned)ngroups, deadline);
     __syncthreads();
     if (!ctl[1]) return false;
     for (int o = first + threadIdx.x; o < nslots; o += NT) {
@@ -113,6 +166,73 @@ __device__ __forceinline__ bool grid_sum(const ResidentWs &ws, int ep, int first
     }
     __syncthreads();
     return true;
+}
+
+// Block-level sums of the waves' per-lane partial sums through a TRANSPOSE in LDS: lane L of wave w writes its KC column partials
+// (and its norm partial) to rows of RES_ROW doubles, four threads per row add 16 values each (stride 4: conflict-free thanks to the
+// 4 doubles of padding), one thread per output adds the quarters and the row-waves.  ~0.4 us where KC dependent wave_sum chains took
+// 2 us.  T: (NW * KC + NW) * RES_ROW doubles, Q: (NW * KC + NW) * 4 doubles.  Fixed order throughout.
+//   vals[jj]: this lane's partial of column c0 + jj, `part` of ED (complex: one call per part) ; nrm: only when part == 0
+template <int KC, int NW, int ED>
+__device__ __forceinline__ void block_sums(const double (&vals)[KC], double nrm, bool with_cols, int part, int k, int WC, int kcw, double *T,
+                                           double *Q, double *mine) {
+    constexpr int NT = NW * 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int WR = NW / WC;
+    if (with_cols) {
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) T[(wave * KC + jj) * RES_ROW + lane] = vals[jj];
+    }
+    if (part == 0) T[(NW * KC + wave) * RES_ROW + lane] = nrm;
+    __syncthreads();
+    const int row0 = with_cols ? 0 : NW * KC, row1 = part == 0 ? NW * KC + NW : NW * KC;
+    for (int idx = row0 * 4 + threadIdx.x; idx < row1 * 4; idx += NT) {
+        const double *p = T + (idx >> 2) * RES_ROW + (idx & 3);
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += p[4 * i];
+        Q[idx] = s;
+    }
+    __syncthreads();
+    auto rowsum = [&](int row) { return (Q[row * 4] + Q[row * 4 + 1]) + (Q[row * 4 + 2] + Q[row * 4 + 3]); };
+    if (with_cols) {
+        for (int j = threadIdx.x; j < k; j += NT) {
+            const int cg = j / kcw, jj = j - cg * kcw;
+            double s = 0.0;
+            for (int w = 0; w < WR; ++w) s += rowsum((w * WC + cg) * KC + jj);
+            mine[j * ED + part] = s;
+        }
+    }
+    if (part == 0 && threadIdx.x == NT - 1) {
+        double s = 0.0;
+        for (int w = 0; w < WR; ++w) s += rowsum(NW * KC + w * WC);          // wave-column 0 of every row-wave carries the norm
+        mine[k * ED] = s;
+        if (ED == 2) mine[k * ED + 1] = 0.0;
+    }
+    __syncthreads();
+}
+
+// acc (per column: real = the lane's two rows, complex = (re, im)) + norm partial -> mine[0, (k + 1) * ED)
+template <bool CPLX, int KC, int NW>
+__device__ __forceinline__ void block_sums_acc(const v2d (&acc)[KC], double nrm, bool with_cols, int k, int WC, int kcw, double *T, double *Q,
+                                               double *mine) {
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    double v[KC];
+    if constexpr (CPLX) {
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) v[jj] = acc[jj].x;
+        block_sums<KC, NW, ED>(v, nrm, with_cols, 0, k, WC, kcw, T, Q, mine);
+        if (with_cols) {
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) v[jj] = acc[jj].y;
+            block_sums<KC, NW, ED>(v, 0.0, true, 1, k, WC, kcw, T, Q, mine);
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) v[jj] = acc[jj].x + acc[jj].y;
+        block_sums<KC, NW, ED>(v, nrm, with_cols, 0, k, WC, kcw, T, Q, mine);
+    }
 }
 
 // y as this lane stored it a moment ago: served from L2 (the line the CU's L1 holds predates the store)
@@ -147,83 +267,234 @@ __device__ __forceinline__ void res_load_cols(const double *__restrict__ Xw, int
     }
 }
 
-// One phase over the block's tiles [t0, t1): panel_sweep's tile body (SC = 1, G = 1) with the coefficients taken from LDS.
-//   MODE 1: dot   MODE 2: update (kept in registers) + dot   MODE 4: two-coefficient update, stored
-// Leaves the block's partial sums in mine[0, (k + 1) * ED): slots 0..k-1 = h (MODE 1, 2), slot k = the norm of what y became.
-template <bool CPLX, int KC, int NW, bool NT, int MODE>
-__device__ __forceinline__ void res_phase(const double *__restrict__ X, int64_t ldx, int k, double *__restrict__ y, int64_t n,
-                                          const double *h1, const double *h2, int WC, int kcw, int64_t t0, int64_t t1, bool reverse,
-                                          v2d *u_lds, double *red_lds, double *mine) {
-    constexpr int ROWS = K<CPLX>::ROWS;
-    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
-    constexpr int WROWS = 64 * ROWS;
-    constexpr bool UPDATE = MODE != 1, DOT = MODE <= 2, TWO = MODE == 4;
-    constexpr int NU = TWO ? 2 : 1;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wc = wave % WC, wr = wave / WC, WR = NW / WC;
-    const int c0 = wc * kcw;
-    int nc = k - c0;
-    nc = nc > kcw ? kcw : nc;
-    nc = nc < 0 ? 0 : nc;
-
-    // projection coefficients: read from LDS at every use (all lanes the same address: a broadcast).  Held in registers across the
-    // tile loop they would cost 2-4 VGPRs per column and set (they arrive from LDS, not through scalar loads); the index is laundered
-    // through an empty asm so that the compiler cannot hoist the reads.  Columns beyond nc read column c0 (finite) against zeros of X.
-    auto hcoef = [&](const double *h, int jj) -> v2d {
+// u = sum_jj xv[jj] * h[c0 + jj]: the coefficients are read from LDS at every use (all lanes the same address: a broadcast).  Held in
+// registers across the tiles they would cost 2-4 VGPRs per column (they arrive from LDS, not through scalar loads); the index is
+// laundered through an empty asm so that the compiler cannot hoist the reads.  Slots beyond nc read column 0 against zeros of X.
+template <bool CPLX, int KC>
+__device__ __forceinline__ v2d res_project(const v2d (&xv)[KC], const double *h, int c0, int nc) {
+    v2d u = v2d{0.0, 0.0};
+#pragma unroll
+    for (int jj = 0; jj < KC; ++jj) {
         int cj = jj < nc ? c0 + jj : 0;
         asm volatile("" : "+v"(cj));
-        if constexpr (CPLX) return *reinterpret_cast<const v2d *>(h + 2 * cj);
-        else return v2d{h[cj], 0.0};
-    };
-    v2d acc[DOT ? KC : 1];
-#pragma unroll
-    for (int jj = 0; jj < (DOT ? KC : 1); ++jj) acc[jj] = v2d{0.0, 0.0};
-    double nrm = 0.0;
+        if constexpr (CPLX) u += cmul(xv[jj], *reinterpret_cast<const v2d *>(h + 2 * cj));
+        else u += xv[jj] * h[cj];
+    }
+    return u;
+}
 
-    const int64_t tile_rows = (int64_t)WR * WROWS;
-    const double *Xw = X + (int64_t)c0 * ldx * ED;
-    const int64_t colstride = ldx * ED;
-    const int64_t roff = (int64_t)wr * WROWS + (int64_t)lane * ROWS;
-    int buf = 0;
-    for (int64_t i = t0; i < t1; ++i) {
-        const int64_t t = reverse ? t1 - 1 - (i - t0) : i;
-        const int64_t r = t * tile_rows + roff;
-        const bool full = (t + 1) * tile_rows <= n;
-        v2d xv[KC];
-        v2d yv = load_y<CPLX>(y, r, n, full);
-        res_load_cols<CPLX, KC, NT>(Xw, colstride, r, n, full, nc, xv);
-        if constexpr (UPDATE) {
-            v2d u = v2d{0.0, 0.0}, u2 = v2d{0.0, 0.0};
+// the wave-columns' shares of X h for one tile meet in LDS (double buffered: one barrier per tile); every wave of a row-wave ends with
+// the same bits
+template <int NW>
+__device__ __forceinline__ v2d res_exchange(v2d u, v2d *u_lds, int &buf, int WC, int wr) {
+    if (WC == 1) return u;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    v2d *ub = u_lds + buf * (NW * 64);
+    ub[wave * 64 + lane] = u;
+    __syncthreads();
+    v2d s = v2d{0.0, 0.0};
+    for (int w = 0; w < WC; ++w) s += ub[(wr * WC + w) * 64 + lane];
+    buf ^= 1;
+    return s;
+}
+
+struct ResGeom {
+    int lane, wave, wc, wr, WR, c0, nc;
+    int64_t tile_rows, t0, t1, roff, colstride;
+};
+template <bool CPLX, int NW>
+__device__ __forceinline__ ResGeom res_geom(int k, int64_t n, int64_t ldx, int WC, int kcw) {
+    constexpr int ROWS = K<CPLX>::ROWS;
+    ResGeom q;
+    q.lane = threadIdx.x & 63;
+    q.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    q.wc = q.wave % WC;
+    q.wr = q.wave / WC;
+    q.WR = NW / WC;
+    q.c0 = q.wc * kcw;
+    int nc = k - q.c0;
+    nc = nc > kcw ? kcw : nc;
+    q.nc = nc < 0 ? 0 : nc;
+    q.tile_rows = (int64_t)q.WR * 64 * ROWS;
+    const int64_t ntiles = (n + q.tile_rows - 1) / q.tile_rows;
+    q.t0 = ntiles * blockIdx.x / gridDim.x;
+    q.t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
+    q.roff = (int64_t)q.wr * 64 * ROWS + (int64_t)q.lane * ROWS;
+    q.colstride = ldx * K<CPLX>::ELEM_DOUBLES;
+    return q;
+}
+
+// results, breakdown flag and the counters' clean-up shared by the two kernels
+template <int NTHR>
+__device__ __forceinline__ void res_publish(const double *h1, const double *h2, double nrm2, int k, int ED, double *out, int rs, double tol_break,
+                                            int *stop_out, int step) {
+    if (blockIdx.x != 0) return;
+    const int nslots = (k + 1) * ED;
+    double *r0 = out, *r1 = out + rs, *r2 = out + 2 * (int64_t)rs;
+    for (int o = threadIdx.x; o < nslots; o += NTHR) { r0[o] = h1[o]; r1[o] = h2[o]; }
+    if (threadIdx.x == 0) {
+        r2[k * ED] = nrm2;
+        r2[k * ED + 1] = 0.0;
+        if (stop_out && !(sqrt(fabs(nrm2)) >= tol_break)) *stop_out = step;
+    }
+}
+__device__ __forceinline__ void res_leave(const ResidentWs &ws) {
+    // the last block to leave clears the counters for the next launch (nobody polls any more: every block is past its last wait)
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(res_ctr(ws, RES_EXIT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == gridDim.x - 1)
+            for (int i = 0; i <= RES_EXIT; ++i) __hip_atomic_store(res_ctr(ws, i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// flags: bit 0 = normalise y'' (skipped below tol_scale) ; bit 1 (dgs_resident) = phase 2 walks the tiles backwards
+// out: three result sections of `rs` doubles (h1 | ||y||^2 ; h2 | ||y'||^2 ; slot k = ||y''||^2, slot k*ED+1 of the THIRD section =
+// launch status: 0 done, 1 given up before anything was written to y, 2 failed after y'' was stored).
+#define LK_RES_ARGS                                                                                                                       \
+    const double *__restrict__ X, int64_t ldx, int k, double *__restrict__ y, int64_t n, ResidentWs ws, double *__restrict__ out, int rs, \
+        int WC, int kcw, int flags, double tol_scale, double tol_break, int *__restrict__ stop_out, long long spin_ticks, Guard guard
+
+// ---- the panel in registers ------------------------------------------------------------------------------------------------------
+// RT = 32 / KC tiles of KC columns per wave: 32 16-byte values = 128 VGPRs per lane hold the block's part of X for the whole step.
+template <bool CPLX, int KC, int NW>
+__global__ __launch_bounds__(NW * 64) void dgs_onchip(LK_RES_ARGS) {
+    if (stopped(guard)) return;
+    constexpr int ED = K<CPLX>::ELEM_DOUBLES;
+    constexpr int NTHR = NW * 64;
+    constexpr int RT = 32 / KC;
+    constexpr int CAPS = (KC * NW + 1) * ED + 1;
+    __shared__ v2d u_lds[2 * NW * 64];
+    __shared__ double T[(NW * KC + NW) * RES_ROW], Q[(NW * KC + NW) * 4];
+    __shared__ __attribute__((aligned(16))) double mine[CAPS], h1[CAPS], h2[CAPS], h3[CAPS];
+    __shared__ int ctl[2];
+    const ResGeom q = res_geom<CPLX, NW>(k, n, ldx, WC, kcw);
+    const int nb = (int)(q.t1 - q.t0);                     // <= RT (the launcher's grid guarantees it)
+    const double *Xw = X + (int64_t)q.c0 * q.colstride;
+
+    // every load of the step is issued before anything else
+    v2d xk[RT][KC], yk[RT];
 #pragma unroll
-            for (int jj = 0; jj < KC; ++jj) {
-                if constexpr (CPLX) u += cmul(xv[jj], hcoef(h1, jj));
-                else u += xv[jj] * hcoef(h1, jj).x;
-            }
-            if constexpr (TWO) {
+    for (int i = 0; i < RT; ++i) {
+        if (i < nb) {
+            const int64_t t = q.t0 + i, r = t * q.tile_rows + q.roff;
+            const bool full = (t + 1) * q.tile_rows <= n;
+            yk[i] = load_y<CPLX>(y, r, n, full);
+            res_load_cols<CPLX, KC, false>(Xw, q.colstride, r, n, full, q.nc, xk[i]);
+        } else {
+            yk[i] = v2d{0.0, 0.0};
+#pragma unroll
+            for (int jj = 0; jj < KC; ++jj) xk[i][jj] = v2d{0.0, 0.0};
+        }
+    }
+    if (threadIdx.x == 0) ctl[0] = ld_agent(res_ctr(ws, RES_ABORT)) != 0u;
+    __syncthreads();
+    if (ctl[0]) return;                                   // a block that became resident after the launch was given up
+    const long long start = wall_clock64();
+    const long long deadline = start + spin_ticks, deadline_late = deadline + 1000000000ll;
+    double *r2 = out + 2 * (int64_t)rs;
+    auto give_up = [&](double status) {
+        if (threadIdx.x == 0) {
+            r2[k * ED + 1] = status;
+            if (stop_out) *stop_out = guard.step;
+        }
+    };
+    auto stamp = [&](int i) { if (blockIdx.x == 0 && threadIdx.x == 0) ws.tim[i] = wall_clock64(); };
+    stamp(0);
+
+    v2d acc[KC];
+    double nrm = 0.0;
+    auto dots = [&]() {
+#pragma unroll
+        for (int jj = 0; jj < KC; ++jj) acc[jj] = v2d{0.0, 0.0};
+        nrm = 0.0;
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            if (i < nb) {
 #pragma unroll
                 for (int jj = 0; jj < KC; ++jj) {
-                    if constexpr (CPLX) u2 += cmul(xv[jj], hcoef(h2, jj));
-                    else u2 += xv[jj] * hcoef(h2, jj).x;
+                    if constexpr (CPLX) acc[jj] += cmulconj(xk[i][jj], yk[i]);
+                    else acc[jj] += xk[i][jj] * yk[i];
                 }
+                nrm += yk[i].x * yk[i].x + yk[i].y * yk[i].y;
             }
-            if (WC > 1) {
-                v2d *ub = u_lds + buf * (NU * NW * 64);
-                ub[wave * 64 + lane] = u;
-                if constexpr (TWO) ub[NW * 64 + wave * 64 + lane] = u2;
-                __syncthreads();
-                v2d s = v2d{0.0, 0.0}, s2 = v2d{0.0, 0.0};
-                for (int w = 0; w < WC; ++w) s += ub[(wr * WC + w) * 64 + lane];
-                if constexpr (TWO)
-                    for (int w = 0; w < WC; ++w) s2 += ub[NW * 64 + (wr * WC + w) * 64 + lane];
-                u = s;
-                u2 = s2;
-                buf ^= 1;
+        }
+    };
+    int buf = 0;
+    auto update = [&](const double *h) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            if (i < nb) {                                  // (block-uniform: the barrier inside res_exchange is safe)
+                const v2d u = res_project<CPLX, KC>(xk[i], h, q.c0, q.nc);
+                yk[i] -= res_exchange<NW>(u, u_lds, buf, WC, q.wr);
             }
-            yv -= u;
+        }
+    };
+
+    dots();                                                                                   // phase 1
+    block_sums_acc<CPLX, KC, NW>(acc, nrm, true, k, WC, kcw, T, Q, mine);
+    stamp(1);
+    if (!grid_sum<NTHR>(ws, 0, 0, (k + 1) * ED, mine, h1, ctl, T, deadline)) { give_up(1.0); return; }
+    stamp(2);
+    update(h1);                                                                               // phase 2
+    dots();
+    block_sums_acc<CPLX, KC, NW>(acc, nrm, true, k, WC, kcw, T, Q, mine);
+    stamp(3);
+    if (!grid_sum<NTHR>(ws, 1, 0, (k + 1) * ED, mine, h2, ctl, T, deadline_late)) { give_up(1.0); return; }
+    stamp(4);
+    update(h2);                                                                               // phase 3
+    nrm = 0.0;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+        if (i < nb) nrm += yk[i].x * yk[i].x + yk[i].y * yk[i].y;
+    block_sums_acc<CPLX, KC, NW>(acc, nrm, false, k, WC, kcw, T, Q, mine);
+    stamp(5);
+    if (!grid_sum<NTHR>(ws, 2, k * ED, (k + 1) * ED, mine, h3, ctl, T, deadline_late)) { give_up(1.0); return; }   // (y not stored yet: still a clean give-up)
+    stamp(6);
+    const double nr = sqrt(fabs(h3[k * ED]));
+    res_publish<NTHR>(h1, h2, h3[k * ED], k, ED, out, rs, tol_break, stop_out, guard.step);
+    const double scale = ((flags & 1) && nr >= tol_scale) ? 1.0 / nr : 1.0;                   // phase 4: y'' leaves the chip ONCE, scaled
+    if (q.wc == 0) {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            if (i < nb) {
+                const int64_t t = q.t0 + i, r = t * q.tile_rows + q.roff;
+                store_rows<CPLX>(y, r, n, (t + 1) * q.tile_rows <= n, yk[i] * scale, 0);
+            }
+        }
+    }
+    stamp(7);
+    res_leave(ws);
+}
+
+// ---- the panel in the caches -------------------------------------------------------------------------------------------------------
+// One phase over the block's tiles [t0, t1): panel_sweep's tile body (SC = 1, G = 1).
+//   MODE 1: dot   MODE 2: update (kept in registers) + dot   MODE 4: two-coefficient update, stored
+template <bool CPLX, int KC, int NW, int MODE>
+__device__ __forceinline__ void res_phase(const double *__restrict__ X, double *__restrict__ y, int64_t n, int k, const ResGeom &q,
+                                          const double *h1, const double *h2, int WC, int kcw, bool reverse, v2d *u_lds, double *T, double *Q,
+                                          double *mine) {
+    constexpr bool UPDATE = MODE != 1, DOT = MODE <= 2, TWO = MODE == 4;
+    v2d acc[KC];
+#pragma unroll
+    for (int jj = 0; jj < KC; ++jj) acc[jj] = v2d{0.0, 0.0};
+    double nrm = 0.0;
+    const double *Xw = X + (int64_t)q.c0 * q.colstride;
+    int buf = 0;
+    for (int64_t i = q.t0; i < q.t1; ++i) {
+        const int64_t t = reverse ? q.t1 - 1 - (i - q.t0) : i;
+        const int64_t r = t * q.tile_rows + q.roff;
+        const bool full = (t + 1) * q.tile_rows <= n;
+        v2d xv[KC];
+        v2d yv = load_y<CPLX>(y, r, n, full);
+        res_load_cols<CPLX, KC, false>(Xw, q.colstride, r, n, full, q.nc, xv);
+        if constexpr (UPDATE) {
+            const v2d u = res_project<CPLX, KC>(xv, h1, q.c0, q.nc);
+            yv -= res_exchange<NW>(u, u_lds, buf, WC, q.wr);
             if constexpr (TWO) {
-                yv -= u2;
-                if (wc == 0) store_rows<CPLX>(y, r, n, full, yv, 0);
+                const v2d u2 = res_project<CPLX, KC>(xv, h2, q.c0, q.nc);
+                yv -= res_exchange<NW>(u2, u_lds, buf, WC, q.wr);
+                if (q.wc == 0) store_rows<CPLX>(y, r, n, full, yv, 0);
             }
         }
         if constexpr (DOT) {
@@ -233,123 +504,68 @@ __device__ __forceinline__ void res_phase(const double *__restrict__ X, int64_t 
                 else acc[jj] += xv[jj] * yv;
             }
         }
-        if (wc == 0) nrm += yv.x * yv.x + yv.y * yv.y;
+        nrm += yv.x * yv.x + yv.y * yv.y;
     }
-
-    constexpr int SLOTS = KC * ED + 1;
-    if constexpr (DOT) {
-#pragma unroll
-        for (int jj = 0; jj < KC; ++jj) {
-            if constexpr (CPLX) {
-                const double re = wave_sum(acc[jj].x), im = wave_sum(acc[jj].y);
-                if (lane == 0) { red_lds[wave * SLOTS + 2 * jj] = re; red_lds[wave * SLOTS + 2 * jj + 1] = im; }
-            } else {
-                const double s = wave_sum(acc[jj].x + acc[jj].y);
-                if (lane == 0) red_lds[wave * SLOTS + jj] = s;
-            }
-        }
-    }
-    {
-        const double s = wave_sum(nrm);
-        if (lane == 0) red_lds[wave * SLOTS + KC * ED] = s;
-    }
-    __syncthreads();
-    if constexpr (DOT) {
-        for (int o = threadIdx.x; o < k * ED; o += NW * 64) {
-            const int j = o / ED, part = o % ED;
-            const int cgj = j / kcw, jj = j - cgj * kcw;
-            double s = 0.0;
-            for (int w = 0; w < WR; ++w) s += red_lds[(w * WC + cgj) * SLOTS + jj * ED + part];
-            mine[o] = s;
-        }
-    }
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int w = 0; w < WR; ++w) s += red_lds[(w * WC) * SLOTS + KC * ED];
-        mine[k * ED] = s;
-        if constexpr (CPLX) mine[k * ED + 1] = 0.0;
-    }
-    __syncthreads();
+    block_sums_acc<CPLX, KC, NW>(acc, nrm, DOT, k, WC, kcw, T, Q, mine);
 }
 
-// flags: bit 0 = normalise y'' (skipped below tol_scale) ; bit 1 = phase 2 walks the tiles backwards
-// out: three result sections of `rs` doubles (h1 | ||y||^2 ; h2 | ||y'||^2 ; slot k = ||y''||^2, slot k*ED+1 of the THIRD section =
-// launch status: 0 done, 1 given up before anything was written to y, 2 failed after y'' was stored).
-template <bool CPLX, int KC, int NW, bool NT>
-__global__ __launch_bounds__(NW * 64) void dgs_resident(const double *__restrict__ X, int64_t ldx, int k, double *__restrict__ y, int64_t n,
-                                                         ResidentWs ws, double *__restrict__ out, int rs, int WC, int kcw, int flags,
-                                                         double tol_scale, double tol_break, int *__restrict__ stop_out,
-                                                         long long spin_ticks, Guard guard) {
+template <bool CPLX, int KC, int NW>
+__global__ __launch_bounds__(NW * 64) void dgs_resident(LK_RES_ARGS) {
     if (stopped(guard)) return;
-    constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int NTHR = NW * 64;
-    constexpr int CAPS = (KC * NW + 1) * ED;
-    __shared__ v2d u_lds[2 * 2 * NW * 64];
-    __shared__ double red_lds[NW * (KC * ED + 1)];
-    __shared__ __attribute__((aligned(16))) double mine[CAPS + 1], h1[CAPS + 1], h2[CAPS + 1], h3[CAPS + 1];
+    constexpr int CAPS = (KC * NW + 1) * ED + 1;
+    __shared__ v2d u_lds[2 * NW * 64];
+    __shared__ double T[(NW * KC + NW) * RES_ROW], Q[(NW * KC + NW) * 4];
+    __shared__ __attribute__((aligned(16))) double mine[CAPS], h1[CAPS], h2[CAPS], h3[CAPS];
     __shared__ int ctl[2];
-    unsigned *abortw = res_ctr(ws, RES_ABORT);
-    if (threadIdx.x == 0) ctl[0] = __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (threadIdx.x == 0) ctl[0] = ld_agent(res_ctr(ws, RES_ABORT)) != 0u;
     __syncthreads();
     if (ctl[0]) return;                                   // a block that became resident after the launch was given up
-    __syncthreads();
     // the FIRST wait is the one that can starve (a block not yet resident); past it every block is on the chip.  The later waits
     // still carry a (generous) bound so that a defect can never hang the device; one firing there is reported as a failure.
     const long long start = wall_clock64();
     const long long deadline = start + spin_ticks, deadline_late = deadline + 1000000000ll;
-    const int WR = NW / WC;
-    const int64_t tile_rows = (int64_t)WR * 64 * ROWS;
-    const int64_t ntiles = (n + tile_rows - 1) / tile_rows;
-    const int64_t t0 = ntiles * blockIdx.x / gridDim.x, t1 = ntiles * (blockIdx.x + 1) / gridDim.x;
+    const ResGeom q = res_geom<CPLX, NW>(k, n, ldx, WC, kcw);
     const int nslots = (k + 1) * ED;
-    double *r0 = out, *r1 = out + rs, *r2 = out + 2 * (int64_t)rs;
+    double *r2 = out + 2 * (int64_t)rs;
     auto give_up = [&](double status) {
         if (threadIdx.x == 0) {
             r2[k * ED + 1] = status;
             if (stop_out) *stop_out = guard.step;
         }
     };
-
-    res_phase<CPLX, KC, NW, NT, 1>(X, ldx, k, y, n, nullptr, nullptr, WC, kcw, t0, t1, false, u_lds, red_lds, mine);
-    if (!grid_sum<NTHR>(ws, 0, 0, nslots, mine, h1, ctl, deadline)) { give_up(1.0); return; }
-    res_phase<CPLX, KC, NW, NT, 2>(X, ldx, k, y, n, h1, nullptr, WC, kcw, t0, t1, (flags & 2) != 0, u_lds, red_lds, mine);
-    if (!grid_sum<NTHR>(ws, 1, 0, nslots, mine, h2, ctl, deadline_late)) { give_up(1.0); return; }
-    res_phase<CPLX, KC, NW, NT, 4>(X, ldx, k, y, n, h1, h2, WC, kcw, t0, t1, false, u_lds, red_lds, mine);
-    if (!grid_sum<NTHR>(ws, 2, k * ED, nslots, mine, h3, ctl, deadline_late)) { give_up(2.0); return; }
-
+    auto stamp = [&](int i) { if (blockIdx.x == 0 && threadIdx.x == 0) ws.tim[i] = wall_clock64(); };
+    stamp(0);
+    res_phase<CPLX, KC, NW, 1>(X, y, n, k, q, nullptr, nullptr, WC, kcw, false, u_lds, T, Q, mine);
+    stamp(1);
+    if (!grid_sum<NTHR>(ws, 0, 0, nslots, mine, h1, ctl, T, deadline)) { give_up(1.0); return; }
+    stamp(2);
+    res_phase<CPLX, KC, NW, 2>(X, y, n, k, q, h1, nullptr, WC, kcw, (flags & 2) != 0, u_lds, T, Q, mine);
+    stamp(3);
+    if (!grid_sum<NTHR>(ws, 1, 0, nslots, mine, h2, ctl, T, deadline_late)) { give_up(1.0); return; }
+    stamp(4);
+    res_phase<CPLX, KC, NW, 4>(X, y, n, k, q, h1, h2, WC, kcw, false, u_lds, T, Q, mine);
+    stamp(5);
+    if (!grid_sum<NTHR>(ws, 2, k * ED, nslots, mine, h3, ctl, T, deadline_late)) { give_up(2.0); return; }
+    stamp(6);
     const double nr = sqrt(fabs(h3[k * ED]));
-    if (blockIdx.x == 0) {
-        for (int o = threadIdx.x; o < nslots; o += NTHR) { r0[o] = h1[o]; r1[o] = h2[o]; }
-        if (threadIdx.x == 0) {
-            r2[k * ED] = h3[k * ED];
-            r2[k * ED + 1] = 0.0;
-            if (stop_out && !(nr >= tol_break)) *stop_out = guard.step;
-        }
-    }
+    res_publish<NTHR>(h1, h2, h3[k * ED], k, ED, out, rs, tol_break, stop_out, guard.step);
     if ((flags & 1) && nr >= tol_scale) {
         // the lanes that stored y'' scale it: same wave, same lane, same address as the store (ordered by the hardware)
         const double inv = 1.0 / nr;
-        const int lane = threadIdx.x & 63;
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-        const int wc = wave % WC, wr = wave / WC;
-        if (wc == 0) {
-            for (int64_t t = t0; t < t1; ++t) {
-                const int64_t r = t * tile_rows + (int64_t)wr * 64 * ROWS + (int64_t)lane * ROWS;
-                const bool full = (t + 1) * tile_rows <= n;
+        if (q.wc == 0) {
+            for (int64_t t = q.t0; t < q.t1; ++t) {
+                const int64_t r = t * q.tile_rows + q.roff;
+                const bool full = (t + 1) * q.tile_rows <= n;
                 v2d yv = load_y_l2<CPLX>(y, r, n, full);
                 yv *= inv;
                 store_rows<CPLX>(y, r, n, full, yv, 0);
             }
         }
     }
-    // the last block to leave clears the counters for the next launch (nobody polls any more: every block is past its last wait)
-    if (threadIdx.x == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(res_ctr(ws, RES_EXIT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == gridDim.x - 1) {
-            for (int i = 0; i <= RES_EXIT; ++i) __hip_atomic_store(res_ctr(ws, i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    stamp(7);
+    res_leave(ws);
 }
 
 }  // namespace lk
