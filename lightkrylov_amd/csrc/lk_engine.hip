@@ -160,6 +160,8 @@ struct lk_context_s {
     double *res_part = nullptr, *res_xsum = nullptr;
     unsigned *res_cnt = nullptr;
     long long *res_tim = nullptr;
+    void *res_gran = nullptr;              // {value, tag} granules of the flat grid sums
+    unsigned long long res_epoch = 0;      // launches so far (the tag of a launch's granules)
     int64_t resident_stats[3] = {0, 0, 0};   // single launches enqueued, launches that gave up, launches that kept the panel in registers
     int lazy = 0;
     struct {
@@ -1408,7 +1410,7 @@ int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass, double *red_base 
 
 // ---- single-launch step (lk_resident.hip.h) -------------------------------------------------------------------
 constexpr int RES_S = RED_SECTION;                   // slot stride of the hand-off buffers: (128 + 1) * 2 doubles
-constexpr int RES_MAX_GRID = 1024;
+constexpr int RES_MAX_GRID = 512;
 
 int resident_ws(lk_context_t c, ResidentWs *ws) {
     if (!c->res_cnt) {
@@ -1416,10 +1418,15 @@ int resident_ws(lk_context_t c, ResidentWs *ws) {
         HIPCHK(hipMalloc((void **)&c->res_xsum, (size_t)RES_EPISODES * RES_GROUPS * RES_S * sizeof(double)));
         HIPCHK(hipMalloc((void **)&c->res_cnt, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned)));
         HIPCHK(hipMemsetAsync(c->res_cnt, 0, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned), c->stream));
+        const size_t gran_bytes = (size_t)RES_EPISODES * RES_MAX_GRID * RES_S * 16;
+        HIPCHK(hipMalloc(&c->res_gran, gran_bytes));
+        HIPCHK(hipMemsetAsync(c->res_gran, 0, gran_bytes, c->stream));          // (tag 0 is never a launch's)
         HIPCHK(hipMalloc((void **)&c->res_tim, 8 * sizeof(long long)));
         HIPCHK(hipMemsetAsync(c->res_tim, 0, 8 * sizeof(long long), c->stream));
     }
     ws->tim = c->res_tim;
+    ws->gran = (v2d *)c->res_gran;
+    ws->epoch = ++c->res_epoch;
     ws->part = c->res_part;
     ws->xsum = c->res_xsum;
     ws->cnt = c->res_cnt;
@@ -1473,7 +1480,7 @@ int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bo
         for (int KC : {16, 8, 4}) {
             if (k > KC * NW) continue;
             const Shape sh = shape(KC);
-            if (sh.ntiles <= (int64_t)(32 / KC) * maxg) { onchip_kc = KC; break; }
+            if (sh.ntiles <= (int64_t)res_onchip_tiles(KC) * maxg) { onchip_kc = KC; break; }
         }
     const Shape sh = shape(onchip_kc ? onchip_kc : 16);
     int64_t g = sh.ntiles < maxg ? sh.ntiles : maxg;
@@ -1613,6 +1620,7 @@ int lk_finalize(lk_context_t c) {
     if (c->res_xsum) (void)hipFree(c->res_xsum);
     if (c->res_cnt) (void)hipFree(c->res_cnt);
     if (c->res_tim) (void)hipFree(c->res_tim);
+    if (c->res_gran) (void)hipFree(c->res_gran);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return LK_OK;

@@ -47,6 +47,8 @@ struct ResidentWs {
     double *xsum;     // [RES_EPISODES][RES_GROUPS][S]  group sums
     unsigned *cnt;    // [RES_NCNT][RES_CNT_STRIDE]     all zero between launches (the last block to leave clears them)
     int S;            // slot stride (>= (k + 1) * ED)
+    v2d *gran;        // [RES_EPISODES][grid][S]        {value, tag} granules of the flat sums (never cleared: tags are unique per launch)
+    unsigned long long epoch;   // this launch's number (> 0)
     long long *tim;   // [8] wall_clock64 of block 0 at the phase boundaries of the last launch (lk_resident_phase_ticks)
 };
 
@@ -54,6 +56,24 @@ __device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_sto
 __device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned *res_ctr(const ResidentWs &ws, int i) { return ws.cnt + (size_t)i * RES_CNT_STRIDE; }
+
+// 16-byte agent-scope (sc1) accesses for the {value, tag} granules: one store instruction publishes value and tag together, one load
+// reads them together (a naturally aligned 16-byte access is a single request to one cache line).
+__device__ __forceinline__ void st16_agent(v2d *p, v2d v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void ld16x8_agent(const v2d *const (&p)[8], v2d (&g)[8]) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %9, off sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc1\n\t"
+                 "global_load_dwordx4 %3, %11, off sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc1\n\t"
+                 "global_load_dwordx4 %5, %13, off sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc1\n\t"
+                 "global_load_dwordx4 %7, %15, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(g[0]), "=&v"(g[1]), "=&v"(g[2]), "=&v"(g[3]), "=&v"(g[4]), "=&v"(g[5]), "=&v"(g[6]), "=&v"(g[7])
+                 : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+                 : "memory");
+}
 
 // One lane waits until counter `ctr` reaches `target`.  Returns 0 when the launch was given up (abort word raised, by this block
 // past its deadline or by another one).
@@ -89,46 +109,64 @@ __device__ __forceinline__ bool grid_sum(const ResidentWs &ws, int ep, int first
     double *part = ws.part + ((size_t)ep * G) * ws.S;
     double *xs = ws.xsum + ((size_t)ep * RES_GROUPS) * ws.S;
     unsigned *ctr0 = res_ctr(ws, ep * (RES_GROUPS + 1));
-    for (int o = first + threadIdx.x; o < nslots; o += NT) st_agent(part + (size_t)b * ws.S + o, mine[o]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const bool flat = (int64_t)cnt * G <= (int64_t)NT * 16 && cnt <= NT;   // <= 16 loads per thread
+    const bool flat = (int64_t)cnt * G <= (int64_t)NT * 24 && cnt <= NT;   // <= 24 granules per thread
     if (flat) {
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr0 + (size_t)g * RES_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x < 64) {
-            int ok = 1;
-            if ((int)threadIdx.x < ngroups) {
-                const int mi = (G - (int)threadIdx.x + RES_GROUPS - 1) / RES_GROUPS;
-                ok = res_wait(ws, ctr0 + (size_t)threadIdx.x * RES_CNT_STRIDE, (unsigned)mi, deadline);
-            }
-            ok = __all(ok);
-            if (threadIdx.x == 0) ctl[1] = ok;
-        }
-        __syncthreads();
-        if (!ctl[1]) return false;
-        int R = NT / cnt;                                            // interleaved runs of blocks, one thread per (run, slot)
+        // {value, tag} granules, tag = (launch number, episode): no drain, no counter -- a reader that sees the tag sees the value.
+        // Thread (run r, slot o) reads the granules of blocks r, r + R, ... (8 per batch), re-reads until every tag is this episode's,
+        // and adds them in block order; thread o then adds the R runs in order.
+        const double tagd = __longlong_as_double((long long)(ws.epoch * 4ull + (unsigned)ep + 1ull));
+        v2d *gran = ws.gran + ((size_t)ep * G) * ws.S;
+        for (int o = first + threadIdx.x; o < nslots; o += NT) st16_agent(gran + (size_t)b * ws.S + o, v2d{mine[o], tagd});
+        int R = NT / cnt;
         R = R > 32 ? 32 : R;
         const int run = threadIdx.x / cnt, o = first + (int)threadIdx.x % cnt;
-        if (run < R) {
-            double s = 0.0;
-            for (int bb = run; bb < G; bb += 8 * R) {                // eight loads in flight, added in block order
-                double v[8];
+        const bool mineok = run < R;
+        double s = 0.0;
+        if (threadIdx.x == 0) ctl[1] = 1;
+        for (int bb0 = run; ; bb0 += 8 * R) {                         // (block-uniform trip count: every thread runs ceil(G / (8 R)) batches)
+            if (bb0 - run >= G) break;
+            const v2d *p[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = bb + i * R < G ? ld_agent(part + (size_t)(bb + i * R) * ws.S + o) : 0.0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s += v[i];
+            for (int i = 0; i < 8; ++i) {
+                const int bb = bb0 + i * R;
+                p[i] = gran + (size_t)((mineok && bb < G) ? bb : b) * ws.S + (mineok ? o : first);   // (idle slots read an own granule)
             }
-            scr[threadIdx.x] = s;
+            v2d g8[8];
+            for (unsigned it = 0;; ++it) {
+                ld16x8_agent(p, g8);
+                int ok = 1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ok &= __double_as_longlong(g8[i].y) == __double_as_longlong(tagd);
+                if (__syncthreads_and(ok)) break;
+                if (threadIdx.x == 0) {
+                    if ((it & 7) == 0 && ld_agent(res_ctr(ws, RES_ABORT)) != 0u) ctl[1] = 0;
+                    else if (wall_clock64() > deadline) {
+                        __hip_atomic_store(res_ctr(ws, RES_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ctl[1] = 0;
+                    }
+                }
+                __syncthreads();
+                if (!ctl[1]) return false;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (mineok) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += (bb0 + i * R < G) ? g8[i].x : 0.0;
+            }
         }
+        if (mineok) scr[threadIdx.x] = s;
         __syncthreads();
         for (int oo = threadIdx.x; oo < cnt; oo += NT) {
-            double s = 0.0;
-            for (int r = 0; r < R; ++r) s += scr[r * cnt + oo];
-            tot[first + oo] = s;
+            double t = 0.0;
+            for (int r = 0; r < R; ++r) t += scr[r * cnt + oo];
+            tot[first + oo] = t;
         }
         __syncthreads();
         return true;
     }
+    for (int o = first + threadIdx.x; o < nslots; o += NT) st_agent(part + (size_t)b * ws.S + o, mine[o]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned ticket = __hip_atomic_fetch_add(ctr0 + (size_t)g * RES_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ctl[0] = ticket == (unsigned)(members - 1);
@@ -299,6 +337,8 @@ __device__ __forceinline__ v2d res_exchange(v2d u, v2d *u_lds, int &buf, int WC,
     return s;
 }
 
+constexpr int res_onchip_tiles(int KC) { return KC >= 16 ? 2 : (KC >= 8 ? 5 : 9); }   // tiles a block of dgs_onchip keeps in registers
+
 struct ResGeom {
     int lane, wave, wc, wr, WR, c0, nc;
     int64_t tile_rows, t0, t1, roff, colstride;
@@ -356,13 +396,14 @@ __device__ __forceinline__ void res_leave(const ResidentWs &ws) {
         int WC, int kcw, int flags, double tol_scale, double tol_break, int *__restrict__ stop_out, long long spin_ticks, Guard guard
 
 // ---- the panel in registers ------------------------------------------------------------------------------------------------------
-// RT = 32 / KC tiles of KC columns per wave: 32 16-byte values = 128 VGPRs per lane hold the block's part of X for the whole step.
+// RT tiles of KC columns per wave -- 2 x 16, 5 x 8 or 9 x 4: up to 40 16-byte values = 160 VGPRs per lane -- hold the block's part of X
+// for the whole step: 320 KB per CU, 80 MB on the chip.
 template <bool CPLX, int KC, int NW>
 __global__ __launch_bounds__(NW * 64) void dgs_onchip(LK_RES_ARGS) {
     if (stopped(guard)) return;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int NTHR = NW * 64;
-    constexpr int RT = 32 / KC;
+    constexpr int RT = res_onchip_tiles(KC);
     constexpr int CAPS = (KC * NW + 1) * ED + 1;
     __shared__ v2d u_lds[2 * NW * 64];
     __shared__ double T[(NW * KC + NW) * RES_ROW], Q[(NW * KC + NW) * 4];
@@ -402,6 +443,7 @@ __global__ __launch_bounds__(NW * 64) void dgs_onchip(LK_RES_ARGS) {
     auto stamp = [&](int i) { if (blockIdx.x == 0 && threadIdx.x == 0) ws.tim[i] = wall_clock64(); };
     stamp(0);
 
+    // accumulators: complex (re, im); real ONE double per column, the lane's two rows through the same chain (32 VGPRs less)
     v2d acc[KC];
     double nrm = 0.0;
     auto dots = [&]() {
@@ -414,7 +456,7 @@ __global__ __launch_bounds__(NW * 64) void dgs_onchip(LK_RES_ARGS) {
 #pragma unroll
                 for (int jj = 0; jj < KC; ++jj) {
                     if constexpr (CPLX) acc[jj] += cmulconj(xk[i][jj], yk[i]);
-                    else acc[jj] += xk[i][jj] * yk[i];
+                    else acc[jj].x = fma(xk[i][jj].y, yk[i].y, fma(xk[i][jj].x, yk[i].x, acc[jj].x));
                 }
                 nrm += yk[i].x * yk[i].x + yk[i].y * yk[i].y;
             }
