@@ -157,7 +157,6 @@ struct lk_context_s {
     int resident_rev = 1;      // phase 2 walks a block's tiles backwards (starts on what phase 1 read last)
     int resident_spin_ms = 2000;   // bound on the first grid-wide wait; beyond it the launch gives up and the three-sweep schedule runs
     bool resident_off = false; // a launch gave up once (the device is shared with another persistent kernel): not tried again
-    double *res_part = nullptr, *res_xsum = nullptr;
     unsigned *res_cnt = nullptr;
     long long *res_tim = nullptr;
     void *res_gran = nullptr;              // {value, tag} granules of the flat grid sums
@@ -1410,15 +1409,13 @@ int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass, double *red_base 
 
 // ---- single-launch step (lk_resident.hip.h) -------------------------------------------------------------------
 constexpr int RES_S = RED_SECTION;                   // slot stride of the hand-off buffers: (128 + 1) * 2 doubles
-constexpr int RES_MAX_GRID = 512;
+constexpr int RES_MAX_GRID = RES_GRID_CAP;
 
 int resident_ws(lk_context_t c, ResidentWs *ws) {
     if (!c->res_cnt) {
-        HIPCHK(hipMalloc((void **)&c->res_part, (size_t)RES_EPISODES * RES_MAX_GRID * RES_S * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&c->res_xsum, (size_t)RES_EPISODES * RES_GROUPS * RES_S * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&c->res_cnt, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned)));
-        HIPCHK(hipMemsetAsync(c->res_cnt, 0, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned), c->stream));
-        const size_t gran_bytes = (size_t)RES_EPISODES * RES_MAX_GRID * RES_S * 16;
+        HIPCHK(hipMalloc((void **)&c->res_cnt, (size_t)RES_CNT_STRIDE * sizeof(unsigned)));
+        HIPCHK(hipMemsetAsync(c->res_cnt, 0, (size_t)RES_CNT_STRIDE * sizeof(unsigned), c->stream));
+        const size_t gran_bytes = (size_t)RES_EPISODES * (RES_GRID_CAP + RES_GROUPS) * RES_S * 16;
         HIPCHK(hipMalloc(&c->res_gran, gran_bytes));
         HIPCHK(hipMemsetAsync(c->res_gran, 0, gran_bytes, c->stream));          // (tag 0 is never a launch's)
         HIPCHK(hipMalloc((void **)&c->res_tim, 8 * sizeof(long long)));
@@ -1427,18 +1424,16 @@ int resident_ws(lk_context_t c, ResidentWs *ws) {
     ws->tim = c->res_tim;
     ws->gran = (v2d *)c->res_gran;
     ws->epoch = ++c->res_epoch;
-    ws->part = c->res_part;
-    ws->xsum = c->res_xsum;
     ws->cnt = c->res_cnt;
     ws->S = RES_S;
     return LK_OK;
 }
 
-// the counters of a launch that gave up are left as they stood: clear them (stream ordered) and stop trying on this context
+// a launch that gave up leaves the abort word raised: clear it (stream ordered) and stop trying on this context
 int resident_recover(lk_context_t c) {
     c->resident_off = true;
     c->resident_stats[1] += 1;
-    if (c->res_cnt) HIPCHK(hipMemsetAsync(c->res_cnt, 0, (size_t)RES_NCNT * RES_CNT_STRIDE * sizeof(unsigned), c->stream));
+    if (c->res_cnt) HIPCHK(hipMemsetAsync(c->res_cnt, 0, (size_t)RES_CNT_STRIDE * sizeof(unsigned), c->stream));
     return LK_OK;
 }
 
@@ -1616,8 +1611,6 @@ int lk_finalize(lk_context_t c) {
     c->seg_events.clear();
     if (c->step_red) (void)hipFree(c->step_red);
     if (c->step_red_host) (void)hipHostFree(c->step_red_host);
-    if (c->res_part) (void)hipFree(c->res_part);
-    if (c->res_xsum) (void)hipFree(c->res_xsum);
     if (c->res_cnt) (void)hipFree(c->res_cnt);
     if (c->res_tim) (void)hipFree(c->res_tim);
     if (c->res_gran) (void)hipFree(c->res_gran);

@@ -19,35 +19,31 @@
 //                 re-forms y' from y as sweep 3 of the three-sweep schedule does.
 // In-kernel timeline that shaped them (block 0's clock, first version of dgs_resident): an EMPTY phase cost 4.6 us -- 2 us of it
 // the 16 dependent wave_sum chains of the dot epilogue, replaced here by a transpose through LDS --, a grid-wide sum 6 us: seven
-// dependent memory round trips (payload drain, ticket, group reduce, drain, top counter, poll, read), cut to four for small payloads
-// (every block adds all partials itself: "flat").
+// dependent memory round trips (payload drain, ticket, group reduce, drain, top counter, poll, read) -- now two publish-to-seen hops
+// of tagged granules (grid_sum below).
 //
-// Hand-off protocol (MI355X_MICROARCH.md, "inter-workgroup visibility", table row 1): payload written with agent-scope (sc1,
-// write-through) 8-byte stores, every storing wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds to an agent-scope
-// counter; ONE wave per block polls the counters with agent-scope loads (+ s_sleep), joins a workgroup barrier, and every payload
-// load is an agent-scope (sc1) load.  Counters are sharded over 8 block groups (b % 8: the blocks that share an XCD under round-robin
-// placement; placement is speed only).  All blocks must be co-resident: the grid is at most one block per CU.  A spin that outlasts
-// its deadline (another persistent kernel holding the CUs) raises the abort word: nothing has been written to y at that point (the
-// first wait comes before any store), the launcher falls back to the three-sweep schedule and resets the counters.
+// Hand-off protocol (MI355X_MICROARCH.md, "inter-workgroup visibility"): 16-byte {value, tag} granules written by ONE agent-scope
+// (sc1, write-through) store instruction and read by agent-scope 16-byte loads -- a reader that sees this launch's tag sees the value,
+// so nothing has to be drained or counted and nothing is left to clear (the guide's data-tagged granule, R2, with a 64-bit payload).
+// All blocks must be co-resident: the grid is at most one block per CU.  A wait that outlasts its deadline (another persistent
+// kernel holding the CUs) raises the abort word: nothing has been written to y at that point (the first wait comes before any
+// store), the launcher falls back to the three-sweep schedule and clears the word.
 #pragma once
 #include "lk_kernels.hip.h"
 
 namespace lk {
 
-constexpr int RES_GROUPS = 8;        // block groups (b % 8)
+constexpr int RES_GROUPS = 8;        // block groups (b % 8: the blocks that share an XCD under round-robin placement; speed only)
 constexpr int RES_EPISODES = 3;      // grid-wide sums per launch
-constexpr int RES_CNT_STRIDE = 32;   // unsigneds between two counters: a 128-byte line each
-constexpr int RES_NCNT = RES_EPISODES * (RES_GROUPS + 1) + 2;   // per episode: 8 group counters + top ; exit counter ; abort word
-constexpr int RES_EXIT = RES_EPISODES * (RES_GROUPS + 1);
-constexpr int RES_ABORT = RES_EXIT + 1;
+constexpr int RES_GRID_CAP = 512;    // blocks the hand-off buffers hold
+constexpr int RES_ABORT = 0;         // word 0 of `cnt`: the launch was given up
+constexpr int RES_CNT_STRIDE = 32;
 constexpr int RES_ROW = 68;          // doubles per row of the transpose buffer: 64 lanes + 4 (the quarter sums then read conflict-free)
 
 struct ResidentWs {
-    double *part;     // [RES_EPISODES][grid][S]        block partials
-    double *xsum;     // [RES_EPISODES][RES_GROUPS][S]  group sums
-    unsigned *cnt;    // [RES_NCNT][RES_CNT_STRIDE]     all zero between launches (the last block to leave clears them)
+    unsigned *cnt;    // the abort word (zero between launches unless one gave up: the launcher clears it)
     int S;            // slot stride (>= (k + 1) * ED)
-    v2d *gran;        // [RES_EPISODES][grid][S]        {value, tag} granules of the flat sums (never cleared: tags are unique per launch)
+    v2d *gran;        // [RES_EPISODES][RES_GRID_CAP + RES_GROUPS][S]  {value, tag} granules (never cleared: tags are unique per launch)
     unsigned long long epoch;   // this launch's number (> 0)
     long long *tim;   // [8] wall_clock64 of block 0 at the phase boundaries of the last launch (lk_resident_phase_ticks)
 };
@@ -75,135 +71,86 @@ __device__ __forceinline__ void ld16x8_agent(const v2d *const (&p)[8], v2d (&g)[
                  : "memory");
 }
 
-// One lane waits until counter `ctr` reaches `target`.  Returns 0 when the launch was given up (abort word raised, by this block
-// past its deadline or by another one).
-__device__ __forceinline__ int res_wait(const ResidentWs &ws, const unsigned *ctr, unsigned target, long long deadline) {
-    unsigned *abortw = res_ctr(ws, RES_ABORT);
-    for (unsigned it = 0;; ++it) {
-        if (ld_agent(ctr) >= target) return 1;
-        if ((it & 15) == 0) {
-            if (ld_agent(abortw) != 0u) return 0;
-            if (wall_clock64() > deadline) {
-                __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return 0;
-            }
+// Sum over `nrows` rows (row i at src + (row0 + i * rstep) * stride) of the tagged granules of slots [first, first + cnt) -> dst[0, cnt)
+// (LDS), in row order.  Thread (run r, slot o) reads rows r, r + R, ... eight per batch, re-reads a batch until every tag is this
+// episode's (a reader that sees the tag sees the value: one 16-byte store published both), and adds them in row order; thread o then
+// adds the R runs in order.  Returns false when the launch was given up (block-uniform).
+template <int NT>
+__device__ __forceinline__ bool res_gather(const ResidentWs &ws, const v2d *src, int row0, int rstep, int nrows, int stride, int first, int cnt,
+                                           double tagd, double *dst, double *scr, int *ctl, long long deadline) {
+    int R = (nrows + 7) / 8;
+    if (R > NT / cnt) R = NT / cnt;
+    if (R < 1) R = 1;
+    const int run = threadIdx.x / cnt, oo = (int)threadIdx.x % cnt;
+    const bool active = run < R && cnt <= NT;
+    double s = 0.0;
+    if (threadIdx.x == 0) ctl[1] = 1;
+    for (int i0 = 0; i0 * R < nrows; i0 += 8) {                       // (block-uniform trip count)
+        const v2d *p[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = run + (i0 + i) * R;
+            p[i] = src + (size_t)(row0 + (active && row < nrows ? row : 0) * rstep) * stride + first + (active ? oo : 0);
         }
-        __builtin_amdgcn_s_sleep(1);
+        v2d g8[8];
+        for (unsigned it = 0;; ++it) {
+            int ok = 1;
+            if (active) {
+                ld16x8_agent(p, g8);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ok &= __double_as_longlong(g8[i].y) == __double_as_longlong(tagd);
+            }
+            if (__syncthreads_and(ok)) break;
+            if (threadIdx.x == 0) {
+                if ((it & 7) == 7 && ld_agent(res_ctr(ws, RES_ABORT)) != 0u) ctl[1] = 0;
+                else if (wall_clock64() > deadline) {
+                    __hip_atomic_store(res_ctr(ws, RES_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ctl[1] = 0;
+                }
+            }
+            __syncthreads();
+            if (!ctl[1]) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += (run + (i0 + i) * R < nrows) ? g8[i].x : 0.0;
+        }
     }
+    if (active) scr[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = threadIdx.x; o < cnt; o += NT) {
+        double t = 0.0;
+        for (int r = 0; r < R; ++r) t += scr[r * cnt + o];
+        dst[o] = t;
+    }
+    __syncthreads();
+    return true;
 }
 
 // Sum over the grid of this block's partials mine[first, nslots) (LDS) -> tot[first, nslots) (LDS), identical bits in every block.
 // Returns false when the launch was given up (block-uniform).  `ctl` = 2 ints, `scr` = NT doubles of LDS.
-//   flat (small payloads): every block adds ALL blocks' partials itself -- block order b = r, r + R, ... within R interleaved runs,
-//     then the runs in order -- after one wave has seen the 8 group counters full: four dependent round trips (drain, add, poll, read)
-//   else: the last block to arrive in a group adds its members in member order and publishes the group sum, every block adds the
-//     8 group sums: seven round trips, but G + 8 instead of G loads per slot and block.
+// Two levels of {value, tag} granules, tag = (launch number, episode) -- no drain, no counter, nothing to clear afterwards:
+//   every block publishes its partials; the LEADER of each block group (blocks 0..7; group g = the blocks g, g + 8, ...) gathers its
+//   members' in member order and publishes the group sum; every block gathers the 8 group sums in group order.
+// Two publish-to-seen hops on the critical path, G + 8 * G granule reads per slot in all (every block reading every partial
+// itself costs G^2: measured slower from 9 slots on).
 template <int NT>
 __device__ __forceinline__ bool grid_sum(const ResidentWs &ws, int ep, int first, int nslots, const double *mine, double *tot, int *ctl,
                                          double *scr, long long deadline) {
     const int b = blockIdx.x, G = gridDim.x;
-    const int g = b % RES_GROUPS;
     const int ngroups = G < RES_GROUPS ? G : RES_GROUPS;
-    const int members = (G - g + RES_GROUPS - 1) / RES_GROUPS;       // blocks g, g + 8, ... < G
     const int cnt = nslots - first;
-    double *part = ws.part + ((size_t)ep * G) * ws.S;
-    double *xs = ws.xsum + ((size_t)ep * RES_GROUPS) * ws.S;
-    unsigned *ctr0 = res_ctr(ws, ep * (RES_GROUPS + 1));
-    const bool flat = (int64_t)cnt * G <= (int64_t)NT * 24 && cnt <= NT;   // <= 24 granules per thread
-    if (flat) {
-        // {value, tag} granules, tag = (launch number, episode): no drain, no counter -- a reader that sees the tag sees the value.
-        // Thread (run r, slot o) reads the granules of blocks r, r + R, ... (8 per batch), re-reads until every tag is this episode's,
-        // and adds them in block order; thread o then adds the R runs in order.
-        const double tagd = __longlong_as_double((long long)(ws.epoch * 4ull + (unsigned)ep + 1ull));
-        v2d *gran = ws.gran + ((size_t)ep * G) * ws.S;
-        for (int o = first + threadIdx.x; o < nslots; o += NT) st16_agent(gran + (size_t)b * ws.S + o, v2d{mine[o], tagd});
-        int R = NT / cnt;
-        R = R > 32 ? 32 : R;
-        const int run = threadIdx.x / cnt, o = first + (int)threadIdx.x % cnt;
-        const bool mineok = run < R;
-        double s = 0.0;
-        if (threadIdx.x == 0) ctl[1] = 1;
-        for (int bb0 = run; ; bb0 += 8 * R) {                         // (block-uniform trip count: every thread runs ceil(G / (8 R)) batches)
-            if (bb0 - run >= G) break;
-            const v2d *p[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int bb = bb0 + i * R;
-                p[i] = gran + (size_t)((mineok && bb < G) ? bb : b) * ws.S + (mineok ? o : first);   // (idle slots read an own granule)
-            }
-            v2d g8[8];
-            for (unsigned it = 0;; ++it) {
-                ld16x8_agent(p, g8);
-                int ok = 1;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ok &= __double_as_longlong(g8[i].y) == __double_as_longlong(tagd);
-                if (__syncthreads_and(ok)) break;
-                if (threadIdx.x == 0) {
-                    if ((it & 7) == 0 && ld_agent(res_ctr(ws, RES_ABORT)) != 0u) ctl[1] = 0;
-                    else if (wall_clock64() > deadline) {
-                        __hip_atomic_store(res_ctr(ws, RES_ABORT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ctl[1] = 0;
-                    }
-                }
-                __syncthreads();
-                if (!ctl[1]) return false;
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (mineok) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s += (bb0 + i * R < G) ? g8[i].x : 0.0;
-            }
-        }
-        if (mineok) scr[threadIdx.x] = s;
-        __syncthreads();
-        for (int oo = threadIdx.x; oo < cnt; oo += NT) {
-            double t = 0.0;
-            for (int r = 0; r < R; ++r) t += scr[r * cnt + oo];
-            tot[first + oo] = t;
-        }
-        __syncthreads();
-        return true;
+    const double tagd = __longlong_as_double((long long)(ws.epoch * 4ull + (unsigned)ep + 1ull));
+    v2d *g0 = ws.gran + ((size_t)ep * (RES_GRID_CAP + RES_GROUPS)) * ws.S;          // [G][S] block partials | [8][S] group sums
+    v2d *g1 = g0 + (size_t)RES_GRID_CAP * ws.S;
+    for (int o = first + threadIdx.x; o < nslots; o += NT) st16_agent(g0 + (size_t)b * ws.S + o, v2d{mine[o], tagd});
+    if (b < ngroups) {
+        const int members = (G - b + RES_GROUPS - 1) / RES_GROUPS;
+        if (!res_gather<NT>(ws, g0, b, RES_GROUPS, members, ws.S, first, cnt, tagd, tot + first, scr, ctl, deadline)) return false;
+        for (int o = first + threadIdx.x; o < nslots; o += NT) st16_agent(g1 + (size_t)b * ws.S + o, v2d{tot[o], tagd});
     }
-    for (int o = first + threadIdx.x; o < nslots; o += NT) st_agent(part + (size_t)b * ws.S + o, mine[o]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(ctr0 + (size_t)g * RES_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ctl[0] = ticket == (unsigned)(members - 1);
-    }
-    __syncthreads();
-    if (ctl[0]) {                                                    // the group's last arrival adds its members in member order
-        for (int o = first + threadIdx.x; o < nslots; o += NT) {
-            double s = 0.0;
-            int m = 0;
-            for (; m + 8 <= members; m += 8) {
-                double v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = ld_agent(part + (size_t)(g + (m + i) * RES_GROUPS) * ws.S + o);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) s += v[i];
-            }
-            for (; m < members; ++m) s += ld_agent(part + (size_t)(g + m * RES_GROUPS) * ws.S + o);
-            st_agent(xs + (size_t)g * ws.S + o, s);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr0 + (size_t)RES_GROUPS * RES_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x == 0) ctl[1] = res_wait(ws, ctr0 + (size_t)RES_GROUPS * RES_CNT_STRIDE, (unsigned)ngroups, deadline);
-    __syncthreads();
-    if (!ctl[1]) return false;
-    for (int o = first + threadIdx.x; o < nslots; o += NT) {
-        double v[RES_GROUPS];
-#pragma unroll
-        for (int i = 0; i < RES_GROUPS; ++i) v[i] = i < ngroups ? ld_agent(xs + (size_t)i * ws.S + o) : 0.0;
-        double s = v[0];
-#pragma unroll
-        for (int i = 1; i < RES_GROUPS; ++i) s += v[i];
-        tot[o] = s;
-    }
-    __syncthreads();
-    return true;
+    return res_gather<NT>(ws, g1, 0, 1, ngroups, ws.S, first, cnt, tagd, tot + first, scr, ctl, deadline);
 }
 
 // Block-level sums of the waves' per-lane partial sums through a TRANSPOSE in LDS: lane L of wave w writes its KC column partials
@@ -365,7 +312,7 @@ __device__ __forceinline__ ResGeom res_geom(int k, int64_t n, int64_t ldx, int W
     return q;
 }
 
-// results, breakdown flag and the counters' clean-up shared by the two kernels
+// results and breakdown flag, shared by the two kernels
 template <int NTHR>
 __device__ __forceinline__ void res_publish(const double *h1, const double *h2, double nrm2, int k, int ED, double *out, int rs, double tol_break,
                                             int *stop_out, int step) {
@@ -379,15 +326,6 @@ __device__ __forceinline__ void res_publish(const double *h1, const double *h2, 
         if (stop_out && !(sqrt(fabs(nrm2)) >= tol_break)) *stop_out = step;
     }
 }
-__device__ __forceinline__ void res_leave(const ResidentWs &ws) {
-    // the last block to leave clears the counters for the next launch (nobody polls any more: every block is past its last wait)
-    if (threadIdx.x == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(res_ctr(ws, RES_EXIT), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == gridDim.x - 1)
-            for (int i = 0; i <= RES_EXIT; ++i) __hip_atomic_store(res_ctr(ws, i), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 // flags: bit 0 = normalise y'' (skipped below tol_scale) ; bit 1 (dgs_resident) = phase 2 walks the tiles backwards
 // out: three result sections of `rs` doubles (h1 | ||y||^2 ; h2 | ||y'||^2 ; slot k = ||y''||^2, slot k*ED+1 of the THIRD section =
 // launch status: 0 done, 1 given up before anything was written to y, 2 failed after y'' was stored).
@@ -506,7 +444,6 @@ __global__ __launch_bounds__(NW * 64) void dgs_onchip(LK_RES_ARGS) {
         }
     }
     stamp(7);
-    res_leave(ws);
 }
 
 // ---- the panel in the caches -------------------------------------------------------------------------------------------------------
@@ -607,7 +544,6 @@ __global__ __launch_bounds__(NW * 64) void dgs_resident(LK_RES_ARGS) {
         }
     }
     stamp(7);
-    res_leave(ws);
 }
 
 }  // namespace lk

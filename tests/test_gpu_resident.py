@@ -185,7 +185,9 @@ def test_arnoldi_on_the_single_launch_against_oracle(rctx, dtype, n, m):
         info = lk.arnoldi(lk.diag_linop_gpu(d, ctx), X, H)
         after = ctx.resident_stats()
         assert info == info_o == 0
-        assert after[0] - before[0] == (m if route else 0)          # every step: the batched ones and the last, host-synchronous one
+        # every step whose panel fits "resident_max_mb" (192 MB): the batched ones and the last, host-synchronous one
+        fit = sum(1 for k in range(1, m + 1) if n * (k + 1) * np.dtype(dtype).itemsize <= 192 * 2**20)
+        assert after[0] - before[0] == (fit if route else 0)
         for j in range(m):
             assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL * np.abs(Ho[:, j]).max()
         Xg = X.download()
