@@ -152,7 +152,7 @@ struct lk_context_s {
     int blas1_grid_mult = 2;   // blocks of 256 threads per CU for the one-to-three-stream kernels
     // single-launch Gram-Schmidt step for cache-resident panels (lk_resident.hip.h)
     int resident = 1;          // 0: never; 1: when the panel X(:, :k) | y fits `resident_max_mb` (one rank only: the phases meet inside the launch)
-    int resident_max_mb = 192; // ... MB of panel the single launch takes (the memory-side cache holds 256 MB)
+    int resident_max_mb = 320; // ... MB of panel the single launch takes (measured crossover with the three sweeps: profiles/r06_resident_phases.jsonl)
     int resident_onchip = 1;   // panels that fit the register files (64 MB on the chip) stay there for the whole step: X is read once
     int resident_rev = 1;      // phase 2 walks a block's tiles backwards (starts on what phase 1 read last)
     int resident_spin_ms = 2000;   // bound on the first grid-wide wait; beyond it the launch gives up and the three-sweep schedule runs
@@ -1446,6 +1446,33 @@ bool resident_applies(lk_basis_t Bx, int k) {
     return mb <= (double)c->resident_max_mb;
 }
 
+int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bool normalize, double tol_scale, double tol_break, int *stop_out);
+
+// One Gram-Schmidt step + normalise of an ASYNCHRONOUS batch (lk_arnoldi / lk_lanczos / lk_bidiag): results into the step slot, the
+// normalise skipped below tol_scale, the device stop flag raised below tol_break.  A cache-resident panel takes the single launch
+// (lk_resident.hip.h); a launch that gives up raises the stop flag and leaves status 1 in the slot -- resident_status() below.
+int dgs_step_async(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *slot, int rs, double tol_scale, double tol_break) {
+    lk_context_t c = Bx->ctx;
+    const int ED = Bx->ed();
+    if (resident_applies(Bx, k)) return dgs_resident_launch(Bx, k, By->col(jy), slot, rs, true, tol_scale, tol_break, c->stop_dev);
+    LKCHK(dgs_device(Bx, k, By->col(jy), true, slot, rs));
+    return scal_launch(By, jy, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, tol_scale, c->stop_dev, tol_break);
+}
+// host side of a finished batch: did the step that used `slot` give up (1: redo it on the three-sweep schedule; the context has been
+// switched over) or fail (error)?  0 = it ran, or it never was a single launch.
+int resident_status(lk_basis_t Bx, int k, const double *slot_host, int rs, int *redo) {
+    *redo = 0;
+    if (!resident_applies(Bx, k)) return LK_OK;
+    const double status = slot_host[2 * (size_t)rs + (size_t)k * Bx->ed() + 1];
+    if (status == 1.0) {
+        LKCHK(resident_recover(Bx->ctx));
+        *redo = 1;
+    } else if (status != 0.0) {
+        return fail(LK_ERR_HIP, "the single-launch Gram-Schmidt step failed after its first phase (status %g)", status);
+    }
+    return LK_OK;
+}
+
 // h1 | h2 | ||y''||^2 into the three sections at `out` (stride rs) exactly where dgs_device leaves them, + the normalise and the
 // device-side stop test of scal_launch when `normalize` (tol_scale: no scaling below it; tol_break: raises *stop_out).
 // Kernel choice: dgs_onchip (the panel stays in registers, X read once) when the row tiles of some shape -- 16 / 8 / 4 columns per wave,
@@ -1470,12 +1497,14 @@ int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bo
         sh.ntiles = (Bx->n + tile_rows - 1) / tile_rows;
         return sh;
     };
-    int onchip_kc = 0;
+    // among the shapes whose tiles fit: the one that leaves the fewest register slots empty (WC * KC - k), the widest on a tie
+    // (fewer wave-columns to exchange between)
+    int onchip_kc = 0, waste = INT_MAX;
     if (c->resident_onchip)
         for (int KC : {16, 8, 4}) {
             if (k > KC * NW) continue;
             const Shape sh = shape(KC);
-            if (sh.ntiles <= (int64_t)res_onchip_tiles(KC) * maxg) { onchip_kc = KC; break; }
+            if (sh.ntiles <= (int64_t)res_onchip_tiles(KC) * maxg && sh.WC * KC - k < waste) { onchip_kc = KC; waste = sh.WC * KC - k; }
         }
     const Shape sh = shape(onchip_kc ? onchip_kc : 16);
     int64_t g = sh.ntiles < maxg ? sh.ntiles : maxg;
@@ -3565,7 +3594,6 @@ static int lanczos_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
     }
     HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
     const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;     // below it: stop flag AND no scaling (lanczos.fypp:32-36)
-    const int ED = X->ed();
     c->guard_on = true;
     c->prof_sweeps_only = true;
     int rc = LK_OK;
@@ -3580,9 +3608,7 @@ static int lanczos_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
             if (rc == LK_OK) rc = sweepm<3>(X, i - 1, 1, X->col(k), a, nullptr, 1, a + RED_SECTION);
         }
         if (rc != LK_OK) break;
-        rc = dgs_device(X, k, X->col(k), true, slot, rs);                   // :62 (no beta)
-        if (rc != LK_OK) break;
-        rc = scal_launch(X, k, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, tol_break, c->stop_dev, tol_break);
+        rc = dgs_step_async(X, k, X, k, slot, rs, tol_break, tol_break);   // :62 (no beta), :29-39
     }
     c->guard_on = false;
     c->guard_step = 0;
@@ -3652,7 +3678,10 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
         const bool stopped_early = *c->stop_host != 0;
         double beta = 0.0;
         const int rs = red_stride(kfused);
-        for (int s = k; s <= done; ++s) {
+        int redo = 0;
+        LKCHK(resident_status(X, done, c->step_red_host + (size_t)(done - k) * RED_SECTIONS * rs, rs, &redo));
+        const int upto = redo ? done - 1 : done;              // (a single launch that gave up stopped the batch at `done`: that step runs again)
+        for (int s = k; s <= upto; ++s) {
             const double *r2 = c->step_red_host + ((size_t)(s - k) * RED_SECTIONS + 2) * rs;
             const int i0 = s > 1 ? s - 1 : 1;
             double *Ts = T + (size_t)(s - 1) * ldt * ED;
@@ -3665,6 +3694,7 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
             Ts[(size_t)s * ED] = beta;                                                      // T(k+1, k) :29
             if (ED == 2) Ts[(size_t)s * ED + 1] = 0.0;
         }
+        if (redo) { k = done; continue; }
         if (!stopped_early) { k = done + 1; continue; }                                       // (on to the steps beyond KMAX_WIDE, if any)
         if (beta < tol) { *info = done; break; }                                            // :32-36 (no scaling)
         // the device stops at max(tol, atol_dp); a caller's smaller tol lets the reference go on: normalise and resume
@@ -3685,7 +3715,6 @@ static int bidiag_batch_async(lk_linop_t A, lk_basis_t U, lk_basis_t V, int k0, 
     LKCHK(ensure_step_buffers(c, 2 * nsteps, rs));
     HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
     const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
-    const int ED = U->ed();
     c->guard_on = true;
     c->prof_sweeps_only = true;
     int rc = LK_OK;
@@ -3695,17 +3724,16 @@ static int bidiag_batch_async(lk_linop_t A, lk_basis_t U, lk_basis_t V, int k0, 
         c->guard_step = 2 * k - 1;
         rc = lk_linop_apply(A, LK_OP_H, U, k - 1, V, k - 1);                                   // :27
         if (rc != LK_OK) break;
-        if (k > 1) rc = dgs_device(V, k - 1, V->col(k - 1), true, sv, rs);                    // :30-33
-        else rc = dot_device(V, 0, V, 0, sv + 2 * rs);                                        // ||V(1)||^2 where the DGS would leave it
-        if (rc != LK_OK) break;
-        rc = scal_launch(V, k - 1, 1.0, 0.0, sv + 2 * rs + (size_t)(k - 1) * ED, tol_break, c->stop_dev, tol_break);   // :36-42
+        if (k > 1) rc = dgs_step_async(V, k - 1, V, k - 1, sv, rs, tol_break, tol_break);     // :30-33, :36-42
+        else {
+            rc = dot_device(V, 0, V, 0, sv + 2 * rs);                                         // ||V(1)||^2 where the DGS would leave it
+            if (rc == LK_OK) rc = scal_launch(V, 0, 1.0, 0.0, sv + 2 * rs, tol_break, c->stop_dev, tol_break);
+        }
         if (rc != LK_OK) break;
         c->guard_step = 2 * k;
         rc = lk_linop_apply(A, LK_OP_N, V, k - 1, U, k);                                       // :45
         if (rc != LK_OK) break;
-        rc = dgs_device(U, k, U->col(k), true, su, rs);                                       // :48-49
-        if (rc != LK_OK) break;
-        rc = scal_launch(U, k, 1.0, 0.0, su + 2 * rs + (size_t)k * ED, tol_break, c->stop_dev, tol_break);             // :52-58
+        rc = dgs_step_async(U, k, U, k, su, rs, tol_break, tol_break);                        // :48-49, :52-58
     }
     c->guard_on = false;
     c->guard_step = 0;
@@ -3739,21 +3767,34 @@ int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, 
     const int kfused = kend < KMAX_WIDE ? kend : KMAX_WIDE;
     int done_half = 2 * (kstart - 1);
     bool stopped_early = false;
-    if (kstart <= kfused) {
-    LKCHK(bidiag_batch_async(A, U, V, kstart, kfused, tol, &done_half));
-    stopped_early = *c->stop_host != 0;
-    const int rs = red_stride(kfused);
-    for (int hs = 2 * kstart - 1; hs <= done_half; ++hs) {
-        const int k = (hs + 1) / 2;
-        const bool right = hs & 1;
-        const double *r2 = c->step_red_host + ((size_t)(hs - (2 * kstart - 1)) * RED_SECTIONS + 2) * rs;
-        const double nrm = std::sqrt(std::fabs(r2[(size_t)(right ? k - 1 : k) * ED]));
-        if (nrm != nrm) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
-        double *Bk = B + (size_t)(k - 1) * ldb * ED;
-        const size_t row = right ? (size_t)(k - 1) : (size_t)k;                           // B(k, k) = alpha ; B(k+1, k) = beta
-        Bk[row * ED] = nrm;
-        if (ED == 2) Bk[row * ED + 1] = 0.0;
-    }
+    for (int ks = kstart; ks <= kfused;) {
+        LKCHK(bidiag_batch_async(A, U, V, ks, kfused, tol, &done_half));
+        stopped_early = *c->stop_host != 0;
+        const int rs = red_stride(kfused);
+        int redo = 0;
+        if (stopped_early) {
+            // the half step the batch stopped at: did its single-launch Gram-Schmidt step give up?  Then the whole step runs again
+            // (both halves: recomputing the right half from the untouched U(k) gives the same bits) on the three-sweep schedule.
+            const int kq = (done_half + 1) / 2;
+            const bool right = done_half & 1;
+            const double *slot = c->step_red_host + (size_t)(done_half - (2 * ks - 1)) * RED_SECTIONS * rs;
+            if (!(right && kq == 1)) LKCHK(resident_status(right ? V : U, right ? kq - 1 : kq, slot, rs, &redo));
+        }
+        const int upto = redo ? done_half - 1 : done_half;
+        for (int hs = 2 * ks - 1; hs <= upto; ++hs) {
+            const int k = (hs + 1) / 2;
+            const bool right = hs & 1;
+            const double *r2 = c->step_red_host + ((size_t)(hs - (2 * ks - 1)) * RED_SECTIONS + 2) * rs;
+            const double nrm = std::sqrt(std::fabs(r2[(size_t)(right ? k - 1 : k) * ED]));
+            if (nrm != nrm) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+            double *Bk = B + (size_t)(k - 1) * ldb * ED;
+            const size_t row = right ? (size_t)(k - 1) : (size_t)k;                           // B(k, k) = alpha ; B(k+1, k) = beta
+            Bk[row * ED] = nrm;
+            if (ED == 2) Bk[row * ED + 1] = 0.0;
+        }
+        if (!redo) break;
+        ks = (done_half + 1) / 2;
+        stopped_early = false;
     }
     if (stopped_early) { *info = (done_half + 1) / 2; return LK_OK; }                     // :41, :57
     // beyond 512 basis columns (round 5; the reference has no cap, golub_kahan.fypp:18): one step at a time, host-synchronous

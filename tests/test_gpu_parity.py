@@ -15,6 +15,19 @@ from tests._tol import assert_close, assert_columns_close, assert_ritz_close
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=[1, 0], ids=["single_launch", "three_sweeps"])
+def ctx(request, ctx):
+    """Every test of this file that takes the shared context runs on BOTH schedules of the Gram-Schmidt step: the single persistent
+    launch for cache-resident panels (csrc/lk_resident.hip.h, the default) and the three sweeps -- at these sizes the single launch
+    would otherwise take every panel and the sweeps would lose their small-size coverage.  (Full-size cases never fit the caches:
+    once is enough.)"""
+    if request.param == 0 and "full_size" in request.node.name:
+        pytest.skip("the panel does not fit the caches: the three-sweep schedule ran in the other parametrisation")
+    ctx.set_tuning("resident", request.param)
+    yield ctx
+    ctx.set_tuning("resident", 1)
+
 KINDS = [np.float64, np.complex128]
 SIZES = [1, 2, 3, 63, 64, 65, 127, 128, 129, 1000, 4099, 100_003]
 RTOL_RED = 1e-12

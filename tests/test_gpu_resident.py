@@ -20,7 +20,7 @@ CASES = [(1000, 1), (1001, 2), (999, 3), (4096, 15), (4097, 16), (4099, 17), (10
 
 def fits_onchip(n, k, dtype, num_cu=256):
     """the launcher's rule (lk_engine.hip, dgs_resident_launch): some shape -- 16 / 8 / 4 columns per wave, 2 / 5 / 9 tiles per block --
-    whose row tiles fit one block per CU"""
+    whose row tiles fit one block per CU (which of the fitting shapes runs does not matter here)"""
     rows = 1 if dtype is np.complex128 else 2
     for kc, rt in ((16, 2), (8, 5), (4, 9)):
         if k > kc * 8:
@@ -261,5 +261,53 @@ def test_a_launch_that_cannot_get_the_chip_gives_up_cleanly_and_the_step_still_r
             assert lk.arnoldi(lk.diag_linop_gpu(d, ctx), X, H2) == 0
             assert ctx.resident_stats()[0] > st[0] and ctx.resident_stats()[1] == 1
             assert np.abs(H2 - H).max() <= 1e-13 * np.abs(H).max()
+        finally:
+            ctx.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_lanczos_and_bidiagonalization_on_the_single_launch_and_through_a_give_up(dtype):
+    """lk_lanczos / lk_bidiag (lanczos.fypp:7-64, golub_kahan.fypp:7-64) take the single launch per step too; a launch that gives up
+    (resident_spin_ms = 0) stops the batch, the step runs again on the three-sweep schedule: T and B against the oracle either way."""
+    n, m = 60_001, 24
+    d = (1.0 + np.arange(n) / n)
+    x0 = seeded(n, dtype, 21)
+    x0 /= np.linalg.norm(x0)
+    Xo = np.zeros((n, m + 1), dtype=dtype, order="F")
+    Xo[:, 0] = x0
+    To = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.lanczos(ora.DiagOp(d.astype(dtype)), Xo, To) == 0
+    dz = d.astype(dtype) * (np.exp(0.4j * np.arange(n) / n) if dtype is np.complex128 else 1.0)
+    Uo = np.zeros((n, m + 1), dtype=dtype, order="F")
+    Uo[:, 0] = x0
+    Vo = np.zeros((n, m + 1), dtype=dtype, order="F")
+    Bo = np.zeros((m + 1, m), dtype=dtype, order="F")
+    assert ora.bidiagonalization(ora.DiagOp(dz), ora.DiagOp(dz.conj()), Uo, Vo, Bo) == 0
+    for spin in (2000, 0):
+        ctx = lk.Context(device=0)
+        try:
+            ctx.set_tuning("resident_spin_ms", spin)
+            X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+            X.upload(x0.reshape(-1, 1), 0)
+            T = np.zeros((m + 1, m), dtype=dtype, order="F")
+            assert lk.lanczos(lk.diag_linop_gpu(d.astype(dtype), ctx), X, T) == 0
+            st = ctx.resident_stats()
+            assert (st[1] == 0 and st[0] == m) if spin else st[:2] == (1, 1), st
+            for j in range(m):
+                assert np.abs(T[:, j] - To[:, j]).max() <= RTOL * np.abs(To[:, j]).max()
+            ctx.set_tuning("resident", 1)                         # (re-arm after the give-up)
+            U = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+            U.upload(x0.reshape(-1, 1), 0)
+            V = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+            B = np.zeros((m + 1, m), dtype=dtype, order="F")
+            before = ctx.resident_stats()
+            assert lk.bidiagonalization(lk.diag_linop_gpu(dz, ctx), U, V, B) == 0
+            after = ctx.resident_stats()
+            # 2 m half steps, the first right half has no basis to orthogonalise against
+            assert (after[0] - before[0], after[1] - before[1]) == ((2 * m - 1, 0) if spin else (1, 1)), (before, after)
+            for j in range(m):
+                assert np.abs(B[:, j] - Bo[:, j]).max() <= RTOL * np.abs(Bo[:, j]).max()
+            Ud = U.download()
+            assert np.abs(Ud.conj().T @ Ud - np.eye(m + 1)).max() <= 1e-12
         finally:
             ctx.close()
