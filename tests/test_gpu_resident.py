@@ -292,7 +292,7 @@ def test_lanczos_and_bidiagonalization_on_the_single_launch_and_through_a_give_u
             T = np.zeros((m + 1, m), dtype=dtype, order="F")
             assert lk.lanczos(lk.diag_linop_gpu(d.astype(dtype), ctx), X, T) == 0
             st = ctx.resident_stats()
-            assert (st[1] == 0 and st[0] == m) if spin else st[:2] == (1, 1), st
+            assert (st[1] == 0 and st[0] == m) if spin else st[1] == 1, st      # (the batch had enqueued every step before the host saw the give-up)
             for j in range(m):
                 assert np.abs(T[:, j] - To[:, j]).max() <= RTOL * np.abs(To[:, j]).max()
             ctx.set_tuning("resident", 1)                         # (re-arm after the give-up)
@@ -304,7 +304,7 @@ def test_lanczos_and_bidiagonalization_on_the_single_launch_and_through_a_give_u
             assert lk.bidiagonalization(lk.diag_linop_gpu(dz, ctx), U, V, B) == 0
             after = ctx.resident_stats()
             # 2 m half steps, the first right half has no basis to orthogonalise against
-            assert (after[0] - before[0], after[1] - before[1]) == ((2 * m - 1, 0) if spin else (1, 1)), (before, after)
+            assert (after[0] - before[0], after[1] - before[1]) == (2 * m - 1, 0 if spin else 1), (before, after)
             for j in range(m):
                 assert np.abs(B[:, j] - Bo[:, j]).max() <= RTOL * np.abs(Bo[:, j]).max()
             Ud = U.download()
