@@ -123,46 +123,29 @@ int lk_set_allgather(lk_context_t ctx, lk_allgather_fn fn, void *user);
 /* row block owned by this rank: global rows [row0, row0 + n_local) of n_global; only used
  * so that counter-based rand fills are identical for every partition. */
 int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
-/* tuning knobs (integers): "stream_update" (barrier-free single-coefficient update sweep); "recompute_update" (two-pass DGS: sweep 2 keeps y'
- * in registers and sweep 3 re-forms it, so y' is never written to HBM); "store_policy" (cache policy of the sweeps'
- * 16-byte y store: 0 plain, 1 nt, 2 sc1 = write-through [default], 3 sc0 sc1) and "store_split"; "async_arnoldi"
- * (default 1: lk_arnoldi enqueues all steps with a device-side breakdown flag, one host synchronisation per call; 0:
- * one host round trip per step); "cplx_wide" (complex sweeps on 8 waves x 16 columns when k exceeds this threshold, default 32, 0 = never); "pool_slab_cols" (columns per
- * pool slab); "lazy" (see lk_lazy_stats).  None of those changes a result bit (tests/test_gpu_tuning_knobs.py).
- * Shapes and kernel selectors -- same results to rounding (different summation order), each checked against the oracle:
- * "grid_mult" / "grid_mult_s2" / "update_grid_mult" / "gemm_grid_mult" (blocks per CU of the panel kernels: the number of
- * per-block partial sums a dot is assembled from);
- * "dot_colwise" (default 1: DGS sweep 1 / innerprod one column at a time, panel_dot_cw; 0: all columns per tile) with
- * "cw_u" (16-byte loads per lane and column: 4, 8, 0 = by size) and "cw_grid_mult"; "xhy_mfma" (default 1: X^H Y with five or
- * more right-hand sides -- Gram, innerprod_matrix, block DGS -- in one pass over X on the FP64 matrix cores; 0: four
- * right-hand sides per pass on the vector units) and "xhy_small"; "gemm_mfma" likewise for the tall-skinny product, from "gemm_mfma_min" output columns on (default 5; narrower
- * products stream X through the vector units with 1 / 2 / 4 accumulators per lane); "gemm_store_policy" (cache policy of its
- * output stores, as "store_policy");
- * "wide_regs" (shape of the update sweeps against 129..384 basis columns: 2 [default] = 8 waves x 32 / 24 register columns for
- * 129..256 real / 129..192 complex columns and the lane split on 24-column groups up to 384; 1 = the first only; 0 = round 3's lane
- * split on 16-column groups everywhere) and "kc32" (the 32-column register tile for the real update sweeps of k <= 128 columns too:
- * -1 [default] = for k > 32 when the GLOBAL problem (lk_set_partition; the local rows without one) has >= 2^25 rows -- every rank of a
- * sharded run picks the same shape --, 0 = never, v = for k > v; sweeps 2 and 3 of the DGS only).
- * "gemm_3m" (default 1: the complex MFMA kernels -- tall-skinny product, X^H Y with <= 32 right-hand sides, Gram -- use three real products per
- * complex one, Re = P1 - P2, Im = P3 - P1 - P2; 0: four, the doubled real problem; same results normwise).
- * "gemm_prefetch_y" (default 1: the accumulating real MFMA product with <= 32 outputs -- the block Gram-Schmidt's updates -- loads the tile of Y
- * ahead of its k-loop; 0: after it; no result bit changes).
- * "wide_s3" (default 1: sweep 3 of a lane-split DGS holds both column groups of a wave-column in one wave's registers on tiles twice as
- * tall; 0: lane-split like sweep 2) changes NO result bit: it reproduces the lane split's summation order (tests/test_gpu_wide_bases.py).
- * Round 5, matrix-core kernels (same results to rounding): "xhy_db" (default 1: panel_xhy_mfma with a double-buffered LDS tile, one barrier per
- * tile, for the 128-column variants; 2: the <= 32 right-hand-side variants too; 0: never); "gram_tiles" (default 1: the real Gram matrix of 33..64
- * columns by panel_gram_mfma -- upper tiles dealt to the waves, two blocks per CU --; 2: up to 128 columns; 0: never) with "gram_grid_mult";
- * "gram_cyc" (default 2: the real Gram matrix of 113..128 columns by panel_gram_cyc -- upper tiles dealt cyclically, all waves on the same
- * straight-line code, two tile buffers --, value = blocks per CU in the grid; 0: panel_xhy_mfma) and "gram_cyc4" (default 3: the same deal for
- * 49..64 columns, four column blocks x two row halves, panel_gram_cyc4; 0: panel_gram_mfma);
- * "gemm_roll" (default 1: the real tall-skinny product with 33..64 outputs per pass keeps a ring of four k-steps of X in flight, refilled as
- * they are consumed and carried across tiles, on straight-line code; 2: every variant that has a ring; 0: batches of four k-steps everywhere --
- * same MFMAs in the same order, bit-identical results); "xhy_tr32" (default 0: operand prefetch on 32-row tiles -- measured slower, kept
- * for A/B, profiles/r05_*); "mfma_4x4" (default 0; 1: the real kind's matrix-core kernels issue every 16x16x4 product as four
- * v_mfma_f64_4x4x4_4b_f64 -- 1.5 x the issue rate in isolation, slower in every kernel, profiles/r05_fp64_mfma_peak.txt --; 2: panel_xhy_mfma
- * on 32-row tiles with the software-pipelined loop as well).  DIAGNOSTIC keys that switch parts of a kernel off -- WRONG RESULTS, phase timing only, used by
- * tools/bench_gram.py and tools/bench_upd_phases.py: "xhy_debug" (1 = panel_xhy_mfma without its MFMAs, 2 = without its global loads after
- * the first tile), "upd_debug" (bits: 1 update MFMAs, 2 dot MFMAs, 4 global loads, 8 store of Y' of panel_xhy_upd_mfma). */
+/* Tuning keys (integers; 30 of them -- round 6 removed every key whose other setting was measured slower and never defaulted, the
+ * record of those A/Bs is docs/TUNING_LOG.md).  None changes a result beyond rounding; the ones marked [bits] change no result bit.
+ *   schedule      "async_arnoldi" (1: lk_arnoldi / lk_lanczos / lk_bidiag enqueue all steps behind a device-side breakdown flag, one host
+ *                 synchronisation per call; 0: one round trip per step) [bits]; "lazy", "lazy_speculate" (see lk_lazy_stats) [bits];
+ *                 "pool_slab_cols" (columns per pool slab) [bits]
+ *   single launch "resident", "resident_max_mb", "resident_onchip", "resident_rev", "resident_spin_ms" (see lk_resident_stats)
+ *   sweeps        "recompute_update" (1: sweep 2 keeps y' in registers, sweep 3 re-forms it: y' never goes to HBM) [bits]; "store_policy"
+ *                 (cache policy of the sweeps' 16-byte y store: 0 plain, 1 nt, 2 sc1 = write-through [default], 3 sc0 sc1) and
+ *                 "store_split" [bits]; "dot_colwise" (1: sweep 1 / innerprod one column at a time, panel_dot_cw; 0: all columns per
+ *                 tile) with "cw_u" (16-byte loads per lane and column: 4, 8, 0 = by size) and "cw_grid_mult"; "grid_mult", "blas1_grid_mult" (blocks per CU: the number of per-block partial sums a dot is assembled from);
+ *                 "wide_regs" (update sweeps against 129..384 columns: 2 = register tiles of 32 / 24 columns + the lane split on 24-column
+ *                 groups, 1 = the first only, 0 = lane split on 16-column groups) and "wide_s3" (1: sweep 3 of a lane-split step holds both
+ *                 column groups of a wave-column in one wave's registers) [bits]
+ *   matrix cores  "xhy_mfma" (1: X^H Y with five or more right-hand sides -- Gram, innerprod_matrix, block Gram-Schmidt -- in one pass over
+ *                 X on the FP64 MFMAs; 0: four right-hand sides per pass on the vector units); "block_fused" (block Gram-Schmidt: 1 = three
+ *                 passes per group for the real kind, 2 = for both kinds, 0 = four); "gemm_mfma_min" (tall-skinny product on the MFMAs from
+ *                 this many output columns on; default 5 real / 9 complex); "gemm_3m" (1: the complex MFMA kernels use three real products
+ *                 per complex one); "xhy_db" (panel_xhy_mfma with a double-buffered LDS tile: 1 = the 128-column variants, 2 = all, 0 = never); "gemm_roll" (1: the real product with 33..64 outputs keeps a ring of four k-steps of X in flight; 2:
+ *                 every variant that has a ring; 0: batches) [bits]; "gram_tiles" / "gram_grid_mult" (real Gram matrix of 33..64 columns by
+ *                 panel_gram_mfma), "gram_cyc" (113..128 columns by panel_gram_cyc; value = blocks per CU, 0 = off), "gram_cyc4" (49..64)
+ *   operators     "csr_stream" (1: CSR product through LDS for matrices with short rows; 0: lanes-per-row kernel)
+ * A build made with -DLK_DIAGNOSTICS (make -C lightkrylov_amd/csrc diagnostics; NOT what build() produces) adds "xhy_debug" / "upd_debug",
+ * which switch parts of a kernel off for phase timing and give WRONG results; the shipped library rejects them as unknown keys. */
 int lk_set_tuning(lk_context_t ctx, const char *key, int value);
 
 /* Lazy batching of the per-object path (tuning key "lazy", off by default).  When on, k consecutive

@@ -94,16 +94,12 @@ struct lk_context_s {
                                // value = blocks per CU in the grid (three are resident); 0 = panel_gram_mfma
     int gram_cyc = 2;          // real Gram matrix of 113..128 columns by panel_gram_cyc (cyclic tile deal: every wave the same straight-line code; two tile buffers, loads two tiles ahead;
                                // n = 10^7, k = 128: 4.22 -> 3.83 ms): value = blocks per CU in the grid (two are resident); 0 = panel_xhy_mfma
-    int mfma_4x4 = 0;          // matrix-core kernels issue their products as v_mfma_f64_4x4x4_4b_f64 instead of v_mfma_f64_16x16x4_f64 (A/B; slower in every kernel): same lanes, same
-                               // accumulators, four A operands per step (lk_kernels.hip.h, mfma_f64_16x16x4_by4); 0: the 16x16x4 instruction
-    int upd_debug = 0;         // diagnostic only (wrong results): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
-    int xhy_debug = 0;         // diagnostic only (wrong results): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
+    int upd_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
+    int xhy_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
     int gemm_roll = 1;         // MFMA tall-skinny product: rolling prefetch of X (a ring of 4 k-steps refilled as they are consumed, carried across tiles) instead of batches of 4
                                // k-steps (loaded, waited for, multiplied).  1: the real kind with 33..64 outputs per pass, on the STRAIGHT-LINE ring (no branch between loads and MFMAs,
                                // exact vmcnt counts; k = 128, q = 64 at n = 10^7: 3.45-3.73 -> 3.16-3.24 ms); 2: every variant that has a ring (the narrow real ones measure the same
                                // as the batch schedule, the complex doubled-real ones keep the guarded ring, +2-5 % on narrow products); 0: never (profiles/r05_ab_gemm_roll.jsonl)
-    int xhy_tr32 = 0;          // the 128-column real variant of panel_xhy_mfma on 32-row tiles with the next row step's operands read ahead of the current step's MFMAs: measured SLOWER
-                               // (Gram k = 128: 5.5 vs 4.2 ms, profiles/r05_gram_phases.jsonl -- twice the barriers per row cost more than the reads gain): off
     int xhy_db = 1;            // panel_xhy_mfma with a double-buffered LDS tile (1: the 128-column variants; 2: the <= 32 right-hand-side ones too; 0: never)
     int gram_tiles = 1;        // real Gram matrix by panel_gram_mfma (upper tiles dealt to the waves, 32-row tiles): 1 = for 33..64 columns (measured: 1.80 / 1.38 ms
                                // at k = 64 / 48, n = 10^7, against 1.90 / 1.60; slower beyond -- 4.6 vs 4.1 ms at k = 128), 2 = up to 128, 0 = never (panel_xhy_mfma<false, 8, 64>)
@@ -739,7 +735,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     // share a CU and cover each other's barriers and load latency (n = 10^7 real, k = 128, p = 16: 2.54 -> 1.92 ms on 3 blocks
     // per CU, one pass over X at 6.5 TB/s being 1.77; complex 3.73 -> 2.29 ms on 2)
     const bool small = c->xhy_small && PJ <= 2;
-    const int TR = (small || cp || c->xhy_tr32 || c->mfma_4x4 >= 2) ? 32 : 64;     // ("mfma_4x4" = 2: the pipelined 4x4x4 loop lives on the 32-row tiles)     // (complex, more than 32 right-hand sides: 32-row tiles too -- sixteen staged chunks beside 2 x 8 accumulators spilled 68 B)
+    const int TR = (small || cp) ? 32 : 64;     // (complex, more than 32 right-hand sides: 32-row tiles too -- sixteen staged chunks beside 2 x 8 accumulators spilled 68 B)
     const int64_t ntiles = (Bx->n * ED + TR - 1) / TR;
     int64_t g = (int64_t)c->num_cu * (small ? (c->xhy_grid_mult ? c->xhy_grid_mult : (cp ? 2 : 3)) : 1);
     if (g > ntiles) g = ntiles;
@@ -872,8 +868,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         const size_t ldsg = (size_t)KP * 16 * 34 * sizeof(double);
         {
             ProfScope ps(c, "xhy_mfma", (double)Bx->n * 8.0 * k);
-            if (c->mfma_4x4) hipLaunchKernelGGL(panel_gram_mfma<true>, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
-            else hipLaunchKernelGGL(panel_gram_mfma<false>, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
+            hipLaunchKernelGGL(panel_gram_mfma, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
         }
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, partg, (int)gg, npartg, (int)gg, k, p, ED, flags, outg);
@@ -898,20 +893,16 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
                                p, Bx->n, flags | (c->xhy_debug << 4), NI, part, npart);
             return LK_OK;
         };
-        // variant = (kind, <= 32 | <= 128 right-hand sides, rows per tile, double-buffered, 4x4x4 MFMAs)
-        auto pick = [&](auto cplx, auto m4) -> int {
-            constexpr bool CP = decltype(cplx)::value, M4 = decltype(m4)::value;
-            if (small) return db ? go(&panel_xhy_mfma<CP, 2, 32, true, M4>) : go(&panel_xhy_mfma<CP, 2, 32, false, M4>);
-            if constexpr (CP) return db ? go(&panel_xhy_mfma<true, 8, 32, true, M4>) : go(&panel_xhy_mfma<true, 8, 32, false, M4>);
-            else {
-                if (TR == 32) return db ? go(&panel_xhy_mfma<false, 8, 32, true, M4>) : go(&panel_xhy_mfma<false, 8, 32, false, M4>);
-                return db ? go(&panel_xhy_mfma<false, 8, 64, true, M4>) : go(&panel_xhy_mfma<false, 8, 64, false, M4>);
-            }
+        // variant = (kind, <= 32 | <= 128 right-hand sides, rows per tile, double-buffered)
+        auto pick = [&](auto cplx) -> int {
+            constexpr bool CP = decltype(cplx)::value;
+            if (small) return db ? go(&panel_xhy_mfma<CP, 2, 32, true>) : go(&panel_xhy_mfma<CP, 2, 32, false>);
+            if constexpr (CP) return db ? go(&panel_xhy_mfma<true, 8, 32, true>) : go(&panel_xhy_mfma<true, 8, 32, false>);
+            else return db ? go(&panel_xhy_mfma<false, 8, 64, true>) : go(&panel_xhy_mfma<false, 8, 64, false>);
         };
-        using T_ = std::true_type; using F_ = std::false_type;
         if (three) LKCHK(go(&panel_xhy_mfma3m));
-        else if (cp) LKCHK(c->mfma_4x4 ? pick(T_{}, T_{}) : pick(T_{}, F_{}));
-        else LKCHK(c->mfma_4x4 ? pick(F_{}, T_{}) : pick(F_{}, F_{}));
+        else if (cp) LKCHK(pick(std::true_type{}));
+        else LKCHK(pick(std::false_type{}));
     }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, part, nvb, npart, grid, k, p, ED, flags, out);
@@ -1045,12 +1036,6 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
             if (lds > 48 * 1024)
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             // (the rolling prefetch of X beside the prefetched tile of Y does not fit the register file: batch schedule here)
-            if (c->mfma_4x4) {
-                if (lds > 48 * 1024)
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, true, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                                   c->gemm_store_policy);
-            } else
             hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, true, false>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
                                c->gemm_store_policy);
             HIPCHK(hipGetLastError());
@@ -1059,16 +1044,6 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
     }
     constexpr bool CAN_ROLL = !(CPLX && NG >= 8);          // (64 complex outputs as the doubled real problem: the ring does not fit the register file)
     bool rolled = false;
-    if constexpr (!CPLX) {
-        if ((c->gemm_roll >= 2 || (c->gemm_roll == 1 && NG == 4)) && c->mfma_4x4 && (kk & 15) == 0) {          // rolling prefetch of X + the 4x4x4 products
-            if (lds > 48 * 1024)
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<false, NG, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((panel_gemm_mfma<false, NG, false, true, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                               c->gemm_store_policy);
-            HIPCHK(hipGetLastError());
-            return LK_OK;
-        }
-    }
     if constexpr (CAN_ROLL) {
         // "gemm_roll" = 1 (default): the real product with 33..64 outputs per pass -- the restart update X <- X Z of krylov_schur -- on the straight-line
         // ring (k = 128, q = 64 at n = 10^7: 3.45-3.73 -> 3.16-3.24 ms, 51 TFLOP/s); the narrower ones measured the same on either schedule
@@ -1076,15 +1051,6 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
         // (the real kind's straight-line ring is unrolled for the basis widths 128 and 64: any other width keeps the batch schedule)
         if ((CPLX || kk == 128 || kk == 64) && (c->gemm_roll >= 2 || (c->gemm_roll == 1 && !CPLX && NG == 4))) {
             hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                               c->gemm_store_policy);
-            rolled = true;
-        }
-    }
-    if constexpr (!CPLX) {
-        if (!rolled && c->mfma_4x4) {          // the real kind's products on v_mfma_f64_4x4x4_4b_f64
-            if (lds > 48 * 1024)
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<false, NG, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((panel_gemm_mfma<false, NG, false, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
                                c->gemm_store_policy);
             rolled = true;
         }
@@ -1678,29 +1644,18 @@ int lk_set_partition(lk_context_t c, int64_t row0, int64_t n_global) {
 
 int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!c || !key) return fail(LK_ERR_INVALID, "lk_set_tuning: null argument");
-    if (!strcmp(key, "grid_mult_s3")) { c->grid_mult_s3 = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
-    if (!strcmp(key, "grid_mult_s2")) { c->grid_mult_s2 = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
     if (!strcmp(key, "grid_mult")) {
         if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "grid_mult must be in [1,16]");
         c->grid_mult = value;
         return LK_OK;
     }
-    if (!strcmp(key, "lap5_grid_mult")) { if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: lap5_grid_mult in [1, 64]"); c->lap5_grid_mult = value; return LK_OK; }
     if (!strcmp(key, "dot_colwise")) { c->dot_colwise = value != 0; return LK_OK; }
     if (!strcmp(key, "cw_u")) { c->cw_u = value == 8 ? 8 : (value == 4 ? 4 : 0); return LK_OK; }
     if (!strcmp(key, "cw_grid_mult")) { if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "lk_set_tuning: cw_grid_mult must be in [1, 16]"); c->cw_grid_mult = value; return LK_OK; }
-    if (!strcmp(key, "xcd_map")) { c->xcd_map = value != 0; return LK_OK; }
-    if (!strcmp(key, "prof_ext")) { c->prof_ext = value != 0; return LK_OK; }
-    if (!strcmp(key, "xhy_small")) { c->xhy_small = value != 0; return LK_OK; }
-    if (!strcmp(key, "xhy_grid_mult")) { c->xhy_grid_mult = value < 0 ? 0 : (value > 4 ? 4 : value); return LK_OK; }
+    if (!strcmp(key, "xhy_db")) { c->xhy_db = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "xhy_mfma")) { c->xhy_mfma = value != 0; return LK_OK; }
     if (!strcmp(key, "block_fused")) { c->block_fused = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "csr_stream")) { c->csr_stream = value != 0; return LK_OK; }
-    if (!strcmp(key, "csr_lanes")) {
-        if (value != 0 && (value < 1 || value > 64 || (value & (value - 1)))) return fail(LK_ERR_INVALID, "lk_set_tuning: csr_lanes must be 0 or a power of two in [1, 64]");
-        c->csr_lanes = value;
-        return LK_OK;
-    }
     if (!strcmp(key, "blas1_grid_mult")) {
         if (value < 1 || value > 64) return fail(LK_ERR_INVALID, "lk_set_tuning: blas1_grid_mult must be in [1, 64]");
         c->blas1_grid_mult = value;
@@ -1711,7 +1666,6 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "resident_onchip")) { c->resident_onchip = value != 0; return LK_OK; }
     if (!strcmp(key, "resident_rev")) { c->resident_rev = value != 0; return LK_OK; }
     if (!strcmp(key, "resident_spin_ms")) { c->resident_spin_ms = value < 0 ? 0 : (value > 20000 ? 20000 : value); return LK_OK; }
-    if (!strcmp(key, "stream_update")) { c->stream_update = value != 0; return LK_OK; }
     if (!strcmp(key, "lazy")) {
         LKCHK(lazy_flush(c));
         c->forget_memos();
@@ -1719,7 +1673,6 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "lazy_speculate")) { c->lazy_speculate = value != 0; c->spec.armed = false; return LK_OK; }
-    if (!strcmp(key, "stream_two")) { c->stream_two = value != 0; return LK_OK; }
     if (!strcmp(key, "recompute_update")) { c->recompute_update = value != 0; return LK_OK; }
     if (!strcmp(key, "store_policy")) {
         if (value < 0 || value > 3) return fail(LK_ERR_INVALID, "store_policy must be in [0,3]");
@@ -1727,45 +1680,27 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         return LK_OK;
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
-    if (!strcmp(key, "gemm_prefetch_y")) { c->gemm_prefetch_y = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gram_cyc4")) { c->gram_cyc4 = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
     if (!strcmp(key, "gram_cyc")) { c->gram_cyc = value < 0 ? 0 : (value > 8 ? 8 : value); return LK_OK; }
-    if (!strcmp(key, "mfma_4x4")) { c->mfma_4x4 = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
+#ifdef LK_DIAGNOSTICS
+    // phase-timing switches that turn parts of a kernel OFF (wrong results): only in a build made with -DLK_DIAGNOSTICS (make diagnostics), never
+    // in the library build() produces
     if (!strcmp(key, "upd_debug")) { c->upd_debug = value & 15; return LK_OK; }
     if (!strcmp(key, "xhy_debug")) { c->xhy_debug = value & 3; return LK_OK; }
+#endif
     if (!strcmp(key, "gemm_roll")) { c->gemm_roll = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
-    if (!strcmp(key, "xhy_tr32")) { c->xhy_tr32 = value ? 1 : 0; return LK_OK; }
-    if (!strcmp(key, "xhy_db")) { c->xhy_db = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "gram_tiles")) { c->gram_tiles = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "gram_grid_mult")) { c->gram_grid_mult = value < 1 ? 1 : (value > 8 ? 8 : value); return LK_OK; }
-    if (!strcmp(key, "kc32")) { c->kc32 = value < 0 ? -1 : value; return LK_OK; }
     if (!strcmp(key, "wide_s3")) { c->wide_s3 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "wide_regs")) { c->wide_regs = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
-    if (!strcmp(key, "cplx_wide")) { c->cplx_wide = value < 0 ? 0 : value; return LK_OK; }
     if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }
     if (!strcmp(key, "pool_slab_cols")) {
         if (value < 2 || value > 4096) return fail(LK_ERR_INVALID, "pool_slab_cols must be in [2,4096]");
         c->pool_slab_cols = value;
         return LK_OK;
     }
-    if (!strcmp(key, "gemm_mfma")) { c->gemm_mfma = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_mfma_min")) { c->gemm_mfma_min = value < 0 ? 0 : value; return LK_OK; }
-    if (!strcmp(key, "gemm_store_policy")) {
-        if (value < 0 || value > 3) return fail(LK_ERR_INVALID, "gemm_store_policy must be in [0,3]");
-        c->gemm_store_policy = value;
-        return LK_OK;
-    }
-    if (!strcmp(key, "gemm_grid_mult")) {
-        if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "gemm_grid_mult must be in [1,16]");
-        c->gemm_grid_mult = value;
-        return LK_OK;
-    }
-    if (!strcmp(key, "update_grid_mult")) {
-        if (value < 1 || value > 16) return fail(LK_ERR_INVALID, "update_grid_mult must be in [1,16]");
-        c->update_grid_mult = value;
-        return LK_OK;
-    }
     return fail(LK_ERR_INVALID, "lk_set_tuning: unknown key '%s'", key);
 }
 

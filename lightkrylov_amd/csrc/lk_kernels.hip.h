@@ -1018,28 +1018,11 @@ __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, 
 // Cp: coefficient tiles packed per lane by pack_coef_mfma: [group][k-step t][64 lanes].
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// D(16 x 16) += A(16 x 4) B(4 x 16) in the lane layout of v_mfma_f64_16x16x4_f64 -- A[i = l & 15][kk = l >> 4], B[kk = l >> 4][j = l & 15],
-// D[i = (l >> 4) + 4 reg][j = l & 15] -- issued as FOUR v_mfma_f64_4x4x4_4b_f64 (round 5).  Both instructions sustain
-// 0.9+ of the 78.6 TFLOP/s spec back to back (tools/mfma_f64_peak.hip, profiles/r05_fp64_mfma_peak.txt: 77.6 / 70-76).
-// The 4x4x4 instruction multiplies four independent 4 x 4 x 4 blocks; its lanes (found empirically: tools/mfma_f64_4x4_probe.hip) are
-//     A: lane 16 k + 4 blk + i      B: lane 16 k + 4 blk + j      D: lane 16 i + 4 blk + j
-// so with the SAME B register (row kk = l >> 4, column j = l & 15 = 4 blk + j') and A_m[lane] = A[i = 4 m + (l & 3)][kk = l >> 4] -- the four
-// output rows 4m .. 4m + 3 of the tile, replicated over the four blocks -- instruction m leaves D[i = (l >> 4) + 4 m][j = l & 15] in its lane:
-// component m of the 16x16x4 accumulator.  Only the A operand changes: four values per lane instead of one (in an LDS tile: the entries
-// 4 m + (l & 3) of the lane's 16-entry row instead of entry l & 15; four lanes read the same word -- a broadcast).
-__device__ __forceinline__ v4d mfma_f64_16x16x4_by4(const double (&a4)[4], double b, v4d acc) {
-    acc[0] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[0], b, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[1], b, acc[1], 0, 0, 0);
-    acc[2] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[2], b, acc[2], 0, 0, 0);
-    acc[3] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[3], b, acc[3], 0, 0, 0);
-    return acc;
-}
-
 // PF (round 4; real kind, <= 32 outputs, launched for accumulating calls only: the block Gram-Schmidt's updates Y -= X H): the tile of Y that
 // the result is added to is loaded BEFORE the k-loop, 16 more 16-byte loads in flight per lane under the MFMAs, instead of after it, where a
 // wave had nothing else to issue: block DGS k = 128, p = 32: 10.3 -> 9.8 ms, k = 32, p = 32: 4.9 -> 4.5 ms.  (Compiled into the plain
 // product as well it cost that one 13 %, so it is a template flag; for the complex three-product kernel it changed nothing and is not built.)
-template <bool CPLX, int NG, bool PFY = false, bool ROLL = false, bool M4 = false>
+template <bool CPLX, int NG, bool PFY = false, bool ROLL = false>
 __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                        double *__restrict__ Y, int64_t ldy, int qn,
                                                        const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
@@ -1099,7 +1082,7 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
         // the way through the k-loop.  (Rounds 2-4 loaded a BATCH of U k-steps, waited for all of it -- s_waitcnt vmcnt(0) -- and
         // only then issued its 4 U NG MFMAs: every batch paid an HBM round trip with an idle matrix pipe and nothing in flight behind
         // it; a double-buffered variant of that with half-size batches had measured slower.)  ROLL = false keeps the batch schedule.
-        if constexpr (ROLL && !CPLX && !M4) {
+        if constexpr (ROLL && !CPLX) {
           constexpr int UR = RING;              // ring depth in k-steps: 2 UR loads of 16 B per lane in flight
           if (fast && (nt == 32 || nt == 16)) {
             // straight-line ring (full tile, k = 128 or 64: the launcher sends no other width here): NO branch between the loads and the MFMAs of a k-step, so the compiler keeps
@@ -1225,14 +1208,6 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                                 acc[g][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xb.x, acc[g][1][0], 0, 0, 0);
                                 acc[g][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xa.y, acc[g][0][0], 0, 0, 0);
                                 acc[g][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, xb.y, acc[g][1][0], 0, 0, 0);
-                            } else if constexpr (M4) {
-                                double a4[4];
-#pragma unroll
-                                for (int mm = 0; mm < 4; ++mm) a4[mm] = tiles[(g * nt + t) * 64 + (lane & 48) + 4 * mm + (lane & 3)];
-                                acc[g][0][0] = mfma_f64_16x16x4_by4(a4, xa.x, acc[g][0][0]);
-                                acc[g][0][1] = mfma_f64_16x16x4_by4(a4, xa.y, acc[g][0][1]);
-                                acc[g][1][0] = mfma_f64_16x16x4_by4(a4, xb.x, acc[g][1][0]);
-                                acc[g][1][1] = mfma_f64_16x16x4_by4(a4, xb.y, acc[g][1][1]);
                             } else {
                                 acc[g][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xa.x, acc[g][0][0], 0, 0, 0);
                                 acc[g][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, xa.y, acc[g][0][1], 0, 0, 0);
@@ -1265,36 +1240,6 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
                     }
                 }
             }
-            if constexpr (M4 && !CPLX) {
-                // the products on v_mfma_f64_4x4x4_4b_f64 (mfma_f64_16x16x4_by4), software-pipelined over the U NG (k-step, output group) pairs of
-                // the batch: the four A operands of pair i + 1 -- the entries 4 m + (lane & 3) of the lane's 16-output row of its coefficient
-                // tile -- are read from LDS BEFORE the sixteen MFMAs of pair i are issued (256 cycles of matrix pipe cover the LDS latency; read
-                // just ahead of their use, as the compiler schedules them on its own, every pair waited ~100 cycles for them)
-                double a4c[4], a4n[4];
-                auto geta = [&](int idx, double (&dst)[4]) {
-                    const int u = idx / NG, g = idx % NG, t = t0 + u;
-                    const int tt = t < nt ? t : nt - 1;
-#pragma unroll
-                    for (int mm = 0; mm < 4; ++mm) dst[mm] = tiles[(g * nt + tt) * 64 + (lane & 48) + 4 * mm + (lane & 3)];
-                };
-                geta(0, a4c);
-#pragma unroll
-                for (int idx = 0; idx < U * NG; ++idx) {
-                    const int u = idx / NG, g = idx % NG;
-                    if (idx + 1 < U * NG) geta(idx + 1, a4n);
-                    __builtin_amdgcn_sched_barrier(0);                 // (keep the reads AHEAD of the MFMAs: the scheduler sinks them to their use)
-                    if (t0 + u < nt) {
-#pragma unroll
-                        for (int g2 = 0; g2 < 2; ++g2) {
-                            acc[g][g2][0] = mfma_f64_16x16x4_by4(a4c, x[u][g2].x, acc[g][g2][0]);
-                            acc[g][g2][1] = mfma_f64_16x16x4_by4(a4c, x[u][g2].y, acc[g][g2][1]);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int mm = 0; mm < 4; ++mm) a4c[mm] = a4n[mm];
-                }
-            } else
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int t = t0 + u;
@@ -1584,7 +1529,7 @@ __global__ __launch_bounds__(256) void pack_coef_mfma3m(const double *__restrict
 // PJM = J tiles a wave can hold (8: up to 128 right-hand sides; 2: up to 32, half the registers), TR = real rows per tile
 // (64, or 32 for the small variant: 40 KB of LDS at k = 128, so that two or three blocks share a CU and cover each other's
 // barriers when there are only a few MFMAs per tile).
-template <bool CPLX, int PJM, int TR, bool DB = false, bool M4 = false>
+template <bool CPLX, int PJM, int TR, bool DB = false>
 __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                       const double *__restrict__ Y, int64_t ldy, int p, int64_t n, int flags,
                                                       int NI, double *__restrict__ partial, double *__restrict__ npartial) {
@@ -1619,8 +1564,11 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     for (int s = 0; s < NYP; ++s) nacc[s] = 0.0;
     v2d xs[NXP], ys[NYP];
 
-    constexpr bool m4 = M4;                                           // the products on v_mfma_f64_4x4x4_4b_f64 (tuning key "mfma_4x4")
-    const bool dbg_nomfma = flags & 16, dbg_noload = flags & 32;      // diagnostics (tools/bench_gram.py xhy_debug=...): wrong results, phase timing only
+#ifdef LK_DIAGNOSTICS
+    const bool dbg_nomfma = flags & 16, dbg_noload = flags & 32;      // diagnostics build only (tools/bench_gram.py xhy_debug=...): WRONG results, phase timing
+#else
+    constexpr bool dbg_nomfma = false, dbg_noload = false;
+#endif
     auto gload = [&](int64_t T) {
         if (dbg_noload && T != (int64_t)blockIdx.x) return;
         const int64_t rbase = T * TR;
@@ -1675,99 +1623,7 @@ __global__ __launch_bounds__(512) void panel_xhy_mfma(const double *__restrict__
     // this wave's MFMAs on the tile staged in `Xb` / `Yb`
     auto contract = [&](const double *Xb, const double *Yb) {
         if (dbg_nomfma) return;
-        constexpr bool PF = !CPLX && PJM == 8 && TR == 32;      // (the variants with registers to spare: 64-row tiles and the complex kind spill with it)
-        if (PF && active && WR == 1) {
-            // one tile row per wave (k > 64): the operands of row step s + 1 are read from LDS BEFORE the MFMAs of step s are issued, so
-            // the LDS latency of a step (one A and up to eight B operands, then a full s_waitcnt) runs under 8 x 64 cycles of matrix
-            // pipe instead of in front of them (round 5: the waves of this kernel were parked in s_waitcnt for half their cycles)
-            double a_n = Xb[(16 * wi + acol) * S + arow], b_n[PJM], b2_n[CPLX ? PJM : 1];
-#pragma unroll
-            for (int J = 0; J < PJM; ++J) {
-                b_n[J] = 0.0;
-                if constexpr (CPLX) b2_n[J] = 0.0;
-                if (J < PJ && (!upper || J >= wi)) {
-                    b_n[J] = Yb[(16 * J + acol) * S + arow];
-                    if constexpr (CPLX) b2_n[J] = Yb[(16 * J + acol) * S + (arow ^ 1)];
-                }
-            }
-#pragma unroll 1
-            for (int step = 0; step < TR / 4; ++step) {
-                const double a = a_n;
-                double b[PJM], b2[CPLX ? PJM : 1];
-#pragma unroll
-                for (int J = 0; J < PJM; ++J) { b[J] = b_n[J]; if constexpr (CPLX) b2[J] = b2_n[J]; }
-                if (step + 1 < TR / 4) {
-                    const int ro = 4 * (step + 1) + arow;
-                    a_n = Xb[(16 * wi + acol) * S + ro];
-#pragma unroll
-                    for (int J = 0; J < PJM; ++J)
-                        if (J < PJ && (!upper || J >= wi)) {
-                            b_n[J] = Yb[(16 * J + acol) * S + ro];
-                            if constexpr (CPLX) b2_n[J] = Yb[(16 * J + acol) * S + (ro ^ 1)];
-                        }
-                }
-                __builtin_amdgcn_sched_barrier(0);                     // (the reads stay AHEAD of the MFMAs: the scheduler sinks them to their use otherwise)
-#pragma unroll
-                for (int J = 0; J < PJM; ++J) {
-                    if (J < PJ && (!upper || J >= wi)) {
-                        acc_re[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[J], acc_re[J], 0, 0, 0);
-                        if constexpr (CPLX) acc_im[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (arow & 1) ? -b2[J] : b2[J], acc_im[J], 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else if (m4 && active && TR == 32 && PJM == 8 && !CPLX) {
-            // 4x4x4 products, software-pipelined: the twelve operands of row step s + 1 (four A, up to eight B) are read from LDS BEFORE the 32
-            // MFMAs of step s are issued -- at 16 cycles per MFMA a `ds_read -> s_waitcnt -> 4 MFMAs` chain per tile would expose the LDS
-            // latency in front of every 64 cycles of matrix work (measured: 5.4 ms against 4.3 for the 16x16x4 loop below)
-            double a4n[4], bn[PJM];
-            auto fetch = [&](int step) {
-                const int ro = 4 * step + arow;
-#pragma unroll
-                for (int mm = 0; mm < 4; ++mm) a4n[mm] = Xb[(16 * wi + 4 * mm + (lane & 3)) * S + ro];
-#pragma unroll
-                for (int J = 0; J < PJM; ++J)
-                    if (J < PJ && (!upper || J >= wi)) bn[J] = Yb[(16 * J + acol) * S + ro];
-            };
-#pragma unroll
-            for (int J = 0; J < PJM; ++J) bn[J] = 0.0;
-            fetch(wr);
-#pragma unroll 1
-            for (int step = wr; step < TR / 4; step += WR) {
-                double a4[4], b[PJM];
-#pragma unroll
-                for (int mm = 0; mm < 4; ++mm) a4[mm] = a4n[mm];
-#pragma unroll
-                for (int J = 0; J < PJM; ++J) b[J] = bn[J];
-                if (step + WR < TR / 4) fetch(step + WR);
-                __builtin_amdgcn_sched_barrier(0);                     // (the scheduler sinks the reads to their use otherwise)
-#pragma unroll
-                for (int J = 0; J < PJM; ++J)
-                    if (J < PJ && (!upper || J >= wi)) acc_re[J] = mfma_f64_16x16x4_by4(a4, b[J], acc_re[J]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else if (m4 && active) {
-            // the same products on the 4x4x4 instruction (A/B knob; slower in every kernel): four A operands per row step -- the columns
-            // 16 wi + 4 m + (lane & 3) of X's tile --, the B operands and the accumulators exactly as below
-            for (int step = wr; step < TR / 4; step += WR) {
-                const int ro = 4 * step + arow;
-                double a4[4];
-#pragma unroll
-                for (int mm = 0; mm < 4; ++mm) a4[mm] = Xb[(16 * wi + 4 * mm + (lane & 3)) * S + ro];
-#pragma unroll
-                for (int J = 0; J < PJM; ++J) {
-                    if (J < PJ && (!upper || J >= wi)) {
-                        const double b = Yb[(16 * J + acol) * S + ro];
-                        acc_re[J] = mfma_f64_16x16x4_by4(a4, b, acc_re[J]);
-                        if constexpr (CPLX) {
-                            double b2 = Yb[(16 * J + acol) * S + (ro ^ 1)];
-                            b2 = (ro & 1) ? -b2 : b2;
-                            acc_im[J] = mfma_f64_16x16x4_by4(a4, b2, acc_im[J]);
-                        }
-                    }
-                }
-            }
-        } else if (active) {
+        if (active) {
             for (int step = wr; step < TR / 4; step += WR) {
                 const int ro = 4 * step + arow;
                 const double a = Xb[(16 * wi + acol) * S + ro];
@@ -2091,7 +1947,6 @@ __global__ __launch_bounds__(512) void panel_gram_mfma3m(const double *__restric
 // stride 34 words: conflict free); the next tile's loads are in flight while the current tile's MFMAs run.
 // Results: partial[block][slot], slot = j (k + 1) + i for i in tile row I, j in tile column J >= I -- panel_xhy_mfma's layout with
 // flags = 3 (Y is X, upper tiles only), summed by finish_xhy; no norm slots.
-template <bool M4>
 __global__ __launch_bounds__(512) void panel_gram_mfma(const double *__restrict__ X, int64_t ldx, int k, int64_t n,
                                                        double *__restrict__ partial) {
     constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = 512 / CH, NXP = 128 / CPP;      // 32 columns staged per block-wide pass
@@ -2160,22 +2015,7 @@ __global__ __launch_bounds__(512) void panel_gram_mfma(const double *__restrict_
         for (int step = 0; step < TR / 4; ++step) {
             const int ro = 4 * step + arow;
             int lastI = -1;
-            if constexpr (M4) {
-                // the same products on v_mfma_f64_4x4x4_4b_f64 (mfma_f64_16x16x4_by4): four A operands per tile row, the B operand as below
-                double a4[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int q = 0; q < MAXT; ++q) {
-                    if (q < nt) {
-                        if (tI[q] != lastI) {
-#pragma unroll
-                            for (int mm = 0; mm < 4; ++mm) a4[mm] = Xt[(16 * tI[q] + 4 * mm + (lane & 3)) * S + ro];
-                            lastI = tI[q];
-                        }
-                        const double b = Xt[(16 * tJ[q] + acol) * S + ro];
-                        acc[q] = mfma_f64_16x16x4_by4(a4, b, acc[q]);
-                    }
-                }
-            } else {
+            {
                 double a = 0.0;
 #pragma unroll
                 for (int q = 0; q < MAXT; ++q) {
@@ -2214,7 +2054,12 @@ __global__ __launch_bounds__(512) void panel_gram_mfma(const double *__restrict_
 // of pair i (pinned with sched_barrier) -- on operands whose LDS column offsets are the only thing that depends on the wave.  Tiles, staging,
 // strides and the prefetch of the next tile's global loads as panel_gram_mfma (32 rows x 128 columns, S = 34: conflict-free operand reads).
 // The two halves of the d = 4 tiles meet in LDS once, at the end.  Results: partial[block][slot] as panel_gram_mfma.
-__global__ __launch_bounds__(512, 4) void panel_gram_cyc(const double *__restrict__ X, int64_t ldx, int k, int64_t n, double *__restrict__ partial, int dbg) {
+__global__ __launch_bounds__(512, 4) void panel_gram_cyc(const double *__restrict__ X, int64_t ldx, int k, int64_t n, double *__restrict__ partial, int dbg_arg) {
+#ifdef LK_DIAGNOSTICS
+    const int dbg = dbg_arg;                        // diagnostics build only (xhy_debug): WRONG results, phase timing
+#else
+    constexpr int dbg = 0;
+#endif
     constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = 512 / CH, NXP = 128 / CPP;
     extern __shared__ __attribute__((aligned(16))) double gc_lds[];
     const int t = threadIdx.x, lane = t & 63;
@@ -2518,7 +2363,11 @@ __global__ __launch_bounds__(256, CPLX ? 1 : 2) void panel_xhy_upd_mfma(const do
     for (int s = 0; s < NYP; ++s) nacc[s] = 0.0;
     v2d xs[NXP], ys[NYP];
 
-    const int dbg = policy >> 4;                    // diagnostics (upd_debug): wrong results, phase timing only
+#ifdef LK_DIAGNOSTICS
+    const int dbg = policy >> 4;                    // diagnostics build only (upd_debug): WRONG results, phase timing
+#else
+    constexpr int dbg = 0;
+#endif
     policy &= 15;
     auto gload = [&](int64_t T) {
         if ((dbg & 4) && T != (int64_t)blockIdx.x) return;

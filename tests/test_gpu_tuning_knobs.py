@@ -117,12 +117,11 @@ def test_lazy_gram_loop_of_the_reference_costs_one_pass(dtype):
 
 @pytest.mark.parametrize("dtype", KINDS)
 @pytest.mark.parametrize("cfg", [dict(), dict(xhy_db=0), dict(xhy_db=2), dict(gram_tiles=0), dict(gram_tiles=2), dict(gram_tiles=2, gram_grid_mult=3), dict(gram_cyc=1), dict(gram_cyc=3),
-                                 dict(xhy_tr32=1), dict(gemm_roll=0), dict(gemm_roll=2), dict(mfma_4x4=1), dict(mfma_4x4=2), dict(mfma_4x4=1, gram_tiles=2),
-                                 dict(mfma_4x4=1, gemm_roll=2)],
+                                 dict(gemm_roll=0), dict(gemm_roll=2)],
                          ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "defaults")
 def test_matrix_core_kernel_variants_agree_with_the_oracle(dtype, cfg):
-    """Round 5's kernel variants behind lk_set_tuning (double-buffered tiles, dealt Gram tiles, operand / rolling prefetch, the products on
-    v_mfma_f64_4x4x4_4b_f64) are schedules of the SAME sums: Gram (AbstractVectors.fypp:645-657), innerprod_matrix (:670-695), the block
+    """The matrix-core kernel variants behind lk_set_tuning (double-buffered tiles, dealt Gram tiles, rolling prefetch) are schedules of
+    the SAME sums: Gram (AbstractVectors.fypp:645-657), innerprod_matrix (:670-695), the block
     DGS (gram_schmidt.fypp:59-105) and linear_combination (AbstractVectors.fypp:596-642) against the oracle at ragged sizes."""
     c = lk.Context(device=0)
     for key, val in cfg.items():
@@ -315,3 +314,15 @@ def test_lincomb_across_the_kernel_dispatch_boundaries(dtype):
                 assert np.abs(got - X @ Z).max() <= tol, (n, k, q)
             del B
     c.close()
+
+
+def test_the_shipped_library_has_no_key_that_gives_wrong_results():
+    """Round-5 review: the phase-timing switches ("xhy_debug", "upd_debug": parts of a kernel OFF, wrong results) and the variants measured
+    slower and never defaulted ("mfma_4x4", "xhy_tr32") are not reachable through the ABI of the library build() produces."""
+    c = lk.Context(device=0)
+    try:
+        for key in ("xhy_debug", "upd_debug", "mfma_4x4", "xhy_tr32"):
+            with pytest.raises(Exception, match="unknown key"):
+                c.set_tuning(key, 1)
+    finally:
+        c.close()

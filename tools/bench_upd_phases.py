@@ -5,6 +5,11 @@ import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lightkrylov_amd as lk
+from lightkrylov_amd import _capi
+# the keys that switch parts of a kernel off exist only in the phase-timing build (make -C lightkrylov_amd/csrc diagnostics)
+_diag = os.path.join(os.path.dirname(_capi.LIB_PATH), "liblightkrylov_hip_diag.so")
+if os.path.exists(_diag):
+    _capi.LIB_PATH = _diag
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 p = int(sys.argv[3]) if len(sys.argv) > 3 else 32

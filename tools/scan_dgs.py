@@ -1,5 +1,5 @@
 """Single-vector double Gram-Schmidt step across sizes: TB/s on the algorithmic 3k+5 columns for a grid of (rows, basis columns), both kinds --
-where the fused sweeps sit on the streaming ceiling and where they turn launch-bound or change shape (register tiles, lane split, kc32).
+where the fused sweeps sit on the streaming ceiling and where they turn launch-bound or change shape (register tiles, lane split, single launch).
   python tools/scan_dgs.py [f64|c128] [KEY=INT ...] [sizes=300000,1000000] [ks=8,32,128]
 (round 6: "dgs_sweep*" includes the single launch of csrc/lk_resident.hip.h, tag dgs_sweep_resident; resident=0 gives the three-sweep schedule)"""
 import json, os, sys
