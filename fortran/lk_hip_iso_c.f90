@@ -460,6 +460,27 @@ module lightkrylov_hip_c
             integer(c_int), intent(out) :: info
             integer(c_int) :: rc
         end function
+        function lk_qr(Q, j0, p, R, ldr, tol, info) bind(C, name="lk_qr") result(rc)
+            import :: c_int, c_ptr, c_double, c_int64_t
+            type(c_ptr), value :: Q
+            integer(c_int), value :: j0, p
+            real(c_double), intent(inout) :: R(*)
+            integer(c_int64_t), value :: ldr
+            real(c_double), value :: tol
+            integer(c_int), intent(out) :: info
+            integer(c_int) :: rc
+        end function
+        function lk_arnoldi_block(A, X, H, ldh, blksize, kstart, kend, tol, trans, info) bind(C, name="lk_arnoldi_block") result(rc)
+            import :: c_int, c_ptr, c_double, c_int64_t
+            type(c_ptr), value :: A, X
+            real(c_double), intent(inout) :: H(*)
+            integer(c_int64_t), value :: ldh
+            integer(c_int), value :: blksize, kstart, kend
+            real(c_double), value :: tol
+            integer(c_int), value :: trans
+            integer(c_int), intent(out) :: info
+            integer(c_int) :: rc
+        end function
         function lk_lanczos(A, X, T, ldt, kstart, kend, tol, info) bind(C, name="lk_lanczos") result(rc)
             import :: c_int, c_ptr, c_double, c_int64_t
             type(c_ptr), value :: A, X

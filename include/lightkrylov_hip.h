@@ -388,7 +388,7 @@ int lk_linop_destroy(lk_linop_t op);
 int lk_linop_apply(lk_linop_t op, int trans, lk_basis_t Bx, int jx, lk_basis_t By, int jy);
 
 /* ---- the caller of the path: Arnoldi --------------------------------------------------
- * arnoldi(A, X, H, info, kstart, kend, tol, transpose) with blksize = 1.
+ * arnoldi(A, X, H, info, kstart, kend, tol, transpose) with blksize = 1 (lk_arnoldi_block: any blksize).
  * src/Krylov/arnoldi.fypp:8-76 (+ the 1-column qr_no_pivoting, src/Krylov/qr.fypp:116-167).
  * X: basis with m+1 columns; H: host (ldh x m) column-major array of the basis dtype;
  * kstart/kend 1-based inclusive; tol: breakdown tolerance (reference default atol_dp).
@@ -429,6 +429,24 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
  * (ldb x kdim) column-major array of the basis dtype, only B(k, k) and B(k+1, k) are written.  tol >= atol_dp.  Steps against more than
  * 512 basis columns run one host round trip each (the reference has no cap, golub_kahan.fypp:18). */
 int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, int kstart, int kend, double tol, int *info);
+
+/* ---- qr_no_pivoting and the block Arnoldi factorisation (round 6) ------------------------------------------
+ * qr_no_pivoting(Q, R, info, tol): src/Krylov/qr.fypp:116-167, on columns [j0, j0 + p) of a panel.  Column j: double Gram-Schmidt
+ * against the j columns before it with beta = R(:j-1, j) (:131-134), beta = ||q_j|| (:135), NaN aborts (:137-143); beta < tol => info = j
+ * (first such column), R(j, j) = 0, the column is re-drawn from the counter generator (stream 0x5EED + panel column + 1), orthogonalised
+ * again and its new norm taken (:146-162), else R(j, j) = beta; q_j scaled by 1 / beta (:164).  R: host p x p column-major (leading
+ * dimension ldr elements) of the basis dtype, zeroed by the call.  Host-synchronous, column by column. */
+int lk_qr(lk_basis_t Q, int j0, int p, double *R, int64_t ldr, double tol, int *info);
+/* arnoldi(A, X, H, info, kstart, kend, tol, transpose, blksize): src/Krylov/arnoldi.fypp:8-76 with blksize = p > 1 (p = 1 is lk_arnoldi).
+ * X holds (kdim + 1) p columns (kdim = (ncols - p) / p, :26), H is host ((kdim + 1) p x kdim p), column-major, leading dimension ldh.
+ * Step k (kpm = (k-1) p, kp = k p): X(kp + i) = A X(kpm + i) (:39-47), the batch Gram-Schmidt of the new block against X(:kp) into
+ * H(:kp, kpm+1:kp) (:50-51, panel x panel on the matrix cores from five columns on), qr_no_pivoting of the block into
+ * H(kp+1:kp+p, kpm+1:kp) (:55), min |diagonal| < tol => info = kp, exit (:58-71).  All steps of a call are enqueued asynchronously
+ * behind a device-side stop flag that counts (step, column): a column below max(tol, atol_dp) stops everything behind it, the host
+ * finishes that block (re-draw, remaining columns) exactly as lk_qr would; ONE copy and ONE host synchronisation per call otherwise.
+ * Bases beyond 512 columns, and "async_arnoldi" = 0, run one round trip per step through lk_dgs_block / lk_qr. */
+int lk_arnoldi_block(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int blksize, int kstart, int kend, double tol, int trans,
+                     int *info);
 
 #ifdef __cplusplus
 }

@@ -100,6 +100,8 @@ SIGNATURES = {
     "lk_arnoldi_segments": (_int, [_p, _p, _dp, _i64, _int, _int, C.c_double, _int, _ip, _int, PROGRESS_FN, _p, _ip]),
     "lk_lanczos": (_int, [_p, _p, _dp, _i64, _int, _int, C.c_double, _ip]),
     "lk_bidiag": (_int, [_p, _p, _p, _dp, _i64, _int, _int, C.c_double, _ip]),
+    "lk_qr": (_int, [_p, _int, _int, _dp, _i64, C.c_double, _ip]),
+    "lk_arnoldi_block": (_int, [_p, _p, _dp, _i64, _int, _int, _int, C.c_double, _int, _ip]),
 }
 
 

@@ -155,7 +155,9 @@ struct lk_context_s {
     bool resident_off = false; // a launch gave up once (the device is shared with another persistent kernel): not tried again
     unsigned *res_cnt = nullptr;
     long long *res_tim = nullptr;
-    void *res_gran = nullptr;              // {value, tag} granules of the flat grid sums
+    double *blk_red = nullptr, *blk_red_host = nullptr;   // coefficient sections of the block Gram-Schmidt (lk_dgs_block, lk_arnoldi_block): device + pinned
+    int64_t blk_cap = 0;
+    void *res_gran = nullptr;              // {value, tag} granules of the grid sums
     unsigned long long res_epoch = 0;      // launches so far (the tag of a launch's granules)
     int64_t resident_stats[3] = {0, 0, 0};   // single launches enqueued, launches that gave up, launches that kept the panel in registers
     int lazy = 0;
@@ -681,7 +683,7 @@ int block_sweeps(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int pn, const dou
     {
         ProfScope ps(c, "dgs_block_sweep2", (double)Bx->n * ED * 8.0 * (k + pn));
         hipLaunchKernelGGL((panel_sweep_p<CPLX, KC, NW, P, true, false>), dim3(s.grid), dim3(NW * 64), 0, c->stream, Bx->col(0), Bx->ld, k,
-                           By->col(jy0), By->ld, pn, Bx->n, out1, nullptr, k + 1, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, 0);
+                           By->col(jy0), By->ld, pn, Bx->n, out1, nullptr, k + 1, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw, 0, c->guard());
     }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(finish_partials, dim3((nslots + 3) / 4), dim3(256), 0, c->stream, c->partial, (int64_t)MAX_GRID, s.grid, nslots, out2);
@@ -691,7 +693,7 @@ int block_sweeps(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int pn, const dou
         ProfScope ps(c, "dgs_block_sweep3", (double)Bx->n * ED * 8.0 * (k + 2 * pn));
         hipLaunchKernelGGL((panel_sweep_p<CPLX, KC, NW, P, false, true>), dim3(s.grid), dim3(NW * 64), 0, c->stream, Bx->col(0), Bx->ld, k,
                            By->col(jy0), By->ld, pn, Bx->n, out1, out2, k + 1, c->partial, (int64_t)MAX_GRID, s.WC, s.kcw,
-                           1 | (c->store_policy << 1));
+                           1 | (c->store_policy << 1), c->guard());
     }
     HIPCHK(hipGetLastError());
     return LK_OK;
@@ -938,7 +940,7 @@ int upd_dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, c
         auto go = [&](auto kern) -> int {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, c->stream, (const double *)Bx->col(c0), Bx->ld, k, By->col(jy0), By->ld, p, Bx->n,
-                               H1dev, part, npart, c->gemm_store_policy | (c->upd_debug << 4));
+                               H1dev, part, npart, c->gemm_store_policy | (c->upd_debug << 4), c->guard());
             return LK_OK;
         };
         if (cp) LKCHK(go(&panel_xhy_upd_mfma<true>));
@@ -988,7 +990,7 @@ int gemm_launch_valu(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int q
         ProfScope ps(c, "lincomb", (double)Bx->n * ED * 8.0 * (k + qn * (accumulate ? 2 : 1)));
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(256), 0, c->stream, (const double *)Bx->col(c0), Bx->ld, k, By->col(jy0 + q0), By->ld, qn,
-                               Cp, Bx->n, accumulate, QGB, c->gemm_store_policy);
+                               Cp, Bx->n, accumulate, QGB, c->gemm_store_policy, c->guard());
         };
         // columns in flight per lane: 16 (real) / 8 (complex) loads of 16 B for the narrow shapes, half that beside 8-16 accumulators
         if (cp) {
@@ -1037,7 +1039,7 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gemm_mfma<CPLX, NG, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             // (the rolling prefetch of X beside the prefetched tile of Y does not fit the register file: batch schedule here)
             hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, true, false>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                               c->gemm_store_policy);
+                               c->gemm_store_policy, c->guard());
             HIPCHK(hipGetLastError());
             return LK_OK;
         }
@@ -1051,13 +1053,13 @@ int gemm_mfma_one(lk_context_t c, const double *X, int64_t ldx, int kk, double *
         // (the real kind's straight-line ring is unrolled for the basis widths 128 and 64: any other width keeps the batch schedule)
         if ((CPLX || kk == 128 || kk == 64) && (c->gemm_roll >= 2 || (c->gemm_roll == 1 && !CPLX && NG == 4))) {
             hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, false, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                               c->gemm_store_policy);
+                               c->gemm_store_policy, c->guard());
             rolled = true;
         }
     }
     if (!rolled)
         hipLaunchKernelGGL((panel_gemm_mfma<CPLX, NG, false, false>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                           c->gemm_store_policy);
+                           c->gemm_store_policy, c->guard());
     HIPCHK(hipGetLastError());
     return LK_OK;
 }
@@ -1080,10 +1082,10 @@ int gemm_mfma3m_one(lk_context_t c, const double *X, int64_t ldx, int kk, double
     if (g < 1) g = 1;
     if (roll)
         hipLaunchKernelGGL((panel_gemm_mfma3m<NG, NR, true>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                           c->gemm_store_policy);
+                           c->gemm_store_policy, c->guard());
     else
         hipLaunchKernelGGL((panel_gemm_mfma3m<NG, NR>), dim3((unsigned)g), dim3(512), lds, c->stream, X, ldx, kk, Y, ldy, qn, Cp, n, accumulate,
-                           c->gemm_store_policy);
+                           c->gemm_store_policy, c->guard());
     HIPCHK(hipGetLastError());
     return LK_OK;
 }
@@ -1352,21 +1354,21 @@ int fused_sub_with_dots(lk_context_t c) {
 
 // Core of double_gram_schmidt_step for one vector; results stay in c->red (device):
 //   section 0: h1[0..k), nrm2(y)    section 1: h2[0..k), nrm2(y')   section 2 (slot k): nrm2(y'')
-int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass, double *red_base = nullptr, int stride = 0) {
+int dgs_device(lk_basis_t Bx, int k, double *y, bool two_pass, double *red_base = nullptr, int stride = 0, int c0 = 0) {
     lk_context_t c = Bx->ctx;
     double *base = red_base ? red_base : c->red;
     if (!stride) stride = red_stride(k);
     double *r0 = base, *r1 = base + stride, *r2 = base + 2 * stride;
     if (k <= KMAX_WIDE) {
-        LKCHK((sweepm<1>(Bx, 0, k, y, nullptr, nullptr, 1, r0)));    // h1 = X^H y ; ||y||^2
+        LKCHK((sweepm<1>(Bx, c0, k, y, nullptr, nullptr, 1, r0)));    // h1 = X^H y ; ||y||^2
         if (two_pass && c->recompute_update) {
-            LKCHK((sweepm<2>(Bx, 0, k, y, r0, nullptr, 0, r1)));     // y' = y - X h1 (registers only); h2 = X^H y'; ||y'||^2
-            LKCHK((sweepm<4>(Bx, 0, k, y, r0, r1, 1, r2)));          // y'' = (y - X h1) - X h2 ; ||y''||^2
+            LKCHK((sweepm<2>(Bx, c0, k, y, r0, nullptr, 0, r1)));     // y' = y - X h1 (registers only); h2 = X^H y'; ||y'||^2
+            LKCHK((sweepm<4>(Bx, c0, k, y, r0, r1, 1, r2)));          // y'' = (y - X h1) - X h2 ; ||y''||^2
         } else if (two_pass) {
-            LKCHK((sweepm<2>(Bx, 0, k, y, r0, nullptr, 1, r1)));     // y' = y - X h1 ; h2 = X^H y' ; ||y'||^2
-            LKCHK((sweepm<3>(Bx, 0, k, y, r1, nullptr, 1, r2)));     // y'' = y' - X h2 ; ||y''||^2
+            LKCHK((sweepm<2>(Bx, c0, k, y, r0, nullptr, 1, r1)));     // y' = y - X h1 ; h2 = X^H y' ; ||y'||^2
+            LKCHK((sweepm<3>(Bx, c0, k, y, r1, nullptr, 1, r2)));     // y'' = y' - X h2 ; ||y''||^2
         } else {
-            LKCHK((sweepm<3>(Bx, 0, k, y, r0, nullptr, 1, r1)));     // y' = y - X h1 ; ||y'||^2
+            LKCHK((sweepm<3>(Bx, c0, k, y, r0, nullptr, 1, r1)));     // y' = y - X h1 ; ||y'||^2
         }
         return LK_OK;
     }
@@ -1407,21 +1409,22 @@ int resident_recover(lk_context_t c) {
 // launch; a sharded run needs the all-reduce between them), for k <= 128, and while the panel fits the memory-side cache.
 bool resident_applies(lk_basis_t Bx, int k) {
     lk_context_t c = Bx->ctx;
-    if (!c->resident || c->resident_off || c->nranks > 1 || c->allreduce || k < 1 || k > KMAX_FUSED) return false;
+    if (!c->resident || c->resident_off || c->nranks > 1 || k < 1 || k > KMAX_FUSED) return false;   // (an all-reduce over ONE rank is the identity)
     const double mb = (double)Bx->n * Bx->ed() * 8.0 * (k + 1) / (1024.0 * 1024.0);
     return mb <= (double)c->resident_max_mb;
 }
 
-int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bool normalize, double tol_scale, double tol_break, int *stop_out);
+int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bool normalize, double tol_scale, double tol_break, int *stop_out,
+                        int c0 = 0);
 
 // One Gram-Schmidt step + normalise of an ASYNCHRONOUS batch (lk_arnoldi / lk_lanczos / lk_bidiag): results into the step slot, the
 // normalise skipped below tol_scale, the device stop flag raised below tol_break.  A cache-resident panel takes the single launch
 // (lk_resident.hip.h); a launch that gives up raises the stop flag and leaves status 1 in the slot -- resident_status() below.
-int dgs_step_async(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *slot, int rs, double tol_scale, double tol_break) {
+int dgs_step_async(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *slot, int rs, double tol_scale, double tol_break, int c0 = 0) {
     lk_context_t c = Bx->ctx;
     const int ED = Bx->ed();
-    if (resident_applies(Bx, k)) return dgs_resident_launch(Bx, k, By->col(jy), slot, rs, true, tol_scale, tol_break, c->stop_dev);
-    LKCHK(dgs_device(Bx, k, By->col(jy), true, slot, rs));
+    if (resident_applies(Bx, k)) return dgs_resident_launch(Bx, k, By->col(jy), slot, rs, true, tol_scale, tol_break, c->stop_dev, c0);
+    LKCHK(dgs_device(Bx, k, By->col(jy), true, slot, rs, c0));
     return scal_launch(By, jy, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, tol_scale, c->stop_dev, tol_break);
 }
 // host side of a finished batch: did the step that used `slot` give up (1: redo it on the three-sweep schedule; the context has been
@@ -1443,7 +1446,8 @@ int resident_status(lk_basis_t Bx, int k, const double *slot_host, int rs, int *
 // device-side stop test of scal_launch when `normalize` (tol_scale: no scaling below it; tol_break: raises *stop_out).
 // Kernel choice: dgs_onchip (the panel stays in registers, X read once) when the row tiles of some shape -- 16 / 8 / 4 columns per wave,
 // 2 / 4 / 8 tiles per block -- fit one block per CU; else dgs_resident (three walks served from the caches).
-int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bool normalize, double tol_scale, double tol_break, int *stop_out) {
+int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bool normalize, double tol_scale, double tol_break, int *stop_out,
+                        int c0) {
     lk_context_t c = Bx->ctx;
     ResidentWs ws;
     LKCHK(resident_ws(c, &ws));
@@ -1481,10 +1485,10 @@ int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bo
     ProfScope ps(c, "dgs_sweep_resident", bytes, c->prof_ext);
     auto go = [&](auto kern) {
         if (ps.on && ps.ext)
-            hipExtLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), 0, c->stream, ps.rec.e0, ps.rec.e1, 0, Bx->col(0), Bx->ld, k, y, Bx->n, ws,
+            hipExtLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), 0, c->stream, ps.rec.e0, ps.rec.e1, 0, Bx->col(c0), Bx->ld, k, y, Bx->n, ws,
                                   out, rs, sh.WC, sh.kcw, flags, tol_scale, tol_break, stop_out, spin, c->guard());
         else
-            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), 0, c->stream, Bx->col(0), Bx->ld, k, y, Bx->n, ws, out, rs, sh.WC, sh.kcw,
+            hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(NW * 64), 0, c->stream, Bx->col(c0), Bx->ld, k, y, Bx->n, ws, out, rs, sh.WC, sh.kcw,
                                flags, tol_scale, tol_break, stop_out, spin, c->guard());
     };
     switch (onchip_kc) {
@@ -1608,6 +1612,8 @@ int lk_finalize(lk_context_t c) {
     if (c->step_red_host) (void)hipHostFree(c->step_red_host);
     if (c->res_cnt) (void)hipFree(c->res_cnt);
     if (c->res_tim) (void)hipFree(c->res_tim);
+    if (c->blk_red) (void)hipFree(c->blk_red);
+    if (c->blk_red_host) (void)hipHostFree(c->blk_red_host);
     if (c->res_gran) (void)hipFree(c->res_gran);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2579,90 +2585,108 @@ static int gemm_subtract(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int qn, c
     return gemm_launch(Bx, c0, k, By, jy0, qn, Cdev, ldc, -1.0, 1, c->scratch);
 }
 
-int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h, int *info) {
-    if (!Bx || !By) return fail(LK_ERR_INVALID, "lk_dgs_block: null basis");
-    DevGuard dev_guard(Bx->ctx);
-    if (p < 1 || jy0 < 0 || jy0 + p > By->ncols) return fail(LK_ERR_INVALID, "lk_dgs_block: bad column range");
+// ---- block Gram-Schmidt: the panel x panel schedule, split into "enqueue" and "collect" so that one call (lk_dgs_block) or a whole
+// block Arnoldi batch (lk_arnoldi_block) synchronises ONCE ------------------------------------------------------------------------
+// DGS_basis_against_basis (gram_schmidt.fypp:59-105):  H1 = X^H Y | Y -= X H1 | H2 = X^H Y | Y -= X H2, up to 32 / 4 columns of Y per
+// pass over X.  The coefficient sections of every group land in a device slot (compact: per group, per column panel of X, pass 1
+// then pass 2, pn * (kk + 1) * ED doubles each, slot kk of a column = ||Y_q||^2); `collect` reads a host copy of it.
+static bool dgs_block_fused_ok(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p) {
+    return k >= 1 && k <= KMAX_WIDE && k <= Bx->ncols && p >= 2 && Bx->ctx == By->ctx && Bx->dtype == By->dtype && Bx->n == By->n &&
+           !(Bx->data == By->data && jy0 < k) && (k <= KMAX_FUSED || Bx->ctx->xhy_mfma);
+}
+static bool dgs_block_on_mfma(lk_basis_t Bx, int k, int p) { return Bx->ctx->xhy_mfma && (p >= XHY_MIN_P || k > KMAX_FUSED); }
+static int64_t dgs_block_slot_doubles(lk_basis_t Bx, int k, int p) {
+    const int ED = Bx->ed();
+    if (dgs_block_on_mfma(Bx, k, p)) {
+        const int npan = (k + XHY_MAX - 1) / XHY_MAX;
+        return (int64_t)2 * p * (k + npan) * ED;
+    }
+    return (int64_t)2 * p * (k + 1) * ED;
+}
+
+// mode 0: enqueue the kernels of every group and the device-to-device copies of its coefficient sections into slot_dev
+// mode 1: read a host copy of the slot: h (k x p column-major, may be NULL), *info (last zero column, pass 2: gram_schmidt.fypp:171-173)
+static int dgs_block_walk(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *slot_dev, const double *slot_host, double *h, int *info,
+                          int mode) {
+    lk_context_t c = Bx->ctx;
     const int ED = Bx->ed();
     int inf = 0;
-    if (k >= 1 && k <= KMAX_WIDE && k <= Bx->ncols && p >= 2 && Bx->ctx == By->ctx && Bx->dtype == By->dtype &&
-        Bx->n == By->n && !(Bx->data == By->data && jy0 < k) && (k <= KMAX_FUSED || Bx->ctx->xhy_mfma)) {
-        // panel x panel schedule, up to FOUR columns of Y per pass over X (4 passes per group instead of 4 per column):
-        //   H1 = X^H Y | Y -= X H1 | H2 = X^H Y | Y -= X H2      (DGS_basis_against_basis, gram_schmidt.fypp:59-105)
-        lk_context_t c = Bx->ctx;
-        LKCHK(lazy_enter(c, true));
-        if (c->xhy_mfma && (p >= XHY_MIN_P || k > KMAX_FUSED)) {
-            // many right-hand sides: coefficients AND updates on the matrix cores, THREE passes over X per group of up to 32
-            // columns of Y (H1 = X^H Y | Y' = Y - X H1 with H2 = X^H Y' in the same pass | Y'' = Y' - X H2); "block_fused" = 0
-            // keeps the four-pass schedule (H1 | update | H2 | update).  One copy + synchronisation per group.
-            // A basis WIDER than 128 columns (round 5; block Arnoldi with p = 4 is there after 32 steps, the reference routine is
-            // size-generic) runs the same schedule over column PANELS of X, <= 128 columns each, every panel's coefficients in a
-            // slot of its own on the device:
-            //   A: H1_c = X_c^H Y for every panel c                                            (k columns of X)
-            //   B: Y -= X_c H1_c, panel by panel; the LAST panel's update is the fused one -- it leaves the finished Y' and
-            //      brings H2_last = X_last^H Y' and ||Y'||^2 along                             (k columns)
-            //   C: H2_c = X_c^H Y' for the other panels                                        (k - |last panel| columns)
-            //   D: Y' -= X_c H2_c for every panel                                              (k columns)
-            // = 4k - |last| columns of X per group of up to 32 columns of Y (any p >= 2: below 5 right-hand sides too, where a basis
-            // of <= 128 columns takes the panel_dot_p route) instead of 3k per COLUMN on the single-vector path.
-            const int npan = (k + XHY_MAX - 1) / XHY_MAX, last = npan - 1;
-            auto pc0 = [&](int cp_) { return cp_ * XHY_MAX; };
-            auto pkk = [&](int cp_) { return (k - pc0(cp_)) < XHY_MAX ? (k - pc0(cp_)) : XHY_MAX; };
-            const bool fused = c->block_fused == 2 || (c->block_fused && Bx->dtype == LK_F64);   // complex: the 4-pass schedule is faster (2 = force)
-            std::vector<double> host((size_t)2 * npan * XHY_SLOT);
-            double *o1[XHY_SLOTS / 2] = {nullptr, nullptr, nullptr, nullptr}, *o2[XHY_SLOTS / 2] = {nullptr, nullptr, nullptr, nullptr};
-            for (int j = 0; j < p; j += XHY_GROUP) {
-                const int pn = (p - j) < XHY_GROUP ? (p - j) : XHY_GROUP;
-                for (int cp_ = 0; cp_ < npan; ++cp_)                                                // A: H1 = X^H Y
+    int64_t off = 0;
+    auto put = [&](const double *src, int64_t cnt) -> int {       // (mode 0) section -> slot
+        HIPCHK(hipMemcpyAsync(slot_dev + off, src, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return LK_OK;
+    };
+    if (dgs_block_on_mfma(Bx, k, p)) {
+        // many right-hand sides: coefficients AND updates on the matrix cores, THREE passes over X per group of up to 32 columns of Y
+        // (H1 = X^H Y | Y' = Y - X H1 with H2 = X^H Y' in the same pass | Y'' = Y' - X H2); "block_fused" = 0 keeps four passes.  A basis
+        // wider than 128 columns runs the same schedule over column PANELS of X (<= 128 columns each, coefficients in a slot of their own):
+        //   A: H1_c = X_c^H Y for every panel c | B: Y -= X_c H1_c, the LAST panel's update fused with H2_last = X_last^H Y' and ||Y'||^2 |
+        //   C: H2_c = X_c^H Y' for the other panels | D: Y' -= X_c H2_c for every panel     = 4k - |last| columns of X per group
+        const int npan = (k + XHY_MAX - 1) / XHY_MAX, last = npan - 1;
+        auto pc0 = [&](int cp_) { return cp_ * XHY_MAX; };
+        auto pkk = [&](int cp_) { return (k - pc0(cp_)) < XHY_MAX ? (k - pc0(cp_)) : XHY_MAX; };
+        const bool fused = c->block_fused == 2 || (c->block_fused && Bx->dtype == LK_F64);   // complex: the 4-pass schedule is faster (2 = force)
+        double *o1[XHY_SLOTS / 2] = {nullptr, nullptr, nullptr, nullptr}, *o2[XHY_SLOTS / 2] = {nullptr, nullptr, nullptr, nullptr};
+        for (int j = 0; j < p; j += XHY_GROUP) {
+            const int pn = (p - j) < XHY_GROUP ? (p - j) : XHY_GROUP;
+            if (mode == 0) {
+                for (int cp_ = 0; cp_ < npan; ++cp_)                                                // A
                     LKCHK(dots_mfma(Bx, pc0(cp_), pkk(cp_), By, jy0 + j, pn, 0, cp_, &o1[cp_], cp_ == 0));
-                for (int cp_ = 0; cp_ < last; ++cp_)                                                // B: Y' = Y - X H1 ...
+                for (int cp_ = 0; cp_ < last; ++cp_)                                                // B
                     LKCHK(gemm_subtract(Bx, pkk(cp_), By, jy0 + j, pn, o1[cp_], (int64_t)(pkk(cp_) + 1), pc0(cp_)));
                 if (fused) {
-                    LKCHK(upd_dots_mfma(Bx, pc0(last), pkk(last), By, jy0 + j, pn, o1[last], XHY_SLOTS / 2 + last, &o2[last]));   // ... ; H2_last = X_last^H Y'
+                    LKCHK(upd_dots_mfma(Bx, pc0(last), pkk(last), By, jy0 + j, pn, o1[last], XHY_SLOTS / 2 + last, &o2[last]));
                 } else {
                     LKCHK(gemm_subtract(Bx, pkk(last), By, jy0 + j, pn, o1[last], (int64_t)(pkk(last) + 1), pc0(last)));
                     LKCHK(dots_mfma(Bx, pc0(last), pkk(last), By, jy0 + j, pn, 0, XHY_SLOTS / 2 + last, &o2[last], false));
                 }
-                for (int cp_ = 0; cp_ < last; ++cp_)                                                // C: H2 = X^H Y' (the other panels)
+                for (int cp_ = 0; cp_ < last; ++cp_)                                                // C
                     LKCHK(dots_mfma(Bx, pc0(cp_), pkk(cp_), By, jy0 + j, pn, 0, XHY_SLOTS / 2 + cp_, &o2[cp_], false));
-                for (int cp_ = 0; cp_ < npan; ++cp_)                                                // D: Y'' = Y' - X H2
+                for (int cp_ = 0; cp_ < npan; ++cp_)                                                // D
                     LKCHK(gemm_subtract(Bx, pkk(cp_), By, jy0 + j, pn, o2[cp_], (int64_t)(pkk(cp_) + 1), pc0(cp_)));
-                for (int cp_ = 0; cp_ < npan; ++cp_) {
-                    const size_t cnt = (size_t)pn * (pkk(cp_) + 1) * ED;
-                    HIPCHK(hipMemcpyAsync(host.data() + (size_t)cp_ * XHY_SLOT, o1[cp_], cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-                    HIPCHK(hipMemcpyAsync(host.data() + (size_t)(npan + cp_) * XHY_SLOT, o2[cp_], cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-                }
-                HIPCHK(hipStreamSynchronize(c->stream));
-                if (c->prof) prof_collect(c);
+            }
+            // sections of this group: [panel][pass]
+            std::vector<int64_t> o1off(npan), o2off(npan);
+            for (int cp_ = 0; cp_ < npan; ++cp_) {
+                const int64_t cnt = (int64_t)pn * (pkk(cp_) + 1) * ED;
+                o1off[cp_] = off;
+                if (mode == 0) LKCHK(put(o1[cp_], cnt));
+                off += cnt;
+                o2off[cp_] = off;
+                if (mode == 0) LKCHK(put(o2[cp_], cnt));
+                off += cnt;
+            }
+            if (mode == 1) {
                 for (int q = 0; q < pn; ++q) {
-                    // ||Y_q||^2 rides in slot kk of every panel's column q: before pass 1 from panel 0, of the finished Y' from the
-                    // last panel (whose coefficients were formed last)
+                    // ||Y_q||^2 rides in slot kk of every panel's column q: before pass 1 from panel 0, of the finished Y' from the last panel
                     const int k0 = pkk(0), kl = pkk(last);
-                    const double n1 = std::sqrt(std::fabs(host[((size_t)q * (k0 + 1) + k0) * ED]));
-                    const double n2 = std::sqrt(std::fabs(host[(size_t)(npan + last) * XHY_SLOT + ((size_t)q * (kl + 1) + kl) * ED]));
+                    const double n1 = std::sqrt(std::fabs(slot_host[o1off[0] + ((int64_t)q * (k0 + 1) + k0) * ED]));
+                    const double n2 = std::sqrt(std::fabs(slot_host[o2off[last] + ((int64_t)q * (kl + 1) + kl) * ED]));
                     if (n2 < ATOL_DP) inf = j + q + 1;                              // gram_schmidt.fypp:171-173 (pass 2 overwrites)
                     if (n1 != n1 || n2 != n2) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
                     if (h)
                         for (int cp_ = 0; cp_ < npan; ++cp_) {
                             const int kk = pkk(cp_);
-                            const double *r1 = host.data() + (size_t)cp_ * XHY_SLOT + (size_t)q * (kk + 1) * ED;
-                            const double *r2 = host.data() + (size_t)(npan + cp_) * XHY_SLOT + (size_t)q * (kk + 1) * ED;
+                            const double *r1 = slot_host + o1off[cp_] + (int64_t)q * (kk + 1) * ED;
+                            const double *r2 = slot_host + o2off[cp_] + (int64_t)q * (kk + 1) * ED;
                             double *hq = h + ((size_t)(j + q) * k + pc0(cp_)) * ED;
                             for (int i = 0; i < kk * ED; ++i) hq[i] = r1[i] + r2[i];                                             // :97
                         }
                 }
             }
-            if (info) *info = inf;
-            return LK_OK;
         }
-        for (int j = 0; j < p; j += 4) {
-            const int pn = (p - j) < 4 ? (p - j) : 4;
-            // both passes stay on the device (pass 2 reads the Y that pass 1's update wrote); ONE copy + sync per group
-            double *out1 = c->red, *out2 = c->red + (size_t)RED_MULTI * RED_SECTION;
-            const bool cpx = Bx->dtype == LK_C128;
+        if (info) *info = inf;
+        return LK_OK;
+    }
+    for (int j = 0; j < p; j += 4) {
+        const int pn = (p - j) < 4 ? (p - j) : 4;
+        double *out1 = c->red, *out2 = c->red + (size_t)RED_MULTI * RED_SECTION;
+        const bool cpx = Bx->dtype == LK_C128;
+        const int64_t cnt = (int64_t)pn * (k + 1) * ED;
+        if (mode == 0) {
             if (c->block_fused && (pn <= 2 || (!cpx && k <= 64))) {
-                // THREE passes over X for the group: multi-right-hand-side dots, then the fused update + dot sweep
-                // (Y' stays in registers), then the two-coefficient update that writes Y''
+                // THREE passes over X for the group: multi-right-hand-side dots, then the fused update + dot sweep (Y' stays in registers),
+                // then the two-coefficient update that writes Y''
                 LKCHK(dots_p(Bx, 0, k, By, jy0 + j, pn, out1));
                 if (cpx) LKCHK((block_sweeps<true, 16, 8, 2>(Bx, k, By, jy0 + j, pn, out1, out2)));   // 8 waves x 16 columns (16 x 8 on 1024 threads spilled)
                 else if (pn <= 2) LKCHK((block_sweeps<false, 16, 8, 2>(Bx, k, By, jy0 + j, pn, out1, out2)));
@@ -2674,8 +2698,14 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
                     LKCHK(gemm_subtract(Bx, k, By, jy0 + j, pn, out, (int64_t)(k + 1)));
                 }
             }
-            LKCHK(fetch(c, 0, RED_TOTAL));
-            const double *r1 = c->red_host, *r2 = c->red_host + (size_t)RED_MULTI * RED_SECTION;
+            LKCHK(put(out1, cnt));
+        }
+        const double *r1 = slot_host ? slot_host + off : nullptr;
+        off += cnt;
+        if (mode == 0) LKCHK(put(out2, cnt));
+        const double *r2 = slot_host ? slot_host + off : nullptr;
+        off += cnt;
+        if (mode == 1) {
             for (int q = 0; q < pn; ++q) {
                 const double n1 = std::sqrt(std::fabs(r1[((size_t)q * (k + 1) + k) * ED]));
                 const double n2 = std::sqrt(std::fabs(r2[((size_t)q * (k + 1) + k) * ED]));
@@ -2686,8 +2716,39 @@ int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h,
                         h[((size_t)(j + q) * k) * ED + i] = r1[(size_t)q * (k + 1) * ED + i] + r2[(size_t)q * (k + 1) * ED + i];   // :97
             }
         }
-        if (info) *info = inf;
-        return LK_OK;
+    }
+    if (info) *info = inf;
+    return LK_OK;
+}
+
+static int ensure_block_buffers(lk_context_t c, int64_t doubles) {
+    if (c->blk_cap >= doubles) return LK_OK;
+    if (c->blk_red) HIPCHK(hipFree(c->blk_red));
+    if (c->blk_red_host) HIPCHK(hipHostFree(c->blk_red_host));
+    c->blk_red = nullptr; c->blk_red_host = nullptr; c->blk_cap = 0;
+    HIPCHK(hipMalloc((void **)&c->blk_red, (size_t)doubles * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&c->blk_red_host, (size_t)doubles * sizeof(double), hipHostMallocDefault));
+    c->blk_cap = doubles;
+    return LK_OK;
+}
+
+int lk_dgs_block(lk_basis_t Bx, int k, lk_basis_t By, int jy0, int p, double *h, int *info) {
+    if (!Bx || !By) return fail(LK_ERR_INVALID, "lk_dgs_block: null basis");
+    DevGuard dev_guard(Bx->ctx);
+    if (p < 1 || jy0 < 0 || jy0 + p > By->ncols) return fail(LK_ERR_INVALID, "lk_dgs_block: bad column range");
+    const int ED = Bx->ed();
+    int inf = 0;
+    if (dgs_block_fused_ok(Bx, k, By, jy0, p)) {
+        // panel x panel schedule; ONE copy + synchronisation per call (round 6; one per group of columns before)
+        lk_context_t c = Bx->ctx;
+        LKCHK(lazy_enter(c, true));
+        const int64_t need = dgs_block_slot_doubles(Bx, k, p);
+        LKCHK(ensure_block_buffers(c, need));
+        LKCHK(dgs_block_walk(Bx, k, By, jy0, p, c->blk_red, nullptr, nullptr, nullptr, 0));
+        HIPCHK(hipMemcpyAsync(c->blk_red_host, c->blk_red, (size_t)need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->prof) prof_collect(c);
+        return dgs_block_walk(Bx, k, By, jy0, p, nullptr, c->blk_red_host, h, info, 1);
     }
     for (int j = 0; j < p; ++j) {
         int ij = 0;
@@ -3860,6 +3921,236 @@ static int arnoldi_impl(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int 
         if (stop || stop_requested) break;
         // a stop the reference would NOT have taken (tol below atol_dp with a colinear column): resume after it
         k = done + 1;
+    }
+    return LK_OK;
+}
+
+// ---- qr_no_pivoting and the block Arnoldi factorisation ---------------------------------------------------------------------------
+// a view of columns [c0, c0 + ncols) of a panel (not owned): the basis Q(:j-1) a column of the block is orthogonalised against
+static lk_basis_s basis_view(lk_basis_t B, int c0, int ncols) {
+    lk_basis_s v = *B;
+    v.data = B->col(c0);
+    v.ncols = ncols;
+    v.own = false;
+    v.hwm = ncols;
+    return v;
+}
+
+constexpr uint64_t QR_SEED = 0x5EEDull;       // the colinear-column re-draw of column c of a panel uses the counter stream QR_SEED + c + 1 (lk_arnoldi: + k)
+
+// Columns [jbeg, p) of the block that starts at column c0 of X: qr_no_pivoting's loop body (qr.fypp:129-165), host-synchronous.
+// `have_first`: column jbeg has been orthogonalised and its norm is beta0 (an asynchronous batch stopped right behind it; the device
+// scaled it iff beta0 >= atol_dp).  R: p x p column-major (leading dimension ldr elements), only columns >= jbeg are written.
+static int qr_columns_sync(lk_basis_t X, int c0, int p, int jbeg, bool have_first, double beta0, double *R, int64_t ldr, double tol, bool *flag,
+                           int *info) {
+    lk_context_t c = X->ctx;
+    const int ED = X->ed();
+    std::vector<double> hcol((size_t)(p > 1 ? p : 1) * ED);
+    for (int j = jbeg; j < p; ++j) {
+        double *Rj = R + (size_t)j * ldr * ED;
+        double beta;
+        bool scaled = false;
+        if (have_first && j == jbeg) {
+            beta = beta0;
+            scaled = beta0 >= ATOL_DP;
+        } else {
+            for (int i = 0; i < p * ED; ++i) Rj[i] = 0.0;                                    // R = zero   :125
+            if (j > 0) {
+                lk_basis_s Qv = basis_view(X, c0, j);
+                double norms[3];
+                int dinfo = 0;
+                LKCHK(lk_dgs(&Qv, j, X, c0 + j, hcol.data(), norms, 0, &dinfo));           // :131-134
+                memcpy(Rj, hcol.data(), (size_t)j * ED * sizeof(double));
+                beta = norms[2];                                                           // :135 (the norm of what the step left)
+            } else {
+                LKCHK(lk_vec_norm(X, c0, &beta));
+            }
+        }
+        if (beta != beta) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");           // :137-143
+        if (std::fabs(beta) < tol) {                                                       // colinear column  :146-162
+            if (!*flag) { *flag = true; *info = j + 1; }
+            Rj[(size_t)j * ED] = 0.0;
+            if (ED == 2) Rj[(size_t)j * ED + 1] = 0.0;
+            LKCHK(lk_vec_rand(X, c0 + j, QR_SEED + (uint64_t)(c0 + j) + 1, c->row0, 0));
+            if (j > 0) {
+                lk_basis_s Qv = basis_view(X, c0, j);
+                int dinfo = 0;
+                LKCHK(lk_dgs(&Qv, j, X, c0 + j, nullptr, nullptr, 0, &dinfo));
+            }
+            LKCHK(lk_vec_norm(X, c0 + j, &beta));
+            scaled = false;
+        } else {
+            Rj[(size_t)j * ED] = beta;
+            if (ED == 2) Rj[(size_t)j * ED + 1] = 0.0;
+        }
+        if (!scaled) {
+            const double inv[2] = {1.0 / beta, 0.0};
+            LKCHK(lk_vec_scal(X, c0 + j, inv));                                             // :164
+        }
+    }
+    return LK_OK;
+}
+
+int lk_qr(lk_basis_t Q, int j0, int p, double *R, int64_t ldr, double tol, int *info) {
+    if (!Q || !R || !info) return fail(LK_ERR_INVALID, "lk_qr: null argument");
+    if (p < 1 || j0 < 0 || j0 + p > Q->ncols) return fail(LK_ERR_INVALID, "lk_qr: bad column range");
+    if (ldr < p) return fail(LK_ERR_INVALID, "lk_qr: ldr too small");
+    DevGuard dev_guard(Q->ctx);
+    LKCHK(lazy_enter(Q->ctx, true));
+    *info = 0;
+    bool flag = false;
+    return qr_columns_sync(Q, j0, p, 0, false, 0.0, R, ldr, tol, &flag, info);
+}
+
+// Block Arnoldi steps [k0, k1] enqueued back to back (arnoldi.fypp:34-73 with blksize = p): p operator applications, the panel x panel
+// Gram-Schmidt of the new block against X(:, :kp), and qr_no_pivoting of the block column by column -- column j's single-vector step
+// against the j columns before it (the single launch of lk_resident.hip.h for cache-resident panels), its norm and scale with the device
+// stop flag.  The guard counts (step, column): seq = (k - k0) (p + 1) + 1 for the operator + block part, + 1 + j for column j, so a
+// column below max(tol, atol_dp) -- or a single launch that gave up -- stops everything behind it, the rest of that block included
+// (the host finishes it: qr_columns_sync).  One copy + one synchronisation per batch.
+static int arnoldi_block_batch(lk_linop_t A, lk_basis_t X, int p, int k0, int k1, double tol, int trans, std::vector<int64_t> &blk_off,
+                               int64_t *qr_off) {
+    lk_context_t c = X->ctx;
+    const int ED = X->ed();
+    const int nsteps = k1 - k0 + 1;
+    const int rs = RED_SECTION;                                          // the block's columns see at most p - 1 <= 31 basis columns
+    blk_off.assign(nsteps + 1, 0);
+    for (int s = 0; s < nsteps; ++s) blk_off[s + 1] = blk_off[s] + dgs_block_slot_doubles(X, (k0 + s) * p, p);
+    *qr_off = blk_off[nsteps];
+    const int64_t total = *qr_off + (int64_t)nsteps * p * RED_SECTIONS * rs;
+    LKCHK(ensure_block_buffers(c, total));
+    HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
+    const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
+    c->guard_on = true;
+    c->prof_sweeps_only = true;
+    int rc = LK_OK;
+    for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
+        const int kpm = (k - 1) * p, kp = k * p;
+        const int seq0 = (k - k0) * (p + 1) + 1;
+        c->guard_step = seq0;
+        for (int i = 0; i < p && rc == LK_OK; ++i) rc = lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, kpm + i, X, kp + i);   // :39-47
+        if (rc != LK_OK) break;
+        rc = dgs_block_walk(X, kp, X, kp, p, c->blk_red + blk_off[k - k0], nullptr, nullptr, nullptr, 0);                 // :50-51
+        for (int j = 0; j < p && rc == LK_OK; ++j) {                                                                    // :55
+            c->guard_step = seq0 + 1 + j;
+            double *slot = c->blk_red + *qr_off + ((int64_t)(k - k0) * p + j) * RED_SECTIONS * rs;
+            if (j > 0) {
+                lk_basis_s Qv = basis_view(X, kp, j);
+                rc = dgs_step_async(&Qv, j, X, kp + j, slot, rs, ATOL_DP, tol_break);
+            } else {
+                rc = dot_device(X, kp, X, kp, slot + 2 * rs);
+                if (rc == LK_OK) rc = scal_launch(X, kp, 1.0, 0.0, slot + 2 * rs, ATOL_DP, c->stop_dev, tol_break);
+            }
+        }
+    }
+    c->guard_on = false;
+    c->guard_step = 0;
+    c->prof_sweeps_only = false;
+    LKCHK(rc);
+    HIPCHK(hipMemcpyAsync(c->blk_red_host, c->blk_red, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->stop_host, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->prof) prof_collect(c);
+    (void)ED;
+    return LK_OK;
+}
+
+int lk_arnoldi_block(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int blksize, int kstart, int kend, double tol, int trans, int *info) {
+    if (!A || !X || !H || !info) return fail(LK_ERR_INVALID, "lk_arnoldi_block: null argument");
+    const int p = blksize;
+    if (p < 1) return fail(LK_ERR_INVALID, "lk_arnoldi_block: blksize must be positive");
+    if (p == 1) return lk_arnoldi(A, X, H, ldh, kstart, kend, tol, trans, info);
+    const int kdim = (X->ncols - p) / p;                          // arnoldi.fypp:26
+    if (kdim < 1) return fail(LK_ERR_INVALID, "lk_arnoldi_block: the basis needs at least 2 blocks of %d columns", p);
+    if (kstart < 1 || kend > kdim || kstart > kend + 1) return fail(LK_ERR_INVALID, "lk_arnoldi_block: bad kstart/kend %d..%d (kdim %d)", kstart, kend, kdim);
+    if (ldh < (int64_t)(kdim + 1) * p) return fail(LK_ERR_INVALID, "lk_arnoldi_block: ldh too small");
+    lk_context_t c = X->ctx;
+    DevGuard dev_guard(c);
+    const int ED = X->ed();
+    *info = 0;
+    LKCHK(lazy_enter(c, true));
+    auto Hat = [&](int i, int j) { return H + ((size_t)j * ldh + i) * ED; };
+    // one step on the host-synchronous schedule (wide bases, "async_arnoldi" = 0): the entries of the ABI, one round trip each
+    auto step_sync = [&](int k, int *stop) -> int {
+        const int kpm = (k - 1) * p, kp = k * p;
+        for (int i = 0; i < p; ++i) LKCHK(lk_linop_apply(A, trans ? LK_OP_H : LK_OP_N, X, kpm + i, X, kp + i));
+        std::vector<double> hb((size_t)kp * p * ED), R((size_t)p * p * ED, 0.0);
+        int dinfo = 0;
+        lk_basis_s Yv = basis_view(X, kp, p);
+        LKCHK(lk_dgs_block(X, kp, &Yv, 0, p, hb.data(), &dinfo));
+        for (int q = 0; q < p; ++q) memcpy(Hat(0, kpm + q), hb.data() + (size_t)q * kp * ED, (size_t)kp * ED * sizeof(double));
+        int qinfo = 0;
+        bool flag = false;
+        LKCHK(qr_columns_sync(X, kp, p, 0, false, 0.0, R.data(), p, ATOL_DP, &flag, &qinfo));
+        for (int q = 0; q < p; ++q) memcpy(Hat(kp, kpm + q), R.data() + (size_t)q * p * ED, (size_t)p * ED * sizeof(double));
+        double mn = HUGE_VAL;
+        for (int i = 0; i < p; ++i) mn = std::fmin(mn, std::fabs(Hat(kp + i, kpm + i)[0]));                            // :58-62 (real part)
+        *stop = mn < tol;
+        return LK_OK;
+    };
+    int k = kstart;
+    while (k <= kend) {
+        int stop = 0;
+        const bool wide = (int64_t)(kend + 1) * p > KMAX_WIDE || !dgs_block_fused_ok(X, k * p, X, k * p, p);
+        if (!c->async_arnoldi || wide || k == kend) {
+            LKCHK(step_sync(k, &stop));
+            if (stop) { *info = k * p; break; }                                                                       // :65-71
+            ++k;
+            continue;
+        }
+        std::vector<int64_t> blk_off;
+        int64_t qr_off = 0;
+        const int k0 = k;
+        LKCHK(arnoldi_block_batch(A, X, p, k0, kend, tol, trans, blk_off, &qr_off));
+        const int rs = RED_SECTION;
+        const int stop_seq = *c->stop_host;
+        // (step, column) the batch stopped at: everything in front of it ran
+        const int ks = stop_seq ? k0 + (stop_seq - 1) / (p + 1) : kend + 1;
+        const int js = stop_seq ? (stop_seq - 1) % (p + 1) - 1 : -1;
+        if (stop_seq && js < 0) return fail(LK_ERR_INVALID, "internal: the block Arnoldi batch stopped outside a column");
+        const double *host = c->blk_red_host;
+        bool exit_loop = false;
+        for (int s = k0; s <= (stop_seq ? ks : kend); ++s) {
+            const int kpm = (s - 1) * p, kp = s * p;
+            std::vector<double> hb((size_t)kp * p * ED);
+            int dinfo = 0;
+            LKCHK(dgs_block_walk(X, kp, X, kp, p, nullptr, host + blk_off[s - k0], hb.data(), &dinfo, 1));
+            for (int q = 0; q < p; ++q) memcpy(Hat(0, kpm + q), hb.data() + (size_t)q * kp * ED, (size_t)kp * ED * sizeof(double));
+            const int jlast = (stop_seq && s == ks) ? js : p - 1;           // columns of this block the device finished (jlast: up to its norm)
+            double beta_last = 0.0;
+            bool redo_last = false;
+            for (int j = 0; j <= jlast; ++j) {
+                const double *slot = host + qr_off + ((int64_t)(s - k0) * p + j) * RED_SECTIONS * rs;
+                double *Rj = Hat(kp, kpm + j);
+                for (int i = 0; i < p * ED; ++i) Rj[i] = 0.0;
+                if (j > 0) {
+                    lk_basis_s Qv = basis_view(X, kp, j);
+                    int redo = 0;
+                    LKCHK(resident_status(&Qv, j, slot, rs, &redo));
+                    if (redo) { redo_last = true; break; }                  // (only the column the batch stopped at can have given up)
+                    for (int i = 0; i < j * ED; ++i) Rj[i] = slot[i] + slot[rs + i];                                  // gram_schmidt.fypp:49
+                }
+                const double beta = std::sqrt(std::fabs(slot[2 * rs + (size_t)j * ED]));
+                if (beta != beta) return fail(LK_ERR_NAN, "|beta| = NaN detected! Abort");
+                Rj[(size_t)j * ED] = beta;
+                beta_last = beta;
+            }
+            if (stop_seq && s == ks) {
+                // the host finishes the block behind the stop: the column that raised it (colinear: re-draw; below the caller's tol: already
+                // scaled; a single launch that gave up: from scratch) and the columns after it
+                bool flag = false;
+                int qinfo = 0;
+                std::vector<double> R((size_t)p * p * ED, 0.0);
+                for (int q = 0; q < p; ++q) memcpy(R.data() + (size_t)q * p * ED, Hat(kp, kpm + q), (size_t)p * ED * sizeof(double));
+                LKCHK(qr_columns_sync(X, kp, p, js, !redo_last, beta_last, R.data(), p, ATOL_DP, &flag, &qinfo));
+                for (int q = js; q < p; ++q) memcpy(Hat(kp, kpm + q), R.data() + (size_t)q * p * ED, (size_t)p * ED * sizeof(double));
+            }
+            double mn = HUGE_VAL;
+            for (int i = 0; i < p; ++i) mn = std::fmin(mn, std::fabs(Hat(kp + i, kpm + i)[0]));                        // :58-62
+            if (mn < tol) { *info = kp; exit_loop = true; break; }                                                    // :65-71
+        }
+        if (exit_loop) break;
+        k = stop_seq ? ks + 1 : kend + 1;                                   // (a stop the reference would not have taken: on with the next step)
     }
     return LK_OK;
 }

@@ -718,8 +718,9 @@ __global__ __launch_bounds__(NW * 64) void panel_sweep_p(const double *__restric
                                                           double *__restrict__ Y, int64_t ldy, int pn, int64_t n,
                                                           const double *__restrict__ hin, const double *__restrict__ hin2,
                                                           int kslots, double *__restrict__ partial, int64_t pstride, int WC,
-                                                          int kcw, int store) {
+                                                          int kcw, int store, Guard guard) {
     static_assert(!(DOT && TWO), "pass B carries the dots, pass C the second coefficient set");
+    if (stopped(guard)) return;
     constexpr int ROWS = K<CPLX>::ROWS;
     constexpr int ED = K<CPLX>::ELEM_DOUBLES;
     constexpr int WROWS = 64 * ROWS;
@@ -953,7 +954,8 @@ template <bool CPLX, int KC, int QB>
 __global__ __launch_bounds__(256) void panel_gemm(const double *__restrict__ X, int64_t ldx, int k,
                                                   double *__restrict__ Y, int64_t ldy, int qn,
                                                   const double *__restrict__ Cp, int64_t n, int accumulate, int QGB,
-                                                  int policy) {
+                                                  int policy, Guard guard) {
+    if (stopped(guard)) return;
     // QB = accumulators per lane = output columns per wave: 16 for wide products; 1 / 2 / 4 / 8 for narrow ones, where the
     // kernel is a pure stream over X (q = 1: the GMRES solution update, gmres.fypp:201, and every X * v) -- with QB = 16 a
     // single output column paid 16x the FMAs and ran VALU-limited at 4.9 TB/s.
@@ -1025,7 +1027,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 template <bool CPLX, int NG, bool PFY = false, bool ROLL = false>
 __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                        double *__restrict__ Y, int64_t ldy, int qn,
-                                                       const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
+                                                       const double *__restrict__ Cp, int64_t n, int accumulate, int policy, Guard guard) {
+    if (stopped(guard)) return;
     constexpr int QB = CPLX ? 8 : 16;            // output columns per group
     constexpr int RG = CPLX ? 16 : 32;           // rows per row group (one MFMA N extent; x2 rows per lane for real)
     constexpr int NACC = CPLX ? 1 : 2;
@@ -1318,7 +1321,8 @@ __global__ __launch_bounds__(512) void panel_gemm_mfma(const double *__restrict_
 template <int NG, int NR, bool ROLL = false>  // NR: row groups of 16 rows per wave (2; 1 for 64 outputs, whose 12 accumulators of 8 registers leave no room for 24)
 __global__ __launch_bounds__(512) void panel_gemm_mfma3m(const double *__restrict__ X, int64_t ldx, int k,
                                                          double *__restrict__ Y, int64_t ldy, int qn,
-                                                         const double *__restrict__ Cp, int64_t n, int accumulate, int policy) {
+                                                         const double *__restrict__ Cp, int64_t n, int accumulate, int policy, Guard guard) {
+    if (stopped(guard)) return;
     constexpr int QB = 16;                       // complex output columns per group
     constexpr int RG = 16;                       // rows per row group (the MFMA's N extent)
     constexpr int U = 8 / NR;                    // k-steps of X in flight per wave: NR U = 8 loads of 16 B per lane
@@ -2320,7 +2324,8 @@ template <bool CPLX>
 __global__ __launch_bounds__(256, CPLX ? 1 : 2) void panel_xhy_upd_mfma(const double *__restrict__ X, int64_t ldx, int k,
                                                           double *__restrict__ Y, int64_t ldy, int p, int64_t n,
                                                           const double *__restrict__ H1, double *__restrict__ partial,
-                                                          double *__restrict__ npartial, int policy) {
+                                                          double *__restrict__ npartial, int policy, Guard guard) {
+    if (stopped(guard)) return;
     constexpr int ER = CPLX ? 2 : 1;
     constexpr int NT = 256;                                                   // threads per block
     constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = NT / CH;   // 16 columns staged per block-wide pass

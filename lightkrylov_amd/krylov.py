@@ -120,10 +120,24 @@ def double_gram_schmidt_step(y, X, if_chk_orthonormal: bool = True, beta: np.nda
     return info
 
 
+def _panel_columns(Q):
+    """Q -> (panel, first column, count) when Q is (a view of) ONE device panel, else None"""
+    if isinstance(Q, krylov_basis_gpu):
+        return Q, 0, len(Q)
+    return None
+
+
 # ------------------------------------------------------------------------------------------
 def qr(Q, R: np.ndarray, tol: float = atol_dp) -> int:
     """qr_no_pivoting: in-place DGS-based QR of the basis Q, R upper triangular.
     src/Krylov/qr.fypp:116-167.  Returns info (index of the first colinear column, 1-based)."""
+    # columns of ONE device panel: the whole factorisation inside the engine (lk_qr)
+    cols = _panel_columns(Q)
+    if cols is not None and R.flags.f_contiguous and R.dtype == cols[0].dtype and R.shape[0] >= len(Q):
+        B, j0, p = cols
+        cinfo = C.c_int()
+        _capi.check(B._lib.lk_qr(B._h, j0, p, R.ctypes.data_as(_DP), R.shape[0], float(tol), C.byref(cinfo)))
+        return cinfo.value
     info, flag = 0, False
     R[...] = 0
     for j in range(len(Q)):
@@ -199,6 +213,20 @@ def arnoldi(A: abstract_linop, X, H: np.ndarray, kstart: int = 1, kend: int | No
             A.rmatvec_counter += max(n_steps, 0)
         else:
             A.matvec_counter += max(n_steps, 0)
+        return cinfo.value
+
+    # block factorisation inside the engine: p operator applications, the panel x panel Gram-Schmidt and the p-column qr of every step
+    # enqueued asynchronously, one host synchronisation per call (lk_arnoldi_block)
+    if (p > 1 and isinstance(X, krylov_basis_gpu) and isinstance(A, _engine_linop) and _progress is None
+            and H.flags.f_contiguous and H.dtype == X.dtype and H.shape[0] >= (kdim + 1) * p):
+        cinfo = C.c_int()
+        _capi.check(X._lib.lk_arnoldi_block(A._h, X._h, H.ctypes.data_as(_DP), H.shape[0], p, int(kstart), int(kend), float(tol),
+                                            1 if transpose else 0, C.byref(cinfo)))
+        n_steps = (cinfo.value // p if cinfo.value else kend) - kstart + 1
+        if transpose:
+            A.rmatvec_counter += max(n_steps, 0) * p
+        else:
+            A.matvec_counter += max(n_steps, 0) * p
         return cinfo.value
 
     gpu = isinstance(X, krylov_basis_gpu)
