@@ -58,6 +58,8 @@ module lightkrylov_gpu
     public :: lk_gpu_init, lk_gpu_finalize, lk_gpu_release_all, lk_gpu_context, lk_gpu_pool_stats
     public :: lk_gpu_set_partition, lk_gpu_comm_unique_id, lk_gpu_comm_init
     public :: gpu_arnoldi_rdp, gpu_arnoldi_cdp
+    public :: gpu_arnoldi_segments_rdp, gpu_arnoldi_segments_cdp, lk_gpu_progress
+    public :: gpu_lanczos_rdp, gpu_lanczos_cdp, gpu_bidiag_rdp, gpu_bidiag_cdp, gpu_qr_rdp, gpu_qr_cdp
 
     type(c_ptr), save :: ctx = c_null_ptr
     integer(c_int64_t), save :: part_row0 = 0          ! first global row of this rank's block (lk_gpu_set_partition)
@@ -157,6 +159,17 @@ module lightkrylov_gpu
     !> a sparse operator in CSR with Fortran's 1-based `rowptr(n+1)` / `colind(nnz)`; matvec and rmatvec on the device
     interface csr_linop_gpu
         module procedure csr_linop_gpu_from_rdp, csr_linop_gpu_from_cdp
+    end interface
+
+    !> progress function of gpu_arnoldi_segments_*: called with the first and last step whose columns of H have just become final;
+    !> a non-zero return value asks the engine to stop (at most 24 further steps have been enqueued)
+    abstract interface
+        function lk_gpu_progress(user, kfirst, klast) bind(C) result(stop)
+            import :: c_ptr, c_int
+            type(c_ptr), value :: user
+            integer(c_int), value :: kfirst, klast
+            integer(c_int) :: stop
+        end function
     end interface
 
 contains
@@ -755,39 +768,200 @@ contains
         end if
     end function
 
-    ! ---- fused path from Fortran: the whole Arnoldi step loop inside the engine ----------------
-    !> Same contract as LightKrylov's `arnoldi` (src/Krylov/arnoldi.fypp:8-76) for an engine operator
-    !> and a panel basis: X is an engine basis handle with kdim+1 columns, H the host Hessenberg array.
-    subroutine gpu_arnoldi_rdp(op, X, H, info, kstart, kend, tol)
+    ! ---- fused paths from Fortran: the whole step loop of a factorisation inside the engine ----------------
+    ! X, U, V are engine basis handles (lk_basis_create), op an engine operator handle; H, T, B, R the caller's host arrays.
+    ! A complex(dp) Fortran array IS the engine's layout (interleaved doubles): passed through c_f_pointer, no copy.
+    !> Same contract as LightKrylov's `arnoldi` (src/Krylov/arnoldi.fypp:8-76): X holds (kdim+1)*blksize columns, H is
+    !> ((kdim+1)*blksize x kdim*blksize); blksize > 1 runs the block factorisation (lk_arnoldi_block).
+    subroutine gpu_arnoldi_rdp(op, X, H, info, kstart, kend, tol, transpose, blksize)
         type(c_ptr), intent(in) :: op, X
         real(dp), intent(inout) :: H(:, :)
         integer, intent(out) :: info
-        integer, optional, intent(in) :: kstart, kend
+        integer, optional, intent(in) :: kstart, kend, blksize
         real(dp), optional, intent(in) :: tol
-        integer(c_int) :: k0, k1, cinfo
+        logical, optional, intent(in) :: transpose
+        integer(c_int) :: k0, k1, cinfo, p, tr
         real(c_double) :: t
+        p = 1; if (present(blksize)) p = blksize
         k0 = 1; if (present(kstart)) k0 = kstart
-        k1 = size(H, 2); if (present(kend)) k1 = kend
+        k1 = size(H, 2)/p; if (present(kend)) k1 = kend
         t = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) t = tol      ! atol_dp, Constants.f90:35
-        call chk(lk_arnoldi(op, X, H, int(size(H, 1), c_int64_t), k0, k1, t, 0_c_int, cinfo), 'gpu_arnoldi_rdp')
+        tr = 0; if (present(transpose)) tr = merge(1, 0, transpose)
+        call chk(lk_arnoldi_block(op, X, H, int(size(H, 1), c_int64_t), p, k0, k1, t, tr, cinfo), 'gpu_arnoldi_rdp')
         info = cinfo
     end subroutine
 
-    !> complex(dp) kind of the same call: H is the host Hessenberg array, passed to the engine as interleaved doubles.
-    subroutine gpu_arnoldi_cdp(op, X, H, info, kstart, kend, tol)
+    subroutine gpu_arnoldi_cdp(op, X, H, info, kstart, kend, tol, transpose, blksize)
         type(c_ptr), intent(in) :: op, X
         complex(dp), intent(inout), target, contiguous :: H(:, :)
+        integer, intent(out) :: info
+        integer, optional, intent(in) :: kstart, kend, blksize
+        real(dp), optional, intent(in) :: tol
+        logical, optional, intent(in) :: transpose
+        integer(c_int) :: k0, k1, cinfo, p, tr
+        real(c_double) :: t
+        real(c_double), pointer :: Hr(:)
+        p = 1; if (present(blksize)) p = blksize
+        k0 = 1; if (present(kstart)) k0 = kstart
+        k1 = size(H, 2)/p; if (present(kend)) k1 = kend
+        t = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) t = tol
+        tr = 0; if (present(transpose)) tr = merge(1, 0, transpose)
+        call c_f_pointer(c_loc(H), Hr, [2*size(H)])
+        call chk(lk_arnoldi_block(op, X, Hr, int(size(H, 1), c_int64_t), p, k0, k1, t, tr, cinfo), 'gpu_arnoldi_cdp')
+        info = cinfo
+    end subroutine
+
+    !> arnoldi (blksize = 1) delivered in SEGMENTS while the device runs on: on_columns(user, kfirst, klast) -- a bind(C) function of
+    !> the interface lk_gpu_progress, non-zero return = stop -- is called as soon as columns kfirst..klast of H are final;
+    !> seg_last = last step of each segment, ascending.  What eigs' per-step Ritz test needs (IterativeSolvers.fypp:1059-1093).
+    subroutine gpu_arnoldi_segments_rdp(op, X, H, info, seg_last, on_columns, user, kstart, kend, tol, transpose)
+        type(c_ptr), intent(in) :: op, X
+        real(dp), intent(inout) :: H(:, :)
+        integer, intent(out) :: info
+        integer, intent(in) :: seg_last(:)
+        procedure(lk_gpu_progress) :: on_columns
+        type(c_ptr), optional, intent(in) :: user
+        integer, optional, intent(in) :: kstart, kend
+        real(dp), optional, intent(in) :: tol
+        logical, optional, intent(in) :: transpose
+        integer(c_int) :: k0, k1, cinfo, tr
+        integer(c_int), allocatable :: segs(:)
+        real(c_double) :: t
+        type(c_ptr) :: u
+        k0 = 1; if (present(kstart)) k0 = kstart
+        k1 = size(H, 2); if (present(kend)) k1 = kend
+        t = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) t = tol
+        tr = 0; if (present(transpose)) tr = merge(1, 0, transpose)
+        u = c_null_ptr; if (present(user)) u = user
+        allocate(segs(max(size(seg_last), 1))); segs = 0; segs(:size(seg_last)) = int(seg_last, c_int)
+        call chk(lk_arnoldi_segments(op, X, H, int(size(H, 1), c_int64_t), k0, k1, t, tr, segs, int(size(seg_last), c_int), &
+                                     c_funloc(on_columns), u, cinfo), 'gpu_arnoldi_segments_rdp')
+        info = cinfo
+    end subroutine
+
+    subroutine gpu_arnoldi_segments_cdp(op, X, H, info, seg_last, on_columns, user, kstart, kend, tol, transpose)
+        type(c_ptr), intent(in) :: op, X
+        complex(dp), intent(inout), target, contiguous :: H(:, :)
+        integer, intent(out) :: info
+        integer, intent(in) :: seg_last(:)
+        procedure(lk_gpu_progress) :: on_columns
+        type(c_ptr), optional, intent(in) :: user
+        integer, optional, intent(in) :: kstart, kend
+        real(dp), optional, intent(in) :: tol
+        logical, optional, intent(in) :: transpose
+        integer(c_int) :: k0, k1, cinfo, tr
+        integer(c_int), allocatable :: segs(:)
+        real(c_double) :: t
+        real(c_double), pointer :: Hr(:)
+        type(c_ptr) :: u
+        k0 = 1; if (present(kstart)) k0 = kstart
+        k1 = size(H, 2); if (present(kend)) k1 = kend
+        t = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) t = tol
+        tr = 0; if (present(transpose)) tr = merge(1, 0, transpose)
+        u = c_null_ptr; if (present(user)) u = user
+        allocate(segs(max(size(seg_last), 1))); segs = 0; segs(:size(seg_last)) = int(seg_last, c_int)
+        call c_f_pointer(c_loc(H), Hr, [2*size(H)])
+        call chk(lk_arnoldi_segments(op, X, Hr, int(size(H, 1), c_int64_t), k0, k1, t, tr, segs, int(size(seg_last), c_int), &
+                                     c_funloc(on_columns), u, cinfo), 'gpu_arnoldi_segments_cdp')
+        info = cinfo
+    end subroutine
+
+    !> lanczos_tridiagonalization (src/Krylov/lanczos.fypp:7-64) for a symmetric / Hermitian engine operator: X holds kdim+1 columns,
+    !> T is (kdim+1 x kdim); every step of the call enqueued asynchronously, one host synchronisation (lk_lanczos).
+    subroutine gpu_lanczos_rdp(op, X, T, info, kstart, kend, tol)
+        type(c_ptr), intent(in) :: op, X
+        real(dp), intent(inout) :: T(:, :)
         integer, intent(out) :: info
         integer, optional, intent(in) :: kstart, kend
         real(dp), optional, intent(in) :: tol
         integer(c_int) :: k0, k1, cinfo
-        real(c_double) :: t
-        real(c_double), pointer :: Hr(:)
+        real(c_double) :: tl
         k0 = 1; if (present(kstart)) k0 = kstart
-        k1 = size(H, 2); if (present(kend)) k1 = kend
-        t = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) t = tol
-        call c_f_pointer(c_loc(H), Hr, [2*size(H)])
-        call chk(lk_arnoldi(op, X, Hr, int(size(H, 1), c_int64_t), k0, k1, t, 0_c_int, cinfo), 'gpu_arnoldi_cdp')
+        k1 = size(T, 2); if (present(kend)) k1 = kend
+        tl = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) tl = tol
+        call chk(lk_lanczos(op, X, T, int(size(T, 1), c_int64_t), k0, k1, tl, cinfo), 'gpu_lanczos_rdp')
+        info = cinfo
+    end subroutine
+
+    subroutine gpu_lanczos_cdp(op, X, T, info, kstart, kend, tol)
+        type(c_ptr), intent(in) :: op, X
+        complex(dp), intent(inout), target, contiguous :: T(:, :)
+        integer, intent(out) :: info
+        integer, optional, intent(in) :: kstart, kend
+        real(dp), optional, intent(in) :: tol
+        integer(c_int) :: k0, k1, cinfo
+        real(c_double) :: tl
+        real(c_double), pointer :: Tr(:)
+        k0 = 1; if (present(kstart)) k0 = kstart
+        k1 = size(T, 2); if (present(kend)) k1 = kend
+        tl = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) tl = tol
+        call c_f_pointer(c_loc(T), Tr, [2*size(T)])
+        call chk(lk_lanczos(op, X, Tr, int(size(T, 1), c_int64_t), k0, k1, tl, cinfo), 'gpu_lanczos_cdp')
+        info = cinfo
+    end subroutine
+
+    !> lanczos_bidiagonalization (src/Krylov/golub_kahan.fypp:7-64): U holds kdim+1 columns, V kdim (two different bases), B is
+    !> (kdim+1 x kdim); both halves of every step enqueued asynchronously (lk_bidiag).
+    subroutine gpu_bidiag_rdp(op, U, V, B, info, kstart, kend, tol)
+        type(c_ptr), intent(in) :: op, U, V
+        real(dp), intent(inout) :: B(:, :)
+        integer, intent(out) :: info
+        integer, optional, intent(in) :: kstart, kend
+        real(dp), optional, intent(in) :: tol
+        integer(c_int) :: k0, k1, cinfo
+        real(c_double) :: tl
+        k0 = 1; if (present(kstart)) k0 = kstart
+        k1 = size(B, 2); if (present(kend)) k1 = kend
+        tl = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) tl = tol
+        call chk(lk_bidiag(op, U, V, B, int(size(B, 1), c_int64_t), k0, k1, tl, cinfo), 'gpu_bidiag_rdp')
+        info = cinfo
+    end subroutine
+
+    subroutine gpu_bidiag_cdp(op, U, V, B, info, kstart, kend, tol)
+        type(c_ptr), intent(in) :: op, U, V
+        complex(dp), intent(inout), target, contiguous :: B(:, :)
+        integer, intent(out) :: info
+        integer, optional, intent(in) :: kstart, kend
+        real(dp), optional, intent(in) :: tol
+        integer(c_int) :: k0, k1, cinfo
+        real(c_double) :: tl
+        real(c_double), pointer :: Br(:)
+        k0 = 1; if (present(kstart)) k0 = kstart
+        k1 = size(B, 2); if (present(kend)) k1 = kend
+        tl = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) tl = tol
+        call c_f_pointer(c_loc(B), Br, [2*size(B)])
+        call chk(lk_bidiag(op, U, V, Br, int(size(B, 1), c_int64_t), k0, k1, tl, cinfo), 'gpu_bidiag_cdp')
+        info = cinfo
+    end subroutine
+
+    !> qr_no_pivoting (src/Krylov/qr.fypp:116-167) of columns j0+1 .. j0+size(R, 2) of the panel Q (j0 defaults to 0); R is p x p.
+    subroutine gpu_qr_rdp(Q, R, info, tol, j0)
+        type(c_ptr), intent(in) :: Q
+        real(dp), intent(inout) :: R(:, :)
+        integer, intent(out) :: info
+        real(dp), optional, intent(in) :: tol
+        integer, optional, intent(in) :: j0
+        integer(c_int) :: cinfo, c0
+        real(c_double) :: tl
+        c0 = 0; if (present(j0)) c0 = j0
+        tl = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) tl = tol
+        call chk(lk_qr(Q, c0, int(size(R, 2), c_int), R, int(size(R, 1), c_int64_t), tl, cinfo), 'gpu_qr_rdp')
+        info = cinfo
+    end subroutine
+
+    subroutine gpu_qr_cdp(Q, R, info, tol, j0)
+        type(c_ptr), intent(in) :: Q
+        complex(dp), intent(inout), target, contiguous :: R(:, :)
+        integer, intent(out) :: info
+        real(dp), optional, intent(in) :: tol
+        integer, optional, intent(in) :: j0
+        integer(c_int) :: cinfo, c0
+        real(c_double) :: tl
+        real(c_double), pointer :: Rr(:)
+        c0 = 0; if (present(j0)) c0 = j0
+        tl = 10.0_dp**(-precision(1.0_dp)); if (present(tol)) tl = tol
+        call c_f_pointer(c_loc(R), Rr, [2*size(R)])
+        call chk(lk_qr(Q, c0, int(size(R, 2), c_int), Rr, int(size(R, 1), c_int64_t), tl, cinfo), 'gpu_qr_cdp')
         info = cinfo
     end subroutine
 end module lightkrylov_gpu

@@ -148,6 +148,64 @@ program test_iso_c
     rc = lk_linop_destroy(Az)
     rc = lk_basis_destroy(Xz)
 
+    ! ---- the other fused factorisations through the same binding (round 6): lk_lanczos, lk_bidiag, lk_arnoldi_block -- every entry the
+    !      python test compares with the oracle is printed as `<name>_<i>_<j> value`
+    block
+        type(c_ptr) :: XL, UB, VB, XK
+        real(c_double) :: T(m + 1, m), Bd(m + 1, m)
+        real(c_double), target :: x2(n, 2)
+        real(c_double) :: HB(2*(m/2 + 1), 2*(m/2))
+        integer(c_int) :: li
+        rc = lk_basis_create(ctx, LK_F64, int(n, c_int64_t), int(m + 1, c_int), XL); call chk(rc, 'lk_basis_create(XL)')
+        rc = lk_basis_upload(XL, 0_c_int, 1_c_int, c_loc(x0), int(n, c_int64_t)); call chk(rc, 'lk_basis_upload(XL)')
+        T = 0.0d0
+        rc = lk_lanczos(A, XL, T, int(m + 1, c_int64_t), 1_c_int, int(m, c_int), 1.0d-15, li); call chk(rc, 'lk_lanczos')
+        print '(A,I0)', 'lz_info ', li
+        do j = 1, m
+            do i = 1, m + 1
+                print '(A,I0,A,I0,ES25.16E3)', 'lz_T_', i, '_', j, T(i, j)
+            end do
+        end do
+        rc = lk_basis_destroy(XL)
+        rc = lk_basis_create(ctx, LK_F64, int(n, c_int64_t), int(m + 1, c_int), UB); call chk(rc, 'lk_basis_create(UB)')
+        rc = lk_basis_create(ctx, LK_F64, int(n, c_int64_t), int(m, c_int), VB); call chk(rc, 'lk_basis_create(VB)')
+        rc = lk_basis_upload(UB, 0_c_int, 1_c_int, c_loc(x0), int(n, c_int64_t)); call chk(rc, 'lk_basis_upload(UB)')
+        Bd = 0.0d0
+        rc = lk_bidiag(A, UB, VB, Bd, int(m + 1, c_int64_t), 1_c_int, int(m, c_int), 1.0d-15, li); call chk(rc, 'lk_bidiag')
+        print '(A,I0)', 'bd_info ', li
+        do j = 1, m
+            do i = 1, m + 1
+                print '(A,I0,A,I0,ES25.16E3)', 'bd_B_', i, '_', j, Bd(i, j)
+            end do
+        end do
+        rc = lk_basis_destroy(UB); rc = lk_basis_destroy(VB)
+        ! block Arnoldi, blksize = 2: starting block = [x0, cos(i)] orthonormalised by lk_qr on the device
+        do i = 1, n
+            x2(i, 1) = x0(i)
+            x2(i, 2) = cos(real(i, c_double))
+        end do
+        rc = lk_basis_create(ctx, LK_F64, int(n, c_int64_t), int(2*(m/2 + 1), c_int), XK); call chk(rc, 'lk_basis_create(XK)')
+        rc = lk_basis_upload(XK, 0_c_int, 2_c_int, c_loc(x2), int(n, c_int64_t)); call chk(rc, 'lk_basis_upload(XK)')
+        block
+            real(c_double) :: R2(2, 2)
+            rc = lk_qr(XK, 0_c_int, 2_c_int, R2, 2_c_int64_t, 1.0d-15, li); call chk(rc, 'lk_qr')
+            print '(A,I0)', 'qr_info ', li
+            print '(A,ES25.16E3)', 'qr_R11 ', R2(1, 1)
+            print '(A,ES25.16E3)', 'qr_R12 ', R2(1, 2)
+            print '(A,ES25.16E3)', 'qr_R22 ', R2(2, 2)
+        end block
+        HB = 0.0d0
+        rc = lk_arnoldi_block(A, XK, HB, int(size(HB, 1), c_int64_t), 2_c_int, 1_c_int, int(m/2, c_int), 1.0d-15, 0_c_int, li)
+        call chk(rc, 'lk_arnoldi_block')
+        print '(A,I0)', 'bk_info ', li
+        do j = 1, size(HB, 2)
+            do i = 1, size(HB, 1)
+                print '(A,I0,A,I0,ES25.16E3)', 'bk_H_', i, '_', j, HB(i, j)
+            end do
+        end do
+        rc = lk_basis_destroy(XK)
+    end block
+
     ! ---- column pool, driven the way the LightKrylov plugin drives it (fortran/dense_vector_gpu.f90): V(1..m+1)
     !      acquired in order land in consecutive columns of ONE slab; 200 emulated Gram-Schmidt passes, each of which
     !      "allocates" its two temporaries (linear_combination's y, AbstractVectors.fypp:595-598) at two recurring

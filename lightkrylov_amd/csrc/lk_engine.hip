@@ -4022,7 +4022,6 @@ static int arnoldi_block_batch(lk_linop_t A, lk_basis_t X, int p, int k0, int k1
     HIPCHK(hipMemsetAsync(c->stop_dev, 0, sizeof(int), c->stream));
     const double tol_break = tol > ATOL_DP ? tol : ATOL_DP;
     c->guard_on = true;
-    c->prof_sweeps_only = true;
     int rc = LK_OK;
     for (int k = k0; k <= k1 && rc == LK_OK; ++k) {
         const int kpm = (k - 1) * p, kp = k * p;
@@ -4045,7 +4044,6 @@ static int arnoldi_block_batch(lk_linop_t A, lk_basis_t X, int p, int k0, int k1
     }
     c->guard_on = false;
     c->guard_step = 0;
-    c->prof_sweeps_only = false;
     LKCHK(rc);
     HIPCHK(hipMemcpyAsync(c->blk_red_host, c->blk_red, (size_t)total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->stop_host, c->stop_dev, sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -32,6 +32,8 @@ def test_fortran_host_program_runs_arnoldi_on_the_gpu():
     out = subprocess.run([EXE], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     vals = {ln.split()[0]: float(ln.split()[1]) for ln in out.stdout.splitlines() if len(ln.split()) == 2}
+    from oracle import oracle as ora
+    n, m = 1000, 8
     z = np.load(os.path.join(ROOT, "tests", "golden", "survey_reference_run_n1000_m8.npz"))
     assert vals["info"] == 0
     for key, ref in (("H11", float(z["H11"])), ("H21", float(z["H21"])), ("Hlast", float(z["Hlast"]))):
@@ -60,6 +62,41 @@ def test_fortran_host_program_runs_arnoldi_on_the_gpu():
     assert abs(got11 - Ho[0, 0]) <= 1e-12 * abs(Ho[0, 0])           # libm sin/cos of the two hosts may differ by an ulp
     assert abs(got12 - Ho[0, 1]) <= 1e-12 * np.abs(Ho[:, 1]).max()
     assert abs(vals["z_Hlast"] - Ho[m, m - 1].real) <= 1e-12 * abs(Ho[m, m - 1])
+    # round 6: lk_lanczos, lk_bidiag, lk_qr and lk_arnoldi_block from the Fortran host, every entry against the oracle at 1e-12 (normwise per column)
+    i = np.arange(1, n + 1, dtype=np.float64)
+    dr = 1.0 + (i - 1) / n
+    xr = np.sin(i)
+    xr /= np.sqrt(np.sum(xr ** 2))
+    def entries(prefix, rows, cols):
+        M = np.zeros((rows, cols))
+        for a in range(rows):
+            for b in range(cols):
+                M[a, b] = vals[f"{prefix}_{a + 1}_{b + 1}"]
+        return M
+    Xo = np.zeros((n, m + 1), order="F"); Xo[:, 0] = xr
+    To = np.zeros((m + 1, m), order="F")
+    assert ora.lanczos(ora.DiagOp(dr), Xo, To) == 0 and vals["lz_info"] == 0
+    T = entries("lz_T", m + 1, m)
+    Uo = np.zeros((n, m + 1), order="F"); Uo[:, 0] = xr
+    Vo = np.zeros((n, m + 1), order="F")
+    Bo = np.zeros((m + 1, m), order="F")
+    assert ora.bidiagonalization(ora.DiagOp(dr), ora.DiagOp(dr), Uo, Vo, Bo) == 0 and vals["bd_info"] == 0
+    B = entries("bd_B", m + 1, m)
+    for j in range(m):
+        assert np.abs(T[:, j] - To[:, j]).max() <= 1e-12 * np.abs(To[:, j]).max(), ("lanczos", j)
+        assert np.abs(B[:, j] - Bo[:, j]).max() <= 1e-12 * np.abs(Bo[:, j]).max(), ("bidiag", j)
+    p, kd = 2, m // 2
+    Y = np.asfortranarray(np.stack([xr, np.cos(i)], axis=1))
+    Ro = np.zeros((p, p), order="F")
+    assert ora.qr_no_pivoting(Y, Ro) == 0 and vals["qr_info"] == 0
+    for key, ref in (("qr_R11", Ro[0, 0]), ("qr_R12", Ro[0, 1]), ("qr_R22", Ro[1, 1])):
+        assert abs(vals[key] - ref) <= 1e-12 * np.abs(Ro).max(), key
+    Xb = np.zeros((n, p * (kd + 1)), order="F"); Xb[:, :p] = Y
+    Hbo = np.zeros((p * (kd + 1), p * kd), order="F")
+    assert ora.arnoldi_block(ora.DiagOp(dr), Xb, Hbo, p) == 0 and vals["bk_info"] == 0
+    Hb = entries("bk_H", p * (kd + 1), p * kd)
+    for j in range(p * kd):
+        assert np.abs(Hb[:, j] - Hbo[:, j]).max() <= 1e-12 * np.abs(Hbo[:, j]).max(), ("block arnoldi", j)
     # column pool driven like the LightKrylov plugin: consecutive columns in one slab, and 200 emulated Gram-Schmidt
     # passes with recurring temporaries carve nothing new
     assert vals["pool_consecutive"] == 1 and vals["pool_slabs"] == 1

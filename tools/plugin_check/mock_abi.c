@@ -253,6 +253,22 @@ int lk_linop_apply(mock_op *o, int trans, mock_basis *bx, int jx, mock_basis *by
 int lk_arnoldi(void *A, void *X, double *H, int64_t ldh, int k0, int k1, double tol, int trans, int *info) {
     (void)A; (void)X; (void)H; (void)ldh; (void)k0; (void)k1; (void)tol; (void)trans; (void)info; return fail("lk_arnoldi is not in the mock");
 }
+int lk_arnoldi_block(void *A, void *X, double *H, int64_t ldh, int p, int k0, int k1, double tol, int trans, int *info) {
+    (void)A; (void)X; (void)H; (void)ldh; (void)p; (void)k0; (void)k1; (void)tol; (void)trans; (void)info; return fail("lk_arnoldi_block is not in the mock");
+}
+int lk_arnoldi_segments(void *A, void *X, double *H, int64_t ldh, int k0, int k1, double tol, int trans, const int *segs, int nseg, void *fn, void *user, int *info) {
+    (void)A; (void)X; (void)H; (void)ldh; (void)k0; (void)k1; (void)tol; (void)trans; (void)segs; (void)nseg; (void)fn; (void)user; (void)info;
+    return fail("lk_arnoldi_segments is not in the mock");
+}
+int lk_lanczos(void *A, void *X, double *T, int64_t ldt, int k0, int k1, double tol, int *info) {
+    (void)A; (void)X; (void)T; (void)ldt; (void)k0; (void)k1; (void)tol; (void)info; return fail("lk_lanczos is not in the mock");
+}
+int lk_bidiag(void *A, void *U, void *V, double *B, int64_t ldb, int k0, int k1, double tol, int *info) {
+    (void)A; (void)U; (void)V; (void)B; (void)ldb; (void)k0; (void)k1; (void)tol; (void)info; return fail("lk_bidiag is not in the mock");
+}
+int lk_qr(void *Q, int j0, int p, double *R, int64_t ldr, double tol, int *info) {
+    (void)Q; (void)j0; (void)p; (void)R; (void)ldr; (void)tol; (void)info; return fail("lk_qr is not in the mock");
+}
 int lk_comm_get_unique_id(void *id) { memset(id, 0, 128); return LK_OK; }
 int lk_comm_init_rank(mock_ctx *c, int nranks, int rank, const void *id) { (void)c; (void)rank; (void)id; return nranks == 1 ? LK_OK : fail("no collective in the mock"); }
 int lk_comm_info(mock_ctx *c, int *nranks, int *rank) { (void)c; if (nranks) *nranks = 1; if (rank) *rank = 0; return LK_OK; }
