@@ -405,7 +405,12 @@ int lk_arnoldi(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, i
  * before the call returns; columns beyond a breakdown are never reported.  fn returns 0 to go on, non-zero to STOP: nothing more is
  * enqueued (the device is kept at most 24 steps ahead of the segment being delivered, so at most that many steps beyond the last
  * reported one have touched the basis), nothing more is reported, and the call returns with info = 0 (eigs stops a cycle at the first
- * step with enough converged pairs, :1087-1093).  fn must not call into the same context.  fn may be NULL (then this is lk_arnoldi). */
+ * step with enough converged pairs, :1087-1093).  fn must not call into the same context.  fn may be NULL (then this is lk_arnoldi).
+ * ROW-SHARDED CONTEXTS (nranks > 1): every step carries three all-reduces, and each rank stops enqueueing where ITS fn says so -- the
+ * library has no agreement step here (one more collective per delivery would drain the 24 steps of lookahead this entry exists for).
+ * So the value fn returns for a given (kfirst, klast) must be THE SAME ON EVERY RANK: a function of H (identical on all ranks after the
+ * all-reduce) is; wall-clock time, or state set asynchronously by another thread, is not -- ranks that stop at different steps leave
+ * unmatched collectives behind (a hang, or sums paired across steps).  The mirror's eigs never asks a sharded cycle to stop early. */
 typedef int (*lk_progress_fn)(void *user, int kfirst, int klast);
 int lk_arnoldi_segments(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int kstart, int kend, double tol, int trans,
                         const int *seg_last, int nseg, lk_progress_fn fn, void *user, int *info);

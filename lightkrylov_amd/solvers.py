@@ -333,10 +333,13 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
     def median_selector(lam):                                                      # :1137-1142
         return np.abs(lam) > np.median(np.abs(lam))
 
-    def ritz_test(k):
-        """Ritz values of H(1:k, 1:k) and their residuals |H(k+1,k) * last eigenvector component|   :1065-1082"""
-        vecs, vals = _hostlapack.geev(H[:k, :k])                                   # :1065 (same LAPACK routine as `eig`)
-        beta = H[k, k - 1]
+    def ritz_test(k, Hk=None):
+        """Ritz values of H(1:k, 1:k) and their residuals |H(k+1,k) * last eigenvector component|   :1065-1082
+        (Hk: a private copy of H(1:k+1, 1:k) -- the pipelined cycle hands every test its own, so that a test still running when the
+        cycle is cut short never reads H while the restart rewrites it)"""
+        Hk = H if Hk is None else Hk
+        vecs, vals = _hostlapack.geev(Hk[:k, :k])                                  # :1065 (same LAPACK routine as `eig`)
+        beta = Hk[k, k - 1]
         r = np.empty(k)
         if dt == np.complex128:
             r[:] = np.abs(beta * vecs[k - 1, :k])                                  # :1071
@@ -357,6 +360,7 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
     # per-step tests -- independent once H is known -- run afterwards on several host threads, in step order, stopping at
     # the first k the reference would have stopped at.  Steps computed beyond it only touched eigs' private work basis.
     can_pipeline = isinstance(Xwrk, krylov_basis_gpu) and isinstance(A, _engine_linop) and not write_intermediate
+    multi_rank = getattr(getattr(Xwrk, "ctx", None), "nranks", 1) > 1
     pipelined = can_pipeline and (_hostlapack.threaded() if pipelined is None else bool(pipelined))
     nthreads = max(1, min(32, os.cpu_count() or 1))
 
@@ -389,7 +393,10 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                 # columns kfirst..klast of H are final (called by the engine on the device helper thread while the device runs on): the tests
                 # are handed to the pool by the FEEDER thread -- sixteen `submit`s would hold the engine's loop for half a millisecond
                 feeder.submit(feed, kfirst, klast)
-                return enough.is_set()                                             # true: enqueue nothing more
+                # true: enqueue nothing more.  `enough` is raised by the collecting thread WHEN its Ritz tests finish -- a matter of host
+                # timing -- so on a row-sharded context the ranks would stop enqueueing at different steps and their all-reduces would no
+                # longer pair up (round-5 advisor): there the cycle always runs to kdim; the extra steps touch eigs' private basis only.
+                return enough.is_set() and not multi_rank
 
             def feed(kfirst, klast):
                 _mark(f"columns {kfirst}..{klast} delivered")
@@ -399,7 +406,7 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
                     # the last tests (same LAPACK calls on the same data; discarded on an early stop) ...
                     ahead["schur"] = pool.submit(_schur_then_final_eig, H.copy(order="F"), kdim_, median_selector, last_cycle)
                 for kk in range(kfirst, klast + 1):
-                    tests[kk] = pool.submit(ritz_test, kk)
+                    tests[kk] = pool.submit(ritz_test, kk, H[:kk + 1, :kk].copy(order="F"))
                 arrived.put((kfirst, klast))
 
             def run_cycle():
@@ -412,21 +419,37 @@ def eigs(A: abstract_linop, X, x0: abstract_vector | None = None, kdim: int | No
             with _hostlapack.blas_threads(1):
                 cycle = device.submit(run_cycle)
                 k = kstart - 1
-                while True:
-                    item = arrived.get()
-                    if item is None:
-                        break
-                    for k in range(item[0], item[1] + 1):
-                        _vals, r = tests[k].result()
-                        res[:k] = r
-                        niter += 1
-                        conv = int(np.count_nonzero(res[:k] < tolerance))          # :1087
-                        if conv >= nev:
-                            stopped = True
+                collected = False
+                try:
+                    while True:
+                        item = arrived.get()
+                        if item is None:
                             break
-                    if stopped:
+                        for k in range(item[0], item[1] + 1):
+                            _vals, r = tests[k].result()
+                            res[:k] = r
+                            niter += 1
+                            conv = int(np.count_nonzero(res[:k] < tolerance))      # :1087
+                            if conv >= nev:
+                                stopped = True
+                                break
+                        if stopped:
+                            enough.set()
+                            break
+                    collected = True
+                finally:
+                    if not collected:
+                        # a Ritz test raised (geev failure, KeyboardInterrupt): the device thread is still inside lk_arnoldi_segments, writing H
+                        # and Xwrk on the context's stream -- tell it to stop, wait for it and for the feeder, drop the tests; only then let
+                        # the exception travel (round-5 advisor: the shared one-thread `device` pool stayed occupied otherwise)
                         enough.set()
-                        break
+                        try:
+                            cycle.result()
+                        except BaseException:  # noqa: BLE001 - the original exception is the one to report
+                            pass
+                        feeder.submit(lambda: None).result()
+                        for tf in tests.values():
+                            tf.cancel()
                 ainfo = cycle.result()                                             # (steps the device ran beyond an early stop only touched
                 kdone = ainfo if ainfo > 0 else kdim_                              #  eigs' private work basis; they are wiped below)
                 feeder.submit(lambda: None).result()                               # every delivery has been handed to the pool

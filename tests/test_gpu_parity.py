@@ -266,10 +266,11 @@ def test_arnoldi_diag_against_oracle(ctx, dtype, n, m, fused):
     # Hessenberg entries: normwise per column, 1e-12 (north_star)
     for j in range(m):
         assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL_RED * np.abs(Ho[:, j]).max(), f"column {j}"
-    # Ritz values within 1e-12 (relative to the spectral radius: the operator is normal)
-    rg = np.sort_complex(np.linalg.eigvals(H[:m, :m]))
-    ro = np.sort_complex(np.linalg.eigvals(Ho[:m, :m]))
-    assert np.abs(rg - ro).max() <= 1e-12 * np.abs(ro).max() * (10 if m > 100 else 1)
+    # Ritz values: 1e-12 * kappa_i * ||H||, kappa_i the COMPUTED condition number of each eigenvalue of the projected matrix (1 for the
+    # real kind, whose H is symmetric tridiagonal; the rotated spectrum of the complex kind gives a non-normal H): tests/_tol.py
+    rg = np.linalg.eigvals(H[:m, :m])
+    ro = np.linalg.eigvals(Ho[:m, :m])
+    assert_ritz_close(rg, ro, Ho[:m, :m], f"arnoldi diag n={n} m={m} {np.dtype(dtype)}")
     # invariants of test/TestKrylov.fypp:194-242 at machine precision instead of rtol_dp
     Xg = X.download()
     assert np.abs(Xg.conj().T @ Xg - np.eye(m + 1)).max() <= 1e-12

@@ -109,7 +109,7 @@ def test_reference_call_sequence_replayed_on_the_engine():
                     chk(lib.lk_basis_download(B, cj, 1, got.ctypes.data_as(C.c_void_p), max(n, 1)))
                     err = np.abs(got - want[j]).max() / max(np.abs(want[j]).max(), 1e-300)
                     worst_down = max(worst_down, err)
-                    assert err <= 1e-11, f"download #{ndown}: {err:.2e}"
+                    assert err <= 1e-12, f"download #{ndown}: {err:.2e}"
                     ndown += 1
             elif op == "zero":
                 chk(lib.lk_vec_zero(*ref(int(t[1]), int(t[2]))))
