@@ -136,8 +136,11 @@ def test_arnoldi_with_256_basis_columns_is_one_asynchronous_batch(dtype):
         assert lk.arnoldi(lk.diag_linop_gpu(d, c), X, H) == 0
         c.sync()
         cnt = [c.profile_get(f"dgs_sweep{i}")[0] for i in (1, 2, 3)]
+        single = c.profile_get("dgs_sweep_resident")[0]
         c.profile_enable(False)
-        assert cnt == [m, m, m]                                             # three launches per step, whatever the width
+        # one persistent launch per step while the basis has <= 128 columns (this panel fits the caches), three sweeps per step beyond,
+        # whatever the width
+        assert single == 128 and cnt == [m - single] * 3
         out[mode] = (H.copy(), X.download())
         if mode == 1:
             G = lk.Gram(X[:128]); G2 = lk.innerprod(X[:128], X[128:m + 1])
