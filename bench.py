@@ -189,7 +189,7 @@ def kernel_source_hash() -> str:
     """SHA-256 over the device code and its launcher: what a PMC traffic record must have been measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("lk_kernels.hip.h", "lk_engine.hip"):
+    for f in ("lk_kernels.hip.h", "lk_engine.hip", "lk_resident.hip.h"):
         h.update(open(os.path.join(ROOT, "lightkrylov_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
