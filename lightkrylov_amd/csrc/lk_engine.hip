@@ -330,7 +330,7 @@ struct ProfScope {
     bool on;
     ProfRec rec;
     bool ext = false;   // the launch itself carries the two events (hipExtLaunchKernelGGL): nothing is recorded on the stream
-    ProfScope(lk_context_t ctx, const char *tag, double bytes, bool ext_launch = false) : c(ctx), on(ctx->prof), ext(ext_launch) {
+    ProfScope(lk_context_t ctx, const char *tag, double bytes, bool ext_launch = false, bool enable = true) : c(ctx), on(ctx->prof && enable), ext(ext_launch) {
         if (on && c->prof_sweeps_only && strncmp(tag, "dgs_sweep", 9) != 0 && strcmp(tag, "matvec") != 0 && strncmp(tag, "comm_", 5) != 0) on = false;
         if (!on) return;
         auto get = [&]() {
@@ -2466,15 +2466,24 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
         if (y + Bx->n * ED > x0 && y < x1) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: y is one of the basis columns");
     }
     double n0 = 0, n1 = 0, n2 = 0;
-    ProfScope ps(c, "dgs", (double)Bx->n * ED * 8.0 * (two_pass ? (3.0 * k + 5.0) : (2.0 * k + 3.0)));
+    bool single = two_pass && k <= KMAX_WIDE && resident_applies(Bx, k);
+    const double dgs_bytes = (double)Bx->n * ED * 8.0 * (two_pass ? (3.0 * k + 5.0) : (2.0 * k + 3.0));
+    // "dgs" = the step on the device.  Three sweeps: stream markers either side of the six kernels.  Single launch: the kernel's own dispatch
+    // timestamps (as inside the asynchronous batches) -- two marker packets around ONE 20 us kernel would add half of its time to it.
+    ProfScope ps(c, "dgs", dgs_bytes, false, !single);
     if (k <= KMAX_WIDE) {
         const int rs = red_stride(k);
         const int last = two_pass ? 2 : 1;
-        bool single = two_pass && resident_applies(Bx, k);
         if (single) {
             // the whole step -- both passes and the normalise -- as ONE persistent launch (lk_resident.hip.h)
+            c->span_first = nullptr;
             LKCHK(dgs_resident_launch(Bx, k, y, c->red, rs, (flags & LK_DGS_NORMALIZE) != 0, ATOL_DP, 0.0, nullptr));
-            ps.end();
+            if (c->prof && c->span_first) {
+                ProfRec span;
+                span.e0 = c->span_first; span.e1 = c->span_last; span.tag = "dgs"; span.borrowed = true;
+                span.bytes = dgs_bytes;
+                c->prof_pending.push_back(span);
+            }
             LKCHK(fetch(c, 0, 3, rs));
             const double status = c->red_host[2 * rs + (size_t)k * ED + 1];
             if (status == 1.0) {            // gave up before touching y (the chip is shared with another persistent kernel)

@@ -2,7 +2,7 @@
 where the fused sweeps sit on the streaming ceiling and where they turn launch-bound or change shape (register tiles, lane split, single launch).
   python tools/scan_dgs.py [f64|c128] [KEY=INT ...] [sizes=300000,1000000] [ks=8,32,128]
 (round 6: "dgs_sweep*" includes the single launch of csrc/lk_resident.hip.h, tag dgs_sweep_resident; resident=0 gives the three-sweep schedule)"""
-import json, os, sys
+import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lightkrylov_amd as lk
@@ -36,7 +36,11 @@ for n in sizes:
         c, ms, by = ctx.profile_get("dgs")
         c2, ms2, by2 = ctx.profile_get("dgs_sweep*")
         ctx.profile_enable(False)
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(reps):
+            lk.double_gram_schmidt_step(B[kmax], B[:k], False)
+        ctx.sync(); wall_us = (time.perf_counter() - t0) / reps * 1e6      # host-visible latency of a synchronous call, profiling off (python included)
         row[str(k)] = {"dgs_TBps": round(s * nn * (3 * k + 5) / (ms / reps) / 1e9, 2), "sweeps_only_TBps": round(by2 / ms2 / 1e9, 2) if ms2 > 0 else None,
-                       "ms": round(ms / reps, 4), "single_launch": c2 == reps}
+                       "ms": round(ms / reps, 4), "wall_us_per_sync_call": round(wall_us, 1), "single_launch": c2 == reps}
     print(json.dumps({"dtype": np.dtype(dtype).name, "n": nn, "knobs": knobs, "by_k": row}), flush=True)
     del B
