@@ -19,6 +19,12 @@ if [ -f "$D/cfg5_8rank_one_gpu.log" ]; then (echo "$hdr"; j "$D/cfg5_2rank_one_g
 (echo "$hdr"; j "$D/blas1.log") > "profiles/${TAG}_blas1_n1e8.jsonl"
 (echo "$hdr"; j "$D/per_object_arnoldi.log") > "profiles/${TAG}_per_object_arnoldi.jsonl"
 if [ -f "$D/per_object_c.log" ]; then (echo "$hdr"; j "$D/per_object_c.log") > "profiles/${TAG}_per_object_c.jsonl"; fi
+if [ -f "$D/small_arnoldi_f64.log" ]; then
+  (echo "$hdr"; j "$D/scan_small_single.log"; j "$D/scan_small_sweeps.log") > "profiles/${TAG}_dgs_small_n_scan.jsonl"
+  (echo "$hdr"; j "$D/small_arnoldi_f64.log" "$D/small_arnoldi_c128.log") > "profiles/${TAG}_small_arnoldi.jsonl"
+  (echo "$hdr"; j "$D/resident_phases_f64.log") > "profiles/${TAG}_resident_phases_f64.jsonl"
+  (echo "$hdr"; j "$D/block_arnoldi_f64.log") > "profiles/${TAG}_block_arnoldi.jsonl"
+fi
 (echo "$hdr"; j "$D/bench_default.log") > "profiles/${TAG}_bench_default_stdout.jsonl"
 (echo "$hdr"; j "$D/cfg2.log") > "profiles/${TAG}_cfg2_f64_n1e7_m64.jsonl"
 (echo "$hdr"; j "$D/configs.log") > "profiles/${TAG}_configs.jsonl"

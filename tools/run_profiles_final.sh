@@ -39,6 +39,15 @@ python3 "$R/tools/bench_gram.py" 1e7 > "$D/gram.log" 2>&1
 python3 "$R/tools/bench_wide.py" 1e7 f64 > "$D/wide_f64.log" 2>&1
 python3 "$R/tools/bench_wide.py" 5e6 c128 > "$D/wide_c128.log" 2>&1
 python3 "$R/tools/bench_per_object_arnoldi.py" 1e7 64 > "$D/per_object_arnoldi.log" 2>&1
+# the same per-object call sequence from a COMPILED host (what the Fortran plugin costs without an interpreter)
+gcc -O2 -o /tmp/bench_per_object "$R/tools/bench_per_object.c" -I"$R/include" -L"$R/lightkrylov_amd" -llightkrylov_hip -lm -Wl,-rpath,"$R/lightkrylov_amd" && (/tmp/bench_per_object 10000000 64; /tmp/bench_per_object 1000000 128; /tmp/bench_per_object 100000000 32) > "$D/per_object_c.log" 2>&1
+# round 6: the launch-bound regime (single-launch step) and the block factorisation
+python3 "$R/tools/scan_dgs.py" f64 sizes=175000,300000,1000000 ks=8,32,64,128 > "$D/scan_small_single.log" 2>&1
+python3 "$R/tools/scan_dgs.py" f64 resident=0 sizes=175000,300000,1000000 ks=8,32,64,128 > "$D/scan_small_sweeps.log" 2>&1
+python3 "$R/tools/bench_small_arnoldi.py" f64 > "$D/small_arnoldi_f64.log" 2>&1
+python3 "$R/tools/bench_small_arnoldi.py" c128 > "$D/small_arnoldi_c128.log" 2>&1
+python3 "$R/tools/resident_phases.py" f64 sizes=1000,175000,300000,1000000 ks=1,8,32,64,128 > "$D/resident_phases_f64.log" 2>&1
+python3 "$R/tools/bench_block_arnoldi.py" f64 > "$D/block_arnoldi_f64.log" 2>&1
 for op in dense lap5 csr; do python3 "$R/bench.py" --operator $op --steps 3 --warmup 1 > "$D/bench_$op.log" 2> "$D/bench_$op.err"; done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_block_wide_fetch" -o block -- python3 "$R/tools/bench_block_wide.py" 4e6 panels_only > "$D/pmc_block_wide_fetch.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/block_stats" -o block -- python3 "$R/tools/bench_block_dgs.py" 32 1 > "$D/block_stats.log" 2>&1
