@@ -107,6 +107,56 @@ int main(void) {
     CHECK(lk_dgs(W, 1, W, 1, h, norms, 0, &dinfo));           /* orthogonalise W1 against W0 */
     EXPECT(fabs(h[0] - 2.0) < 1e-13 && fabs(norms[2] - 1.0) < 1e-13 && dinfo == 0);
 
+    /* round 6: qr_no_pivoting and the block Arnoldi factorisation as engine calls (arnoldi.fypp:20-73 with blksize = 2; qr.fypp:116-167):
+     * A X = X+ H+ on every column, X orthonormal, the single-launch step's statistics available, continued ranges = the one-shot run */
+    {
+        const int p = 2, kd = 6, nc = (kd + 1) * p;
+        lk_basis_t XB; int binfo = -99, qinfo = -99;
+        CHECK(lk_basis_create(ctx, LK_F64, n, nc, &XB));
+        CHECK(lk_vec_rand(XB, 0, 21, 0, 0));
+        CHECK(lk_vec_rand(XB, 1, 22, 0, 0));
+        double R[4] = {0, 0, 0, 0};
+        CHECK(lk_qr(XB, 0, p, R, p, 1e-15, &qinfo));
+        EXPECT(qinfo == 0 && R[0] > 0.0 && R[3] > 0.0 && R[1] == 0.0);
+        double *HB = calloc((size_t)nc * kd * p, sizeof(double)), *HB2 = calloc((size_t)nc * kd * p, sizeof(double));
+        CHECK(lk_arnoldi_block(A, XB, HB, nc, p, 1, kd, 1e-15, 0, &binfo));
+        EXPECT(binfo == 0);
+        double *xb = malloc((size_t)n * nc * sizeof(double));
+        CHECK(lk_basis_download(XB, 0, nc, xb, n));
+        double borth = 0.0, bres = 0.0;
+        for (int a = 0; a < nc; ++a)
+            for (int b2 = 0; b2 <= a; ++b2) {
+                double g = 0.0;
+                for (int64_t i = 0; i < n; ++i) g += xb[(size_t)a * n + i] * xb[(size_t)b2 * n + i];
+                g = fabs(g - (a == b2 ? 1.0 : 0.0));
+                if (g > borth) borth = g;
+            }
+        for (int j = 0; j < kd * p; ++j)
+            for (int64_t i = 0; i < n; i += 997) {           /* a sample of rows of A X(:, j) - X+ H(:, j) */
+                double r = d[i] * xb[(size_t)j * n + i];
+                for (int a = 0; a < nc; ++a) r -= xb[(size_t)a * n + i] * HB[(size_t)j * nc + a];
+                if (fabs(r) > bres) bres = fabs(r);
+            }
+        EXPECT(borth < 1e-12 && bres < 1e-12);
+        /* the same factorisation in two ranges from the same starting block */
+        lk_basis_t XC;
+        CHECK(lk_basis_create(ctx, LK_F64, n, nc, &XC));
+        CHECK(lk_vec_rand(XC, 0, 21, 0, 0));
+        CHECK(lk_vec_rand(XC, 1, 22, 0, 0));
+        CHECK(lk_qr(XC, 0, p, R, p, 1e-15, &qinfo));
+        CHECK(lk_arnoldi_block(A, XC, HB2, nc, p, 1, 2, 1e-15, 0, &binfo));
+        CHECK(lk_arnoldi_block(A, XC, HB2, nc, p, 3, kd, 1e-15, 0, &binfo));
+        for (int i = 0; i < nc * kd * p; ++i) EXPECT(HB[i] == HB2[i]);
+        EXPECT(lk_arnoldi_block(A, XC, HB2, nc - 1, p, 1, kd, 1e-15, 0, &binfo) == LK_ERR_INVALID);   /* ldh too small */
+        EXPECT(lk_qr(XC, nc - 1, p, R, p, 1e-15, &qinfo) == LK_ERR_INVALID);                          /* columns beyond the panel */
+        int64_t rs3[3] = {-1, -1, -1};
+        CHECK(lk_resident_stats(ctx, rs3));
+        EXPECT(rs3[0] > 0 && rs3[1] == 0);                   /* these panels fit the caches: single launches ran, none gave up */
+        EXPECT(lk_set_tuning(ctx, "xhy_debug", 1) == LK_ERR_INVALID);   /* wrong-result diagnostics are not in the shipped library */
+        free(xb); free(HB); free(HB2);
+        lk_basis_destroy(XB); lk_basis_destroy(XC);
+    }
+
     /* error convention: negative status + message, nothing aborts */
     EXPECT(lk_vec_zero(X, m + 5) == LK_ERR_INVALID && strstr(lk_last_error(), "out of range"));
     EXPECT(lk_dgs(X, 3, X, 1, h, norms, 0, &dinfo) == LK_ERR_INVALID);   /* y among the basis columns */

@@ -56,3 +56,24 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".f90")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_tuning_keys_are_few_documented_and_none_of_them_breaks_results():
+    """Round-5 review, hygiene: the product build knows at most 30 tuning keys, every one of them is named in the header's documentation,
+    and the phase-timing switches that give WRONG results exist only under -DLK_DIAGNOSTICS (which build() never defines)."""
+    import re
+    eng = open(os.path.join(ROOT, "lightkrylov_amd", "csrc", "lk_engine.hip")).read()
+    hdr = open(os.path.join(ROOT, "include", "lightkrylov_hip.h")).read()
+    body = eng[eng.index("int lk_set_tuning("):eng.index("int lk_profile_enable(")]
+    diag = re.findall(r"#ifdef LK_DIAGNOSTICS(.*?)#endif", body, flags=re.S)
+    diag_keys = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', "".join(diag)))
+    keys = set(re.findall(r'strcmp\(key, "([a-z_0-9]+)"\)', body)) - diag_keys
+    assert diag_keys == {"xhy_debug", "upd_debug"}
+    assert len(keys) <= 30, sorted(keys)
+    for k in keys | diag_keys:
+        assert f'"{k}"' in hdr, f'tuning key "{k}" is not documented in include/lightkrylov_hip.h'
+    for gone in ("mfma_4x4", "xhy_tr32"):
+        assert gone not in keys and f'"{gone}"' not in hdr
+    mk = open(os.path.join(ROOT, "lightkrylov_amd", "csrc", "Makefile")).read()
+    product_rule = mk[mk.index("$(OUT):"):mk.index("diagnostics:")]
+    assert "LK_DIAGNOSTICS" not in product_rule and "LK_DIAGNOSTICS" not in open(os.path.join(ROOT, "__graft_entry__.py")).read()
