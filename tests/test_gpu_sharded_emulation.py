@@ -655,3 +655,48 @@ def test_sharded_csr_creation_fails_on_every_rank_together(ctx, fault):
         if r != bad:
             assert f"rank {bad} failed" in msgs[r], msgs
     assert np.abs(np.concatenate([r[1] for r in res]) - L @ x_full).max() <= 1e-13 * np.abs(x_full).max() * 4
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.complex128])
+@pytest.mark.parametrize("p", [2, 6])
+def test_sharded_block_arnoldi_matches_single_context(ctx, dtype, p):
+    """lk_arnoldi_block on a row-sharded context (two ranks as threads, emulated all-reduce): the asynchronous block batch -- the block
+    Gram-Schmidt on the vector units (p = 2) and on the matrix cores (p = 6), the p-column qr on the three-sweep schedule (a sharded
+    context never takes the single launch) -- against the single-context factorisation: same H on every rank, to rounding the single rank's."""
+    n, kdim, nranks = 120_001, 6, 2
+    ncol = (kdim + 1) * p
+
+    def dvals(row0, nl):
+        g = (row0 + np.arange(nl)) / n
+        d = 1.0 + g
+        return (d * np.exp(0.3j * g)).astype(dtype) if np.dtype(dtype).kind == "c" else d
+
+    def start(X, c):
+        for j in range(p):
+            X[j].rand(False, seed=70 + j)                          # global vectors, partition independent
+        R = np.zeros((p, p), dtype=dtype, order="F")
+        assert lk.qr(X[:p], R) == 0
+
+    def body(rank, c, row0, nl):
+        X = lk.krylov_basis_gpu(nl, ncol, dtype, c)
+        start(X, c)
+        H = np.zeros((ncol, kdim * p), dtype=dtype, order="F")
+        before = c.resident_stats()[0]
+        info = lk.arnoldi(lk.diag_linop_gpu(dvals(row0, nl), c), X, H, blksize=p)
+        assert c.resident_stats()[0] == before                     # no single launch on a sharded context
+        return info, H, X.download()
+
+    res, grp = _sharded(n, nranks, body)
+    X1 = lk.krylov_basis_gpu(n, ncol, dtype, ctx)
+    start(X1, ctx)
+    H1 = np.zeros((ncol, kdim * p), dtype=dtype, order="F")
+    assert lk.arnoldi(lk.diag_linop_gpu(dvals(0, n), ctx), X1, H1, blksize=p) == 0
+    for info, H, _ in res:
+        assert info == 0
+        assert np.array_equal(H, res[0][1])
+        for j in range(kdim * p):
+            assert np.abs(H[:, j] - H1[:, j]).max() <= 1e-12 * np.abs(H1[:, j]).max(), j
+    Xs = np.concatenate([r[2] for r in res], axis=0)
+    assert np.abs(Xs.conj().T @ Xs - np.eye(ncol)).max() <= 1e-12
+    d = dvals(0, n)
+    assert np.abs(d[:, None] * Xs[:, :kdim * p] - Xs @ res[0][1]).max() <= 1e-12 * np.abs(d).max()
