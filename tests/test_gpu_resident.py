@@ -311,3 +311,56 @@ def test_lanczos_and_bidiagonalization_on_the_single_launch_and_through_a_give_u
             assert np.abs(Ud.conj().T @ Ud - np.eye(m + 1)).max() <= 1e-12
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("dtype", KINDS)
+def test_a_thousand_single_launches_of_random_shapes_are_reproducible_and_agree_with_the_three_sweeps(rctx, dtype):
+    """The hand-off protocol of the grid-wide sums under load: 150 random (rows, columns) shapes -- ragged tiles, fewer tiles than CUs, every
+    kernel shape, uneven work per block --, each run three times back to back on the single launch and once on the three sweeps, inside an
+    ASYNCHRONOUS Arnoldi batch and as host-synchronous steps.  A stale or torn granule would show as a run that is not bit-identical to its
+    repetition (the sums are in a fixed order) or as a step that disagrees with the three-sweep result beyond rounding."""
+    ctx = rctx
+    rng = np.random.default_rng(2026)
+    launches = 0
+    for case in range(150):
+        n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 20_000), rng.integers(20_000, 400_000)]))
+        k = int(min(n, rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33, 48, 64, 65, 100, 127, 128])))
+        Q = orthonormal_basis(n, k, dtype, 1000 + case) if n * k <= 4_000_000 else None
+        B = lk.krylov_basis_gpu(n, k + 1, dtype, ctx)
+        if Q is not None:
+            B.upload(Q, 0)
+        else:
+            for j in range(k):
+                B[j].rand(True, seed=3000 + 131 * case + j)           # (large cases: merely normalised columns -- any X will do here)
+        y = seeded(n, dtype, 5000 + case)
+        runs = []
+        for route in (1, 1, 1, 0):
+            ctx.set_tuning("resident", route)
+            B.upload(y.reshape(-1, 1), k)
+            beta = np.zeros(k, dtype=dtype)
+            norms = []
+            lk.double_gram_schmidt_step(B[k], B[:k], False, beta, _normalize=True, _norms=norms)
+            runs.append((beta, B.download(k, 1)[:, 0], np.array(norms)))
+            launches += route
+        for r in runs[1:3]:
+            assert all(np.array_equal(a, b) for a, b in zip(r, runs[0])), (case, n, k)
+        scale = np.linalg.norm(y)
+        assert np.abs(runs[0][0] - runs[3][0]).max() <= 1e-13 * scale, (case, n, k)
+        assert np.abs(runs[0][2] - runs[3][2]).max() <= 1e-13 * scale, (case, n, k)
+        if runs[3][2][2] > 1e-8 * scale:                                # (the direction of a numerically zero remainder is noise on both schedules)
+            assert np.abs(runs[0][1] - runs[3][1]).max() <= 1e-10 * max(1.0, scale / runs[3][2][2]), (case, n, k)
+        del B
+    # the same under back-to-back launches with nothing in between: asynchronous factorisations of several sizes, three times each
+    for n, m in ((257, 40), (5_003, 128), (90_001, 100), (250_007, 64)):
+        d = (1.0 + np.arange(n) / n).astype(dtype)
+        Hs = []
+        for rep in range(3):
+            ctx.set_tuning("resident", 1)
+            X = lk.krylov_basis_gpu(n, m + 1, dtype, ctx)
+            X[0].rand(True, seed=7)
+            H = np.zeros((m + 1, m), dtype=dtype, order="F")
+            assert lk.arnoldi(lk.diag_linop_gpu(d, ctx), X, H) == 0
+            Hs.append(H)
+            launches += m
+        assert np.array_equal(Hs[0], Hs[1]) and np.array_equal(Hs[0], Hs[2]), (n, m)
+    assert launches > 1000 and ctx.resident_stats()[1] == 0
