@@ -185,7 +185,7 @@ int lk_lazy_speculation_stats(lk_context_t ctx, int64_t *out2);
  * out3 = {single launches enqueued, launches that gave up, launches that kept the panel in registers}. */
 int lk_resident_stats(lk_context_t ctx, int64_t *out3);
 /* In-kernel timeline of the LAST single launch (profiling aid, like lk_profile_get): the 100 MHz wall clock of block 0 at
- * start | phase 1 done | sum 1 done | phase 2 done | sum 2 done | phase 3 done | sum 3 done | scaled.  Synchronises the stream. */
+ * kernel entry | phase 1 done (the panel read included) | sum 1 done | phase 2 done | sum 2 done | phase 3 done | sum 3 done | scaled.  Synchronises the stream. */
 int lk_resident_phase_ticks(lk_context_t ctx, int64_t *out8);
 
 /* per-kernel HIP-event timing on the context's stream (bench.py roofline leg).
