@@ -833,7 +833,9 @@ def main() -> None:
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "Arnoldi iterations/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {exc!r}"}
-        if world == 1 and args.operator == "diag" and not args.shard_of:
+        # (a context leg like cpu_baseline: --no-cpu-baseline drops it too -- the PMC / kernel-trace passes of tools/run_profiles_final.sh must see the
+        #  metric workload's launches only, the small-n sweeps would land in the same kernel instantiations' averages)
+        if world == 1 and args.operator == "diag" and not args.shard_of and not args.no_cpu_baseline:
             try:
                 out["launch_bound_regime"] = launch_bound_regime(ctx)
             except Exception as exc:  # noqa: BLE001 - context only: never costs the metric line

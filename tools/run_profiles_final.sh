@@ -26,6 +26,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$D/stats" -o bench -- p
 for P in 2 4 8; do python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --shard-of $P > "$D/shard_$P.log" 2>/dev/null; done
 (cd "$R" && LK_DIST_BACKEND=gloo LK_FORCE_DEVICE=0 GLOO_SOCKET_IFNAME=lo python3 bench.py --gpus 8 --steps 2 --warmup 1 --no-cpu-baseline > "$D/cfg5_8rank_one_gpu.log" 2> "$D/cfg5_8rank_one_gpu.err")
 (cd "$R" && LK_DIST_BACKEND=gloo LK_FORCE_DEVICE=0 GLOO_SOCKET_IFNAME=lo python3 bench.py --gpus 2 --steps 2 --warmup 1 --no-cpu-baseline > "$D/cfg5_2rank_one_gpu.log" 2> "$D/cfg5_2rank_one_gpu.err")
+if [ "${LK_PROFILE_PARTS:-all}" = "metric" ]; then tail -c 600 "$D/bench_default.log"; exit 0; fi     # (re-take of parts 1-2 only)
 # -- 3. the other kernels and configs
 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/lincomb" -o lincomb -- python3 "$R/tools/bench_lincomb.py" > "$D/lincomb.log" 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/cfg4" -o cfg4 -- python3 "$R/bench.py" --dtype c128 --rows 1000000 --steps 5 --warmup 2 --no-cpu-baseline > "$D/cfg4.log" 2>&1
