@@ -364,3 +364,50 @@ def test_a_thousand_single_launches_of_random_shapes_are_reproducible_and_agree_
             launches += m
         assert np.array_equal(Hs[0], Hs[1]) and np.array_equal(Hs[0], Hs[2]), (n, m)
     assert launches > 1000 and ctx.resident_stats()[1] == 0
+
+
+def test_two_contexts_launching_persistent_kernels_at_once_never_hang_and_stay_correct():
+    """Two contexts (two streams, two host threads) run single-launch factorisations at the same time: each kernel wants every CU, so the
+    two can split the chip and wait for blocks that cannot become resident -- the situation the bounded first wait exists for.  With a
+    20 ms bound (2 s by default) a launch that starves gives up, its step runs on the three sweeps, and every Hessenberg matrix is still
+    the oracle's; nothing hangs.  (Contexts re-arm the single launch before every factorisation so that the collision can recur.)"""
+    import threading
+    n, m, rounds = 300_000, 24, 25
+    d = 1.0 + np.arange(n) / n
+    x0 = seeded(n, np.float64, 7)
+    x0 /= np.linalg.norm(x0)
+    Xo = np.zeros((n, m + 1), order="F")
+    Xo[:, 0] = x0
+    Ho = np.zeros((m + 1, m), order="F")
+    assert ora.arnoldi(ora.DiagOp(d), Xo, Ho) == 0
+    errs, gave_up, launched = [], [0, 0], [0, 0]
+    start = threading.Barrier(2)
+
+    def worker(t):
+        try:
+            ctx = lk.Context(device=0, use_torch_stream=False)
+            ctx.set_tuning("resident_spin_ms", 20)
+            A = lk.diag_linop_gpu(d, ctx)
+            X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
+            start.wait(timeout=60)
+            for _ in range(rounds):
+                ctx.set_tuning("resident", 1)
+                X.upload(x0.reshape(-1, 1), 0)
+                H = np.zeros((m + 1, m), order="F")
+                assert lk.arnoldi(A, X, H) == 0
+                for j in range(m):
+                    assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL * np.abs(Ho[:, j]).max(), (t, j)
+            st = ctx.resident_stats()
+            launched[t], gave_up[t] = st[0], st[1]
+            ctx.close()
+        except BaseException as exc:  # noqa: BLE001
+            errs.append(exc)
+            start.abort()
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not any(t.is_alive() for t in ts), "a worker is still running: a wait did not end"
+    assert not errs, errs
+    assert min(launched) > 0
+    print(f"\n  two contexts at once: single launches {launched}, gave up {gave_up}")
