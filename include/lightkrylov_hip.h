@@ -178,9 +178,10 @@ int lk_lazy_speculation_stats(lk_context_t ctx, int64_t *out2);
  * up to the register files' capacity (64 MB on the chip) stay IN REGISTERS for the whole step: X is read once, k + 2 columns of
  * traffic instead of 3k + 5.  Tuning keys: "resident" (default 1; 0 = always the three-sweep schedule), "resident_max_mb" (default 192:
  * MB of panel the single launch takes), "resident_onchip" (default 1; 0 = never the register-resident kernel), "resident_rev" (tile
- * order of the cache-resident kernel's phase 2) and "resident_spin_ms" (default 2000: bound on the first grid-wide wait -- 0 = give up there at once, the tests' way to the fallback --; a launch
- * that cannot get all its blocks on the chip gives up BEFORE writing anything, the step runs on the three-sweep schedule and the
- * context stops trying).  One rank only: a row-sharded context keeps the three launches, whose sums meet in the all-reduce.  Same
+ * order of the cache-resident kernel's phase 2) and "resident_spin_ms" (default 50: bound on the first grid-wide wait, which normally ends within microseconds -- 0 = give up there at
+ * once, the tests' way to the fallback --; a launch that cannot get all its blocks on the chip, e.g. because another context's persistent
+ * kernel holds part of it, gives up BEFORE writing anything, that step runs on the three-sweep schedule, and the single launch pauses for 16
+ * steps -- doubling with every further give-up -- before it is tried again; setting "resident" = 1 re-arms it at once).  One rank only: a row-sharded context keeps the three launches, whose sums meet in the all-reduce.  Same
  * results to rounding (different summation order).
  * out3 = {single launches enqueued, launches that gave up, launches that kept the panel in registers}. */
 int lk_resident_stats(lk_context_t ctx, int64_t *out3);

@@ -151,8 +151,11 @@ struct lk_context_s {
     int resident_max_mb = 320; // ... MB of panel the single launch takes (measured crossover with the three sweeps: profiles/r06_resident_phases.jsonl)
     int resident_onchip = 1;   // panels that fit the register files (64 MB on the chip) stay there for the whole step: X is read once
     int resident_rev = 1;      // phase 2 walks a block's tiles backwards (starts on what phase 1 read last)
-    int resident_spin_ms = 2000;   // bound on the first grid-wide wait; beyond it the launch gives up and the three-sweep schedule runs
-    bool resident_off = false; // a launch gave up once (the device is shared with another persistent kernel): not tried again
+    int resident_spin_ms = 50;     // bound on the first grid-wide wait (it normally ends within microseconds); beyond it the launch gives up, the
+                               // three-sweep schedule runs that step
+    bool resident_off = false; // a launch gave up (the device is shared with another persistent kernel): the single launch pauses ...
+    int64_t resident_pause = 16;       // ... for this many Gram-Schmidt steps (doubling with every give-up, up to 2^20), then is tried again
+    int64_t resident_fallback_steps = 0, resident_retry_at = 0;   // steps run on the three sweeps while paused; the count at which to re-arm
     unsigned *res_cnt = nullptr;
     long long *res_tim = nullptr;
     double *blk_red = nullptr, *blk_red_host = nullptr;   // coefficient sections of the block Gram-Schmidt (lk_dgs_block, lk_arnoldi_block): device + pinned
@@ -1401,17 +1404,30 @@ int resident_ws(lk_context_t c, ResidentWs *ws) {
 int resident_recover(lk_context_t c) {
     c->resident_off = true;
     c->resident_stats[1] += 1;
+    c->resident_retry_at = c->resident_fallback_steps + c->resident_pause;
+    if (c->resident_pause < ((int64_t)1 << 20)) c->resident_pause *= 2;
     if (c->res_cnt) HIPCHK(hipMemsetAsync(c->res_cnt, 0, (size_t)RES_CNT_STRIDE * sizeof(unsigned), c->stream));
     return LK_OK;
 }
 
 // does the two-pass step of k columns against y run as ONE launch?  Only on a single rank (the phases' sums meet inside the
 // launch; a sharded run needs the all-reduce between them), for k <= 128, and while the panel fits the memory-side cache.
-bool resident_applies(lk_basis_t Bx, int k) {
+bool resident_would_apply(lk_basis_t Bx, int k) {
     lk_context_t c = Bx->ctx;
-    if (!c->resident || c->resident_off || c->nranks > 1 || k < 1 || k > KMAX_FUSED) return false;   // (an all-reduce over ONE rank is the identity)
+    if (!c->resident || c->nranks > 1 || k < 1 || k > KMAX_FUSED) return false;   // (an all-reduce over ONE rank is the identity)
     const double mb = (double)Bx->n * Bx->ed() * 8.0 * (k + 1) / (1024.0 * 1024.0);
     return mb <= (double)c->resident_max_mb;
+}
+bool resident_applies(lk_basis_t Bx, int k) { return !Bx->ctx->resident_off && resident_would_apply(Bx, k); }
+// a step that the pause sent to the three sweeps counts towards its end
+void resident_note_fallback(lk_basis_t Bx, int k) {
+    lk_context_t c = Bx->ctx;
+    if (c->resident_off && resident_would_apply(Bx, k)) c->resident_fallback_steps += 1;
+}
+// Called where NO step is in flight between its enqueue and the host's look at its status (the entry of lk_dgs, the start of an asynchronous
+// batch): the answer of resident_applies must not change in between.
+void resident_maybe_rearm(lk_context_t c) {
+    if (c->resident_off && c->resident_fallback_steps >= c->resident_retry_at) c->resident_off = false;
 }
 
 int dgs_resident_launch(lk_basis_t Bx, int k, double *y, double *out, int rs, bool normalize, double tol_scale, double tol_break, int *stop_out,
@@ -1424,6 +1440,7 @@ int dgs_step_async(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *slot, in
     lk_context_t c = Bx->ctx;
     const int ED = Bx->ed();
     if (resident_applies(Bx, k)) return dgs_resident_launch(Bx, k, By->col(jy), slot, rs, true, tol_scale, tol_break, c->stop_dev, c0);
+    resident_note_fallback(Bx, k);
     LKCHK(dgs_device(Bx, k, By->col(jy), true, slot, rs, c0));
     return scal_launch(By, jy, 1.0, 0.0, slot + 2 * rs + (size_t)k * ED, tol_scale, c->stop_dev, tol_break);
 }
@@ -1667,7 +1684,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
         c->blas1_grid_mult = value;
         return LK_OK;
     }
-    if (!strcmp(key, "resident")) { c->resident = value != 0; if (value) c->resident_off = false; return LK_OK; }
+    if (!strcmp(key, "resident")) { c->resident = value != 0; if (value) { c->resident_off = false; c->resident_pause = 16; } return LK_OK; }
     if (!strcmp(key, "resident_max_mb")) { c->resident_max_mb = value < 0 ? 0 : value; return LK_OK; }
     if (!strcmp(key, "resident_onchip")) { c->resident_onchip = value != 0; return LK_OK; }
     if (!strcmp(key, "resident_rev")) { c->resident_rev = value != 0; return LK_OK; }
@@ -2466,7 +2483,9 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
         if (y + Bx->n * ED > x0 && y < x1) return fail(LK_ERR_INVALID, "double_gram_schmidt_step: y is one of the basis columns");
     }
     double n0 = 0, n1 = 0, n2 = 0;
+    resident_maybe_rearm(c);
     bool single = two_pass && k <= KMAX_WIDE && resident_applies(Bx, k);
+    if (!single && two_pass) resident_note_fallback(Bx, k);
     const double dgs_bytes = (double)Bx->n * ED * 8.0 * (two_pass ? (3.0 * k + 5.0) : (2.0 * k + 3.0));
     // "dgs" = the step on the device.  Three sweeps: stream markers either side of the six kernels.  Single launch: the kernel's own dispatch
     // timestamps (as inside the asynchronous batches) -- two marker packets around ONE 20 us kernel would add half of its time to it.
@@ -2488,6 +2507,7 @@ static int dgs_generic(lk_basis_t Bx, int k, lk_basis_t By, int jy, double *h, d
             const double status = c->red_host[2 * rs + (size_t)k * ED + 1];
             if (status == 1.0) {            // gave up before touching y (the chip is shared with another persistent kernel)
                 LKCHK(resident_recover(c));
+                resident_note_fallback(Bx, k);
                 single = false;
             } else if (status != 0.0) {
                 return fail(LK_ERR_HIP, "double_gram_schmidt_step: the single-launch step failed after its first phase (status %g)", status);
@@ -3679,6 +3699,7 @@ int lk_lanczos(lk_linop_t A, lk_basis_t X, double *T, int64_t ldt, int kstart, i
             continue;
         }
         int done = 0;
+        resident_maybe_rearm(c);
         LKCHK(lanczos_batch_async(A, X, k, kfused, tol, &done));
         const bool stopped_early = *c->stop_host != 0;
         double beta = 0.0;
@@ -3773,6 +3794,7 @@ int lk_bidiag(lk_linop_t A, lk_basis_t U, lk_basis_t V, double *B, int64_t ldb, 
     int done_half = 2 * (kstart - 1);
     bool stopped_early = false;
     for (int ks = kstart; ks <= kfused;) {
+        resident_maybe_rearm(c);
         LKCHK(bidiag_batch_async(A, U, V, ks, kfused, tol, &done_half));
         stopped_early = *c->stop_host != 0;
         const int rs = red_stride(kfused);
@@ -3916,6 +3938,7 @@ static int arnoldi_impl(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int 
         };
         int done = 0, delivered_to = k - 1;
         bool cancelled = false;
+        resident_maybe_rearm(c);
         LKCHK(arnoldi_batch_async(A, X, k, k1, tol, trans, &done, segs.empty() ? nullptr : segs.data(), (int)segs.size(), deliver, &delivered_to,
                                   &cancelled));
         if (cancelled) break;                                    // the caller asked to stop: columns beyond the last report are not delivered
@@ -4108,6 +4131,7 @@ int lk_arnoldi_block(lk_linop_t A, lk_basis_t X, double *H, int64_t ldh, int blk
         std::vector<int64_t> blk_off;
         int64_t qr_off = 0;
         const int k0 = k;
+        resident_maybe_rearm(c);
         LKCHK(arnoldi_block_batch(A, X, p, k0, kend, tol, trans, blk_off, &qr_off));
         const int rs = RED_SECTION;
         const int stop_seq = *c->stop_host;

@@ -26,8 +26,8 @@
 // (sc1, write-through) store instruction and read by agent-scope 16-byte loads -- a reader that sees this launch's tag sees the value,
 // so nothing has to be drained or counted and nothing is left to clear (the guide's data-tagged granule, R2, with a 64-bit payload).
 // All blocks must be co-resident: the grid is at most one block per CU.  A wait that outlasts its deadline (another persistent
-// kernel holding the CUs) raises the abort word: nothing has been written to y at that point (the first wait comes before any
-// store), the launcher falls back to the three-sweep schedule and clears the word.
+// kernel holding part of the chip) raises the abort word: nothing has been written to y at that point (the first wait comes before any
+// store), the host runs that step on the three-sweep schedule, clears the word and pauses the single launch for a while (lk_engine.hip).
 #pragma once
 #include "lk_kernels.hip.h"
 
