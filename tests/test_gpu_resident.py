@@ -366,11 +366,14 @@ def test_a_thousand_single_launches_of_random_shapes_are_reproducible_and_agree_
     assert launches > 1000 and ctx.resident_stats()[1] == 0
 
 
-def test_two_contexts_launching_persistent_kernels_at_once_never_hang_and_stay_correct():
+@pytest.mark.parametrize("rearm", [True, False], ids=["rearmed_every_round", "pause_and_retry"])
+def test_two_contexts_launching_persistent_kernels_at_once_never_hang_and_stay_correct(rearm):
     """Two contexts (two streams, two host threads) run single-launch factorisations at the same time: each kernel wants every CU, so the
     two can split the chip and wait for blocks that cannot become resident -- the situation the bounded first wait exists for.  With a
     20 ms bound (2 s by default) a launch that starves gives up, its step runs on the three sweeps, and every Hessenberg matrix is still
-    the oracle's; nothing hangs.  (Contexts re-arm the single launch before every factorisation so that the collision can recur.)"""
+    the oracle's; nothing hangs.  `rearm`: the contexts re-arm the single launch before every factorisation so that the collision recurs
+    as often as possible; without it the engine's own policy runs -- pause for 16 steps, doubling with every give-up, then try again --
+    and single launches must have been enqueued AFTER a give-up (the pause ends) while give-ups stay rare."""
     import threading
     n, m, rounds = 300_000, 24, 25
     d = 1.0 + np.arange(n) / n
@@ -390,8 +393,12 @@ def test_two_contexts_launching_persistent_kernels_at_once_never_hang_and_stay_c
             A = lk.diag_linop_gpu(d, ctx)
             X = lk.krylov_basis_gpu(n, m + 1, np.float64, ctx)
             start.wait(timeout=60)
+            after_first_give_up = None
             for _ in range(rounds):
-                ctx.set_tuning("resident", 1)
+                if rearm:
+                    ctx.set_tuning("resident", 1)
+                elif after_first_give_up is None and ctx.resident_stats()[1] > 0:
+                    after_first_give_up = ctx.resident_stats()[0]
                 X.upload(x0.reshape(-1, 1), 0)
                 H = np.zeros((m + 1, m), order="F")
                 assert lk.arnoldi(A, X, H) == 0
@@ -399,6 +406,9 @@ def test_two_contexts_launching_persistent_kernels_at_once_never_hang_and_stay_c
                     assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL * np.abs(Ho[:, j]).max(), (t, j)
             st = ctx.resident_stats()
             launched[t], gave_up[t] = st[0], st[1]
+            if not rearm and after_first_give_up is not None:
+                assert st[0] > after_first_give_up, "the single launch never came back after its pause"
+                assert st[1] <= 8, st                         # 16 + 32 + ... steps of pause: a handful of give-ups in 600 steps at most
             ctx.close()
         except BaseException as exc:  # noqa: BLE001
             errs.append(exc)
@@ -410,4 +420,4 @@ def test_two_contexts_launching_persistent_kernels_at_once_never_hang_and_stay_c
     assert not any(t.is_alive() for t in ts), "a worker is still running: a wait did not end"
     assert not errs, errs
     assert min(launched) > 0
-    print(f"\n  two contexts at once: single launches {launched}, gave up {gave_up}")
+    print(f"\n  two contexts at once ({'re-armed every round' if rearm else 'pause and retry'}): single launches {launched}, gave up {gave_up}")
