@@ -3543,7 +3543,10 @@ static int arnoldi_batch_async(lk_linop_t A, lk_basis_t X, int k0, int k1, doubl
             const bool single = resident_applies(X, k);
             // cache-resident panel: both passes, the normalise and the breakdown test in ONE launch (lk_resident.hip.h)
             if (single) rc = dgs_resident_launch(X, k, X->col(k), slot, rs, true, ATOL_DP, tol_break, c->stop_dev);
-            else rc = dgs_device(X, k, X->col(k), true, slot, rs);
+            else {
+                resident_note_fallback(X, k);
+                rc = dgs_device(X, k, X->col(k), true, slot, rs);
+            }
             if (rc != LK_OK) break;
             if (c->prof && c->span_first) {          // "dgs" = first sweep's start .. the end of the last reduction, no events of its own
                 ProfRec span;
