@@ -381,9 +381,12 @@ def double_gram_schmidt_step_block(Y: np.ndarray, X: np.ndarray):
     return M1 + M2, info
 
 
-def qr_no_pivoting(Q: np.ndarray, R: np.ndarray, tol: float = ATOL_DP, rand_seed: int = 12345) -> int:
+def qr_no_pivoting(Q: np.ndarray, R: np.ndarray, tol: float = ATOL_DP, rand_seed: int = 12345, column_seed=None) -> int:
     """In-place double-Gram-Schmidt QR of the columns of Q, R upper triangular.  qr.fypp:116-167 (a colinear column is replaced by
-    counter-RNG numbers -- the reference draws from the unseeded intrinsic generator there, :146-162)."""
+    counter-RNG numbers -- the reference draws from the unseeded intrinsic generator there, :146-162).
+    `column_seed(j)`: the counter stream of the re-draw of column j, filling the column AS STORED (complex: re, im interleaved) -- the
+    stream the engine uses for that column (lk_qr / lk_arnoldi_block: 0x5EED + panel column + 1), so that a colinear case can be compared
+    entry by entry; default: the streams rand_seed + j (real), rand_seed + 2j / + 2j + 1 (complex: re and im filled separately)."""
     info, flag = 0, False
     R[...] = 0
     for j in range(Q.shape[1]):
@@ -397,7 +400,11 @@ def qr_no_pivoting(Q: np.ndarray, R: np.ndarray, tol: float = ATOL_DP, rand_seed
             if not flag:
                 flag, info = True, j + 1
             R[j, j] = 0
-            if np.iscomplexobj(Q):
+            if column_seed is not None:
+                col = np.empty(Q.shape[0], dtype=Q.dtype)
+                fill_counter(col, int(column_seed(j)))
+                Q[:, j] = col
+            elif np.iscomplexobj(Q):
                 re, im = np.empty(Q.shape[0]), np.empty(Q.shape[0])
                 fill_counter(re, rand_seed + 2 * j); fill_counter(im, rand_seed + 2 * j + 1)
                 Q[:, j] = re + 1j * im
@@ -413,7 +420,7 @@ def qr_no_pivoting(Q: np.ndarray, R: np.ndarray, tol: float = ATOL_DP, rand_seed
 
 
 def arnoldi_block(A: _OpBase, X: np.ndarray, H: np.ndarray, blksize: int, kstart: int = 1, kend: int | None = None,
-                  tol: float = ATOL_DP) -> int:
+                  tol: float = ATOL_DP, engine_streams: bool = False) -> int:
     """arnoldi with blksize = p > 1.  src/Krylov/arnoldi.fypp:20-73: p matvecs (:39-47), the batch double Gram-Schmidt step with
     beta = H(:kp, kpm+1:kp) (:50-51), qr of the new block into H(kp+1:kpp, kpm+1:kp) (:55), breakdown on the smallest |diagonal| of
     that block (:58-71).  X: (n, (kdim+1) p) F-order, H: ((kdim+1) p, kdim p) F-order."""
@@ -428,7 +435,8 @@ def arnoldi_block(A: _OpBase, X: np.ndarray, H: np.ndarray, blksize: int, kstart
         beta, _ = double_gram_schmidt_step_block(X[:, kp:kpp], X[:, :kp])
         H[:kp, kpm:kp] = beta
         R = np.zeros((p, p), dtype=X.dtype, order="F")
-        qr_no_pivoting(X[:, kp:kpp], R)
+        # engine_streams: colinear columns are re-drawn from the counter streams lk_arnoldi_block uses (0x5EED + basis column + 1)
+        qr_no_pivoting(X[:, kp:kpp], R, column_seed=(lambda j, kp=kp: 0x5EED + kp + j + 1) if engine_streams else None)
         H[kp:kpp, kpm:kp] = R
         if np.min(np.abs(np.diag(R))) < tol:
             info = kp

@@ -142,6 +142,16 @@ def test_breakdown_inside_a_block_stops_the_batch_and_the_host_finishes_the_bloc
         info = lk.arnoldi(lk.dense_linop_gpu(A, ctx), X, H, blksize=p, tol=1e-10)
         out[asynchronous] = (info, H, X.download())
     info, H, Xg = out[1]
+    # the oracle with the engine's re-draw streams: the WHOLE result -- the re-drawn column, the R entries behind it -- entry by entry
+    Xo = np.zeros((n, ncol), dtype=dtype, order="F")
+    Xo[:, :p] = Q0
+    Ho = np.zeros((ncol, kdim * p), dtype=dtype, order="F")
+    info_o = ora.arnoldi_block(ora.DenseOp(A), Xo, Ho, p, tol=1e-10, engine_streams=True)
+    assert info_o == info
+    for j in range(2 * p):
+        # (the colinear column's own norm before the re-draw is rounding noise on both sides: its R(j, j) is set to 0 by both)
+        assert np.abs(H[:, j] - Ho[:, j]).max() <= RTOL * np.abs(Ho[:, j]).max(), j
+    assert np.abs(Xg[:, :3 * p] - Xo[:, :3 * p]).max() <= 1e-10
     # X(:, :2) = Q0; step 1 adds two directions of range(A); step 2 can add only the third: info = 2 p
     assert info == out[0][0] == 2 * p
     assert np.array_equal(H, out[0][1]) and np.array_equal(Xg, out[0][2])
