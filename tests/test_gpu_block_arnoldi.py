@@ -192,6 +192,13 @@ def test_qr_engine_call_against_oracle_including_colinear_columns(bctx, dtype):
     R[...] = 0
     _capi.check(lib.lk_qr(B._h, 2, p, R.ctypes.data_as(C.POINTER(C.c_double)), p, 1e-10, C.byref(info)))
     assert info.value == 4 and R[3, 3] == 0 and R[5, 5] == 0
+    # ... and entry by entry against the oracle drawing from the engine's streams (0x5EED + panel column + 1; the block starts at column 2)
+    Yo2 = Y2.copy(order="F")
+    Ro2 = np.zeros((p, p), dtype=dtype, order="F")
+    assert ora.qr_no_pivoting(Yo2, Ro2, tol=1e-10, column_seed=lambda j: 0x5EED + 2 + j + 1) == 4
+    for j in range(p):
+        assert np.abs(R[:, j] - Ro2[:, j]).max() <= RTOL * max(np.abs(Ro2[:, j]).max(), np.linalg.norm(Y2[:, j])), j
+    assert np.abs(B.download(2, p) - Yo2).max() <= 1e-10
     Qg = B.download(2, p)
     assert np.abs(Qg.conj().T @ Qg - np.eye(p)).max() <= 1e-12
     keep = [j for j in range(p) if j not in (3, 5)]

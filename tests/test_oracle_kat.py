@@ -171,3 +171,33 @@ def test_dgs_matches_two_projections_and_reports_zero_vector():
     z = np.zeros(N)
     _, info = ora.double_gram_schmidt_step(z, Q)
     assert info == 1
+
+
+def test_qr_no_pivoting_with_engine_streams_for_colinear_columns():
+    """qr.fypp:146-162: a colinear column is re-drawn, orthogonalised against the columns before it and normalised.  With `column_seed`
+    the oracle draws from the counter stream the engine uses for that column, so GPU tests can compare the re-drawn columns entry by
+    entry; here: the factorisation still holds on the independent columns, Q comes out orthonormal, R(j, j) = 0 marks the re-draws,
+    `info` is the first of them, and the default streams give the same R on the independent columns (both kinds)."""
+    import numpy as np
+    from oracle import oracle as ora
+    for dtype in (np.float64, np.complex128):
+        n, p = 257, 6
+        Y = np.empty((n, p), dtype=dtype, order="F")
+        for j in range(p):
+            ora.fill_counter(Y[:, j], 40 + j)
+        Y[:, 2] = 3.0 * Y[:, 0]
+        Y[:, 4] = Y[:, 1] - Y[:, 3]
+        Q, R = Y.copy(order="F"), np.zeros((p, p), dtype=dtype, order="F")
+        assert ora.qr_no_pivoting(Q, R, tol=1e-10, column_seed=lambda j: 0x5EED + j + 1) == 3
+        assert R[2, 2] == 0 and R[4, 4] == 0
+        assert np.abs(Q.conj().T @ Q - np.eye(p)).max() <= 1e-12
+        keep = [0, 1, 3, 5]
+        assert np.abs(Y[:, keep] - Q @ R[:, keep]).max() <= 1e-12 * np.abs(Y).max() * p
+        col = np.empty(n, dtype=dtype)
+        ora.fill_counter(col, 0x5EED + 2 + 1)                       # the raw re-draw of column 2 ...
+        h = Q[:, :2].conj().T @ col                                 # ... orthogonalised against columns 0, 1 and normalised is Q(:, 2)
+        w = col - Q[:, :2] @ h
+        assert np.abs(Q[:, 2] - w / np.linalg.norm(w)).max() <= 1e-12
+        Q2, R2 = Y.copy(order="F"), np.zeros((p, p), dtype=dtype, order="F")
+        assert ora.qr_no_pivoting(Q2, R2, tol=1e-10) == 3
+        assert np.array_equal(R2[:, :2], R[:, :2])                  # (columns in front of the first re-draw do not depend on the stream)
