@@ -90,6 +90,7 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
+    int gram_rs = 0;           // real Gram matrix of 33..128 columns by panel_gram_rs (rows of the staged tile dealt to the waves): 0 = off, 1 = resident blocks per CU, else blocks per CU
     int gram_cyc4 = 3;         // real Gram matrix of 49..64 columns by panel_gram_cyc4 (cyclic deal, four column blocks x two row halves; n = 10^7, k = 64: 1.57 -> 1.11 ms):
                                // value = blocks per CU in the grid (three are resident); 0 = panel_gram_mfma
     int gram_cyc = 2;          // real Gram matrix of 113..128 columns by panel_gram_cyc (cyclic tile deal: every wave the same straight-line code; two tile buffers, loads two tiles ahead;
@@ -789,6 +790,50 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         HIPCHK(hipGetLastError());
         if (out_dev) *out_dev = out3;
         return allreduce(c, out3, nslots);
+    }
+    // real Gram matrix of 33..128 columns: the rows of the staged tile dealt to the waves (panel_gram_rs, round 6)
+    if (!cp && !small && flags == 3 && k > 32 && k <= 128 && c->gram_rs > 0 && Bx->n >= 2) {           // (its clamped loads want two rows)
+        const int minb = KP == 3 ? 4 : (KP == 4 ? 3 : (KP <= 6 ? 2 : 1));                                // resident blocks per CU (LDS ring, registers)
+        const int nbuf = KP <= 6 ? 3 : 4;
+        const int64_t nt32 = (Bx->n + 31) / 32;
+        int64_t gg = (int64_t)c->num_cu * (c->gram_rs == 1 ? minb : c->gram_rs);
+        if (gg > nt32) gg = nt32;
+        if (gg < 1) gg = 1;
+        int64_t needg = 2 * sect + npart_n + gg * nslots;
+        if (c->xhy_n < needg && !may_grow)
+            return fail(LK_ERR_INVALID, "internal: xhy workspace too small (%lld < %lld)", (long long)c->xhy_n, (long long)needg);
+        if (c->xhy_n < needg) {
+            const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
+            if (needg < fused) needg = fused;
+            if (c->xhy) HIPCHK(hipFree(c->xhy));
+            c->xhy = nullptr;
+            c->xhy_n = 0;
+            HIPCHK(hipMalloc((void **)&c->xhy, (size_t)needg * sizeof(double)));
+            c->xhy_n = needg;
+        }
+        double *outg = c->xhy + (int64_t)slot * XHY_SLOT, *npartg = c->xhy + 2 * sect, *partg = npartg + npart_n;
+        const size_t ldsg = (size_t)nbuf * KP * 4096;
+        {
+            ProfScope ps(c, "xhy_mfma", (double)Bx->n * 8.0 * k);
+            auto go = [&](auto kern) -> int {
+                if (ldsg > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
+                hipLaunchKernelGGL(kern, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
+                return LK_OK;
+            };
+            switch (KP) {
+            case 3: LKCHK(go(&panel_gram_rs<3, 3, 8>)); break;
+            case 4: LKCHK(go(&panel_gram_rs<4, 3, 6>)); break;
+            case 5: LKCHK(go(&panel_gram_rs<5, 3, 4>)); break;
+            case 6: LKCHK(go(&panel_gram_rs<6, 3, 4>)); break;
+            case 7: LKCHK(go(&panel_gram_rs<7, 4, 2>)); break;
+            default: LKCHK(go(&panel_gram_rs<8, 4, 2>)); break;
+            }
+        }
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, partg, (int)gg, npartg, (int)gg, k, p, ED, flags, outg);
+        HIPCHK(hipGetLastError());
+        if (out_dev) *out_dev = outg;
+        return allreduce(c, outg, nslots);
     }
     // real Gram matrix of 49..64 columns: the cyclic deal on four column blocks x two row halves (panel_gram_cyc4, round 5)
     if (!cp && !small && flags == 3 && k > 48 && k <= 64 && c->gram_cyc4 > 0 && Bx->n >= 2) {
@@ -1704,6 +1749,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "gram_rs")) { c->gram_rs = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
     if (!strcmp(key, "gram_cyc4")) { c->gram_cyc4 = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
     if (!strcmp(key, "gram_cyc")) { c->gram_cyc = value < 0 ? 0 : (value > 8 ? 8 : value); return LK_OK; }
 #ifdef LK_DIAGNOSTICS

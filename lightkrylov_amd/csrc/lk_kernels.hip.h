@@ -11,6 +11,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 namespace lk {
 
@@ -2297,6 +2298,149 @@ __global__ __launch_bounds__(512, 4) void panel_gram_cyc4(const double *__restri
         const int j = e >> 6, i = e & 63;                               // slot (row i, column j) with tile(i) <= tile(j)
         if ((i >> 4) <= (j >> 4) && i < k && j < k) pb[(int64_t)j * (k + 1) + i] = Gs[j * 65 + i];
     }
+}
+
+// Gram matrix G = X^T X of a REAL basis of 33..128 columns: ROW-SPLIT deal, tiles staged by LDS-DMA (round 6; gram_matrix, AbstractVectors.fypp:645-657).
+// The cyclic deals above give a wave a few tiles on every row step -- one LDS operand read per MFMA -- and only 4 and 8 column blocks divide the eight waves; their
+// staging goes through registers (two sets of loads in flight per thread, written to LDS by the thread).  Here
+//  * the ROWS of the staged 32-row tile are dealt: wave w takes the row steps 2 (w & 3), 2 (w & 3) + 1 (eight rows) for HALF of the upper-tile list (waves 0-3 the first
+//    half, waves 4-7 the second: waves w and w + 4 share a SIMD, so every SIMD runs the same number of MFMAs whatever the split).  A wave reads each of its column
+//    blocks ONCE per row step and feeds all its tiles from those registers -- KP reads per ceil(KP (KP + 1) / 4) MFMAs (k = 96: 6 per 10.5 instead of 10 per 9) -- in
+//    straight-line code (the tile list is a compile-time constant) for ANY number of column blocks KP = 3..8; accumulators: 8 ceil(KP (KP + 1) / 4) registers;
+//  * the tile goes from global memory STRAIGHT into LDS (global_load_lds_dwordx4: no staging registers, no LDS writes by the waves) into a ring of NBUF buffers, the
+//    loads NBUF - 1 tiles ahead of the MFMAs, one raw barrier per tile behind a COUNTED vmcnt wait (only the oldest tile's loads are waited for).  A DMA writes the
+//    64 lanes' 16-byte chunks to consecutive LDS addresses, so the tile image is unpadded (column = 256 B = 16 chunks) with chunk c of column j at position
+//    c ^ (j & 15) -- the permutation is applied to the SOURCE address of the load and again by the operand read, whose 32 lanes of a half-wave then hit 32 different
+//    bank pairs.  Columns beyond k load column k - 1 (their entries of G are never stored); the ragged last tile (n mod 32 rows) is staged by ordinary loads, zero
+//    filled, by the block whose turn it is, after its loop.
+// A tile of G is held in four row pieces by the waves of a group: they meet in LDS at the end, one wave after the other in a fixed order.
+// Results: partial[block][slot] as panel_gram_mfma.
+template <int KP> struct GramRowSplit {
+    static constexpr int NT = KP * (KP + 1) / 2, N0 = (NT + 1) / 2, N1 = NT - N0;
+    static constexpr int tile_i(int idx) { int I = 0, rem = idx; while (rem >= KP - I) { rem -= KP - I; ++I; } return I; }
+    static constexpr int tile_j(int idx) { int I = 0, rem = idx; while (rem >= KP - I) { rem -= KP - I; ++I; } return I + rem; }
+};
+template <int KP, int FIRST, int... Q>
+__device__ __forceinline__ void gram_rs_step(const double (&r)[KP], v4d (&acc)[GramRowSplit<KP>::N0], std::integer_sequence<int, Q...>) {
+    using D = GramRowSplit<KP>;
+    // (integral_constant: the tile coordinates must be constants BEFORE the optimiser runs, or r[] is indexed at run time -- through scratch)
+    ((acc[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(r[std::integral_constant<int, D::tile_i(FIRST + Q)>::value],
+                                                    r[std::integral_constant<int, D::tile_j(FIRST + Q)>::value], acc[Q], 0, 0, 0)), ...);
+}
+template <int KP, int FIRST, int... Q>
+__device__ __forceinline__ void gram_rs_store(double *pb, int k, int arow, int acol, const v4d (&acc)[GramRowSplit<KP>::N0], std::integer_sequence<int, Q...>) {
+    using D = GramRowSplit<KP>;
+    auto one = [&](int I, int J, const v4d &a) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + arow + 4 * r, j = 16 * J + acol;
+            if (i < k && j < k) pb[(int64_t)j * (k + 1) + i] = a[r];
+        }
+    };
+    (one(std::integral_constant<int, D::tile_i(FIRST + Q)>::value, std::integral_constant<int, D::tile_j(FIRST + Q)>::value, acc[Q]), ...);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int KP, int NBUF, int WPE>
+__global__ __launch_bounds__(512, WPE) void panel_gram_rs(const double *__restrict__ X, int64_t ldx, int k, int64_t n, double *__restrict__ partial) {
+    using D = GramRowSplit<KP>;
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+    constexpr int BUFB = KP * 4096, FULL = KP / 2, ODD = KP & 1;             // bytes per tile buffer; FULL block-wide passes of 16-byte chunks, and half a pass (waves 0-3)
+    extern __shared__ __attribute__((aligned(16))) double grs_lds[];           // (the ONLY LDS object of the kernel: a second one costs a vmcnt(0) in front of the operand reads)
+    char *lds = reinterpret_cast<char *>(grs_lds);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int arow = lane >> 4, acol = lane & 15;
+    const int grp = wave >> 2, ws = wave & 3;
+    const int64_t nfull = n / 32, G = gridDim.x;
+    int oa[2];                                                                 // byte offsets of this lane's operand in column block 0 on the wave's two row steps
+#pragma unroll
+    for (int e = 0; e < 2; ++e) oa[e] = acol * 256 + (((2 * (2 * ws + e) + (arow >> 1)) ^ acol) << 4) + (arow & 1) * 8;
+    const int pcol = t >> 4, plog = (t & 15) ^ (pcol & 15);                    // the column (of a pass) and the LOGICAL chunk whose data lands at this thread's position
+    v4d acc[D::N0];
+#pragma unroll
+    for (int q = 0; q < D::N0; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    auto run = [&](auto first, auto seq) {
+        constexpr int FIRST = decltype(first)::value;
+        constexpr int LPT = FULL + ((ODD && FIRST == 0) ? 1 : 0);             // DMA instructions per tile of this wave
+        auto issue = [&](int64_t Tc, int buf) {                               // tile Tc (a full one) into buffer buf
+            const double *src = X + 32 * Tc + 2 * plog;
+            char *dst = lds + buf * BUFB + 1024 * wave;
+#pragma unroll
+            for (int s = 0; s < LPT; ++s) {
+                const int col = pcol + 32 * s, colc = col < k ? col : k - 1;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (int64_t)colc * ldx), (lds_ptr_t)(dst + 8192 * s), 16, 0, 0);
+            }
+        };
+        auto steps = [&](const char *Xb) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                double r[KP];
+#pragma unroll
+                for (int b = 0; b < KP; ++b) r[b] = *reinterpret_cast<const double *>(Xb + oa[e] + 4096 * b);   // (the blocks a group never uses are dropped)
+                gram_rs_step<KP, FIRST>(r, acc, seq);
+            }
+        };
+        int64_t T = blockIdx.x;
+        if (T < nfull) {
+#pragma unroll
+            for (int j = 0; j < NBUF - 1; ++j) issue(T + j * G < nfull ? T + j * G : T, j);
+            int buf = 0;
+            for (; T < nfull; T += G) {
+                wait_vmcnt<(NBUF - 2) * LPT>();                               // this wave's loads of tile T have landed ...
+                __builtin_amdgcn_s_barrier();                                 // ... everybody's have, and buffer buf - 1 has been read by all
+                const int64_t Tl = T + (NBUF - 1) * G;
+                issue(Tl < nfull ? Tl : T, buf == 0 ? NBUF - 1 : buf - 1);    // (beyond the panel: a tile that is never read, so that the count above holds)
+                steps(lds + buf * BUFB);
+                buf = buf + 1 == NBUF ? 0 : buf + 1;
+            }
+            wait_vmcnt<0>();
+        }
+        __syncthreads();
+        if ((n & 31) != 0 && (int64_t)blockIdx.x == nfull % G) {              // the ragged tile: ordinary loads, zero filled, into buffer 0 in the same image
+            for (int p = t; p < KP * 256; p += 512) {
+                const int col = p >> 4, lg = (p & 15) ^ (col & 15);
+                const int64_t r0 = 32 * nfull + 2 * lg;
+                v2d v = v2d{0.0, 0.0};
+                if (col < k) {
+                    if (r0 < n) v.x = X[(int64_t)col * ldx + r0];
+                    if (r0 + 1 < n) v.y = X[(int64_t)col * ldx + r0 + 1];
+                }
+                *reinterpret_cast<v2d *>(lds + 16 * p) = v;
+            }
+            __syncthreads();
+            steps(lds);
+        }
+    };
+    // (each group runs its own copy of the whole loop: with the branch inside it the accumulators of the two paths are different values to the register
+    //  allocator, which copies them back and forth and spills)
+    if (grp == 0) run(std::integral_constant<int, 0>{}, std::make_integer_sequence<int, D::N0>{});
+    else run(std::integral_constant<int, D::N0>{}, std::make_integer_sequence<int, D::N1>{});
+    __syncthreads();
+    // the four row pieces of every tile meet in the wave with ws = 0 of each group: waves 1, 2, 3, then 5, 6, 7 hand theirs over through LDS (N0 tiles of 256 doubles
+    // fit the first buffer), one after the other
+    double *Xt = grs_lds;
+    for (int w = 1; w < 8; ++w) {
+        if ((w & 3) == 0) continue;
+        if (wave == w) {
+#pragma unroll
+            for (int q = 0; q < D::N0; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xt[q * 256 + r * 64 + lane] = acc[q][r];
+        }
+        __syncthreads();
+        if (wave == (w & 4)) {
+#pragma unroll
+            for (int q = 0; q < D::N0; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][r] += Xt[q * 256 + r * 64 + lane];
+        }
+        __syncthreads();
+    }
+    double *pb = partial + (int64_t)blockIdx.x * ((int64_t)k * (k + 1));
+    if (wave == 0) gram_rs_store<KP, 0>(pb, k, arow, acol, acc, std::make_integer_sequence<int, D::N0>{});
+    if (wave == 4) gram_rs_store<KP, D::N0>(pb, k, arow, acol, acc, std::make_integer_sequence<int, D::N1>{});
 }
 
 // Pass B of the block Gram-Schmidt with many right-hand sides, FUSED on the matrix cores (gram_schmidt.fypp:59-105):
