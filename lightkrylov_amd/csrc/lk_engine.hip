@@ -90,11 +90,8 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
-    int gram_rs = 0;           // real Gram matrix of 33..128 columns by panel_gram_rs (rows of the staged tile dealt to the waves): 0 = off, 1 = resident blocks per CU, else blocks per CU
-    int gram_cyc4 = 3;         // real Gram matrix of 49..64 columns by panel_gram_cyc4 (cyclic deal, four column blocks x two row halves; n = 10^7, k = 64: 1.57 -> 1.11 ms):
-                               // value = blocks per CU in the grid (three are resident); 0 = panel_gram_mfma
-    int gram_cyc = 2;          // real Gram matrix of 113..128 columns by panel_gram_cyc (cyclic tile deal: every wave the same straight-line code; two tile buffers, loads two tiles ahead;
-                               // n = 10^7, k = 128: 4.22 -> 3.83 ms): value = blocks per CU in the grid (two are resident); 0 = panel_xhy_mfma
+    int gram_rs = 1;           // real Gram matrix of 33..128 columns by panel_gram_rs (rows of the staged tile dealt to the waves, LDS-DMA staging; n = 10^7: k = 48 1.11 -> 0.63 ms,
+                               // k = 96 2.81 -> 1.80, k = 128 3.45 -> 3.0): 1 = as many blocks per CU as are resident, n > 1 = n blocks per CU, 0 = panel_xhy_mfma (one tile row per wave)
     int upd_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
     int xhy_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
     int gemm_roll = 1;         // MFMA tall-skinny product: rolling prefetch of X (a ring of 4 k-steps refilled as they are consumed, carried across tiles) instead of batches of 4
@@ -102,9 +99,6 @@ struct lk_context_s {
                                // exact vmcnt counts; k = 128, q = 64 at n = 10^7: 3.45-3.73 -> 3.16-3.24 ms); 2: every variant that has a ring (the narrow real ones measure the same
                                // as the batch schedule, the complex doubled-real ones keep the guarded ring, +2-5 % on narrow products); 0: never (profiles/r05_ab_gemm_roll.jsonl)
     int xhy_db = 1;            // panel_xhy_mfma with a double-buffered LDS tile (1: the 128-column variants; 2: the <= 32 right-hand-side ones too; 0: never)
-    int gram_tiles = 1;        // real Gram matrix by panel_gram_mfma (upper tiles dealt to the waves, 32-row tiles): 1 = for 33..64 columns (measured: 1.80 / 1.38 ms
-                               // at k = 64 / 48, n = 10^7, against 1.90 / 1.60; slower beyond -- 4.6 vs 4.1 ms at k = 128), 2 = up to 128, 0 = never (panel_xhy_mfma<false, 8, 64>)
-    int gram_grid_mult = 2;    // ... its blocks per CU (two are resident: 87 VGPRs)
     int gemm_3m = 1;           // complex MFMA kernels (tall-skinny product; X^H Y with <= 32 right-hand sides; Gram) with three real products per complex one (0: four, the doubled real problem)
     int kc32 = -1;             // real DGS update sweeps (2 and 3) of k > kc32 (<= 128) columns on 32-column register tiles (0: never; -1: k > 32 when the GLOBAL problem has >= 2^25 rows)
     int wide_s3 = 1;           // sweep 3 of a lane-split (SC = 2) DGS with both column groups of a wave-column in one wave's registers (G = 2), tiles twice as tall
@@ -791,12 +785,12 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         if (out_dev) *out_dev = out3;
         return allreduce(c, out3, nslots);
     }
-    // real Gram matrix of 33..128 columns: the rows of the staged tile dealt to the waves (panel_gram_rs, round 6)
-    if (!cp && !small && flags == 3 && k > 32 && k <= 128 && c->gram_rs > 0 && Bx->n >= 2) {           // (its clamped loads want two rows)
-        const int minb = KP == 3 ? 4 : (KP == 4 ? 3 : (KP <= 6 ? 2 : 1));                                // resident blocks per CU (LDS ring, registers)
+    // real Gram matrix of 33..128 columns: the rows of the staged tile dealt to the waves, tiles staged by LDS-DMA (panel_gram_rs, round 6)
+    if (!cp && !small && flags == 3 && k > 32 && k <= 128 && c->gram_rs > 0) {
+        const int resident = KP == 3 ? 4 : (KP == 4 ? 3 : (KP <= 6 ? 2 : 1));                    // blocks per CU (LDS ring; beyond 96 columns the accumulators)
         const int nbuf = KP <= 6 ? 3 : 4;
         const int64_t nt32 = (Bx->n + 31) / 32;
-        int64_t gg = (int64_t)c->num_cu * (c->gram_rs == 1 ? minb : c->gram_rs);
+        int64_t gg = (int64_t)c->num_cu * (c->gram_rs == 1 ? resident : c->gram_rs);
         if (gg > nt32) gg = nt32;
         if (gg < 1) gg = 1;
         int64_t needg = 2 * sect + npart_n + gg * nslots;
@@ -820,7 +814,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
                 hipLaunchKernelGGL(kern, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
                 return LK_OK;
             };
-            switch (KP) {
+            switch (KP) {                                                                       // <column blocks, ring buffers, waves per SIMD>
             case 3: LKCHK(go(&panel_gram_rs<3, 3, 8>)); break;
             case 4: LKCHK(go(&panel_gram_rs<4, 3, 6>)); break;
             case 5: LKCHK(go(&panel_gram_rs<5, 3, 4>)); break;
@@ -828,97 +822,6 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
             case 7: LKCHK(go(&panel_gram_rs<7, 4, 2>)); break;
             default: LKCHK(go(&panel_gram_rs<8, 4, 2>)); break;
             }
-        }
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, partg, (int)gg, npartg, (int)gg, k, p, ED, flags, outg);
-        HIPCHK(hipGetLastError());
-        if (out_dev) *out_dev = outg;
-        return allreduce(c, outg, nslots);
-    }
-    // real Gram matrix of 49..64 columns: the cyclic deal on four column blocks x two row halves (panel_gram_cyc4, round 5)
-    if (!cp && !small && flags == 3 && k > 48 && k <= 64 && c->gram_cyc4 > 0 && Bx->n >= 2) {
-        const int64_t nt32 = (Bx->n + 31) / 32;
-        int64_t gg = (int64_t)c->num_cu * c->gram_cyc4;
-        if (gg > nt32) gg = nt32;
-        if (gg < 1) gg = 1;
-        int64_t needg = 2 * sect + npart_n + gg * nslots;
-        if (c->xhy_n < needg && !may_grow)
-            return fail(LK_ERR_INVALID, "internal: xhy workspace too small (%lld < %lld)", (long long)c->xhy_n, (long long)needg);
-        if (c->xhy_n < needg) {
-            const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
-            if (needg < fused) needg = fused;
-            if (c->xhy) HIPCHK(hipFree(c->xhy));
-            c->xhy = nullptr;
-            c->xhy_n = 0;
-            HIPCHK(hipMalloc((void **)&c->xhy, (size_t)needg * sizeof(double)));
-            c->xhy_n = needg;
-        }
-        double *outg = c->xhy + (int64_t)slot * XHY_SLOT, *npartg = c->xhy + 2 * sect, *partg = npartg + npart_n;
-        const size_t ldsg = (size_t)2 * 64 * 34 * sizeof(double);
-        {
-            ProfScope ps(c, "xhy_mfma", (double)Bx->n * 8.0 * k);
-            hipLaunchKernelGGL(panel_gram_cyc4, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
-        }
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, partg, (int)gg, npartg, (int)gg, k, p, ED, flags, outg);
-        HIPCHK(hipGetLastError());
-        if (out_dev) *out_dev = outg;
-        return allreduce(c, outg, nslots);
-    }
-    // real Gram matrix of 113..128 columns: upper tiles dealt cyclically, every wave the same straight-line code (panel_gram_cyc, round 5)
-    if (!cp && !small && flags == 3 && k > 112 && k <= 128 && c->gram_cyc > 0 && Bx->n >= 2) {          // (its clamped loads want two rows)
-        const int64_t nt32 = (Bx->n + 31) / 32;
-        int64_t gg = (int64_t)c->num_cu * c->gram_cyc;
-        if (gg > nt32) gg = nt32;
-        if (gg < 1) gg = 1;
-        int64_t needg = 2 * sect + npart_n + gg * nslots;
-        if (c->xhy_n < needg && !may_grow)
-            return fail(LK_ERR_INVALID, "internal: xhy workspace too small (%lld < %lld)", (long long)c->xhy_n, (long long)needg);
-        if (c->xhy_n < needg) {
-            const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
-            if (needg < fused) needg = fused;
-            if (c->xhy) HIPCHK(hipFree(c->xhy));
-            c->xhy = nullptr;
-            c->xhy_n = 0;
-            HIPCHK(hipMalloc((void **)&c->xhy, (size_t)needg * sizeof(double)));
-            c->xhy_n = needg;
-        }
-        double *outg = c->xhy + (int64_t)slot * XHY_SLOT, *npartg = c->xhy + 2 * sect, *partg = npartg + npart_n;
-        const size_t ldsg = (size_t)2 * 128 * 34 * sizeof(double);
-        {
-            ProfScope ps(c, "xhy_mfma", (double)Bx->n * 8.0 * k);
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&panel_gram_cyc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
-            hipLaunchKernelGGL(panel_gram_cyc, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg, c->xhy_debug);
-        }
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, partg, (int)gg, npartg, (int)gg, k, p, ED, flags, outg);
-        HIPCHK(hipGetLastError());
-        if (out_dev) *out_dev = outg;
-        return allreduce(c, outg, nslots);
-    }
-    // real Gram matrix beyond 32 columns: upper tiles dealt to the waves in runs, 32-row tiles, three blocks per CU (panel_gram_mfma, round 5)
-    if (!cp && !small && flags == 3 && (c->gram_tiles == 2 || (c->gram_tiles == 1 && k <= 64))) {
-        const int64_t nt32 = (Bx->n + 31) / 32;
-        int64_t gg = (int64_t)c->num_cu * c->gram_grid_mult;
-        if (gg > nt32) gg = nt32;
-        if (gg < 1) gg = 1;
-        int64_t needg = 2 * sect + npart_n + gg * nslots;
-        if (c->xhy_n < needg && !may_grow)
-            return fail(LK_ERR_INVALID, "internal: xhy workspace too small (%lld < %lld)", (long long)c->xhy_n, (long long)needg);
-        if (c->xhy_n < needg) {
-            const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
-            if (needg < fused) needg = fused;
-            if (c->xhy) HIPCHK(hipFree(c->xhy));
-            c->xhy = nullptr;
-            c->xhy_n = 0;
-            HIPCHK(hipMalloc((void **)&c->xhy, (size_t)needg * sizeof(double)));
-            c->xhy_n = needg;
-        }
-        double *outg = c->xhy + (int64_t)slot * XHY_SLOT, *npartg = c->xhy + 2 * sect, *partg = npartg + npart_n;
-        const size_t ldsg = (size_t)KP * 16 * 34 * sizeof(double);
-        {
-            ProfScope ps(c, "xhy_mfma", (double)Bx->n * 8.0 * k);
-            hipLaunchKernelGGL(panel_gram_mfma, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
         }
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, partg, (int)gg, npartg, (int)gg, k, p, ED, flags, outg);
@@ -1750,8 +1653,6 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "gram_rs")) { c->gram_rs = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
-    if (!strcmp(key, "gram_cyc4")) { c->gram_cyc4 = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
-    if (!strcmp(key, "gram_cyc")) { c->gram_cyc = value < 0 ? 0 : (value > 8 ? 8 : value); return LK_OK; }
 #ifdef LK_DIAGNOSTICS
     // phase-timing switches that turn parts of a kernel OFF (wrong results): only in a build made with -DLK_DIAGNOSTICS (make diagnostics), never
     // in the library build() produces
@@ -1759,8 +1660,6 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     if (!strcmp(key, "xhy_debug")) { c->xhy_debug = value & 3; return LK_OK; }
 #endif
     if (!strcmp(key, "gemm_roll")) { c->gemm_roll = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
-    if (!strcmp(key, "gram_tiles")) { c->gram_tiles = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
-    if (!strcmp(key, "gram_grid_mult")) { c->gram_grid_mult = value < 1 ? 1 : (value > 8 ? 8 : value); return LK_OK; }
     if (!strcmp(key, "wide_s3")) { c->wide_s3 = value ? 1 : 0; return LK_OK; }
     if (!strcmp(key, "wide_regs")) { c->wide_regs = value < 0 ? 0 : (value > 2 ? 2 : value); return LK_OK; }
     if (!strcmp(key, "async_arnoldi")) { c->async_arnoldi = value != 0; return LK_OK; }

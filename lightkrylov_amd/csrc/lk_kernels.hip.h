@@ -1941,365 +1941,6 @@ __global__ __launch_bounds__(512) void panel_gram_mfma3m(const double *__restric
     }
 }
 
-// Gram matrix G = X^T X of a REAL basis (33 <= k <= 128 columns), upper tiles only (round 5; gram_matrix, AbstractVectors.fypp:645-657).
-// panel_xhy_mfma<false, 8, 64> with flags = 3 gives every wave one tile ROW and keeps the accumulators of all 8 tiles of that row plus
-// sixteen staged 16-byte chunks in registers: 215 VGPRs, ONE 8-wave block per CU, whose two barriers and LDS staging per tile nothing
-// covers (4.1 ms at n = 10^7, k = 128: 45 TFLOP/s on the 1.84 10^11 flop of the 36 upper tiles).  Here the KP (KP + 1) / 2 upper tiles
-// (I <= J, row-major) are dealt to the 8 waves in CONTIGUOUS runs -- 36 tiles at k = 128: five for waves 0-3, four for waves 4-7, nine per
-// SIMD (waves w and w + 4 share one) -- so a wave holds at most five accumulators (20 registers) and mostly re-uses the A operand
-// from one tile to the next (same tile row); tiles are 32 rows (35 KB of LDS at k = 128) and four staged chunks per thread, so THREE
-// blocks share a CU and one block's staging and barriers run under the others' MFMAs.  Operand reads as panel_xhy_mfma (column
-// stride 34 words: conflict free); the next tile's loads are in flight while the current tile's MFMAs run.
-// Results: partial[block][slot], slot = j (k + 1) + i for i in tile row I, j in tile column J >= I -- panel_xhy_mfma's layout with
-// flags = 3 (Y is X, upper tiles only), summed by finish_xhy; no norm slots.
-__global__ __launch_bounds__(512) void panel_gram_mfma(const double *__restrict__ X, int64_t ldx, int k, int64_t n,
-                                                       double *__restrict__ partial) {
-    constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = 512 / CH, NXP = 128 / CPP;      // 32 columns staged per block-wide pass
-    constexpr int MAXT = 5;                                                                        // ceil(36 / 8) tiles per wave
-    extern __shared__ __attribute__((aligned(16))) double gr_lds[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int KP = (k + 15) >> 4, KS = (k + CPP - 1) / CPP;
-    double *Xt = gr_lds;
-    const int64_t ntiles = (n + TR - 1) / TR;
-    const int arow = lane >> 4, acol = lane & 15;
-
-    // this wave's run of upper tiles (row-major order (0,0), (0,1), ..., (0,KP-1), (1,1), ...)
-    int tI[MAXT], tJ[MAXT], nt;
-    {
-        const int ntot = KP * (KP + 1) / 2, base = ntot >> 3, rem = ntot & 7;
-        nt = base + (wave < rem ? 1 : 0);
-        const int first = wave * base + (wave < rem ? wave : rem);
-        int idx = 0, got = 0;
-        for (int q = 0; q < MAXT; ++q) { tI[q] = 0; tJ[q] = 0; }
-        for (int I = 0; I < KP; ++I)
-            for (int J = I; J < KP; ++J, ++idx)
-                if (idx >= first && got < nt) {
-#pragma unroll
-                    for (int q = 0; q < MAXT; ++q)
-                        if (q == got) { tI[q] = I; tJ[q] = J; }
-                    ++got;
-                }
-    }
-
-    v4d acc[MAXT];
-#pragma unroll
-    for (int q = 0; q < MAXT; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
-    v2d xs[NXP];
-
-    auto gload = [&](int64_t T) {
-        const int64_t rbase = T * TR;
-#pragma unroll
-        for (int s = 0; s < NXP; ++s) {
-            xs[s] = v2d{0.0, 0.0};
-            if (s < KS) {
-                const int c = t + 512 * s, col = c >> CHS;
-                const int64_t rr = rbase + 2 * (c & (CH - 1));
-                if (col < k) {
-                    const double *pc = X + (int64_t)col * ldx;
-                    if (rr + 1 < n) xs[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(pc + rr));
-                    else if (rr < n) xs[s].x = pc[rr];
-                }
-            }
-        }
-    };
-
-    int64_t T = blockIdx.x;
-    if (T < ntiles) gload(T);
-    for (; T < ntiles; T += gridDim.x) {
-        __syncthreads();                                            // the previous tile's operands have been read
-#pragma unroll
-        for (int s = 0; s < NXP; ++s)
-            if (s < KS) {
-                const int c = t + 512 * s;
-                if ((c >> CHS) < KP * 16) *reinterpret_cast<v2d *>(Xt + (c >> CHS) * S + 2 * (c & (CH - 1))) = xs[s];
-            }
-        __syncthreads();
-        if (T + gridDim.x < ntiles) gload(T + gridDim.x);           // in flight while this tile's MFMAs run
-#pragma unroll 1
-        for (int step = 0; step < TR / 4; ++step) {
-            const int ro = 4 * step + arow;
-            int lastI = -1;
-            {
-                double a = 0.0;
-#pragma unroll
-                for (int q = 0; q < MAXT; ++q) {
-                    if (q < nt) {
-                        if (tI[q] != lastI) { a = Xt[(16 * tI[q] + acol) * S + ro]; lastI = tI[q]; }
-                        const double b = (tJ[q] == tI[q]) ? a : Xt[(16 * tJ[q] + acol) * S + ro];
-                        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-
-    const int64_t nslots = (int64_t)k * (k + 1);
-    double *pb = partial + (int64_t)blockIdx.x * nslots;
-#pragma unroll
-    for (int q = 0; q < MAXT; ++q) {
-        if (q < nt) {
-            const int j = 16 * tJ[q] + acol;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * tI[q] + arow + 4 * r;
-                if (i < k && j < k) pb[(int64_t)j * (k + 1) + i] = acc[q][r];
-            }
-        }
-    }
-}
-
-// Gram matrix G = X^T X of a REAL basis of 113..128 columns with the upper tiles dealt CYCLICALLY (round 5; gram_matrix, AbstractVectors.fypp:645-657).
-// panel_gram_mfma deals runs of the row-major tile list, which makes every wave's list different: its k-loop is a chain of uniform branches with
-// one `ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma` per tile (hipcc -S), and panel_xhy_mfma gives wave w the whole tile row w -- eight tiles for
-// wave 0, one for wave 7.  Here wave w owns the tiles (w, (w + d) mod 8), d = 0..3 -- the 8 diagonal and 24 of the 28 off-diagonal upper tiles, a
-// wrapped one being the transpose of its upper twin -- and HALF of tile (w, (w + 4) mod 8): waves w and w + 4 both hold that tile (one of
-// them transposed), w < 4 takes it on the even row steps, w >= 4 on the odd ones, chosen by the LDS address, not by a branch.  So all eight waves
-// run the SAME straight-line code -- per pair of row steps ten operand reads and nine MFMAs, the reads of pair i + 1 issued before the MFMAs
-// of pair i (pinned with sched_barrier) -- on operands whose LDS column offsets are the only thing that depends on the wave.  Tiles, staging,
-// strides and the prefetch of the next tile's global loads as panel_gram_mfma (32 rows x 128 columns, S = 34: conflict-free operand reads).
-// The two halves of the d = 4 tiles meet in LDS once, at the end.  Results: partial[block][slot] as panel_gram_mfma.
-__global__ __launch_bounds__(512, 4) void panel_gram_cyc(const double *__restrict__ X, int64_t ldx, int k, int64_t n, double *__restrict__ partial, int dbg_arg) {
-#ifdef LK_DIAGNOSTICS
-    const int dbg = dbg_arg;                        // diagnostics build only (xhy_debug): WRONG results, phase timing
-#else
-    constexpr int dbg = 0;
-#endif
-    constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = 512 / CH, NXP = 128 / CPP;
-    extern __shared__ __attribute__((aligned(16))) double gc_lds[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    double *Xt = gc_lds;
-    const int64_t ntiles = (n + TR - 1) / TR;
-    const int arow = lane >> 4, acol = lane & 15;
-    const int par = wave >= 4 ? 1 : 0;
-    int ob[5];                                              // LDS offsets of this lane's operand column in the column blocks (w + d) mod 8
-#pragma unroll
-    for (int d = 0; d < 5; ++d) ob[d] = (16 * ((wave + d) & 7) + acol) * S + arow;
-
-    v4d acc[5];
-#pragma unroll
-    for (int d = 0; d < 5; ++d) acc[d] = v4d{0.0, 0.0, 0.0, 0.0};
-    // Two tile buffers in LDS and the global loads TWO tiles ahead: while the MFMAs of tile T run out of buffer b, every wave -- as it finishes its
-    // share -- writes tile T + grid (in its registers since the iteration before) into buffer b ^ 1 and sends the loads of tile T + 3 grid on their
-    // way; ONE barrier per tile, and 2 x 4 loads of 16 B per lane in flight for two tile times (one tile time -- 36 MFMAs -- is about the HBM
-    // latency under load: with the loads one tile ahead the staging waited for them, 5.4 TB/s with the MFMAs switched off).
-    // The loads are UNCONDITIONAL -- column, row and tile clamped into the panel, what was out of range zeroed when the registers are written to LDS --: a
-    // guarded load (`if (col < k) ... if (rr + 1 < n) ...`) compiles to a chain of basic blocks, and the waitcnt pass puts `s_waitcnt vmcnt(0)` in
-    // front of the loads and LDS writes in them: the four loads of a set went out one round trip at a time (hipcc -S of the first version).
-    v2d xs[2][NXP];
-    auto gload = [&](int64_t T, v2d (&x)[NXP]) {
-        if ((dbg & 2) && T != (int64_t)blockIdx.x) return;                 // diagnostics (xhy_debug): wrong results, phase timing only
-        const int64_t rbase = (T < ntiles ? T : ntiles - 1) * TR;          // (a tile beyond the panel re-reads the last one: never staged)
-        int tv = t;
-        asm volatile("" : "+v"(tv));                                       // (addresses formed per tile: hoisted out of the unrolled trip they are spilled)
-#pragma unroll
-        for (int s = 0; s < NXP; ++s) {
-            const int c = tv + 512 * s, col = c >> CHS;
-            const int64_t rr = rbase + 2 * (c & (CH - 1));
-            const int colc = col < k ? col : k - 1;
-            const int64_t rrc = rr + 1 < n ? rr : n - 2;
-            x[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(X + (int64_t)colc * ldx + rrc));
-        }
-    };
-    auto stage = [&](double *Xb, const v2d (&x)[NXP], int64_t T) {        // T: the tile these registers hold
-        const bool ragged = (T + 1) * TR > n;
-        int tv = t;
-        asm volatile("" : "+v"(tv));
-#pragma unroll
-        for (int s = 0; s < NXP; ++s) {
-            const int c = tv + 512 * s;
-            v2d v = x[s];
-            if (ragged) {
-                const int64_t rr = T * TR + 2 * (c & (CH - 1));
-                if (rr >= n) v = v2d{0.0, 0.0};
-                else if (rr + 1 >= n) v = v2d{v.y, 0.0};               // (the clamped load fetched rows n - 2, n - 1)
-            }
-            if ((c >> CHS) < k) *reinterpret_cast<v2d *>(Xb + (c >> CHS) * S + 2 * (c & (CH - 1))) = v;
-        }
-    };
-    constexpr int BUF = 128 * S;
-    // columns k .. 127 of both buffers stay zero
-    for (int i = t; i < 2 * BUF; i += 512) Xt[i] = 0.0;
-    __syncthreads();
-
-    const int64_t G = gridDim.x;
-    int64_t T = blockIdx.x;
-    if (T < ntiles) { gload(T, xs[0]); stage(Xt, xs[0], T); }
-    gload(T + G, xs[0]);
-    gload(T + 2 * G, xs[1]);
-    __syncthreads();
-    // (two tiles per trip so that the register sets xs[0] / xs[1] and the buffers alternate at compile time)
-    auto tile = [&](auto main_loop, const double *Xb, double *Xo, v2d (&xnext)[NXP], int64_t Tn, int64_t Tl) {
-        if (!(dbg & 1)) {
-#pragma unroll
-            for (int pr = 0; pr < TR / 8; ++pr) {
-                // (no operand prefetch across pairs: with two blocks per CU four waves share a SIMD and cover each other's LDS round trips, and the
-                //  twenty registers of a second operand set are what keeps the kernel from two blocks per CU)
-                double r[2][4], r4[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) r[h][d] = Xb[ob[d] + 4 * (2 * pr + h)];
-                r4[0] = Xb[ob[0] + 4 * (2 * pr + par)];
-                r4[1] = Xb[ob[4] + 4 * (2 * pr + par)];
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) acc[d] = __builtin_amdgcn_mfma_f64_16x16x4f64(r[h][0], r[h][d], acc[d], 0, 0, 0);
-                acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(r4[0], r4[1], acc[4], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (decltype(main_loop)::value || Tn < ntiles) stage(Xo, xnext, Tn);   // the next tile into the other buffer (its loads were issued two tiles ago)
-        gload(Tl, xnext);                                           // ... and that register set goes out again, for the tile three grids on
-        __syncthreads();                                            // buffer Xb has been read by all, buffer Xo is complete
-    };
-    using TailLoop = std::integral_constant<bool, false>;
-    // (two tiles per trip so that the register sets and the buffers alternate at compile time.  Eight tiles per trip -- the queue drain the waitcnt pass puts at
-    //  the head of a loop that carries loads across iterations would come once in eight tiles -- made the allocator carry the register sets as 32-register
-    //  tuples through the unrolled body: 290-360 B of scratch, not kept)
-    for (; T < ntiles; T += 2 * G) {
-        tile(TailLoop{}, Xt, Xt + BUF, xs[0], T + G, T + 3 * G);
-        if (T + G < ntiles) tile(TailLoop{}, Xt + BUF, Xt, xs[1], T + 2 * G, T + 4 * G);
-    }
-
-    // waves 4-7 hand their half of tile (w - 4, w) -- held transposed, as tile (w, w - 4) -- to waves 0-3 (the tile buffers are free by now)
-    if (par) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Xt[(wave - 4) * 256 + (arow + 4 * r) * 16 + acol] = acc[4][r];
-    }
-    __syncthreads();
-    if (!par) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[4][r] += Xt[wave * 256 + acol * 16 + (arow + 4 * r)];
-    }
-    const int64_t nslots = (int64_t)k * (k + 1);
-    double *pb = partial + (int64_t)blockIdx.x * nslots;
-#pragma unroll
-    for (int d = 0; d < 5; ++d) {
-        if (d < 4 || !par) {
-            const int I = wave, J = (wave + d) & 7;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * I + arow + 4 * r, j = 16 * J + acol;
-                if (i < k && j < k) {
-                    if (J >= I) pb[(int64_t)j * (k + 1) + i] = acc[d][r];
-                    else pb[(int64_t)i * (k + 1) + j] = acc[d][r];
-                }
-            }
-        }
-    }
-}
-
-// The cyclic deal for 49..64 real columns (round 5; gram_matrix, AbstractVectors.fypp:645-657): FOUR column blocks, so the eight waves are four blocks x two
-// ROW halves -- wave w owns column block I = w & 3 on the row steps s == h (mod 2), h = w >> 2: the tiles (I, (I + d) mod 4), d = 0, 1, on each of its four
-// steps of a 32-row tile, and tile (I, (I + 2) mod 4) -- which the waves of block I + 2 hold transposed -- on two of them (chosen by the LDS address, not by a
-// branch): ten MFMAs per wave and tile, the same straight-line code on every wave.  Tile buffers, unconditional loads two tiles ahead and the one barrier per
-// tile as panel_gram_cyc; 17 KB per buffer.  A tile of G is held in pieces by two to four waves: they meet in LDS at the end, wave after wave in a fixed order.
-// Results: partial[block][slot] as panel_gram_mfma.
-__global__ __launch_bounds__(512, 4) void panel_gram_cyc4(const double *__restrict__ X, int64_t ldx, int k, int64_t n, double *__restrict__ partial) {
-    constexpr int TR = 32, S = TR + 2, CH = TR / 2, CHS = 4, CPP = 512 / CH, NXP = 64 / CPP;      // two 16-byte chunks per thread and tile
-    constexpr int BUF = 64 * S;
-    extern __shared__ __attribute__((aligned(16))) double g4_lds[];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    double *Xt = g4_lds;
-    const int64_t ntiles = (n + TR - 1) / TR;
-    const int arow = lane >> 4, acol = lane & 15;
-    const int I = wave & 3, h = wave >> 2, par2 = I >= 2 ? 1 : 0;
-    int ob[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) ob[d] = (16 * ((I + d) & 3) + acol) * S + arow;
-    v4d acc[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) acc[d] = v4d{0.0, 0.0, 0.0, 0.0};
-    v2d xs[2][NXP];
-    auto gload = [&](int64_t T, v2d (&x)[NXP]) {
-        const int64_t rbase = (T < ntiles ? T : ntiles - 1) * TR;          // (a tile beyond the panel re-reads the last one: never staged)
-#pragma unroll
-        for (int s = 0; s < NXP; ++s) {
-            const int c = t + 512 * s, col = c >> CHS;
-            const int64_t rr = rbase + 2 * (c & (CH - 1));
-            const int colc = col < k ? col : k - 1;
-            const int64_t rrc = rr + 1 < n ? rr : n - 2;
-            x[s] = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(X + (int64_t)colc * ldx + rrc));
-        }
-    };
-    auto stage = [&](double *Xb, const v2d (&x)[NXP], int64_t T) {
-        const bool ragged = (T + 1) * TR > n;
-#pragma unroll
-        for (int s = 0; s < NXP; ++s) {
-            const int c = t + 512 * s;
-            v2d v = x[s];
-            if (ragged) {
-                const int64_t rr = T * TR + 2 * (c & (CH - 1));
-                if (rr >= n) v = v2d{0.0, 0.0};
-                else if (rr + 1 >= n) v = v2d{v.y, 0.0};
-            }
-            if ((c >> CHS) < k) *reinterpret_cast<v2d *>(Xb + (c >> CHS) * S + 2 * (c & (CH - 1))) = v;
-        }
-    };
-    for (int i = t; i < 2 * BUF; i += 512) Xt[i] = 0.0;       // columns k .. 63 of both buffers stay zero
-    __syncthreads();
-    const int64_t G = gridDim.x;
-    int64_t T = blockIdx.x;
-    if (T < ntiles) { gload(T, xs[0]); stage(Xt, xs[0], T); }
-    gload(T + G, xs[0]);
-    gload(T + 2 * G, xs[1]);
-    __syncthreads();
-    auto tile = [&](const double *Xb, double *Xo, v2d (&xnext)[NXP], int64_t Tn, int64_t Tl) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {                                   // two pairs of own row steps
-            double r[2][2], r2[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int d = 0; d < 2; ++d) r[e][d] = Xb[ob[d] + 4 * (2 * (2 * q + e) + h)];
-            r2[0] = Xb[ob[0] + 4 * (2 * (2 * q + par2) + h)];
-            r2[1] = Xb[ob[2] + 4 * (2 * (2 * q + par2) + h)];
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int d = 0; d < 2; ++d) acc[d] = __builtin_amdgcn_mfma_f64_16x16x4f64(r[e][0], r[e][d], acc[d], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(r2[0], r2[1], acc[2], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (Tn < ntiles) stage(Xo, xnext, Tn);
-        gload(Tl, xnext);
-        __syncthreads();
-    };
-    for (; T < ntiles; T += 2 * G) {
-        tile(Xt, Xt + BUF, xs[0], T + G, T + 3 * G);
-        if (T + G < ntiles) tile(Xt + BUF, Xt, xs[1], T + 2 * G, T + 4 * G);
-    }
-    // the pieces of every tile meet in LDS: G(64 x 64) zeroed, then the eight waves add theirs one after the other (a wrapped tile lands transposed, on its upper twin)
-    double *Gs = Xt;                                                    // 64 x 65 doubles: the tile buffers are free by now
-    for (int i = t; i < 64 * 65; i += 512) Gs[i] = 0.0;
-    __syncthreads();
-    for (int w = 0; w < 8; ++w) {
-        if (wave == w) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const int J = (I + d) & 3;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = 16 * I + arow + 4 * r, j = 16 * J + acol;
-                    if (J >= I) Gs[j * 65 + i] += acc[d][r];
-                    else Gs[i * 65 + j] += acc[d][r];
-                }
-            }
-        }
-        __syncthreads();
-    }
-    const int64_t nslots = (int64_t)k * (k + 1);
-    double *pb = partial + (int64_t)blockIdx.x * nslots;
-    for (int e = t; e < 64 * 64; e += 512) {
-        const int j = e >> 6, i = e & 63;                               // slot (row i, column j) with tile(i) <= tile(j)
-        if ((i >> 4) <= (j >> 4) && i < k && j < k) pb[(int64_t)j * (k + 1) + i] = Gs[j * 65 + i];
-    }
-}
-
 // Gram matrix G = X^T X of a REAL basis of 33..128 columns: ROW-SPLIT deal, tiles staged by LDS-DMA (round 6; gram_matrix, AbstractVectors.fypp:645-657).
 // The cyclic deals above give a wave a few tiles on every row step -- one LDS operand read per MFMA -- and only 4 and 8 column blocks divide the eight waves; their
 // staging goes through registers (two sets of loads in flight per thread, written to LDS by the thread).  Here
@@ -2314,7 +1955,8 @@ __global__ __launch_bounds__(512, 4) void panel_gram_cyc4(const double *__restri
 //    bank pairs.  Columns beyond k load column k - 1 (their entries of G are never stored); the ragged last tile (n mod 32 rows) is staged by ordinary loads, zero
 //    filled, by the block whose turn it is, after its loop.
 // A tile of G is held in four row pieces by the waves of a group: they meet in LDS at the end, one wave after the other in a fixed order.
-// Results: partial[block][slot] as panel_gram_mfma.
+// Results: partial[block][slot], slot = j (k + 1) + i for i in tile row I, j in tile column J >= I -- panel_xhy_mfma's layout with
+// flags = 3 (Y is X, upper tiles only), summed by finish_xhy; no norm slots.
 template <int KP> struct GramRowSplit {
     static constexpr int NT = KP * (KP + 1) / 2, N0 = (NT + 1) / 2, N1 = NT - N0;
     static constexpr int tile_i(int idx) { int I = 0, rem = idx; while (rem >= KP - I) { rem -= KP - I; ++I; } return I; }
@@ -2370,17 +2012,18 @@ __global__ __launch_bounds__(512, WPE) void panel_gram_rs(const double *__restri
 #pragma unroll
             for (int s = 0; s < LPT; ++s) {
                 const int col = pcol + 32 * s, colc = col < k ? col : k - 1;
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (int64_t)colc * ldx), (lds_ptr_t)(dst + 8192 * s), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (int64_t)colc * ldx), (lds_ptr_t)(dst + 8192 * s), 16, 0, 2);     // (aux = 2: non-temporal, the panel is read once)
             }
         };
-        auto steps = [&](const char *Xb) {
+        auto steps = [&](const char *Xb) {                                    // both row steps' operands first, then all the MFMAs back to back
+            double r[2][KP];
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                double r[KP];
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int b = 0; b < KP; ++b) r[b] = *reinterpret_cast<const double *>(Xb + oa[e] + 4096 * b);   // (the blocks a group never uses are dropped)
-                gram_rs_step<KP, FIRST>(r, acc, seq);
-            }
+                for (int b = 0; b < KP; ++b) r[e][b] = *reinterpret_cast<const double *>(Xb + oa[e] + 4096 * b);   // (the blocks a group never uses are dropped)
+            __builtin_amdgcn_sched_barrier(0);
+            gram_rs_step<KP, FIRST>(r[0], acc, seq);
+            gram_rs_step<KP, FIRST>(r[1], acc, seq);
         };
         int64_t T = blockIdx.x;
         if (T < nfull) {

@@ -72,7 +72,7 @@ def test_tuning_keys_are_few_documented_and_none_of_them_breaks_results():
     assert len(keys) <= 30, sorted(keys)
     for k in keys | diag_keys:
         assert f'"{k}"' in hdr, f'tuning key "{k}" is not documented in include/lightkrylov_hip.h'
-    for gone in ("mfma_4x4", "xhy_tr32"):
+    for gone in ("mfma_4x4", "xhy_tr32", "gram_cyc", "gram_cyc4", "gram_tiles", "gram_grid_mult"):
         assert gone not in keys and f'"{gone}"' not in hdr
     mk = open(os.path.join(ROOT, "lightkrylov_amd", "csrc", "Makefile")).read()
     product_rule = mk[mk.index("$(OUT):"):mk.index("diagnostics:")]

@@ -116,7 +116,7 @@ def test_lazy_gram_loop_of_the_reference_costs_one_pass(dtype):
 
 
 @pytest.mark.parametrize("dtype", KINDS)
-@pytest.mark.parametrize("cfg", [dict(), dict(xhy_db=0), dict(xhy_db=2), dict(gram_tiles=0), dict(gram_tiles=2), dict(gram_tiles=2, gram_grid_mult=3), dict(gram_cyc=1), dict(gram_cyc=3),
+@pytest.mark.parametrize("cfg", [dict(), dict(xhy_db=0), dict(xhy_db=2), dict(gram_rs=0), dict(gram_rs=2), dict(gram_rs=5),
                                  dict(gemm_roll=0), dict(gemm_roll=2)],
                          ids=lambda d: ",".join(f"{k}={v}" for k, v in d.items()) or "defaults")
 def test_matrix_core_kernel_variants_agree_with_the_oracle(dtype, cfg):
@@ -208,23 +208,43 @@ def test_rolling_prefetch_product_over_many_tiles_per_block(k, q):
     c.close()
 
 
-@pytest.mark.parametrize("n,k", [(200_003, 128), (70_001, 113), (16_400, 128)])
-def test_cyclic_gram_kernel_over_many_tiles_per_block(n, k):
-    """gram_matrix (AbstractVectors.fypp:645-657) of 113..128 real columns by panel_gram_cyc on panels long enough that every block runs SEVERAL
-    32-row tiles -- both tile buffers, both register sets of the loads two tiles ahead, an odd and an even number of tiles per block, a ragged last
-    tile, a width that is not a multiple of 16 -- against numpy and against the staged kernel it replaces ("gram_cyc" = 0)."""
+@pytest.mark.parametrize("n,k", [(200_003, 128), (70_001, 113), (16_400, 128), (300_017, 97), (150_000, 96), (90_001, 81), (200_003, 64), (70_001, 49), (33, 56),
+                                 (120_007, 48), (50_011, 33), (1_000_001, 40)])
+def test_row_split_gram_kernel_over_many_tiles_per_block(n, k):
+    """gram_matrix (AbstractVectors.fypp:645-657) of 33..128 real columns by panel_gram_rs (rows of the staged tile dealt to the waves, tiles staged by LDS-DMA into a
+    ring of three or four buffers behind counted waits) on panels long enough that every block runs MANY 32-row tiles -- every buffer of the ring, the prefetch running
+    off the end of the panel, a ragged last tile (or none: 150 000 = 32 * 4687.5 -> ragged, 16 400 not), widths that are not a multiple of 16 (the last column block
+    partly beyond the panel), every number of column blocks 3..8, a panel of one tile and a bit -- against numpy, against the kernel behind "gram_rs" = 0, and the same
+    bits from a grid of a different size only up to rounding (the partial sums change)."""
     c = lk.Context(device=0)
     X = basis(n, k, np.float64, 31)
     B = lk.krylov_basis_gpu(n, k, np.float64, c); B.upload(X)
     ref = X.T @ X
     scale = np.linalg.norm(X, axis=0).max() ** 2
     out = {}
-    for cyc in (2, 1, 0):
-        c.set_tuning("gram_cyc", cyc)
-        out[cyc] = lk.Gram(B)
-        assert np.abs(out[cyc] - ref).max() <= 1e-13 * scale, cyc
-        assert np.array_equal(out[cyc], out[cyc].T)
-    assert np.abs(out[2] - out[0]).max() <= 1e-13 * scale
+    for rs in (1, 3, 0):
+        c.set_tuning("gram_rs", rs)
+        out[rs] = lk.Gram(B)
+        assert np.abs(out[rs] - ref).max() <= 1e-13 * scale, rs
+        assert np.array_equal(out[rs], out[rs].T)
+    c.set_tuning("gram_rs", 1)
+    assert np.array_equal(lk.Gram(B), out[1])                        # fixed order of the sums: the same bits again
+    assert np.abs(out[1] - out[0]).max() <= 1e-13 * scale
+    c.close()
+
+
+def test_row_split_gram_kernel_many_times_over_for_races():
+    """The LDS-DMA ring of panel_gram_rs is ordered by counted vmcnt waits and one raw barrier per tile: an early read would show as a rare wrong tile, so the same Gram
+    matrix is taken 200 times at two widths (two and one blocks per CU) and must come out bit-identical every time, and right."""
+    c = lk.Context(device=0)
+    for n, k in ((400_003, 96), (250_001, 128), (600_000, 48)):
+        X = basis(n, k, np.float64, 5)
+        B = lk.krylov_basis_gpu(n, k, np.float64, c); B.upload(X)
+        first = lk.Gram(B)
+        assert np.abs(first - X.T @ X).max() <= 1e-13 * np.linalg.norm(X, axis=0).max() ** 2
+        for _ in range(200):
+            assert np.array_equal(lk.Gram(B), first)
+        del B
     c.close()
 
 
@@ -255,34 +275,14 @@ def test_block_dgs_updates_on_the_ring_over_many_tiles_per_block(dtype):
         assert np.array_equal(b0, b1) and np.array_equal(y0, y1)
 
 
-@pytest.mark.parametrize("n,k", [(200_003, 64), (70_001, 49), (16_400, 64), (33, 56)])
-def test_cyclic_gram_kernel_for_four_column_blocks(n, k):
-    """gram_matrix (AbstractVectors.fypp:645-657) of 49..64 real columns by panel_gram_cyc4 (four column blocks x two row halves; the pieces of a tile held by two to four
-    waves meet in LDS in a fixed order): several tiles per block, a ragged last tile, a width that is not a multiple of 16, a panel shorter than two tiles -- against
-    numpy and the kernel it replaces."""
-    c = lk.Context(device=0)
-    X = basis(n, k, np.float64, 77)
-    B = lk.krylov_basis_gpu(n, k, np.float64, c); B.upload(X)
-    ref = X.T @ X
-    scale = np.linalg.norm(X, axis=0).max() ** 2
-    out = {}
-    for cyc in (3, 2, 0):
-        c.set_tuning("gram_cyc4", cyc)
-        out[cyc] = lk.Gram(B)
-        assert np.abs(out[cyc] - ref).max() <= 1e-13 * scale, cyc
-        assert np.array_equal(out[cyc], out[cyc].T)
-    assert np.array_equal(out[3], out[2]) or np.abs(out[3] - out[2]).max() <= 1e-13 * scale
-    c.close()
-
-
 @pytest.mark.parametrize("dtype", KINDS)
 def test_gram_across_the_kernel_dispatch_boundaries(dtype):
-    """gram_matrix (AbstractVectors.fypp:645-657) at every width and length where lk_gram changes kernels (32 | 33, 48 | 49, 64 | 65, 112 | 113, 128 | 129 columns;
+    """gram_matrix (AbstractVectors.fypp:645-657) at every width and length where lk_gram changes kernels or kernel instances (32 | 33, 48 | 49, 64 | 65, 80 | 81, 96 | 97, 112 | 113, 128 | 129 columns;
     panels of 1, 2, 3 rows, one row short of / at / beyond a tile, a few tiles) against numpy."""
     c = lk.Context(device=0)
     for n in (1, 2, 3, 31, 32, 33, 63, 64, 65, 1000, 4097):
         Xall = basis(n, 130, dtype, 5)
-        for k in (5, 32, 33, 47, 48, 49, 50, 63, 64, 65, 111, 112, 113, 127, 128, 129):
+        for k in (5, 32, 33, 47, 48, 49, 50, 63, 64, 65, 80, 81, 96, 97, 111, 112, 113, 127, 128, 129):
             X = np.asfortranarray(Xall[:, :k])
             B = lk.krylov_basis_gpu(n, k, dtype, c); B.upload(X)
             G = lk.Gram(B)

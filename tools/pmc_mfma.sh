@@ -24,8 +24,8 @@ run() { # name, counters, command...
 }
 for pass in 1a:"$C1a" 1b:"$C1b" 2a:"$C2a" 2b:"$C2b"; do
   tag=${pass%%:*}; ctr=${pass#*:}
-  run gram_old_$tag "$ctr" python3 "$R/tools/bench_gram.py" 1e7 gram_tiles=0
-  run gram_new_$tag "$ctr" python3 "$R/tools/bench_gram.py" 1e7 gram_tiles=1 gram_grid_mult=2
+  run gram_old_$tag "$ctr" python3 "$R/tools/bench_gram.py" 1e7 gram_rs=0
+  run gram_new_$tag "$ctr" python3 "$R/tools/bench_gram.py" 1e7 gram_rs=1
   run block_$tag "$ctr" python3 "$R/tools/bench_block_dgs.py" 32 1
   run lincomb_$tag "$ctr" python3 "$R/tools/bench_lincomb.py"
 done
