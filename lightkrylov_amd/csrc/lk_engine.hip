@@ -90,6 +90,7 @@ struct lk_context_s {
     int store_policy = 2;      // cache policy of the sweeps' y store: 0 plain, 1 nt, 2 sc1 (write-through; +2% on sweep 3), 3 sc0 sc1
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
+    int upd_rs = 1;            // fused pass of the block DGS, real kind, 17..32 right-hand sides: 1 = panel_xhy_upd_rs (row-owner waves, LDS-DMA tiles, coefficients in registers), 0 = panel_xhy_upd_mfma
     int gram_rs = 1;           // real Gram matrix of 33..128 columns by panel_gram_rs (rows of the staged tile dealt to the waves, LDS-DMA staging; n = 10^7: k = 48 1.11 -> 0.63 ms,
                                // k = 96 2.81 -> 1.80, k = 128 3.45 -> 3.0): 1 = as many blocks per CU as are resident, n > 1 = n blocks per CU, 0 = panel_xhy_mfma (one tile row per wave)
     int upd_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
@@ -885,6 +886,40 @@ int upd_dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, c
         return fail(LK_ERR_INVALID, "internal: xhy workspace too small for the fused block pass (%lld < %lld)", (long long)c->xhy_n, (long long)need);
     }
     double *out = c->xhy + (int64_t)slot * XHY_SLOT, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
+    // real kind, 17..32 right-hand sides: row-owner waves on LDS-DMA tiles (panel_xhy_upd_rs, round 6): one block of two four-wave teams per CU, two partial blocks per block
+    if (!cp && p > 16 && p <= 32 && c->upd_rs) {
+        const int KP = (k + 15) / 16;
+        int64_t gr = c->num_cu;
+        if (gr > ntiles) gr = ntiles;
+        if (gr < 1) gr = 1;
+        if (c->xhy_n < 2 * sect + npart_n + 2 * gr * nslots)
+            return fail(LK_ERR_INVALID, "internal: xhy workspace too small for the fused block pass (%lld)", (long long)c->xhy_n);
+        const size_t ldsr = (size_t)4 * (KP * 4096 + 8192);
+        {
+            ProfScope ps(c, "xhy_upd_mfma", (double)Bx->n * 8.0 * (k + 2 * p));
+            auto go = [&](auto kern) -> int {
+                if (ldsr > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsr));
+                hipLaunchKernelGGL(kern, dim3((unsigned)gr), dim3(512), ldsr, c->stream, (const double *)Bx->col(c0), Bx->ld, k, By->col(jy0), By->ld, p, Bx->n, H1dev, part,
+                                   npart, c->guard());
+                return LK_OK;
+            };
+            switch (KP) {
+            case 1: LKCHK(go(&panel_xhy_upd_rs<1>)); break;
+            case 2: LKCHK(go(&panel_xhy_upd_rs<2>)); break;
+            case 3: LKCHK(go(&panel_xhy_upd_rs<3>)); break;
+            case 4: LKCHK(go(&panel_xhy_upd_rs<4>)); break;
+            case 5: LKCHK(go(&panel_xhy_upd_rs<5>)); break;
+            case 6: LKCHK(go(&panel_xhy_upd_rs<6>)); break;
+            case 7: LKCHK(go(&panel_xhy_upd_rs<7>)); break;
+            default: LKCHK(go(&panel_xhy_upd_rs<8>)); break;
+            }
+        }
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, part, (int)(2 * gr), npart, (int)(2 * gr), k, p, ED, 0, out);
+        HIPCHK(hipGetLastError());
+        if (out_dev) *out_dev = out;
+        return allreduce(c, out, nslots);
+    }
     const size_t lds = (size_t)(KG * 32 * 34 + 32 * 34 + KG * 32 * 34 * (cp ? 2 : 1)) * sizeof(double);
     {
         ProfScope ps(c, "xhy_upd_mfma", (double)Bx->n * ED * 8.0 * (k + 2 * p));
@@ -1652,6 +1687,7 @@ int lk_set_tuning(lk_context_t c, const char *key, int value) {
     }
     if (!strcmp(key, "store_split")) { c->store_split = value != 0; return LK_OK; }
     if (!strcmp(key, "gemm_3m")) { c->gemm_3m = value ? 1 : 0; return LK_OK; }
+    if (!strcmp(key, "upd_rs")) { c->upd_rs = value != 0; return LK_OK; }
     if (!strcmp(key, "gram_rs")) { c->gram_rs = value < 0 ? 0 : (value > 16 ? 16 : value); return LK_OK; }
 #ifdef LK_DIAGNOSTICS
     // phase-timing switches that turn parts of a kernel OFF (wrong results): only in a build made with -DLK_DIAGNOSTICS (make diagnostics), never

@@ -2340,6 +2340,186 @@ __global__ __launch_bounds__(256, CPLX ? 1 : 2) void panel_xhy_upd_mfma(const do
     }
 }
 
+// Pass B of the block Gram-Schmidt, real kind, 17..32 right-hand sides -- ROW-OWNER waves on LDS-DMA tiles (round 6; gram_schmidt.fypp:59-105):
+//     Y' = Y - X H1   (stored)      M2 = X^T Y'      ||Y'_q||^2
+// panel_xhy_upd_mfma<false> above spends its time in the LDS-fed MFMA phase (coefficients read from LDS for every update MFMA, Y' written back into the LDS tile and read
+// again as the dot product's operand, three barriers per tile, register staging).  Here a TEAM of four waves takes a 32-row tile and wave w of it OWNS the 16 rows
+// rb = w & 1 of the 16 right-hand sides cb = w >> 1:
+//   update : u = Y_tile - X_tile H1 for those 16 x 16 entries: 4 KP MFMAs in ONE accumulator (started from the staged Y) whose B operands -- the wave's 16 columns of -H1 --
+//            sit in REGISTERS for the whole kernel (8 KP of them), the A operand X(row, column) read straight from the tile;
+//   store  : Y' leaves from the accumulator registers (row = (lane >> 4) + 4 r: the four stores of a lane quartet fill a 128-byte line of one column in L2);
+//   dots   : the accumulator layout of v_mfma_f64_16x16x4 (register r = rows (lane >> 4) + 4 r) IS the B-operand layout of its k-step r, so M2(I, cb) += X_I^T Y' takes
+//            the Y' registers as they are -- no LDS round trip, no barrier: 4 KP MFMAs on KP accumulators, A operands from the tile.
+// A block is TWO teams (eight waves, two per SIMD: with one, the wave's DMA issue, LDS latencies and stores leave the matrix pipe idle -- 4.1 ms against 3.5 at k = 128,
+// p = 32, n = 10^7), each on its own tile of the block's sequence and its own two stages of LDS (X: KP x 4 KB, Y: 8 KB; panel_gram_rs's image: unpadded columns, chunk c of
+// column j at position c ^ (j & 15), the permutation on the source address and on every operand read): 160 KB at k = 128, ONE barrier per iteration for both teams, the
+// team's next tile fetched by LDS-DMA a whole iteration ahead (dealing its ten DMA instructions per wave out between the MFMAs measured the same at k = 128 and
+// slower for narrow bases: not kept).
+// (The Y' stores share the vmcnt counter with the DMA loads: the wait at the head of an iteration is vmcnt(0), both are an iteration or half of one old by then.)
+// A k-step of the update takes the columns 16 g + t + 8 (kk & 1) + 4 (kk >> 1), kk = lane >> 4: the two columns of a half-wave differ in bit 3, so their 16-row reads fall
+// into different halves of the bank row.  Rows beyond n: the ragged last tile is staged by ordinary loads, zero filled, after the loop.
+// Phases at k = 128, p = 32, n = 10^7 (knock-out builds, docs/TUNING_LOG.md): MFMAs alone 2.9 ms (0.73 of the FP64 matrix peak), loads + stores alone 2.9 ms (5.2 TB/s: the
+// bytes in flight are bounded by the LDS ring -- half of 160 KB per CU), together 3.4; accumulator chains (1 / 2 / 4) make no difference.
+// H1: device coefficients in panel_dot_p's layout [q][k + 1].  Results: partial[2 block + rb][slot], npartial[(2 block + rb) p + q] (finish_xhy with 2 grid partial blocks).
+template <int KP>
+__global__ __launch_bounds__(512, 2) void panel_xhy_upd_rs(const double *__restrict__ X, int64_t ldx, int k, double *__restrict__ Y, int64_t ldy, int p, int64_t n,
+                                                           const double *__restrict__ H1, double *__restrict__ partial, double *__restrict__ npartial, Guard guard) {
+    if (stopped(guard)) return;
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+    constexpr int XB = KP * 4096, STAGE = XB + 8192;                               // bytes of X's tile / of a stage (X's tile, then Y's)
+    extern __shared__ __attribute__((aligned(16))) double xur_lds[];               // (the ONLY LDS object of the kernel): stages [team][2]
+    char *lds = reinterpret_cast<char *>(xur_lds);
+    const int t = threadIdx.x, lane = t & 63, tt4 = t & 255;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int arow = lane >> 4, acol = lane & 15;
+    const int team = wave >> 2, wv = wave & 3, rb = wv & 1, cb = wv >> 1;
+    const int64_t nfull = n / 32, G = gridDim.x;
+    // operand offsets inside a stage: od[r] -- rows 16 rb + arow + 4 r of column (16 I + acol) (+ 4096 I): the dot products' A operands and the staged Y in accumulator
+    // layout; ou[t] -- row 16 rb + acol of column 16 g + m, m = t + 8 (arow & 1) + 4 (arow >> 1) (+ 4096 g): the update's A operands
+    int od[4], ou[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) od[r] = acol * 256 + (((8 * rb + 2 * r + (arow >> 1)) ^ acol) << 4) + (arow & 1) * 8;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int m = tt + 8 * (arow & 1) + 4 * (arow >> 1);
+        ou[tt] = m * 256 + (((8 * rb + (acol >> 1)) ^ m) << 4) + (acol & 1) * 8;
+    }
+    // the wave's columns of -H1 as B operands (zero beyond k / p)
+    double hb[KP][4];
+    const int q = 16 * cb + acol;
+#pragma unroll
+    for (int g = 0; g < KP; ++g)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int c = 16 * g + tt + 8 * (arow & 1) + 4 * (arow >> 1);
+            hb[g][tt] = (c < k && q < p) ? -H1[(int64_t)q * (k + 1) + c] : 0.0;
+        }
+    v4d m2[KP];
+#pragma unroll
+    for (int I = 0; I < KP; ++I) m2[I] = v4d{0.0, 0.0, 0.0, 0.0};
+    double nacc = 0.0;
+    const int pcol = tt4 >> 4, plog = (tt4 & 15) ^ (pcol & 15);                   // the column (of a pass) and the LOGICAL chunk whose data lands at this thread's position
+    char *const st0 = lds + team * 2 * STAGE;                                     // the team's two stages
+    auto issue = [&](int64_t Tc, int buf) {                                       // tile Tc (a full one) into the team's stage buf
+        char *dst = st0 + buf * STAGE + 1024 * wv;
+        const double *sx = X + 32 * Tc + 2 * plog;
+#pragma unroll
+        for (int s = 0; s < KP; ++s) {
+            const int col = pcol + 16 * s, colc = col < k ? col : k - 1;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(sx + (int64_t)colc * ldx), (lds_ptr_t)(dst + 4096 * s), 16, 0, 2);
+        }
+        const double *sy = Y + 32 * Tc + 2 * plog;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int col = pcol + 16 * s, colc = col < p ? col : p - 1;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(sy + (int64_t)colc * ldy), (lds_ptr_t)(dst + XB + 4096 * s), 16, 0, 0);
+        }
+    };
+    auto update = [&](const char *st) -> v4d {                                    // Y' (this wave's 16 x 16 entries) of the tile in stage st
+        v4d u;
+        const char *yt = st + XB + 4096 * cb;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = *reinterpret_cast<const double *>(yt + od[r]);
+#pragma unroll
+        for (int g = 0; g < KP; ++g) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                u = __builtin_amdgcn_mfma_f64_16x16x4f64(*reinterpret_cast<const double *>(st + ou[tt] + 4096 * g), hb[g][tt], u, 0, 0, 0);
+        }
+        return u;
+    };
+    auto dots = [&](const char *st, const v4d &yp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int I = 0; I < KP; ++I)
+                m2[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(*reinterpret_cast<const double *>(st + od[r] + 4096 * I), yp[r], m2[I], 0, 0, 0);
+        }
+    };
+    double *yq = Y + (int64_t)(q < p ? q : p - 1) * ldy + 16 * rb + arow;         // this lane's column of Y, at its first row of a tile
+
+    // the block's tiles T_j = blockIdx + j G; team tm takes j = tm, tm + 2, ...: one tile per team and iteration, ONE barrier per iteration for both teams
+    const int64_t nmine = (int64_t)blockIdx.x < nfull ? (nfull - 1 - blockIdx.x) / G + 1 : 0;       // full tiles of this block
+    const int64_t niter = (nmine + 1) / 2;
+    if (team < nmine) issue(blockIdx.x + (int64_t)team * G, 0);
+    for (int64_t it = 0; it < niter; ++it) {
+        const int64_t j = 2 * it + team;
+        const int buf = (int)(it & 1);
+        wait_vmcnt<0>();                                                          // this wave's loads of tile j (and the stores of tile j - 2) are done ...
+        __builtin_amdgcn_s_barrier();                                             // ... everybody's are, and the team's other stage has been read by all
+        if (j + 2 < nmine) issue(blockIdx.x + (j + 2) * G, buf ^ 1);             // the team's next tile: a whole iteration ahead of its use
+        if (j < nmine) {
+            const int64_t T = blockIdx.x + j * G;
+            const char *st = st0 + buf * STAGE;
+            const v4d yp = update(st);
+            if (q < p) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) yq[32 * T + 4 * r] = yp[r];
+                nacc += (yp[0] * yp[0] + yp[1] * yp[1]) + (yp[2] * yp[2] + yp[3] * yp[3]);
+            }
+            dots(st, yp);
+        }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+    if ((n & 31) != 0 && (int64_t)blockIdx.x == nfull % G) {                      // the ragged tile: ordinary loads, zero filled, into team 0's stage 0 in the same image
+        for (int c = t; c < (KP + 2) * 256; c += 512) {
+            const bool isx = c < KP * 256;
+            const int cc = isx ? c : c - KP * 256;
+            const int col = cc >> 4, lg = (cc & 15) ^ (col & 15);
+            const int64_t r0 = 32 * nfull + 2 * lg;
+            const double *src = isx ? X + (int64_t)col * ldx : Y + (int64_t)col * ldy;
+            v2d v = v2d{0.0, 0.0};
+            if (col < (isx ? k : p)) {
+                if (r0 < n) v.x = src[r0];
+                if (r0 + 1 < n) v.y = src[r0 + 1];
+            }
+            *reinterpret_cast<v2d *>(lds + (isx ? 0 : XB) + 16 * cc) = v;
+        }
+        __syncthreads();
+        if (team == 0) {
+            const v4d yp = update(lds);
+            if (q < p) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (32 * nfull + 16 * rb + arow + 4 * r < n) yq[32 * nfull + 4 * r] = yp[r];
+                nacc += (yp[0] * yp[0] + yp[1] * yp[1]) + (yp[2] * yp[2] + yp[3] * yp[3]);  // (the rows beyond n are zero: X and Y were zero filled)
+            }
+            dots(lds, yp);
+        }
+        __syncthreads();
+    }
+    // team 1 hands its sums to team 0 through LDS (wave wv's: KP tiles of 256 doubles and the lane's norm sum), then team 0 writes the block's two partial blocks
+    if (team == 1) {
+#pragma unroll
+        for (int I = 0; I < KP; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xur_lds[(wv * (KP + 1) + I) * 256 + r * 64 + lane] = m2[I][r];
+        xur_lds[(wv * (KP + 1) + KP) * 256 + lane] = nacc;
+    }
+    __syncthreads();
+    if (team == 1) return;
+#pragma unroll
+    for (int I = 0; I < KP; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m2[I][r] += xur_lds[(wv * (KP + 1) + I) * 256 + r * 64 + lane];
+    nacc += xur_lds[(wv * (KP + 1) + KP) * 256 + lane];
+    const int64_t nslots = (int64_t)p * (k + 1);
+    double *pb = partial + (2 * (int64_t)blockIdx.x + rb) * nslots;               // (wave (rb, cb) writes the slots of its right-hand sides 16 cb ..: all of them, between the two)
+#pragma unroll
+    for (int I = 0; I < KP; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + arow + 4 * r;
+            if (i < k && q < p) pb[(int64_t)q * (k + 1) + i] = m2[I][r];
+        }
+    double v = nacc;                                                               // the four lanes of a column (arow = 0..3) hold its rows
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (arow == 0 && q < p) npartial[(2 * (int64_t)blockIdx.x + rb) * p + q] = v;
+}
+
 // out[slot] = sum over vb of partial[vb][slot]; norm slots (i = k) from npartial; tiles panel_xhy_mfma skipped (flag 2:
 // I > J) read as zero.  16 slots x 16 lanes per block: lane v adds the entries vb = v, v + 16, ... in order, then the 16 lane
 // sums are added in lane order -- a fixed summation order whatever the grid (there can be thousands of partial blocks for a

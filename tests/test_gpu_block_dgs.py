@@ -143,6 +143,71 @@ def test_block_dgs_three_pass_schedule_on_the_matrix_cores(dtype, fused, n, k, p
     c.close()
 
 
+@pytest.mark.parametrize("n,k,p", [(1_300_003, 128, 32), (700_001, 128, 17), (400_000, 120, 24), (300_017, 100, 32), (200_003, 64, 32), (90_001, 40, 20), (60_000, 16, 32),
+                                   (50_011, 7, 18), (65, 33, 32), (33, 5, 17), (4099, 128, 32)])
+def test_block_dgs_fused_pass_with_row_owner_waves(n, k, p):
+    """DGS_basis_against_basis (gram_schmidt.fypp:59-105), real kind, 17..32 right-hand sides: the fused pass by panel_xhy_upd_rs ("upd_rs" = 1: a team of four waves per
+    tile, each wave the owner of 16 rows x 16 right-hand sides, coefficients in registers, Y' handed from the update's accumulators straight to the dot products, tiles by
+    LDS-DMA into two stages per team, one barrier per iteration) on panels of MANY tiles per block -- both teams, both stages, an odd number of tiles (one team idle in the
+    last iteration), a ragged last tile or none, basis widths that are not a multiple of 16 (the last column block partly beyond the panel), fewer than 32 right-hand
+    sides (the last ones beyond the panel), panels shorter than two tiles -- every column against the oracle, against the kernel behind "upd_rs" = 0, bit-identical from
+    call to call."""
+    c = lk.Context(device=0)
+    Q = orthonormal_basis(n, k, np.float64, 5)
+    Y = basis(n, p, np.float64, 200)
+    B = lk.krylov_basis_gpu(n, k, np.float64, c); B.upload(Q)
+    out = {}
+    for rs in (1, 0, 1):
+        c.set_tuning("upd_rs", rs)
+        Z = lk.krylov_basis_gpu(n, p, np.float64, c); Z.upload(Y)
+        beta = np.zeros((k, p), order="F")
+        c.profile_reset(); c.profile_enable(True)
+        assert lk.double_gram_schmidt_step(Z, B, False, beta) == 0
+        c.sync()
+        assert c.profile_get("xhy_upd_mfma")[0] == 1
+        c.profile_enable(False)
+        Yg = Z.download()
+        if rs in out:
+            assert np.array_equal(out[rs][0], beta) and np.array_equal(out[rs][1], Yg)       # fixed order of the sums
+        out[rs] = (beta, Yg)
+        del Z
+    beta, Yg = out[1]
+    cols = range(p) if n <= 400_000 else (0, 15, 16, p - 1)                                  # (the scalar oracle takes a while on the long panels)
+    for j in cols:
+        yo = Y[:, j].copy()
+        ho, _ = ora.double_gram_schmidt_step(yo, Q)
+        assert np.abs(beta[:, j] - ho).max() <= 1e-12 * np.linalg.norm(Y[:, j])
+        assert np.abs(Yg[:, j] - yo).max() <= 1e-12 * np.linalg.norm(Y[:, j])
+    assert np.abs(out[1][0] - out[0][0]).max() <= 1e-13 * np.linalg.norm(Y, axis=0).max()
+    assert np.abs(out[1][1] - out[0][1]).max() <= 1e-13 * np.linalg.norm(Y, axis=0).max()
+    assert np.abs(Q.T @ Yg).max() <= 1e-13 * np.linalg.norm(Y, axis=0).max()
+    del B
+    c.close()
+
+
+def test_block_dgs_fused_pass_with_row_owner_waves_many_times_over_for_races():
+    """panel_xhy_upd_rs orders its LDS-DMA stages by a vmcnt(0) wait and one raw barrier per iteration: an early read or an early overwrite of a stage would show as a
+    rare wrong tile, so the same block step is taken 100 times from the same Y and must give the same bits every time."""
+    c = lk.Context(device=0)
+    n, k, p = 600_011, 128, 32
+    Q = orthonormal_basis(n, k, np.float64, 9)
+    Y = basis(n, p, np.float64, 300)
+    B = lk.krylov_basis_gpu(n, k, np.float64, c); B.upload(Q)
+    Z = lk.krylov_basis_gpu(n, p, np.float64, c)
+    first = None
+    for _ in range(100):
+        Z.upload(Y)
+        beta = np.zeros((k, p), order="F")
+        assert lk.double_gram_schmidt_step(Z, B, False, beta) == 0
+        got = (beta, Z.download())
+        if first is None:
+            first = got
+            assert np.abs(Q.T @ got[1]).max() <= 1e-13 * np.linalg.norm(Y, axis=0).max()
+        else:
+            assert np.array_equal(first[0], got[0]) and np.array_equal(first[1], got[1])
+    c.close()
+
+
 @pytest.mark.parametrize("n,k,p", [(4099, 7, 5), (20_003, 64, 16), (9001, 128, 32), (7001, 100, 17), (255, 128, 32), (12_289, 33, 31)])
 def test_complex_innerprod_with_three_real_products_per_complex_one(n, k, p):
     """Round 4: X^H Y with <= 32 right-hand sides, complex kind, on separate real / imaginary planes with P1 = Xr^T Yr, P2 = Xi^T Yi,
