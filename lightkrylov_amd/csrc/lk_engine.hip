@@ -742,11 +742,13 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
     if (g > ntiles) g = ntiles;
     if (g < 1) g = 1;
     const int grid = (int)g, nvb = grid * WR;
-    int64_t need = 2 * sect + npart_n + (int64_t)nvb * nslots;
-    if (c->xhy_n < need && !may_grow)
-        return fail(LK_ERR_INVALID, "internal: xhy workspace too small for a later pass of the block Gram-Schmidt (%lld < %lld)", (long long)c->xhy_n, (long long)need);
-    if (c->xhy_n < need) {
-        // (also room for the fused block pass, one block per CU, so that it never has to grow the buffer between passes)
+    // the workspace: two result sections | norm partials | `blocks` partial result blocks.  It grows only while `may_grow` (a later pass of the block step finds the
+    // coefficients of the earlier ones in it), and then at once to what the fused block pass needs (two partial blocks per CU), so that no pass has to grow it again
+    auto ensure = [&](int64_t blocks) -> int {
+        int64_t need = 2 * sect + npart_n + blocks * nslots;
+        if (c->xhy_n >= need) return LK_OK;
+        if (!may_grow)
+            return fail(LK_ERR_INVALID, "internal: xhy workspace too small for a later pass of the block Gram-Schmidt (%lld < %lld)", (long long)c->xhy_n, (long long)need);
         const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
         if (need < fused) need = fused;
         if (c->xhy) HIPCHK(hipFree(c->xhy));
@@ -754,24 +756,15 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         c->xhy_n = 0;
         HIPCHK(hipMalloc((void **)&c->xhy, (size_t)need * sizeof(double)));
         c->xhy_n = need;
-    }
-    double *out = c->xhy + (int64_t)slot * XHY_SLOT, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
+        return LK_OK;
+    };
     // complex Gram matrix beyond 32 columns: upper tiles dealt to the waves, three real products per complex one (panel_gram_mfma3m)
     if (cp && !small && c->gemm_3m && flags == 3) {
         const int64_t nt32 = (Bx->n + 31) / 32;
         int64_t gg = (int64_t)c->num_cu;
         if (gg > nt32) gg = nt32;
         if (gg < 1) gg = 1;
-        int64_t need3 = 2 * sect + npart_n + gg * nslots;
-        if (c->xhy_n < need3) {
-            const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
-            if (need3 < fused) need3 = fused;
-            if (c->xhy) HIPCHK(hipFree(c->xhy));
-            c->xhy = nullptr;
-            c->xhy_n = 0;
-            HIPCHK(hipMalloc((void **)&c->xhy, (size_t)need3 * sizeof(double)));
-            c->xhy_n = need3;
-        }
+        LKCHK(ensure(gg));
         double *out3 = c->xhy + (int64_t)slot * XHY_SLOT, *npart3 = c->xhy + 2 * sect, *part3 = npart3 + npart_n;
         const size_t lds3 = (size_t)KP * 16 * 34 * 2 * sizeof(double);
         {
@@ -794,18 +787,7 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         int64_t gg = (int64_t)c->num_cu * (c->gram_rs == 1 ? resident : c->gram_rs);
         if (gg > nt32) gg = nt32;
         if (gg < 1) gg = 1;
-        int64_t needg = 2 * sect + npart_n + gg * nslots;
-        if (c->xhy_n < needg && !may_grow)
-            return fail(LK_ERR_INVALID, "internal: xhy workspace too small (%lld < %lld)", (long long)c->xhy_n, (long long)needg);
-        if (c->xhy_n < needg) {
-            const int64_t fused = 2 * sect + npart_n + (int64_t)c->num_cu * 2 * nslots;
-            if (needg < fused) needg = fused;
-            if (c->xhy) HIPCHK(hipFree(c->xhy));
-            c->xhy = nullptr;
-            c->xhy_n = 0;
-            HIPCHK(hipMalloc((void **)&c->xhy, (size_t)needg * sizeof(double)));
-            c->xhy_n = needg;
-        }
+        LKCHK(ensure(gg));
         double *outg = c->xhy + (int64_t)slot * XHY_SLOT, *npartg = c->xhy + 2 * sect, *partg = npartg + npart_n;
         const size_t ldsg = (size_t)nbuf * KP * 4096;
         {
@@ -830,6 +812,8 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         if (out_dev) *out_dev = outg;
         return allreduce(c, outg, nslots);
     }
+    LKCHK(ensure(nvb));
+    double *out = c->xhy + (int64_t)slot * XHY_SLOT, *npart = c->xhy + 2 * sect, *part = npart + npart_n;
     // complex kind, <= 32 right-hand sides: three real products per complex one on separate real / imaginary planes ("gemm_3m")
     const bool three = cp && small && c->gemm_3m && !(flags & 1);
     size_t lds = three ? (size_t)(KP + PJ) * 16 * 18 * 2 * sizeof(double)

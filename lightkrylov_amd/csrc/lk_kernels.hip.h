@@ -2015,13 +2015,24 @@ __global__ __launch_bounds__(512, WPE) void panel_gram_rs(const double *__restri
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (int64_t)colc * ldx), (lds_ptr_t)(dst + 8192 * s), 16, 0, 2);     // (aux = 2: non-temporal, the panel is read once)
             }
         };
-        auto steps = [&](const char *Xb) {                                    // both row steps' operands first, then all the MFMAs back to back
+        // both row steps' operands first, then all the MFMAs back to back.  The reads are inline-asm ds_read_b64, ONE per operand: left to the compiler, two reads off one
+        // address register become a ds_read2st64_b64, whose two elements (column blocks 4 KB apart) hit the same banks -- SQ_LDS_BANK_CONFLICT was half of the LDS cycles
+        // (profiles/r06_pmc_mfma_lds.txt), zero with single reads, and the kernel 1-4 % faster.  An asm read is invisible to the compiler's wait counting: the s_waitcnt
+        // below is ours, and the empty asm statements after it tie every operand to it (asm volatile statements keep their order; the MFMAs depend on the tied values).
+        constexpr int B0 = std::integral_constant<int, D::tile_i(FIRST)>::value;   // the group's first column block (the blocks below it feed none of its tiles)
+        auto steps = [&](const char *Xb) {
             double r[2][KP];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned a = (unsigned)(uintptr_t)(Xb + oa[e]);             // LDS byte address (the low 32 bits of the generic pointer)
+#pragma unroll
+                for (int b = B0; b < KP; ++b) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r[e][b]) : "v"(a), "n"(4096 * b));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int b = 0; b < KP; ++b) r[e][b] = *reinterpret_cast<const double *>(Xb + oa[e] + 4096 * b);   // (the blocks a group never uses are dropped)
-            __builtin_amdgcn_sched_barrier(0);
+                for (int b = B0; b < KP; ++b) asm volatile("" : "+v"(r[e][b]));
             gram_rs_step<KP, FIRST>(r[0], acc, seq);
             gram_rs_step<KP, FIRST>(r[1], acc, seq);
         };
@@ -2416,6 +2427,9 @@ __global__ __launch_bounds__(512, 2) void panel_xhy_upd_rs(const double *__restr
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(sy + (int64_t)colc * ldy), (lds_ptr_t)(dst + XB + 4096 * s), 16, 0, 0);
         }
     };
+    // (Operand reads left to the compiler.  It merges pairs of them into ds_read2st64_b64, whose two elements -- column blocks 4 KB apart -- hit the same banks: a third
+    //  of this kernel's LDS cycles are bank conflicts (SQ_LDS_BANK_CONFLICT, profiles/r06_pmc_mfma_lds.txt).  Single inline-asm reads pipelined with counted lgkmcnt
+    //  waits were built: not faster, and WRONG at some shapes -- the compiler's scalar loads share that counter and return out of order, so a count is no guarantee.)
     auto update = [&](const char *st) -> v4d {                                    // Y' (this wave's 16 x 16 entries) of the tile in stage st
         v4d u;
         const char *yt = st + XB + 4096 * cb;

@@ -17,7 +17,7 @@ run() { # name, counters, command...
   if ! rocprofv3 --pmc $ctr --output-format csv -d "$D/$name" -o p -- "$@" > "$D/$name.log" 2>&1; then
     echo "pmc_mfma: rocprofv3 FAILED for $name (see $D/$name.log): no summary written" | tee "$D/pmc_mfma_$name.txt"; return 1
   fi
-  if ! ls "$D/$name"/*counter_collection.csv "$D/$name"/*/*counter_collection.csv > /dev/null 2>&1; then
+  if [ -z "$(find "$D/$name" -name '*counter_collection.csv' -print -quit)" ]; then
     echo "pmc_mfma: no counter_collection.csv for $name: no summary written" | tee "$D/pmc_mfma_$name.txt"; return 1
   fi
   python3 "$R/tools/pmc_sum.py" "$D/$name" ALL > "$D/pmc_mfma_$name.txt" 2>&1
