@@ -23,9 +23,11 @@ for dtype in (np.float64, np.complex128):
         B = lk.krylov_basis_gpu(nn, k, dtype, ctx)
         for j in range(k):
             B[j].rand(True, seed=10 + j)
-        lk.Gram(B); ctx.sync()
+        for _ in range(10):                       # (warm-up long enough for the clocks: the first few calls after an idle stretch run 10-15 % slower)
+            lk.Gram(B)
+        ctx.sync()
         ctx.profile_reset(); ctx.profile_enable(True)
-        reps = 5
+        reps = 10
         t0 = time.perf_counter()
         for _ in range(reps):
             G = lk.Gram(B)
