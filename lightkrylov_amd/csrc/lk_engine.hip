@@ -91,8 +91,9 @@ struct lk_context_s {
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
     int upd_rs = 1;            // fused pass of the block DGS, real kind, 17..32 right-hand sides: 1 = panel_xhy_upd_rs (row-owner waves, LDS-DMA tiles, coefficients in registers), 0 = panel_xhy_upd_mfma
-    int gram_rs = 1;           // real Gram matrix of 33..128 columns by panel_gram_rs (rows of the staged tile dealt to the waves, LDS-DMA staging; n = 10^7: k = 48 1.11 -> 0.63 ms,
-                               // k = 96 2.81 -> 1.80, k = 128 3.45 -> 3.0): 1 = as many blocks per CU as are resident, n > 1 = n blocks per CU, 0 = panel_xhy_mfma (one tile row per wave)
+    int gram_rs = 1;           // Gram matrix of 33..128 real columns by panel_gram_rs (rows of the staged tile dealt to the waves, LDS-DMA staging; n = 10^7: k = 48 1.11 -> 0.63 ms,
+                               // k = 96 2.81 -> 1.80, k = 128 3.45 -> 3.0) and of 33..80 complex columns by panel_gram_rs3m (n = 5 10^6: k = 48 1.35 -> 0.84, k = 80 2.35 -> 1.82):
+                               // 1 = as many blocks per CU as are resident, n > 1 = n blocks per CU, 0 = panel_xhy_mfma (one tile row per wave) / panel_gram_mfma3m
     int upd_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
     int xhy_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
     int gemm_roll = 1;         // MFMA tall-skinny product: rolling prefetch of X (a ring of 4 k-steps refilled as they are consumed, carried across tiles) instead of batches of 4
@@ -758,6 +759,34 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         c->xhy_n = need;
         return LK_OK;
     };
+    // complex Gram matrix of 33..80 columns: panel_gram_rs's row split and LDS-DMA tiles with three real products per complex one (panel_gram_rs3m, round 6)
+    if (cp && !small && c->gemm_3m && flags == 3 && KP >= 3 && KP <= 5 && c->gram_rs > 0) {
+        const int resident = KP == 3 ? 2 : 1;                                                     // blocks per CU (three accumulators per tile: registers)
+        const int nbuf = KP == 3 ? 3 : 5;
+        const int64_t nt16 = (Bx->n + 15) / 16;
+        int64_t gg = (int64_t)c->num_cu * (c->gram_rs == 1 ? resident : c->gram_rs);
+        if (gg > nt16) gg = nt16;
+        if (gg < 1) gg = 1;
+        LKCHK(ensure(gg));
+        double *outg = c->xhy + (int64_t)slot * XHY_SLOT, *npartg = c->xhy + 2 * sect, *partg = npartg + npart_n;
+        const size_t ldsg = (size_t)nbuf * KP * 4096;
+        {
+            ProfScope ps(c, "xhy_mfma", (double)Bx->n * ED * 8.0 * k);
+            auto go = [&](auto kern) -> int {
+                if (ldsg > 48 * 1024) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsg));
+                hipLaunchKernelGGL(kern, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
+                return LK_OK;
+            };
+            if (KP == 3) LKCHK(go(&panel_gram_rs3m<3, 3, 4>));
+            else if (KP == 4) LKCHK(go(&panel_gram_rs3m<4, 5, 2>));
+            else LKCHK(go(&panel_gram_rs3m<5, 5, 2>));
+        }
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(finish_xhy, dim3((unsigned)((nslots + 15) / 16)), dim3(256), 0, c->stream, partg, (int)gg, npartg, (int)gg, k, p, ED, flags, outg);
+        HIPCHK(hipGetLastError());
+        if (out_dev) *out_dev = outg;
+        return allreduce(c, outg, nslots);
+    }
     // complex Gram matrix beyond 32 columns: upper tiles dealt to the waves, three real products per complex one (panel_gram_mfma3m)
     if (cp && !small && c->gemm_3m && flags == 3) {
         const int64_t nt32 = (Bx->n + 31) / 32;

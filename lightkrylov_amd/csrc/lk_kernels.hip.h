@@ -2097,6 +2097,150 @@ __global__ __launch_bounds__(512, WPE) void panel_gram_rs(const double *__restri
     if (wave == 4) gram_rs_store<KP, D::N0>(pb, k, arow, acol, acc, std::make_integer_sequence<int, D::N1>{});
 }
 
+// Gram matrix G = X^H X of a COMPLEX basis of 33..80 columns: panel_gram_rs's row split and LDS-DMA tiles with panel_gram_mfma3m's three real products per complex
+// one (round 6; gram_matrix, AbstractVectors.fypp:645-657).  A complex element is one 16-byte chunk, so the panel read as a REAL one of 2n rows gives the same tile image
+// (32 real rows = 16 elements per column) and the same DMA code; a k-step of the MFMAs is four ELEMENTS: wave w takes element step w & 3 of the tile for half of the upper
+// tile list (waves 0-3 / 4-7), reads (re, im) of each of its column blocks with ONE ds_read_b128 (inline asm, as panel_gram_rs and for its reason), forms re + im and
+// im - re once per block, and runs P1 = Xr_I^T Xr_J, P2 = Xi_I^T Xi_J, P3 = (Xr + Xi)_I^T (Xi - Xr)_J for its tiles: three accumulators per tile -- 24 registers -- which
+// is what limits this kernel to five column blocks (8 tiles per wave); wider complex bases keep panel_gram_mfma3m.  Re G = P1 + P2, Im G = P3 + P1 - P2, formed after the
+// four element-step pieces of a tile have met in LDS.  Results: partial[block][slot], slot = (j (k + 1) + i) * 2 (+ 1), as panel_gram_mfma3m.
+template <int KP, int FIRST, int... Q>
+__device__ __forceinline__ void gram_rs3m_step(const double (&zr)[KP], const double (&zi)[KP], const double (&sm)[KP], const double (&df)[KP],
+                                               v4d (&p1)[GramRowSplit<KP>::N0], v4d (&p2)[GramRowSplit<KP>::N0], v4d (&p3)[GramRowSplit<KP>::N0], std::integer_sequence<int, Q...>) {
+    using D = GramRowSplit<KP>;
+    ((p1[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[std::integral_constant<int, D::tile_i(FIRST + Q)>::value], zr[std::integral_constant<int, D::tile_j(FIRST + Q)>::value], p1[Q], 0, 0, 0),
+      p2[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zi[std::integral_constant<int, D::tile_i(FIRST + Q)>::value], zi[std::integral_constant<int, D::tile_j(FIRST + Q)>::value], p2[Q], 0, 0, 0),
+      p3[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[std::integral_constant<int, D::tile_i(FIRST + Q)>::value], df[std::integral_constant<int, D::tile_j(FIRST + Q)>::value], p3[Q], 0, 0, 0)),
+     ...);
+}
+template <int KP, int FIRST, int... Q>
+__device__ __forceinline__ void gram_rs3m_store(double *pb, int k, int arow, int acol, const v4d (&p1)[GramRowSplit<KP>::N0], const v4d (&p2)[GramRowSplit<KP>::N0],
+                                                const v4d (&p3)[GramRowSplit<KP>::N0], std::integer_sequence<int, Q...>) {
+    using D = GramRowSplit<KP>;
+    auto one = [&](int I, int J, const v4d &a1, const v4d &a2, const v4d &a3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + arow + 4 * r, j = 16 * J + acol;
+            if (i < k && j < k) {
+                pb[((int64_t)j * (k + 1) + i) * 2] = a1[r] + a2[r];
+                pb[((int64_t)j * (k + 1) + i) * 2 + 1] = (a3[r] + a1[r]) - a2[r];
+            }
+        }
+    };
+    (one(std::integral_constant<int, D::tile_i(FIRST + Q)>::value, std::integral_constant<int, D::tile_j(FIRST + Q)>::value, p1[Q], p2[Q], p3[Q]), ...);
+}
+template <int KP, int NBUF, int WPE>
+__global__ __launch_bounds__(512, WPE) void panel_gram_rs3m(const double *__restrict__ X, int64_t ldx, int k, int64_t n, double *__restrict__ partial) {
+    using D = GramRowSplit<KP>;
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+    constexpr int BUFB = KP * 4096, FULL = KP / 2, ODD = KP & 1;
+    extern __shared__ __attribute__((aligned(16))) double grs3_lds[];          // (the ONLY LDS object of the kernel)
+    char *lds = reinterpret_cast<char *>(grs3_lds);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int arow = lane >> 4, acol = lane & 15;
+    const int grp = wave >> 2, ws = wave & 3;
+    const int64_t ldr = 2 * ldx, nr = 2 * n;                                   // the panel as a real one: column stride and rows
+    const int64_t nfull = nr / 32, G = gridDim.x;
+    const int oc = acol * 256 + (((4 * ws + arow) ^ acol) << 4);               // this lane's element (re, im) in column block 0 on the wave's element step
+    const int pcol = t >> 4, plog = (t & 15) ^ (pcol & 15);
+    v4d p1[D::N0], p2[D::N0], p3[D::N0];
+#pragma unroll
+    for (int q = 0; q < D::N0; ++q) { p1[q] = v4d{0.0, 0.0, 0.0, 0.0}; p2[q] = v4d{0.0, 0.0, 0.0, 0.0}; p3[q] = v4d{0.0, 0.0, 0.0, 0.0}; }
+
+    auto run = [&](auto first, auto seq) {
+        constexpr int FIRST = decltype(first)::value;
+        constexpr int LPT = FULL + ((ODD && FIRST == 0) ? 1 : 0);
+        constexpr int B0 = std::integral_constant<int, D::tile_i(FIRST)>::value;
+        auto issue = [&](int64_t Tc, int buf) {
+            const double *src = X + 32 * Tc + 2 * plog;
+            char *dst = lds + buf * BUFB + 1024 * wave;
+#pragma unroll
+            for (int s = 0; s < LPT; ++s) {
+                const int col = pcol + 32 * s, colc = col < k ? col : k - 1;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (int64_t)colc * ldr), (lds_ptr_t)(dst + 8192 * s), 16, 0, 2);
+            }
+        };
+        auto steps = [&](const char *Xb) {
+            v2d z[KP];
+            const unsigned a = (unsigned)(uintptr_t)(Xb + oc);
+#pragma unroll
+            for (int b = B0; b < KP; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(z[b]) : "v"(a), "n"(4096 * b));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double zr[KP], zi[KP], sm[KP], df[KP];
+#pragma unroll
+            for (int b = B0; b < KP; ++b) {
+                asm volatile("" : "+v"(z[b]));
+                zr[b] = z[b].x; zi[b] = z[b].y; sm[b] = z[b].x + z[b].y; df[b] = z[b].y - z[b].x;
+            }
+#pragma unroll
+            for (int b = 0; b < B0; ++b) { zr[b] = 0.0; zi[b] = 0.0; sm[b] = 0.0; df[b] = 0.0; }       // (never used)
+            gram_rs3m_step<KP, FIRST>(zr, zi, sm, df, p1, p2, p3, seq);
+        };
+        int64_t T = blockIdx.x;
+        if (T < nfull) {
+#pragma unroll
+            for (int j = 0; j < NBUF - 1; ++j) issue(T + j * G < nfull ? T + j * G : T, j);
+            int buf = 0;
+            for (; T < nfull; T += G) {
+                wait_vmcnt<(NBUF - 2) * LPT>();
+                __builtin_amdgcn_s_barrier();
+                const int64_t Tl = T + (NBUF - 1) * G;
+                issue(Tl < nfull ? Tl : T, buf == 0 ? NBUF - 1 : buf - 1);
+                steps(lds + buf * BUFB);
+                buf = buf + 1 == NBUF ? 0 : buf + 1;
+            }
+            wait_vmcnt<0>();
+        }
+        __syncthreads();
+        if ((nr & 31) != 0 && (int64_t)blockIdx.x == nfull % G) {              // the ragged tile: ordinary loads, zero filled, into buffer 0 in the same image
+            for (int p = t; p < KP * 256; p += 512) {
+                const int col = p >> 4, lg = (p & 15) ^ (col & 15);
+                const int64_t e = 16 * nfull + lg;                             // element
+                v2d v = v2d{0.0, 0.0};
+                if (col < k && e < n) v = *reinterpret_cast<const v2d *>(X + (int64_t)col * ldr + 2 * e);
+                *reinterpret_cast<v2d *>(lds + 16 * p) = v;
+            }
+            __syncthreads();
+            steps(lds);
+        }
+    };
+    if (grp == 0) run(std::integral_constant<int, 0>{}, std::make_integer_sequence<int, D::N0>{});
+    else run(std::integral_constant<int, D::N0>{}, std::make_integer_sequence<int, D::N1>{});
+    __syncthreads();
+    // the four element-step pieces of every tile meet in the wave with ws = 0 of each group, one wave after the other (3 N0 tiles of 256 doubles fit the ring)
+    double *Xt = grs3_lds;
+    for (int w = 1; w < 8; ++w) {
+        if ((w & 3) == 0) continue;
+        if (wave == w) {
+#pragma unroll
+            for (int q = 0; q < D::N0; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Xt[(3 * q + 0) * 256 + r * 64 + lane] = p1[q][r];
+                    Xt[(3 * q + 1) * 256 + r * 64 + lane] = p2[q][r];
+                    Xt[(3 * q + 2) * 256 + r * 64 + lane] = p3[q][r];
+                }
+        }
+        __syncthreads();
+        if (wave == (w & 4)) {
+#pragma unroll
+            for (int q = 0; q < D::N0; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    p1[q][r] += Xt[(3 * q + 0) * 256 + r * 64 + lane];
+                    p2[q][r] += Xt[(3 * q + 1) * 256 + r * 64 + lane];
+                    p3[q][r] += Xt[(3 * q + 2) * 256 + r * 64 + lane];
+                }
+        }
+        __syncthreads();
+    }
+    double *pb = partial + (int64_t)blockIdx.x * ((int64_t)k * (k + 1) * 2);
+    if (wave == 0) gram_rs3m_store<KP, 0>(pb, k, arow, acol, p1, p2, p3, std::make_integer_sequence<int, D::N0>{});
+    if (wave == 4) gram_rs3m_store<KP, D::N0>(pb, k, arow, acol, p1, p2, p3, std::make_integer_sequence<int, D::N1>{});
+}
+
 // Pass B of the block Gram-Schmidt with many right-hand sides, FUSED on the matrix cores (gram_schmidt.fypp:59-105):
 //     Y' = Y - X H1   (stored)      M2 = X^H Y'      ||Y'_q||^2
 // in ONE pass over X(:, :k) (k <= 128) and Y(:, :p) (p <= 32) -- the update and the second coefficient pass of

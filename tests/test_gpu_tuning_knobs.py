@@ -208,25 +208,26 @@ def test_rolling_prefetch_product_over_many_tiles_per_block(k, q):
     c.close()
 
 
+@pytest.mark.parametrize("dtype", KINDS)
 @pytest.mark.parametrize("n,k", [(200_003, 128), (70_001, 113), (16_400, 128), (300_017, 97), (150_000, 96), (90_001, 81), (200_003, 64), (70_001, 49), (33, 56),
-                                 (120_007, 48), (50_011, 33), (1_000_001, 40)])
-def test_row_split_gram_kernel_over_many_tiles_per_block(n, k):
-    """gram_matrix (AbstractVectors.fypp:645-657) of 33..128 real columns by panel_gram_rs (rows of the staged tile dealt to the waves, tiles staged by LDS-DMA into a
-    ring of three or four buffers behind counted waits) on panels long enough that every block runs MANY 32-row tiles -- every buffer of the ring, the prefetch running
-    off the end of the panel, a ragged last tile (or none: 150 000 = 32 * 4687.5 -> ragged, 16 400 not), widths that are not a multiple of 16 (the last column block
-    partly beyond the panel), every number of column blocks 3..8, a panel of one tile and a bit -- against numpy, against the kernel behind "gram_rs" = 0, and the same
-    bits from a grid of a different size only up to rounding (the partial sums change)."""
+                                 (120_007, 48), (50_011, 33), (1_000_001, 40), (250_005, 80), (100_000, 72), (17, 70)])
+def test_row_split_gram_kernel_over_many_tiles_per_block(dtype, n, k):
+    """gram_matrix (AbstractVectors.fypp:645-657) of 33..128 real columns by panel_gram_rs and of 33..80 complex columns by panel_gram_rs3m (rows of the staged tile dealt
+    to the waves, tiles staged by LDS-DMA into a ring of three to five buffers behind counted waits, operands by inline-asm LDS reads) on panels long enough that every
+    block runs MANY tiles -- every buffer of the ring, the prefetch running off the end of the panel, a ragged last tile or none, widths that are not a multiple of 16
+    (the last column block partly beyond the panel), every number of column blocks 3..8, panels of one tile and a bit -- against the oracle, against the kernel behind
+    "gram_rs" = 0, the same bits from call to call, and from a grid of a different size only up to rounding (the partial sums change)."""
     c = lk.Context(device=0)
-    X = basis(n, k, np.float64, 31)
-    B = lk.krylov_basis_gpu(n, k, np.float64, c); B.upload(X)
-    ref = X.T @ X
+    X = basis(n, k, dtype, 31)
+    B = lk.krylov_basis_gpu(n, k, dtype, c); B.upload(X)
+    ref = ora.gram(X)
     scale = np.linalg.norm(X, axis=0).max() ** 2
     out = {}
     for rs in (1, 3, 0):
         c.set_tuning("gram_rs", rs)
         out[rs] = lk.Gram(B)
         assert np.abs(out[rs] - ref).max() <= 1e-13 * scale, rs
-        assert np.array_equal(out[rs], out[rs].T)
+        assert np.array_equal(out[rs], out[rs].T)                    # (the reference mirrors the upper triangle without conjugating)
     c.set_tuning("gram_rs", 1)
     assert np.array_equal(lk.Gram(B), out[1])                        # fixed order of the sums: the same bits again
     assert np.abs(out[1] - out[0]).max() <= 1e-13 * scale
@@ -234,14 +235,15 @@ def test_row_split_gram_kernel_over_many_tiles_per_block(n, k):
 
 
 def test_row_split_gram_kernel_many_times_over_for_races():
-    """The LDS-DMA ring of panel_gram_rs is ordered by counted vmcnt waits and one raw barrier per tile: an early read would show as a rare wrong tile, so the same Gram
-    matrix is taken 200 times at two widths (two and one blocks per CU) and must come out bit-identical every time, and right."""
+    """The LDS-DMA ring of panel_gram_rs / panel_gram_rs3m is ordered by counted vmcnt waits and one raw barrier per tile, its operand reads by the kernel's own lgkmcnt
+    wait: an early read would show as a rare wrong tile, so the same Gram matrix is taken 200 times at several widths (two and one blocks per CU, both kinds) and must come
+    out bit-identical every time, and right."""
     c = lk.Context(device=0)
-    for n, k in ((400_003, 96), (250_001, 128), (600_000, 48)):
-        X = basis(n, k, np.float64, 5)
-        B = lk.krylov_basis_gpu(n, k, np.float64, c); B.upload(X)
+    for n, k, dtype in ((400_003, 96, np.float64), (250_001, 128, np.float64), (600_000, 48, np.float64), (300_007, 48, np.complex128), (200_001, 80, np.complex128)):
+        X = basis(n, k, dtype, 5)
+        B = lk.krylov_basis_gpu(n, k, dtype, c); B.upload(X)
         first = lk.Gram(B)
-        assert np.abs(first - X.T @ X).max() <= 1e-13 * np.linalg.norm(X, axis=0).max() ** 2
+        assert np.abs(first - ora.gram(X)).max() <= 1e-13 * np.linalg.norm(X, axis=0).max() ** 2
         for _ in range(200):
             assert np.array_equal(lk.Gram(B), first)
         del B

@@ -4,38 +4,43 @@ way.  This script compiles every instantiation to assembly (hipcc -S, a few seco
   python tools/check_asm_lds_reads.py"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-INST = [(3, 3, 8), (4, 3, 6), (5, 3, 4), (6, 3, 4), (7, 4, 2), (8, 4, 2)]          # as dispatched by lk_engine.hip (dots_mfma)
+INST = [(3, 3, 8), (4, 3, 6), (5, 3, 4), (6, 3, 4), (7, 4, 2), (8, 4, 2)]          # panel_gram_rs as dispatched by lk_engine.hip (dots_mfma)
+INST3M = [(3, 3, 4), (4, 5, 2), (5, 5, 2)]                                          # panel_gram_rs3m (complex: ds_read_b128)
 
 
 def main():
     eng = open(os.path.join(ROOT, "lightkrylov_amd", "csrc", "lk_engine.hip")).read()
     for kp, nb, w in INST:
         assert f"panel_gram_rs<{kp}, {nb}, {w}>" in eng, f"instantiation <{kp}, {nb}, {w}> is not the one the engine launches"
+    for kp, nb, w in INST3M:
+        assert f"panel_gram_rs3m<{kp}, {nb}, {w}>" in eng, f"instantiation 3m <{kp}, {nb}, {w}> is not the one the engine launches"
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.hip")
         with open(src, "w") as f:
             f.write('#include "%s"\n' % os.path.join(ROOT, "lightkrylov_amd", "csrc", "lk_kernels.hip.h"))
             for kp, nb, w in INST:
                 f.write(f"template __global__ void lk::panel_gram_rs<{kp}, {nb}, {w}>(const double *, int64_t, int, int64_t, double *);\n")
+            for kp, nb, w in INST3M:
+                f.write(f"template __global__ void lk::panel_gram_rs3m<{kp}, {nb}, {w}>(const double *, int64_t, int, int64_t, double *);\n")
         out = os.path.join(d, "t.s")
         r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True)
         if r.returncode != 0:
             print(r.stderr[-2000:]); return 2
         lines_all = open(out).read().split("\n")
-    starts = [i for i, l in enumerate(lines_all) if re.match(r"^_ZN2lk13panel_gram_rs\w+:", l)]
-    assert len(starts) == len(INST), (len(starts), len(INST))
+    starts = [i for i, l in enumerate(lines_all) if re.match(r"^_ZN2lk1[35]panel_gram_rs(3m)?I\w+:", l)]
+    assert len(starts) == len(INST) + len(INST3M), (len(starts), len(INST), len(INST3M))
     rc = 0
     for s0 in starts:
         e0 = next(i for i in range(s0, len(lines_all)) if lines_all[i].startswith(".Lfunc_end"))
         lines = lines_all[s0:e0]
         i, regions, bad = 0, 0, []
         while i < len(lines):
-            if "ds_read_b64" in lines[i] and "ASMSTART" in lines[i - 1]:
+            if re.search(r"ds_read_b(64|128)", lines[i]) and "ASMSTART" in lines[i - 1]:
                 dests, j, others = set(), i, []
                 while j < len(lines) and not ("s_waitcnt lgkmcnt(0)" in lines[j] and "ASMSTART" in lines[j - 1]):
                     l = lines[j].strip()
-                    if l.startswith("ds_read_b64"):
-                        m = re.match(r"ds_read_b64 v\[(\d+):(\d+)\]", l)
+                    if l.startswith("ds_read_b64") or l.startswith("ds_read_b128"):
+                        m = re.match(r"ds_read_b\d+ v\[(\d+):(\d+)\]", l)
                         dests.update(range(int(m.group(1)), int(m.group(2)) + 1))
                     elif l and not l.startswith(";"):
                         others.append((l, set(dests)))
