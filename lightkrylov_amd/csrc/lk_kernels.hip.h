@@ -2241,6 +2241,154 @@ __global__ __launch_bounds__(512, WPE) void panel_gram_rs3m(const double *__rest
     if (wave == 4) gram_rs3m_store<KP, D::N0>(pb, k, arow, acol, p1, p2, p3, std::make_integer_sequence<int, D::N1>{});
 }
 
+// panel_gram_rs3m for 81..112 complex columns (six or seven column blocks): FOUR groups of two waves, each a quarter of the upper-tile list (5-7 tiles: 120-168
+// accumulator registers) on two of the tile's four element steps per wave.  Group g = wave >> 1: SIMD s runs the waves s and s + 4, i.e. the groups (0, 2) or (1, 3) --
+// the list is cut so that |g0| + |g2| and |g1| + |g3| differ by at most one tile.  Everything else as panel_gram_rs3m.
+template <int KP> struct GramRowSplit4 {
+    static constexpr int NT = KP * (KP + 1) / 2, BASE = NT / 4, REM = NT % 4, NM = BASE + (REM ? 1 : 0);
+    static constexpr int first(int g) { return g * BASE + (g < REM ? g : REM); }
+    static constexpr int count(int g) { return BASE + (g < REM ? 1 : 0); }
+};
+template <int KP, int NM, int FIRST, int... Q>
+__device__ __forceinline__ void gram3m_step(const double (&zr)[KP], const double (&zi)[KP], const double (&sm)[KP], const double (&df)[KP], v4d (&p1)[NM], v4d (&p2)[NM],
+                                            v4d (&p3)[NM], std::integer_sequence<int, Q...>) {
+    using D = GramRowSplit<KP>;
+    ((p1[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zr[std::integral_constant<int, D::tile_i(FIRST + Q)>::value], zr[std::integral_constant<int, D::tile_j(FIRST + Q)>::value], p1[Q], 0, 0, 0),
+      p2[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(zi[std::integral_constant<int, D::tile_i(FIRST + Q)>::value], zi[std::integral_constant<int, D::tile_j(FIRST + Q)>::value], p2[Q], 0, 0, 0),
+      p3[Q] = __builtin_amdgcn_mfma_f64_16x16x4f64(sm[std::integral_constant<int, D::tile_i(FIRST + Q)>::value], df[std::integral_constant<int, D::tile_j(FIRST + Q)>::value], p3[Q], 0, 0, 0)),
+     ...);
+}
+// (tile by tile: the partner wave's pieces are added and the tile stored before the next one is touched -- all adds first, then all stores, spilled in the epilogue)
+template <int KP, int NM, int FIRST, int... Q>
+__device__ __forceinline__ void gram3m_add_store(double *pb, int k, int arow, int acol, int lane, const double *Xt, const v4d (&p1)[NM], const v4d (&p2)[NM], const v4d (&p3)[NM],
+                                                 std::integer_sequence<int, Q...>) {
+    using D = GramRowSplit<KP>;
+    auto one = [&](int q, int I, int J) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double a1 = p1[q][r] + Xt[(3 * q + 0) * 256 + r * 64 + lane], a2 = p2[q][r] + Xt[(3 * q + 1) * 256 + r * 64 + lane],
+                         a3 = p3[q][r] + Xt[(3 * q + 2) * 256 + r * 64 + lane];
+            const int i = 16 * I + arow + 4 * r, j = 16 * J + acol;
+            if (i < k && j < k) {
+                pb[((int64_t)j * (k + 1) + i) * 2] = a1 + a2;
+                pb[((int64_t)j * (k + 1) + i) * 2 + 1] = (a3 + a1) - a2;
+            }
+        }
+    };
+    (one(Q, std::integral_constant<int, D::tile_i(FIRST + Q)>::value, std::integral_constant<int, D::tile_j(FIRST + Q)>::value), ...);
+}
+template <int KP, int NBUF, int WPE>
+__global__ __launch_bounds__(512, WPE) void panel_gram_rs3m4(const double *__restrict__ X, int64_t ldx, int k, int64_t n, double *__restrict__ partial) {
+    using D = GramRowSplit<KP>;
+    using D4 = GramRowSplit4<KP>;
+    typedef __attribute__((address_space(3))) void *lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+    constexpr int BUFB = KP * 4096, FULL = KP / 2, ODD = KP & 1, NM = D4::NM;
+    extern __shared__ __attribute__((aligned(16))) double grs34_lds[];         // (the ONLY LDS object of the kernel)
+    char *lds = reinterpret_cast<char *>(grs34_lds);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int arow = lane >> 4, acol = lane & 15;
+    const int grp = wave >> 1, half = wave & 1;
+    const int64_t ldr = 2 * ldx, nr = 2 * n;                                   // the panel as a real one: column stride and rows
+    const int64_t nfull = nr / 32, G = gridDim.x;
+    int oc[2];                                                                 // this lane's element (re, im) in column block 0 on the wave's two element steps
+#pragma unroll
+    for (int e = 0; e < 2; ++e) oc[e] = acol * 256 + (((4 * (2 * half + e) + arow) ^ acol) << 4);
+    const int pcol = t >> 4, plog = (t & 15) ^ (pcol & 15);
+    v4d p1[NM], p2[NM], p3[NM];
+#pragma unroll
+    for (int q = 0; q < NM; ++q) { p1[q] = v4d{0.0, 0.0, 0.0, 0.0}; p2[q] = v4d{0.0, 0.0, 0.0, 0.0}; p3[q] = v4d{0.0, 0.0, 0.0, 0.0}; }
+
+    auto run = [&](auto gc) {
+        constexpr int GI = decltype(gc)::value, FIRST = D4::first(GI), CNT = D4::count(GI);
+        constexpr int LPT = FULL + ((ODD && GI < 2) ? 1 : 0);                  // (the half pass of an odd number of column blocks is issued by the waves 0-3 = groups 0, 1)
+        constexpr int B0 = std::integral_constant<int, D::tile_i(FIRST)>::value;
+        constexpr auto seq = std::make_integer_sequence<int, CNT>{};
+        auto issue = [&](int64_t Tc, int buf) {
+            const double *src = X + 32 * Tc + 2 * plog;
+            char *dst = lds + buf * BUFB + 1024 * wave;
+#pragma unroll
+            for (int s = 0; s < LPT; ++s) {
+                const int col = pcol + 32 * s, colc = col < k ? col : k - 1;
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (int64_t)colc * ldr), (lds_ptr_t)(dst + 8192 * s), 16, 0, 2);
+            }
+        };
+        auto steps = [&](const char *Xb) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                v2d z[KP];
+                const unsigned a = (unsigned)(uintptr_t)(Xb + oc[e]);
+#pragma unroll
+                for (int b = B0; b < KP; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(z[b]) : "v"(a), "n"(4096 * b));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                double zr[KP], zi[KP], sm[KP], df[KP];
+#pragma unroll
+                for (int b = B0; b < KP; ++b) {
+                    asm volatile("" : "+v"(z[b]));
+                    zr[b] = z[b].x; zi[b] = z[b].y; sm[b] = z[b].x + z[b].y; df[b] = z[b].y - z[b].x;
+                }
+#pragma unroll
+                for (int b = 0; b < B0; ++b) { zr[b] = 0.0; zi[b] = 0.0; sm[b] = 0.0; df[b] = 0.0; }   // (never used)
+                gram3m_step<KP, NM, FIRST>(zr, zi, sm, df, p1, p2, p3, seq);
+                __builtin_amdgcn_sched_barrier(0);                             // (or the second step's reads move ahead of these MFMAs and both operand sets are live: spills)
+            }
+        };
+        int64_t T = blockIdx.x;
+        if (T < nfull) {
+#pragma unroll
+            for (int j = 0; j < NBUF - 1; ++j) issue(T + j * G < nfull ? T + j * G : T, j);
+            int buf = 0;
+            for (; T < nfull; T += G) {
+                wait_vmcnt<(NBUF - 2) * LPT>();
+                __builtin_amdgcn_s_barrier();
+                const int64_t Tl = T + (NBUF - 1) * G;
+                issue(Tl < nfull ? Tl : T, buf == 0 ? NBUF - 1 : buf - 1);
+                steps(lds + buf * BUFB);
+                buf = buf + 1 == NBUF ? 0 : buf + 1;
+            }
+            wait_vmcnt<0>();
+        }
+        __syncthreads();
+        if ((nr & 31) != 0 && (int64_t)blockIdx.x == nfull % G) {              // the ragged tile: ordinary loads, zero filled, into buffer 0 in the same image
+            for (int p = t; p < KP * 256; p += 512) {
+                const int col = p >> 4, lg = (p & 15) ^ (col & 15);
+                const int64_t e = 16 * nfull + lg;
+                v2d v = v2d{0.0, 0.0};
+                if (col < k && e < n) v = *reinterpret_cast<const v2d *>(X + (int64_t)col * ldr + 2 * e);
+                *reinterpret_cast<v2d *>(lds + 16 * p) = v;
+            }
+            __syncthreads();
+            steps(lds);
+        }
+        __syncthreads();
+        // the two halves of every tile meet in the group's even wave, through LDS: 3 NM tiles of 256 doubles per group -- two groups at a time fit the ring
+        double *Xt = grs34_lds + (GI & 1) * 3 * NM * 256;
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if ((GI >> 1) == rnd && half == 1) {
+#pragma unroll
+                for (int q = 0; q < CNT; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Xt[(3 * q + 0) * 256 + r * 64 + lane] = p1[q][r];
+                        Xt[(3 * q + 1) * 256 + r * 64 + lane] = p2[q][r];
+                        Xt[(3 * q + 2) * 256 + r * 64 + lane] = p3[q][r];
+                    }
+            }
+            __syncthreads();
+            if ((GI >> 1) == rnd && half == 0)
+                gram3m_add_store<KP, NM, FIRST>(partial + (int64_t)blockIdx.x * ((int64_t)k * (k + 1) * 2), k, arow, acol, lane, Xt, p1, p2, p3, seq);
+            __syncthreads();
+        }
+    };
+    // (each group runs its own copy of the whole loop: see panel_gram_rs)
+    if (grp == 0) run(std::integral_constant<int, 0>{});
+    else if (grp == 1) run(std::integral_constant<int, 1>{});
+    else if (grp == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 3>{});
+}
+
 // Pass B of the block Gram-Schmidt with many right-hand sides, FUSED on the matrix cores (gram_schmidt.fypp:59-105):
 //     Y' = Y - X H1   (stored)      M2 = X^H Y'      ||Y'_q||^2
 // in ONE pass over X(:, :k) (k <= 128) and Y(:, :p) (p <= 32) -- the update and the second coefficient pass of

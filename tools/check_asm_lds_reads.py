@@ -6,6 +6,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INST = [(3, 3, 8), (4, 3, 6), (5, 3, 4), (6, 3, 4), (7, 4, 2), (8, 4, 2)]          # panel_gram_rs as dispatched by lk_engine.hip (dots_mfma)
 INST3M = [(3, 3, 4), (4, 5, 2), (5, 5, 2)]                                          # panel_gram_rs3m (complex: ds_read_b128)
+INST3M4 = [(6, 5, 2), (7, 5, 2)]                                                    # panel_gram_rs3m4 (four groups: 2 steps x (main loop + ragged tile) x 4 groups = 16 batches)
 
 
 def main():
@@ -14,6 +15,8 @@ def main():
         assert f"panel_gram_rs<{kp}, {nb}, {w}>" in eng, f"instantiation <{kp}, {nb}, {w}> is not the one the engine launches"
     for kp, nb, w in INST3M:
         assert f"panel_gram_rs3m<{kp}, {nb}, {w}>" in eng, f"instantiation 3m <{kp}, {nb}, {w}> is not the one the engine launches"
+    for kp, nb, w in INST3M4:
+        assert f"panel_gram_rs3m4<{kp}, {nb}, {w}>" in eng, f"instantiation 3m4 <{kp}, {nb}, {w}> is not the one the engine launches"
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.hip")
         with open(src, "w") as f:
@@ -22,13 +25,15 @@ def main():
                 f.write(f"template __global__ void lk::panel_gram_rs<{kp}, {nb}, {w}>(const double *, int64_t, int, int64_t, double *);\n")
             for kp, nb, w in INST3M:
                 f.write(f"template __global__ void lk::panel_gram_rs3m<{kp}, {nb}, {w}>(const double *, int64_t, int, int64_t, double *);\n")
+            for kp, nb, w in INST3M4:
+                f.write(f"template __global__ void lk::panel_gram_rs3m4<{kp}, {nb}, {w}>(const double *, int64_t, int, int64_t, double *);\n")
         out = os.path.join(d, "t.s")
         r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True)
         if r.returncode != 0:
             print(r.stderr[-2000:]); return 2
         lines_all = open(out).read().split("\n")
-    starts = [i for i, l in enumerate(lines_all) if re.match(r"^_ZN2lk1[35]panel_gram_rs(3m)?I\w+:", l)]
-    assert len(starts) == len(INST) + len(INST3M), (len(starts), len(INST), len(INST3M))
+    starts = [i for i, l in enumerate(lines_all) if re.match(r"^_ZN2lk1[356]panel_gram_rs(3m4?)?I\w+:", l)]
+    assert len(starts) == len(INST) + len(INST3M) + len(INST3M4), (len(starts), len(INST), len(INST3M), len(INST3M4))
     rc = 0
     for s0 in starts:
         e0 = next(i for i in range(s0, len(lines_all)) if lines_all[i].startswith(".Lfunc_end"))
@@ -58,7 +63,7 @@ def main():
                 i = j
             i += 1
         print(f"{lines[0].split(':')[0]}: {regions} batches of asm reads, {len(bad)} instructions touching a pending destination")
-        if regions != 4 or bad:
+        if regions != (16 if "rs3m4" in lines[0] else 4) or bad:
             rc = 1
             for o in bad[:8]:
                 print("   ", o)
