@@ -91,8 +91,8 @@ struct lk_context_s {
     int store_split = 0;       // every wave of the column split stores a lane slice instead of the wc == 0 wave
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
     int upd_rs = 1;            // fused pass of the block DGS, real kind, 17..32 right-hand sides: 1 = panel_xhy_upd_rs (row-owner waves, LDS-DMA tiles, coefficients in registers), 0 = panel_xhy_upd_mfma
-    int gram_rs = 1;           // Gram matrix of 33..128 real columns by panel_gram_rs (rows of the staged tile dealt to the waves, LDS-DMA staging; n = 10^7: k = 48 1.11 -> 0.63 ms,
-                               // k = 96 2.81 -> 1.80, k = 128 3.45 -> 3.0) and of 33..112 complex columns by panel_gram_rs3m / rs3m4 (n = 5 10^6: k = 48 1.35 -> 0.84, k = 96 3.33 -> 2.69):
+    int gram_rs = 1;           // Gram matrix of 5..128 real columns by panel_gram_rs (rows of the staged tile dealt to the waves, LDS-DMA staging; n = 10^7: k = 8 0.29 -> 0.12 ms,
+                               // k = 16 0.35 -> 0.21, k = 48 1.11 -> 0.63, k = 96 2.81 -> 1.80, k = 128 3.45 -> 3.0) and of 33..112 complex columns by panel_gram_rs3m / rs3m4 (n = 5 10^6: k = 48 1.35 -> 0.84, k = 96 3.33 -> 2.69):
                                // 1 = as many blocks per CU as are resident, n > 1 = n blocks per CU, 0 = panel_xhy_mfma (one tile row per wave) / panel_gram_mfma3m
     int upd_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
     int xhy_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
@@ -810,10 +810,10 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         if (out_dev) *out_dev = out3;
         return allreduce(c, out3, nslots);
     }
-    // real Gram matrix of 33..128 columns: the rows of the staged tile dealt to the waves, tiles staged by LDS-DMA (panel_gram_rs, round 6)
-    if (!cp && !small && flags == 3 && k > 32 && k <= 128 && c->gram_rs > 0) {
-        const int resident = KP == 3 ? 4 : (KP == 4 ? 3 : (KP <= 6 ? 2 : 1));                    // blocks per CU (LDS ring; beyond 96 columns the accumulators)
-        const int nbuf = KP <= 6 ? 3 : 4;
+    // real Gram matrix of 5..128 columns: the rows of the staged tile dealt to the waves, tiles staged by LDS-DMA (panel_gram_rs, round 6)
+    if (!cp && flags == 3 && k <= 128 && c->gram_rs > 0) {
+        const int resident = KP <= 3 ? 4 : (KP == 4 ? 3 : (KP <= 6 ? 2 : 1));                    // blocks per CU (LDS ring; beyond 96 columns the accumulators)
+        const int nbuf = KP == 1 ? 8 : (KP == 2 ? 5 : (KP <= 6 ? 3 : 4));                        // (narrow tiles: a deeper ring, for the bytes in flight)
         const int64_t nt32 = (Bx->n + 31) / 32;
         int64_t gg = (int64_t)c->num_cu * (c->gram_rs == 1 ? resident : c->gram_rs);
         if (gg > nt32) gg = nt32;
@@ -829,6 +829,8 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
                 return LK_OK;
             };
             switch (KP) {                                                                       // <column blocks, ring buffers, waves per SIMD>
+            case 1: LKCHK(go(&panel_gram_rs<1, 8, 8>)); break;
+            case 2: LKCHK(go(&panel_gram_rs<2, 5, 8>)); break;
             case 3: LKCHK(go(&panel_gram_rs<3, 3, 8>)); break;
             case 4: LKCHK(go(&panel_gram_rs<4, 3, 6>)); break;
             case 5: LKCHK(go(&panel_gram_rs<5, 3, 4>)); break;

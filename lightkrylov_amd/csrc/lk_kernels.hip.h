@@ -1959,8 +1959,9 @@ __global__ __launch_bounds__(512) void panel_gram_mfma3m(const double *__restric
 // flags = 3 (Y is X, upper tiles only), summed by finish_xhy; no norm slots.
 template <int KP> struct GramRowSplit {
     static constexpr int NT = KP * (KP + 1) / 2, N0 = (NT + 1) / 2, N1 = NT - N0;
-    static constexpr int tile_i(int idx) { int I = 0, rem = idx; while (rem >= KP - I) { rem -= KP - I; ++I; } return I; }
-    static constexpr int tile_j(int idx) { int I = 0, rem = idx; while (rem >= KP - I) { rem -= KP - I; ++I; } return I + rem; }
+    // (an index beyond the list -- the second group of a one-tile list -- gives the last tile row instead of running away)
+    static constexpr int tile_i(int idx) { int I = 0, rem = idx; while (I < KP - 1 && rem >= KP - I) { rem -= KP - I; ++I; } return I; }
+    static constexpr int tile_j(int idx) { int I = 0, rem = idx; while (I < KP - 1 && rem >= KP - I) { rem -= KP - I; ++I; } return I + rem < KP ? I + rem : KP - 1; }
 };
 template <int KP, int FIRST, int... Q>
 __device__ __forceinline__ void gram_rs_step(const double (&r)[KP], v4d (&acc)[GramRowSplit<KP>::N0], std::integer_sequence<int, Q...>) {

@@ -210,9 +210,10 @@ def test_rolling_prefetch_product_over_many_tiles_per_block(k, q):
 
 @pytest.mark.parametrize("dtype", KINDS)
 @pytest.mark.parametrize("n,k", [(200_003, 128), (70_001, 113), (16_400, 128), (300_017, 97), (150_000, 96), (90_001, 81), (200_003, 64), (70_001, 49), (33, 56),
-                                 (120_007, 48), (50_011, 33), (1_000_001, 40), (250_005, 80), (100_000, 72), (17, 70)])
+                                 (120_007, 48), (50_011, 33), (1_000_001, 40), (250_005, 80), (100_000, 72), (17, 70), (500_003, 32), (300_001, 17), (200_000, 8),
+                                 (100_001, 5), (2_000_003, 16)])
 def test_row_split_gram_kernel_over_many_tiles_per_block(dtype, n, k):
-    """gram_matrix (AbstractVectors.fypp:645-657) of 33..128 real columns by panel_gram_rs and of 33..80 complex columns by panel_gram_rs3m (rows of the staged tile dealt
+    """gram_matrix (AbstractVectors.fypp:645-657) of 5..128 real columns by panel_gram_rs and of 33..80 complex columns by panel_gram_rs3m (rows of the staged tile dealt
     to the waves, tiles staged by LDS-DMA into a ring of three to five buffers behind counted waits, operands by inline-asm LDS reads) on panels long enough that every
     block runs MANY tiles -- every buffer of the ring, the prefetch running off the end of the panel, a ragged last tile or none, widths that are not a multiple of 16
     (the last column block partly beyond the panel), every number of column blocks 3..8, panels of one tile and a bit -- against the oracle, against the kernel behind
