@@ -141,7 +141,7 @@ int lk_set_partition(lk_context_t ctx, int64_t row0, int64_t n_global);
  *                 passes per group for the real kind, 2 = for both kinds, 0 = four); "gemm_mfma_min" (tall-skinny product on the MFMAs from
  *                 this many output columns on; default 5 real / 9 complex); "gemm_3m" (1: the complex MFMA kernels use three real products
  *                 per complex one); "xhy_db" (panel_xhy_mfma with a double-buffered LDS tile: 1 = the 128-column variants, 2 = all, 0 = never); "gemm_roll" (1: the real product with 33..64 outputs keeps a ring of four k-steps of X in flight; 2:
- *                 every variant that has a ring; 0: batches) [bits]; "gram_rs" (Gram matrix of 5..128 real columns by panel_gram_rs and of 33..112
+ *                 every variant that has a ring; 0: batches) [bits]; "gram_rs" (Gram matrix of 5..128 real columns by panel_gram_rs and of 5..112
  *                 complex columns by panel_gram_rs3m / panel_gram_rs3m4 -- rows of the staged tile dealt to the waves, tiles staged by LDS-DMA: 1 = the resident
  *                 number of blocks per CU, n > 1 = n blocks per CU, 0 = panel_xhy_mfma / panel_gram_mfma3m); "upd_rs" (fused pass of the block Gram-Schmidt, real kind, 17..32 right-hand sides: 1 = panel_xhy_upd_rs --
  *                 row-owner waves on LDS-DMA tiles, coefficients in registers --, 0 = panel_xhy_upd_mfma)

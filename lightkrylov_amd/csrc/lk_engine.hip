@@ -92,7 +92,7 @@ struct lk_context_s {
     int gemm_prefetch_y = 1;   // accumulating real MFMA product (<= 32 outputs): load the tile of Y ahead of the k-loop (0: after it)
     int upd_rs = 1;            // fused pass of the block DGS, real kind, 17..32 right-hand sides: 1 = panel_xhy_upd_rs (row-owner waves, LDS-DMA tiles, coefficients in registers), 0 = panel_xhy_upd_mfma
     int gram_rs = 1;           // Gram matrix of 5..128 real columns by panel_gram_rs (rows of the staged tile dealt to the waves, LDS-DMA staging; n = 10^7: k = 8 0.29 -> 0.12 ms,
-                               // k = 16 0.35 -> 0.21, k = 48 1.11 -> 0.63, k = 96 2.81 -> 1.80, k = 128 3.45 -> 3.0) and of 33..112 complex columns by panel_gram_rs3m / rs3m4 (n = 5 10^6: k = 48 1.35 -> 0.84, k = 96 3.33 -> 2.69):
+                               // k = 16 0.35 -> 0.21, k = 48 1.11 -> 0.63, k = 96 2.81 -> 1.80, k = 128 3.45 -> 3.0) and of 5..112 complex columns by panel_gram_rs3m / rs3m4 (n = 5 10^6: k = 16 0.46 -> 0.22, k = 48 1.35 -> 0.84, k = 96 3.33 -> 2.69):
                                // 1 = as many blocks per CU as are resident, n > 1 = n blocks per CU, 0 = panel_xhy_mfma (one tile row per wave) / panel_gram_mfma3m
     int upd_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): panel_xhy_upd_mfma without 1 = the update MFMAs, 2 = the dot MFMAs, 4 = the global loads after the first tile, 8 = the store of Y'
     int xhy_debug = 0;         // -DLK_DIAGNOSTICS builds only (WRONG results, phase timing): 1 = panel_xhy_mfma without its MFMAs, 2 = without the global loads after the first tile
@@ -759,10 +759,10 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
         c->xhy_n = need;
         return LK_OK;
     };
-    // complex Gram matrix of 33..112 columns: panel_gram_rs's row split and LDS-DMA tiles with three real products per complex one (panel_gram_rs3m / rs3m4, round 6)
-    if (cp && !small && c->gemm_3m && flags == 3 && KP >= 3 && KP <= 7 && c->gram_rs > 0) {
-        const int resident = KP == 3 ? 2 : 1;                                                     // blocks per CU (three accumulators per tile: registers)
-        const int nbuf = KP == 3 ? 3 : 5;                                                         // (84..140 KB at one block per CU)
+    // complex Gram matrix of 5..112 columns: panel_gram_rs's row split and LDS-DMA tiles with three real products per complex one (panel_gram_rs3m / rs3m4, round 6)
+    if (cp && c->gemm_3m && flags == 3 && KP <= 7 && c->gram_rs > 0) {
+        const int resident = KP == 1 ? 4 : (KP == 2 ? 3 : (KP == 3 ? 2 : 1));                     // blocks per CU (three accumulators per tile: registers)
+        const int nbuf = KP == 1 ? 8 : (KP == 2 ? 5 : (KP == 3 ? 3 : 5));                         // (narrow tiles: a deeper ring; 84..140 KB at one block per CU)
         const int64_t nt16 = (Bx->n + 15) / 16;
         int64_t gg = (int64_t)c->num_cu * (c->gram_rs == 1 ? resident : c->gram_rs);
         if (gg > nt16) gg = nt16;
@@ -777,7 +777,9 @@ int dots_mfma(lk_basis_t Bx, int c0, int k, lk_basis_t By, int jy0, int p, int f
                 hipLaunchKernelGGL(kern, dim3((unsigned)gg), dim3(512), ldsg, c->stream, (const double *)Bx->col(c0), Bx->ld, k, Bx->n, partg);
                 return LK_OK;
             };
-            if (KP == 3) LKCHK(go(&panel_gram_rs3m<3, 3, 4>));
+            if (KP == 1) LKCHK(go(&panel_gram_rs3m<1, 8, 8>));
+            else if (KP == 2) LKCHK(go(&panel_gram_rs3m<2, 5, 6>));
+            else if (KP == 3) LKCHK(go(&panel_gram_rs3m<3, 3, 4>));
             else if (KP == 4) LKCHK(go(&panel_gram_rs3m<4, 5, 2>));
             else if (KP == 5) LKCHK(go(&panel_gram_rs3m<5, 5, 2>));
             else if (KP == 6) LKCHK(go(&panel_gram_rs3m4<6, 5, 2>));                              // four groups of two waves: a quarter of the tile list each

@@ -5,7 +5,7 @@ way.  This script compiles every instantiation to assembly (hipcc -S, a few seco
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INST = [(1, 8, 8), (2, 5, 8), (3, 3, 8), (4, 3, 6), (5, 3, 4), (6, 3, 4), (7, 4, 2), (8, 4, 2)]          # panel_gram_rs as dispatched by lk_engine.hip (dots_mfma)
-INST3M = [(3, 3, 4), (4, 5, 2), (5, 5, 2)]                                          # panel_gram_rs3m (complex: ds_read_b128)
+INST3M = [(1, 8, 8), (2, 5, 6), (3, 3, 4), (4, 5, 2), (5, 5, 2)]                                          # panel_gram_rs3m (complex: ds_read_b128)
 INST3M4 = [(6, 5, 2), (7, 5, 2)]                                                    # panel_gram_rs3m4 (four groups: 2 steps x (main loop + ragged tile) x 4 groups = 16 batches)
 
 
